@@ -1,0 +1,321 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY (see oracle/README.md).
+// extern "C" surface of the CPU oracle, loaded with ctypes by tests/, __graft_entry__.smoke() and bench.py's
+// cpu_baseline leg.  Never linked into or called from the product (mega-minecraft_amd/).
+#include "mmo_stages.h"
+#include <thread>
+#include <atomic>
+#include <map>
+#include <functional>
+#include <cstring>
+#include <cstdio>
+
+using namespace mmo;
+
+namespace {
+
+void parallel_for(int n, int nthreads, const std::function<void(int)>& fn)
+{
+    if (nthreads <= 1 || n <= 1) {
+        for (int i = 0; i < n; ++i) fn(i);
+        return;
+    }
+    std::atomic<int> next(0);
+    std::vector<std::thread> th;
+    for (int t = 0; t < nthreads; ++t)
+        th.emplace_back([&]() {
+            for (;;) {
+                int i = next.fetch_add(1);
+                if (i >= n) break;
+                fn(i);
+            }
+        });
+    for (auto& t : th) t.join();
+}
+
+inline int floordiv(int a, int b) { int q = a / b; return (a % b != 0 && ((a < 0) != (b < 0))) ? q - 1 : q; }
+
+}  // namespace
+
+extern "C" {
+
+// ---------------------------------------------------------------- math probes (batch)
+void mmo_sinf(int n, const float* x, float* out) { for (int i = 0; i < n; ++i) out[i] = mm_sinf(x[i]); }
+void mmo_cosf(int n, const float* x, float* out) { for (int i = 0; i < n; ++i) out[i] = mm_cosf(x[i]); }
+void mmo_powf(int n, const float* x, const float* y, float* out) { for (int i = 0; i < n; ++i) out[i] = mm_powf(x[i], y[i]); }
+void mmo_atan2f(int n, const float* y, const float* x, float* out) { for (int i = 0; i < n; ++i) out[i] = mm_atan2f(y[i], x[i]); }
+void mmo_acosf(int n, const float* x, float* out) { for (int i = 0; i < n; ++i) out[i] = mm_acosf(x[i]); }
+void mmo_hash(int n, const uint32_t* x, uint32_t* out) { for (int i = 0; i < n; ++i) out[i] = hash_u32(x[i]); }
+// k draws of u01 from makeSeededRandomEngine(x,y,z[,w]) per seed tuple; use_w selects the 4-arg form
+void mmo_rng_u01(int n, const int* xyzw, int use_w, int k, float* out)
+{
+    for (int i = 0; i < n; ++i) {
+        const int* s = xyzw + 4 * i;
+        Rng r = use_w ? makeSeededRandomEngine(s[0], s[1], s[2], s[3]) : makeSeededRandomEngine(s[0], s[1], s[2]);
+        for (int j = 0; j < k; ++j) out[i * k + j] = r.u01();
+    }
+}
+void mmo_simplex2(int n, const float* xy, float* out) { for (int i = 0; i < n; ++i) out[i] = simplex(vec2(xy[2 * i], xy[2 * i + 1])); }
+void mmo_simplex3(int n, const float* xyz, float* out) { for (int i = 0; i < n; ++i) out[i] = simplex(vec3(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2])); }
+void mmo_fbm2(int n, int octaves, const float* xy, float* out)
+{
+    for (int i = 0; i < n; ++i) {
+        vec2 p(xy[2 * i], xy[2 * i + 1]);
+        out[i] = octaves == 3 ? fbm<3>(p) : octaves == 4 ? fbm<4>(p) : fbm<5>(p);
+    }
+}
+void mmo_fbm3(int n, int octaves, const float* xyz, float* out)
+{
+    for (int i = 0; i < n; ++i) {
+        vec3 p(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]);
+        out[i] = octaves == 3 ? fbm<3>(p) : octaves == 4 ? fbm<4>(p) : fbm<5>(p);
+    }
+}
+// out[i] = {dist, color.xyz, edgeDist}
+void mmo_worley2(int n, const float* xy, float* out5)
+{
+    for (int i = 0; i < n; ++i) {
+        vec3 c; float e;
+        float d = worley(vec2(xy[2 * i], xy[2 * i + 1]), &c, &e);
+        float* o = out5 + 5 * i; o[0] = d; o[1] = c.x; o[2] = c.y; o[3] = c.z; o[4] = e;
+    }
+}
+void mmo_worley3(int n, const float* xyz, float* out5)
+{
+    for (int i = 0; i < n; ++i) {
+        vec3 c; float e;
+        float d = worley(vec3(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]), &c, &e);
+        float* o = out5 + 5 * i; o[0] = d; o[1] = c.x; o[2] = c.y; o[3] = c.z; o[4] = e;
+    }
+}
+void mmo_special_cave_noise(int n, const float* xyz, float* out)
+{
+    for (int i = 0; i < n; ++i) out[i] = specialCaveNoise(vec3(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]));
+}
+void mmo_rand3from3(int n, const float* xyz, float* out3)
+{
+    for (int i = 0; i < n; ++i) {
+        vec3 r = rand3From3(vec3(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]));
+        out3[3 * i] = r.x; out3[3 * i + 1] = r.y; out3[3 * i + 2] = r.z;
+    }
+}
+// per-biome height (DEBUG_BIOME_OVERRIDE-style probe)
+void mmo_biome_height(int n, int biome, const float* xy, float* out) { for (int i = 0; i < n; ++i) out[i] = getHeight((Biome)biome, vec2(xy[2 * i], xy[2 * i + 1])); }
+void mmo_cave_biome(int n, const int* xyz, const float* maxHeight, int seed, uint8_t* out)
+{
+    for (int i = 0; i < n; ++i) out[i] = (uint8_t)getCaveBiome(ivec3{xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]}, maxHeight[i], seed);
+}
+void mmo_should_generate_cave(int n, const int* xyz, const float* maxHeight, const float* obw, uint8_t* out)
+{
+    for (int i = 0; i < n; ++i) out[i] = shouldGenerateCaveAtBlock(ivec3{xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]}, maxHeight[i], obw[i]) ? 1 : 0;
+}
+
+// ---------------------------------------------------------------- constant tables (fixture 3 of SURVEY §8c)
+// layout: [24*6 biome rules u8][5*4 cave rules u8][24 grass u8][20 * (block u8 as f32, thickness, amp/tan, scale/maxSlope)] ...
+void mmo_tables_material_infos(float* out80)
+{
+    for (int i = 0; i < numMaterials; ++i) {
+        const auto& m = T().materialInfos[i];
+        out80[4 * i] = (float)(int)m.block; out80[4 * i + 1] = m.thickness;
+        out80[4 * i + 2] = m.noiseAmplitudeOrTanAngleOfRepose; out80[4 * i + 3] = m.noiseScaleOrMaxSlope;
+    }
+}
+void mmo_tables_biome_material_weights(float* out480) { std::memcpy(out480, T().biomeMaterialWeights, sizeof(float) * numBiomes * numMaterials); }
+void mmo_tables_rules(uint8_t* biome144, uint8_t* cave20, uint8_t* grass24)
+{
+    for (int b = 0; b < numBiomes; ++b) {
+        const auto& w = T().biomeNoiseWeights[b];
+        uint8_t* o = biome144 + 6 * b; o[0] = w.ocean; o[1] = w.beach; o[2] = w.rocky; o[3] = w.magic; o[4] = w.temperature; o[5] = w.moisture;
+        grass24[b] = (uint8_t)T().grassBlock[b];
+    }
+    for (int b = 0; b < numCaveBiomes; ++b) {
+        const auto& w = T().caveBiomeNoiseWeights[b];
+        uint8_t* o = cave20 + 4 * b; o[0] = w.none; o[1] = w.shallow; o[2] = w.warped; o[3] = w.rocky;
+    }
+}
+
+// ---------------------------------------------------------------- per-stage entry points (reference per-chunk layouts)
+void mmo_heightfields(int n, const int* posXZ, float* hf, float* bw, int nthreads)
+{
+    parallel_for(n, nthreads, [&](int i) { generateHeightfield(ivec2{posXZ[2 * i], posXZ[2 * i + 1]}, hf + 256 * i, bw + 6144 * i); });
+}
+void mmo_gather_heightfields(int n, const int* posXZ, const float* hf, float* gathered, int nthreads)
+{
+    parallel_for(n, nthreads, [&](int i) { gatherHeightfield(ivec2{posXZ[2 * i], posXZ[2 * i + 1]}, hf + 256 * i, gathered + 324 * i); });
+}
+void mmo_layers(int n, const int* posXZ, const float* gathered, const float* bw, float* layers, int nthreads)
+{
+    parallel_for(n, nthreads, [&](int i) { generateLayers(ivec2{posXZ[2 * i], posXZ[2 * i + 1]}, gathered + 324 * i, bw + 6144 * i, layers + 5120 * i); });
+}
+int mmo_erode_zone_planes(float* gathered9) { return erodeZonePlanes(gathered9); }
+void mmo_fix_backward_layers(int n, float* layers) { for (int i = 0; i < n; ++i) fixBackwardStratifiedLayers(layers + 5120 * i); }
+void mmo_caves(int n, const int* posXZ, const float* hf, const float* bw, void* caveLayers, int nthreads)
+{
+    parallel_for(n, nthreads, [&](int i) {
+        generateCaves(ivec2{posXZ[2 * i], posXZ[2 * i + 1]}, hf + 256 * i, bw + 6144 * i, (CaveLayer*)caveLayers + 8192 * i);
+    });
+}
+// writes up to maxPer entries per chunk into fp/cfp (chunk-major, stride maxPer) and the true counts into counts[2*i], counts[2*i+1]
+void mmo_feature_placements(int n, const int* posXZ, const float* hf, const float* bw, const float* layers, const void* caveLayers,
+                            void* fp, void* cfp, int maxPer, int* counts, int nthreads)
+{
+    parallel_for(n, nthreads, [&](int i) {
+        std::vector<FeaturePlacement> a; std::vector<CaveFeaturePlacement> b;
+        generateFeaturePlacements(ivec2{posXZ[2 * i], posXZ[2 * i + 1]}, hf + 256 * i, bw + 6144 * i, layers + 5120 * i,
+                                  (const CaveLayer*)caveLayers + 8192 * i, a, b);
+        counts[2 * i] = (int)a.size(); counts[2 * i + 1] = (int)b.size();
+        std::memcpy((FeaturePlacement*)fp + (size_t)maxPer * i, a.data(), sizeof(FeaturePlacement) * std::min((int)a.size(), maxPer));
+        std::memcpy((CaveFeaturePlacement*)cfp + (size_t)maxPer * i, b.data(), sizeof(CaveFeaturePlacement) * std::min((int)b.size(), maxPer));
+    });
+}
+// fill one batch; features for chunk i are fp[fpOff[i] .. fpOff[i+1]) (gathered lists, un-truncated)
+void mmo_fill(int n, const int* posXZ, const float* hf, const float* bw, const float* layers, const void* caveLayers,
+              const void* fp, const int* fpOff, const void* cfp, const int* cfpOff, uint8_t* blocks, int decorators, int nthreads)
+{
+    parallel_for(n, nthreads, [&](int i) {
+        ivec3 wp = {posXZ[2 * i], 0, posXZ[2 * i + 1]};
+        const FeaturePlacement* f = fp ? (const FeaturePlacement*)fp + fpOff[i] : nullptr;
+        const CaveFeaturePlacement* c = cfp ? (const CaveFeaturePlacement*)cfp + cfpOff[i] : nullptr;
+        int nf = fp ? fpOff[i + 1] - fpOff[i] : 0, nc = cfp ? cfpOff[i + 1] - cfpOff[i] : 0;
+        Block* b = (Block*)blocks + (size_t)98304 * i;
+        fillChunk(wp, hf + 256 * i, bw + 6144 * i, layers + 5120 * i, (const CaveLayer*)caveLayers + 8192 * i, f, nf, c, nc, b);
+        if (decorators) placeDecorators(wp, hf + 256 * i, bw + 6144 * i, (const CaveLayer*)caveLayers + 8192 * i, b);
+    });
+}
+void mmo_decorators(int n, const int* posXZ, const float* hf, const float* bw, const void* caveLayers, uint8_t* blocks)
+{
+    for (int i = 0; i < n; ++i)
+        placeDecorators(ivec3{posXZ[2 * i], 0, posXZ[2 * i + 1]}, hf + 256 * i, bw + 6144 * i, (const CaveLayer*)caveLayers + 8192 * i,
+                        (Block*)blocks + (size_t)98304 * i);
+}
+// single-voxel feature probes (fixture 11 of SURVEY §8c): rasterise one placement into a box
+void mmo_place_feature_box(int feature, const int* fpos, int canReplace, const int* boxMin, const int* boxSize, uint8_t* out)
+{
+    FeaturePlacement p; std::memset(&p, 0, sizeof(p));
+    p.feature = (Feature)feature; p.pos = ivec3{fpos[0], fpos[1], fpos[2]}; p.canReplaceBlocks = canReplace != 0;
+    size_t k = 0;
+    for (int z = 0; z < boxSize[2]; ++z) for (int x = 0; x < boxSize[0]; ++x) for (int y = 0; y < boxSize[1]; ++y, ++k) {
+        Block b = Block::AIR;
+        bool placed = placeFeature(p, ivec3{boxMin[0] + x, boxMin[1] + y, boxMin[2] + z}, &b);
+        out[k] = placed ? (uint8_t)b : 255;
+    }
+}
+void mmo_place_cave_feature_box(int feature, const int* fpos, int layerHeight, int canReplace, const int* boxMin, const int* boxSize, uint8_t* out)
+{
+    CaveFeaturePlacement p; std::memset(&p, 0, sizeof(p));
+    p.feature = (CaveFeature)feature; p.pos = ivec3{fpos[0], fpos[1], fpos[2]}; p.layerHeight = layerHeight; p.canReplaceBlocks = canReplace != 0;
+    size_t k = 0;
+    for (int z = 0; z < boxSize[2]; ++z) for (int x = 0; x < boxSize[0]; ++x) for (int y = 0; y < boxSize[1]; ++y, ++k) {
+        Block b = Block::AIR;
+        bool placed = placeCaveFeature(p, ivec3{boxMin[0] + x, boxMin[1] + y, boxMin[2] + z}, &b);
+        out[k] = placed ? (uint8_t)b : 255;
+    }
+}
+
+void mmo_ub_counters(long long* out3, int reset)
+{
+    out3[0] = g_ub.noLayerFound; out3[1] = g_ub.caveLayerOverflow; out3[2] = g_ub.decoratorOutOfRange;
+    if (reset) g_ub = UbCounters{0, 0, 0};
+}
+
+// ---------------------------------------------------------------- region pipeline (the canonical "world" definition)
+// Generates chunks [cx0, cx0+nx) x [cz0, cz0+nz) (chunk coordinates), chunk-major output in z-major order (i = cx + nx*cz).
+// flags: bit0 erosion, bit1 features, bit2 decorators.  Without erosion only E3's fix-up runs (DEBUG_SKIP_EROSION semantics,
+// chunk.cu:713-720).  out_hf / out_layers / out_cave may be null.
+// Canonical region semantics: a zone's 6-chunk erosion padding always uses RAW (pre-erosion) layers; feature
+// placements of the 3-chunk ring around the region are generated from that ring's own eroded layers.
+void mmo_generate_region(int cx0, int cz0, int nx, int nz, int flags, uint8_t* out_blocks, float* out_hf, float* out_layers,
+                         void* out_cave, int nthreads, double* stage_seconds /*nullable, 8*/)
+{
+    const bool doErosion = flags & 1, doFeatures = flags & 2, doDecor = flags & 4;
+    const int ring = doFeatures ? 3 : 0;
+    const int px0 = cx0 - ring, pz0 = cz0 - ring, pnx = nx + 2 * ring, pnz = nz + 2 * ring;   // placement region P
+    const int np = pnx * pnz;
+
+    std::vector<int> ppos(2 * np);
+    for (int z = 0; z < pnz; ++z) for (int x = 0; x < pnx; ++x) { ppos[2 * (x + pnx * z)] = (px0 + x) * 16; ppos[2 * (x + pnx * z) + 1] = (pz0 + z) * 16; }
+    std::vector<float> hf((size_t)256 * np), bw((size_t)6144 * np), layers((size_t)5120 * np);
+    std::vector<CaveLayer> cave((size_t)8192 * np);
+
+    if (!doErosion) {
+        std::vector<float> gathered((size_t)324 * np);
+        mmo_heightfields(np, ppos.data(), hf.data(), bw.data(), nthreads);
+        mmo_gather_heightfields(np, ppos.data(), hf.data(), gathered.data(), nthreads);
+        mmo_layers(np, ppos.data(), gathered.data(), bw.data(), layers.data(), nthreads);
+    } else {
+        // raw area A = union of the 24x24 gathered areas of all zones intersecting P
+        const int zx0 = floordiv(px0, ZONE_SIZE) * ZONE_SIZE, zz0 = floordiv(pz0, ZONE_SIZE) * ZONE_SIZE;
+        const int zx1 = floordiv(px0 + pnx - 1, ZONE_SIZE) * ZONE_SIZE, zz1 = floordiv(pz0 + pnz - 1, ZONE_SIZE) * ZONE_SIZE;
+        const int ax0 = zx0 - 6, az0 = zz0 - 6, anx = (zx1 - zx0) + 24, anz = (zz1 - zz0) + 24;
+        const int na = anx * anz;
+        std::vector<int> apos(2 * na);
+        for (int z = 0; z < anz; ++z) for (int x = 0; x < anx; ++x) { apos[2 * (x + anx * z)] = (ax0 + x) * 16; apos[2 * (x + anx * z) + 1] = (az0 + z) * 16; }
+        std::vector<float> ahf((size_t)256 * na), abw((size_t)6144 * na), alayers((size_t)5120 * na), agath((size_t)324 * na);
+        mmo_heightfields(na, apos.data(), ahf.data(), abw.data(), nthreads);
+        mmo_gather_heightfields(na, apos.data(), ahf.data(), agath.data(), nthreads);
+        mmo_layers(na, apos.data(), agath.data(), abw.data(), alayers.data(), nthreads);
+        agath.clear(); agath.shrink_to_fit();
+
+        std::vector<float> eroded(alayers);      // eroded copy; raw stays in alayers for the other zones' padding
+        std::vector<ivec2> zones;
+        for (int zz = zz0; zz <= zz1; zz += ZONE_SIZE) for (int zx = zx0; zx <= zx1; zx += ZONE_SIZE) zones.push_back(ivec2{zx, zz});
+        parallel_for((int)zones.size(), nthreads, [&](int zi) {
+            const ivec2 zc = zones[zi];
+            std::vector<float> g((size_t)9 * EROSION_GRID_NUM_COLS);
+            // E1 copyLayers(to) chunk.cu:603-656
+            for (int cz = 0; cz < 24; ++cz) for (int cx = 0; cx < 24; ++cx) {
+                const int ai = (zc.x - 6 + cx - ax0) + anx * (zc.y - 6 + cz - az0);
+                for (int l = 0; l < 9; ++l) for (int bz = 0; bz < 16; ++bz) {
+                    const float* src = (l == 8) ? (ahf.data() + (size_t)256 * ai + 16 * bz) : (alayers.data() + (size_t)5120 * ai + 256 * (12 + l) + 16 * bz);
+                    std::memcpy(g.data() + (size_t)EROSION_GRID_NUM_COLS * l + (size_t)EROSION_GRID_SIDE * (cz * 16 + bz) + cx * 16, src, 16 * sizeof(float));
+                }
+            }
+            erodeZonePlanes(g.data());
+            // E3 copyLayers(from): centre 12x12 chunks, 8 eroded planes
+            for (int cz = 0; cz < 12; ++cz) for (int cx = 0; cx < 12; ++cx) {
+                const int ai = (zc.x + cx - ax0) + anx * (zc.y + cz - az0);
+                for (int l = 0; l < 8; ++l) for (int bz = 0; bz < 16; ++bz)
+                    std::memcpy(eroded.data() + (size_t)5120 * ai + 256 * (12 + l) + 16 * bz,
+                                g.data() + (size_t)EROSION_GRID_NUM_COLS * l + (size_t)EROSION_GRID_SIDE * ((cz + 6) * 16 + bz) + (cx + 6) * 16, 16 * sizeof(float));
+            }
+        });
+        for (int z = 0; z < pnz; ++z) for (int x = 0; x < pnx; ++x) {
+            const int pi = x + pnx * z, ai = (px0 + x - ax0) + anx * (pz0 + z - az0);
+            std::memcpy(hf.data() + (size_t)256 * pi, ahf.data() + (size_t)256 * ai, 256 * sizeof(float));
+            std::memcpy(bw.data() + (size_t)6144 * pi, abw.data() + (size_t)6144 * ai, 6144 * sizeof(float));
+            std::memcpy(layers.data() + (size_t)5120 * pi, eroded.data() + (size_t)5120 * ai, 5120 * sizeof(float));
+        }
+    }
+    mmo_fix_backward_layers(np, layers.data());
+    mmo_caves(np, ppos.data(), hf.data(), bw.data(), cave.data(), nthreads);
+
+    std::vector<std::vector<FeaturePlacement>> fps(np);
+    std::vector<std::vector<CaveFeaturePlacement>> cfps(np);
+    if (doFeatures)
+        parallel_for(np, nthreads, [&](int i) {
+            generateFeaturePlacements(ivec2{ppos[2 * i], ppos[2 * i + 1]}, hf.data() + (size_t)256 * i, bw.data() + (size_t)6144 * i,
+                                      layers.data() + (size_t)5120 * i, cave.data() + (size_t)8192 * i, fps[i], cfps[i]);
+        });
+
+    parallel_for(nx * nz, nthreads, [&](int i) {
+        const int x = i % nx, z = i / nx;
+        const int pi = (x + ring) + pnx * (z + ring);
+        std::vector<FeaturePlacement> gf; std::vector<CaveFeaturePlacement> gc;
+        if (doFeatures)
+            for (const ivec2& off : gatherFeaturePlacementsChunkOffsets) {
+                const int ni = (x + ring + off.x) + pnx * (z + ring + off.y);
+                gf.insert(gf.end(), fps[ni].begin(), fps[ni].end());
+                gc.insert(gc.end(), cfps[ni].begin(), cfps[ni].end());
+            }
+        Block* b = (Block*)out_blocks + (size_t)98304 * i;
+        ivec3 wp = {ppos[2 * pi], 0, ppos[2 * pi + 1]};
+        fillChunk(wp, hf.data() + (size_t)256 * pi, bw.data() + (size_t)6144 * pi, layers.data() + (size_t)5120 * pi, cave.data() + (size_t)8192 * pi,
+                  gf.data(), (int)gf.size(), gc.data(), (int)gc.size(), b);
+        if (doDecor) placeDecorators(wp, hf.data() + (size_t)256 * pi, bw.data() + (size_t)6144 * pi, cave.data() + (size_t)8192 * pi, b);
+        if (out_hf) std::memcpy(out_hf + (size_t)256 * i, hf.data() + (size_t)256 * pi, 256 * sizeof(float));
+        if (out_layers) std::memcpy(out_layers + (size_t)5120 * i, layers.data() + (size_t)5120 * pi, 5120 * sizeof(float));
+        if (out_cave) std::memcpy((CaveLayer*)out_cave + (size_t)8192 * i, cave.data() + (size_t)8192 * pi, 8192 * sizeof(CaveLayer));
+    });
+    (void)stage_seconds;
+}
+
+}  // extern "C"

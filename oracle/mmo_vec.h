@@ -1,0 +1,142 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product path;
+// only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use it.
+//
+// Minimal scalar restatement of the glm 0.9.9.8 vector semantics the reference relies on
+// (reference: external/include/glm/detail/func_geometric.inl:25-65 (dot), :8-23 (length,
+// distance), :82-88 (normalize); func_common.inl:104-111 (mix), :212-218 (mod),
+// :249-255 (step), :564-570 (smoothstep), :505-509 (clamp)).
+// Every operation is spelled out component by component in glm's evaluation order so that
+// g++ -O2 -ffp-contract=off produces the same fp32 bits as real glm (checked by
+// oracle/ref_glm_probe.cpp against the vendored glm headers).
+#pragma once
+#include <cmath>
+#include <cstdint>
+
+namespace mmo {
+
+struct ivec2 { int x, y; };
+struct ivec3 { int x, y, z; };
+
+struct vec2 {
+    float x, y;
+    vec2() : x(0), y(0) {}
+    explicit vec2(float s) : x(s), y(s) {}
+    vec2(float x_, float y_) : x(x_), y(y_) {}
+    explicit vec2(ivec2 v) : x((float)v.x), y((float)v.y) {}
+};
+struct vec3 {
+    float x, y, z;
+    vec3() : x(0), y(0), z(0) {}
+    explicit vec3(float s) : x(s), y(s), z(s) {}
+    vec3(float x_, float y_, float z_) : x(x_), y(y_), z(z_) {}
+    vec3(vec2 v, float z_) : x(v.x), y(v.y), z(z_) {}
+    explicit vec3(ivec3 v) : x((float)v.x), y((float)v.y), z((float)v.z) {}
+};
+struct vec4 {
+    float x, y, z, w;
+    vec4() : x(0), y(0), z(0), w(0) {}
+    vec4(float x_, float y_, float z_, float w_) : x(x_), y(y_), z(z_), w(w_) {}
+};
+
+// ---- ivec helpers
+static inline ivec2 operator+(ivec2 a, ivec2 b) { return {a.x + b.x, a.y + b.y}; }
+static inline ivec2 operator-(ivec2 a, ivec2 b) { return {a.x - b.x, a.y - b.y}; }
+static inline ivec2 operator*(ivec2 a, int s) { return {a.x * s, a.y * s}; }
+static inline bool operator==(ivec2 a, ivec2 b) { return a.x == b.x && a.y == b.y; }
+static inline ivec3 operator+(ivec3 a, ivec3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+static inline ivec3 operator-(ivec3 a, ivec3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+static inline bool operator==(ivec3 a, ivec3 b) { return a.x == b.x && a.y == b.y && a.z == b.z; }
+
+// ---- vec2
+static inline vec2 operator+(vec2 a, vec2 b) { return vec2(a.x + b.x, a.y + b.y); }
+static inline vec2 operator-(vec2 a, vec2 b) { return vec2(a.x - b.x, a.y - b.y); }
+static inline vec2 operator*(vec2 a, vec2 b) { return vec2(a.x * b.x, a.y * b.y); }
+static inline vec2 operator/(vec2 a, vec2 b) { return vec2(a.x / b.x, a.y / b.y); }
+static inline vec2 operator+(vec2 a, float s) { return vec2(a.x + s, a.y + s); }
+static inline vec2 operator-(vec2 a, float s) { return vec2(a.x - s, a.y - s); }
+static inline vec2 operator*(vec2 a, float s) { return vec2(a.x * s, a.y * s); }
+static inline vec2 operator*(float s, vec2 a) { return vec2(s * a.x, s * a.y); }
+static inline vec2 operator/(vec2 a, float s) { return vec2(a.x / s, a.y / s); }
+static inline vec2& operator*=(vec2& a, float s) { a.x *= s; a.y *= s; return a; }
+static inline vec2& operator+=(vec2& a, vec2 b) { a.x += b.x; a.y += b.y; return a; }
+
+// ---- vec3
+static inline vec3 operator+(vec3 a, vec3 b) { return vec3(a.x + b.x, a.y + b.y, a.z + b.z); }
+static inline vec3 operator-(vec3 a, vec3 b) { return vec3(a.x - b.x, a.y - b.y, a.z - b.z); }
+static inline vec3 operator*(vec3 a, vec3 b) { return vec3(a.x * b.x, a.y * b.y, a.z * b.z); }
+static inline vec3 operator/(vec3 a, vec3 b) { return vec3(a.x / b.x, a.y / b.y, a.z / b.z); }
+static inline vec3 operator+(vec3 a, float s) { return vec3(a.x + s, a.y + s, a.z + s); }
+static inline vec3 operator-(vec3 a, float s) { return vec3(a.x - s, a.y - s, a.z - s); }
+static inline vec3 operator*(vec3 a, float s) { return vec3(a.x * s, a.y * s, a.z * s); }
+static inline vec3 operator*(float s, vec3 a) { return vec3(s * a.x, s * a.y, s * a.z); }
+static inline vec3 operator/(vec3 a, float s) { return vec3(a.x / s, a.y / s, a.z / s); }
+static inline vec3 operator-(float s, vec3 a) { return vec3(s - a.x, s - a.y, s - a.z); }
+static inline vec3 operator-(vec3 a) { return vec3(-a.x, -a.y, -a.z); }
+static inline vec3& operator*=(vec3& a, float s) { a.x *= s; a.y *= s; a.z *= s; return a; }
+static inline vec3& operator*=(vec3& a, vec3 b) { a.x *= b.x; a.y *= b.y; a.z *= b.z; return a; }
+static inline vec3& operator+=(vec3& a, vec3 b) { a.x += b.x; a.y += b.y; a.z += b.z; return a; }
+static inline vec3& operator-=(vec3& a, vec3 b) { a.x -= b.x; a.y -= b.y; a.z -= b.z; return a; }
+
+// ---- vec4
+static inline vec4 operator+(vec4 a, vec4 b) { return vec4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+static inline vec4 operator-(vec4 a, vec4 b) { return vec4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
+static inline vec4 operator*(vec4 a, vec4 b) { return vec4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
+static inline vec4 operator+(vec4 a, float s) { return vec4(a.x + s, a.y + s, a.z + s, a.w + s); }
+static inline vec4 operator-(vec4 a, float s) { return vec4(a.x - s, a.y - s, a.z - s, a.w - s); }
+static inline vec4 operator*(vec4 a, float s) { return vec4(a.x * s, a.y * s, a.z * s, a.w * s); }
+static inline vec4 operator*(float s, vec4 a) { return vec4(s * a.x, s * a.y, s * a.z, s * a.w); }
+static inline vec4 operator-(float s, vec4 a) { return vec4(s - a.x, s - a.y, s - a.z, s - a.w); }
+static inline vec4 operator-(vec4 a) { return vec4(-a.x, -a.y, -a.z, -a.w); }
+
+// ---- scalar glm functions
+static inline float g_min(float a, float b) { return (b < a) ? b : a; }   // glm::min
+static inline float g_max(float a, float b) { return (a < b) ? b : a; }   // glm::max
+static inline int g_min(int a, int b) { return (b < a) ? b : a; }
+static inline int g_max(int a, int b) { return (a < b) ? b : a; }
+static inline float g_clamp(float x, float lo, float hi) { return g_min(g_max(x, lo), hi); }
+static inline int g_clamp(int x, int lo, int hi) { return g_min(g_max(x, lo), hi); }
+static inline float g_fract(float x) { return x - floorf(x); }
+static inline float g_mod(float a, float b) { return a - b * floorf(a / b); }
+static inline float g_step(float edge, float x) { return (x < edge) ? 0.f : 1.f; }
+static inline float g_mix(float x, float y, float a) { return x * (1.f - a) + y * a; }
+static inline float g_smoothstep(float e0, float e1, float x) {
+    float t = g_clamp((x - e0) / (e1 - e0), 0.f, 1.f);
+    return t * t * (3.f - 2.f * t);
+}
+static inline float g_radians(float deg) { return deg * 0.01745329251994329576923690768489f; }
+
+// ---- vector glm functions
+static inline vec2 g_floor(vec2 v) { return vec2(floorf(v.x), floorf(v.y)); }
+static inline vec3 g_floor(vec3 v) { return vec3(floorf(v.x), floorf(v.y), floorf(v.z)); }
+static inline vec4 g_floor(vec4 v) { return vec4(floorf(v.x), floorf(v.y), floorf(v.z), floorf(v.w)); }
+static inline vec2 g_fract(vec2 v) { return vec2(g_fract(v.x), g_fract(v.y)); }
+static inline vec3 g_fract(vec3 v) { return vec3(g_fract(v.x), g_fract(v.y), g_fract(v.z)); }
+static inline vec2 g_abs(vec2 v) { return vec2(fabsf(v.x), fabsf(v.y)); }
+static inline vec3 g_abs(vec3 v) { return vec3(fabsf(v.x), fabsf(v.y), fabsf(v.z)); }
+static inline vec4 g_abs(vec4 v) { return vec4(fabsf(v.x), fabsf(v.y), fabsf(v.z), fabsf(v.w)); }
+static inline vec3 g_min(vec3 a, vec3 b) { return vec3(g_min(a.x, b.x), g_min(a.y, b.y), g_min(a.z, b.z)); }
+static inline vec3 g_max(vec3 a, vec3 b) { return vec3(g_max(a.x, b.x), g_max(a.y, b.y), g_max(a.z, b.z)); }
+static inline vec4 g_max(vec4 a, vec4 b) { return vec4(g_max(a.x, b.x), g_max(a.y, b.y), g_max(a.z, b.z), g_max(a.w, b.w)); }
+static inline vec2 g_mod(vec2 a, float b) { return vec2(g_mod(a.x, b), g_mod(a.y, b)); }
+static inline vec3 g_step(vec3 edge, vec3 x) { return vec3(g_step(edge.x, x.x), g_step(edge.y, x.y), g_step(edge.z, x.z)); }
+static inline vec4 g_step(vec4 edge, vec4 x) { return vec4(g_step(edge.x, x.x), g_step(edge.y, x.y), g_step(edge.z, x.z), g_step(edge.w, x.w)); }
+static inline vec3 g_mix(vec3 x, vec3 y, float a) { return x * (1.f - a) + y * a; }
+static inline vec2 g_mix(vec2 x, vec2 y, float a) { return x * (1.f - a) + y * a; }
+
+static inline float g_dot(vec2 a, vec2 b) { vec2 t = a * b; return t.x + t.y; }
+static inline float g_dot(vec3 a, vec3 b) { vec3 t = a * b; return t.x + t.y + t.z; }
+static inline float g_dot(vec4 a, vec4 b) { vec4 t = a * b; return (t.x + t.y) + (t.z + t.w); }
+static inline float g_length(vec2 v) { return sqrtf(g_dot(v, v)); }
+static inline float g_length(vec3 v) { return sqrtf(g_dot(v, v)); }
+static inline float g_distance(vec2 a, vec2 b) { return g_length(b - a); }
+static inline float g_distance(vec3 a, vec3 b) { return g_length(b - a); }
+static inline vec3 g_normalize(vec3 v) { return v * (1.f / sqrtf(g_dot(v, v))); }
+static inline vec2 g_normalize(vec2 v) { return v * (1.f / sqrtf(g_dot(v, v))); }
+static inline vec3 g_cross(vec3 x, vec3 y) {
+    return vec3(x.y * y.z - y.y * x.z, x.z * y.x - y.z * x.x, x.x * y.y - y.x * x.y);
+}
+
+static inline ivec2 to_ivec2(vec2 v) { return {(int)v.x, (int)v.y}; }
+static inline ivec3 to_ivec3(vec3 v) { return {(int)v.x, (int)v.y, (int)v.z}; }
+
+}  // namespace mmo
