@@ -1,0 +1,90 @@
+// libmmgen C ABI (include/mmgen.h): argument checks, scratch ownership, stream plumbing.  No torch, no C++ types across.
+#include "../../include/mmgen.h"
+#include "mmgen_kernels.h"
+#include <mutex>
+#include <cstring>
+#include <cstdio>
+
+namespace {
+std::mutex g_mu;
+float* g_colInfo = nullptr;      // [chunks][256] float2 per-column cave info
+size_t g_colInfoChunks = 0;
+int g_device = -1;
+
+int ensure_scratch(int n)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    if ((size_t)n <= g_colInfoChunks) return 0;
+    if (g_colInfo) { hipError_t e = hipFree(g_colInfo); if (e != hipSuccess) return (int)e; g_colInfo = nullptr; g_colInfoChunks = 0; }
+    hipError_t e = hipMalloc((void**)&g_colInfo, (size_t)n * 256 * sizeof(float2));
+    if (e != hipSuccess) return (int)e;
+    g_colInfoChunks = (size_t)n;
+    return 0;
+}
+}  // namespace
+
+extern "C" {
+
+int mmgen_init(int device)
+{
+    hipError_t e = hipSetDevice(device);
+    if (e != hipSuccess) return (int)e;
+    hipDeviceProp_t p;
+    e = hipGetDeviceProperties(&p, device);
+    if (e != hipSuccess) return (int)e;
+    if (std::strncmp(p.gcnArchName, "gfx950", 6) != 0) {
+        std::fprintf(stderr, "mmgen: device %d is %s, this library carries gfx950 code only\n", device, p.gcnArchName);
+        return (int)hipErrorNoBinaryForGpu;
+    }
+    g_device = device;
+    return 0;
+}
+
+const char* mmgen_error_string(int code) { return hipGetErrorString((hipError_t)code); }
+
+int mmgen_reserve(int max_chunks_per_call) { return ensure_scratch(max_chunks_per_call); }
+
+int mmgen_generate_heightfields(const int32_t* d_pos, int n, float* d_hf, float* d_bw, void* stream)
+{
+    if (n < 0 || (n > 0 && (!d_pos || !d_hf || !d_bw))) return (int)hipErrorInvalidValue;
+    return mmk::launch_heightfield(d_pos, n, d_hf, d_bw, nullptr, (hipStream_t)stream);
+}
+
+int mmgen_generate_heightfields_gathered(const int32_t* d_pos, int n, float* d_hf, float* d_bw, float* d_gathered, void* stream)
+{
+    if (n < 0 || (n > 0 && (!d_pos || !d_hf || !d_bw || !d_gathered))) return (int)hipErrorInvalidValue;
+    return mmk::launch_heightfield(d_pos, n, d_hf, d_bw, d_gathered, (hipStream_t)stream);
+}
+
+int mmgen_generate_layers(const float* d_gathered, const float* d_bw, const int32_t* d_pos, int n, float* d_layers, void* stream)
+{
+    if (n < 0 || (n > 0 && (!d_gathered || !d_bw || !d_pos || !d_layers))) return (int)hipErrorInvalidValue;
+    return mmk::launch_layers(d_gathered, d_bw, d_pos, n, d_layers, (hipStream_t)stream);
+}
+
+int mmgen_fix_backward_layers(float* d_layers, int n, void* stream)
+{
+    if (n < 0 || (n > 0 && !d_layers)) return (int)hipErrorInvalidValue;
+    return mmk::launch_fix_backward(d_layers, n, (hipStream_t)stream);
+}
+
+int mmgen_generate_caves(const float* d_hf, const float* d_bw, const int32_t* d_pos, int n, mmgen_cave_layer* d_cl, void* stream)
+{
+    if (n < 0 || (n > 0 && (!d_hf || !d_bw || !d_pos || !d_cl))) return (int)hipErrorInvalidValue;
+    if (n == 0) return 0;
+    int e = ensure_scratch(n);
+    if (e) return e;
+    return mmk::launch_caves(d_hf, d_bw, d_pos, n, d_cl, g_colInfo, (hipStream_t)stream);
+}
+
+int mmgen_fill(const float* d_hf, const float* d_bw, const float* d_layers, const mmgen_cave_layer* d_cl, const int32_t* d_pos, int n,
+               const mmgen_feature_placement* d_fp, const mmgen_cave_feature_placement* d_cfp, const int32_t* d_bounds, uint8_t* d_blocks,
+               void* stream)
+{
+    if (n < 0 || (n > 0 && (!d_hf || !d_bw || !d_layers || !d_cl || !d_pos || !d_blocks))) return (int)hipErrorInvalidValue;
+    if ((d_fp || d_cfp) && !d_bounds) return (int)hipErrorInvalidValue;
+    if (d_fp || d_cfp) return (int)hipErrorNotSupported;   // feature evaluation: see fill with features milestone
+    return mmk::launch_fill(d_hf, d_bw, d_layers, d_cl, d_pos, n, d_blocks, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,14 @@
+// Host-side launchers of the mmgen HIP kernels (internal to libmmgen; the public surface is include/mmgen.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/mmgen_types.h"
+
+namespace mmk {
+int launch_heightfield(const int32_t* pos, int n, float* hf, float* bw, float* gathered /*nullable*/, hipStream_t s);
+int launch_layers(const float* gathered, const float* bw, const int32_t* pos, int n, float* layers, hipStream_t s);
+int launch_fix_backward(float* layers, int n, hipStream_t s);
+int launch_caves(const float* hf, const float* bw, const int32_t* pos, int n, mmgen_cave_layer* caveLayers, float* colInfoScratch, hipStream_t s);
+int launch_fill(const float* hf, const float* bw, const float* layers, const mmgen_cave_layer* caveLayers, const int32_t* pos, int n,
+                uint8_t* blocks, hipStream_t s);
+}  // namespace mmk

@@ -1,0 +1,443 @@
+// mmgen HIP kernels for gfx950 (MI355X): heightfield + biome weights, layers, cave carving, chunk fill.
+// One wave = 64 lanes; all kernels are FP32-VALU bound (no dense contraction → no MFMA), so the design rules are:
+// one lane per column (2D stages) or per voxel with y fastest (3D stages) for coalesced plane / byte stores, per-column
+// invariants hoisted into tiny pre-pass kernels, Worley cell points staged once per workgroup in LDS, wave ballots for
+// run-length extraction.  Compile with -ffp-contract=off (bit-exact contract, see mm_math.cuh).
+//
+// Behavioural spec (reference file:line): kernGenerateHeightfield chunk.cu:150-185, kernGenerateLayers :322-415,
+// shouldGenerateCaveAtBlock :755-810, kernGenerateCaves :812-937, chunkFillPlaceBlock :1202-1380, kernFill :1382-1510.
+#include "mm_biome.cuh"
+#include "mmgen_kernels.h"
+
+namespace mm {
+
+// =========================================================================================================
+// K1 — heightfield + 24 biome weights.  GATHERED variant also produces the 18x18 ring the layer stage needs
+// (the ring heights are a pure function of position, so no neighbour chunk is read).
+// =========================================================================================================
+template <bool GATHERED>
+__global__ void __launch_bounds__(GATHERED ? 384 : 256)
+k_heightfield(const int2* __restrict__ chunkPos, float* __restrict__ hf, float* __restrict__ bw, float* __restrict__ gathered)
+{
+    const int chunk = blockIdx.x;
+    const int t = threadIdx.x;
+    int x, z;
+    if (GATHERED) {
+        if (t >= 324) return;
+        x = (t % 18) - 1;
+        z = (t / 18) - 1;
+    } else {
+        x = t & 15;
+        z = t >> 4;
+    }
+    const int2 cp = chunkPos[chunk];
+    const bool interior = (x >= 0) & (x < 16) & (z >= 0) & (z < 16);
+    const int idx = x + 16 * z;
+
+    const float wx = (float)(cp.x + x), wz = (float)(cp.y + z);
+    const BiomeNoise bn = biome_noise(wx, wz);
+    float height = 0.f;
+    float* wout = bw + (size_t)MMGEN_BIOME_WEIGHTS_SIZE * chunk + idx;
+    for (int b = 0; b < MMGEN_NUM_BIOMES; ++b) {
+        const float w = biome_weight(b, bn);
+        if (w > 0.f) height += w * biome_height(b, wx, wz);
+        if (interior) wout[256 * b] = w;
+    }
+    if (interior) hf[(size_t)256 * chunk + idx] = height;
+    if (GATHERED) gathered[(size_t)MMGEN_GATHERED_HEIGHTFIELD_SIZE * chunk + t] = height;
+}
+
+// =========================================================================================================
+// K2 — layers.  Input: gathered 18x18 heights, biome weights.  Output: 20 layer-start planes.
+// =========================================================================================================
+MM_DEV float stratified_thickness(int layer, float weight, float wx, float wz)
+{
+    if (weight > 0.f) {
+        const float s = kMaterialScaleOrMaxSlope[layer];
+        const float o = (float)layer * 5283.64f;
+        const float v = kMaterialThickness[layer] + kMaterialAmpOrTan[layer] * fbm2<5>(wx * s + o, wz * s + o);
+        return gmax(0.f, v) * weight;
+    }
+    return 0.f;
+}
+
+__global__ void __launch_bounds__(256)
+k_layers(const float* __restrict__ gathered, const float* __restrict__ bw, const int2* __restrict__ chunkPos, float* __restrict__ layers)
+{
+    __shared__ float s_h[MMGEN_GATHERED_HEIGHTFIELD_SIZE];
+    const int chunk = blockIdx.x;
+    const int t = threadIdx.x;
+    const int x = t & 15, z = t >> 4;
+    const float* g = gathered + (size_t)MMGEN_GATHERED_HEIGHTFIELD_SIZE * chunk;
+    s_h[t] = g[t];
+    if (t + 256 < MMGEN_GATHERED_HEIGHTFIELD_SIZE) s_h[t + 256] = g[t + 256];
+    __syncthreads();
+
+    const int2 cp = chunkPos[chunk];
+    const float wx = (float)(cp.x + x), wz = (float)(cp.y + z);
+
+    float tw[MMGEN_NUM_MATERIALS];
+#pragma unroll
+    for (int m = 0; m < MMGEN_NUM_MATERIALS; ++m) tw[m] = 0.f;
+    const float* cbw = bw + (size_t)MMGEN_BIOME_WEIGHTS_SIZE * chunk + t;
+#pragma unroll
+    for (int b = 0; b < MMGEN_NUM_BIOMES; ++b) {
+        const float w = cbw[256 * b];
+#pragma unroll
+        for (int m = 0; m < MMGEN_NUM_MATERIALS; ++m) tw[m] += w * kMatWeights.w[b][m];
+    }
+
+    const int c18 = (x + 1) + 18 * (z + 1);
+    const float maxHeight = s_h[c18];
+    float slope = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const float nh = s_h[c18 + kDirX[i] + 18 * kDirZ[i]];
+        slope = gmax(slope, __builtin_fabsf(nh - maxHeight) * ((i & 1) ? MM_SQRT_2 : 1.f));
+    }
+
+    float* out = layers + (size_t)MMGEN_LAYERS_SIZE * chunk + t;
+
+    // forward stratified layers 0..9: start = running height; stop accumulating once above the surface.  Layers after
+    // the stop carry the running height (the reference leaves them unwritten; they never influence a block).
+    float height = 0.f;
+    bool stopped = false;
+#pragma unroll
+    for (int l = 0; l < MMGEN_NUM_FORWARD_MATERIALS; ++l) {
+        out[256 * l] = height;
+        if (!stopped) {
+            if (height > maxHeight || l == MMGEN_NUM_FORWARD_MATERIALS - 1) stopped = true;
+            else height += stratified_thickness(l, tw[l], wx, wz);
+        }
+    }
+    // backward stratified layers 11, 10: cumulative thickness (turned into a start height by the fix-up after erosion)
+    height = 0.f;
+#pragma unroll
+    for (int l = MMGEN_NUM_STRATIFIED_MATERIALS - 1; l >= MMGEN_NUM_FORWARD_MATERIALS; --l) {
+        height += stratified_thickness(l, tw[l], wx, wz);
+        out[256 * l] = height;
+    }
+    // eroded layers 19..12 from the surface down, thinned by slope
+    height = maxHeight;
+#pragma unroll
+    for (int l = MMGEN_NUM_MATERIALS - 1; l >= MMGEN_NUM_STRATIFIED_MATERIALS; --l) {
+        const float ms = kMaterialScaleOrMaxSlope[l];
+        const float lh = gmax(0.f, kMaterialThickness[l] * ((ms - slope) / ms)) * tw[l];
+        height -= lh;
+        out[256 * l] = height;
+    }
+}
+
+// E3 — fixBackwardStratifiedLayers (chunk.cu:725-749): layers[10], layers[11] = start_12 - cumulative thickness
+__global__ void __launch_bounds__(256) k_fix_backward(float* __restrict__ layers)
+{
+    float* col = layers + (size_t)MMGEN_LAYERS_SIZE * blockIdx.x + threadIdx.x;
+    const float erodedStart = col[256 * MMGEN_NUM_STRATIFIED_MATERIALS];
+    col[256 * 10] = erodedStart - col[256 * 10];
+    col[256 * 11] = erodedStart - col[256 * 11];
+}
+
+// =========================================================================================================
+// K4 — caves.
+//   k_cave_columns : per column, everything of shouldGenerateCaveAtBlock that does not depend on y
+//                    (ocean+beach weight, the whole ravine branch → one y threshold)
+//   k_cave_voxels  : one workgroup (6 waves) per column, lane = y; Worley cell points of the column's reachable
+//                    7x8x7 cell box staged in LDS; solid/air bits → wave ballots → (start,end) runs
+//   k_cave_biomes  : per (layer slot, column) cave-biome pair, lanes = columns so that occupied slots pack densely
+// =========================================================================================================
+__global__ void __launch_bounds__(256)
+k_cave_columns(const float* __restrict__ bw, const int2* __restrict__ chunkPos, float2* __restrict__ colInfo)
+{
+    const int chunk = blockIdx.x, t = threadIdx.x;
+    const int2 cp = chunkPos[chunk];
+    const int wx = cp.x + (t & 15), wz = cp.y + (t >> 4);
+
+    float obw = 0.f;   // canonical order: ascending biome index
+    const float* cbw = bw + (size_t)MMGEN_BIOME_WEIGHTS_SIZE * chunk + t;
+#pragma unroll
+    for (int b = 0; b < MMGEN_NUM_OCEAN_AND_BEACH_BIOMES; ++b) obw += cbw[256 * b];
+
+    const float rx = (float)wx * 0.0015f, rz = (float)wz * 0.0015f;
+    const f2 ro = fbm2from2<4>(rx * 10.f, rz * 10.f);
+    const Worley2 rw = worley2(rx + 0.03f * ro.x, rz + 0.03f * ro.y);
+    const float thr = 0.12f * (1.f - obw);
+    float ravineY = __builtin_inff();
+    if (rw.d1 < thr) {
+        const f3 color = rand3from2(rw.closest.x, rw.closest.y);
+        const float ravineTop = 120.f + 24.f * color.x;
+        const float ratio = 1.f - (rw.d1 / thr);
+        float depth = 60.f + 26.f * fbm2<4>(rx * 8.f + 8391.32f, rz * 8.f + 4821.39f);
+        depth *= smoothstep(0.f, 0.3f, ratio);
+        const float waveOff = 4.f * fbm2<4>(rx * 3.f + 5129.32f, rz * 3.f + 1392.49f);
+        float wave = sinf_((rx + rz) * 15.f + waveOff);
+        wave = smoothstep(0.4f, 0.6f, wave);
+        depth *= wave;
+        if (depth > 0.0001f) ravineY = ravineTop - depth;
+    }
+    colInfo[(size_t)256 * chunk + t] = make_float2(obw, ravineY);
+}
+
+#define CELL_NX 7
+#define CELL_NY 8
+#define CELL_NZ 7
+#define CELL_N (CELL_NX * CELL_NY * CELL_NZ)
+
+struct CellTile {
+    const float* pts;     // LDS, 3 floats per cell
+    int ox, oy, oz;
+    MM_DEV f3 operator()(int cx, int cy, int cz) const
+    {
+        const int ix = cx - ox, iy = cy - oy, iz = cz - oz;
+        if ((unsigned)ix < CELL_NX && (unsigned)iy < CELL_NY && (unsigned)iz < CELL_NZ) {
+            const float* p = pts + 3 * ((ix * CELL_NY + iy) * CELL_NZ + iz);
+            return mk3(p[0], p[1], p[2]);
+        }
+        return rand3from3((float)cx, (float)cy, (float)cz);   // outside the staged box: same value, computed directly
+    }
+};
+
+__global__ void __launch_bounds__(384)
+k_cave_voxels(const float* __restrict__ hf, const float2* __restrict__ colInfo, const int2* __restrict__ chunkPos,
+              mmgen_cave_layer* __restrict__ caveLayers)
+{
+    __shared__ float s_cells[3 * CELL_N];
+    __shared__ unsigned long long s_mask[6];
+    __shared__ int s_layers[3 * MMGEN_MAX_CAVE_LAYERS_PER_COLUMN];
+
+    const int col = blockIdx.x;            // chunk * 256 + idx2d
+    const int chunk = col >> 8, idx2d = col & 255;
+    const int y = threadIdx.x;
+    const int2 cp = chunkPos[chunk];
+    const int wx = cp.x + (idx2d & 15), wz = cp.y + (idx2d >> 4);
+    const float maxHeight = hf[col];
+    const float2 ci = colInfo[col];
+    const float obw = ci.x, ravineY = ci.y;
+
+    const float npx = (float)wx * 0.0050f, npz = (float)wz * 0.0050f;
+    // cell box origin: sample position = noisePos * (1, 1.6, 1) + offset with |offset| < 1.8
+    CellTile tile;
+    tile.pts = s_cells;
+    tile.ox = (int)__builtin_floorf(npx * 1.f) - 3;
+    tile.oy = -3;
+    tile.oz = (int)__builtin_floorf(npz * 1.f) - 3;
+    for (int c = y; c < CELL_N; c += 384) {
+        const int iz = c % CELL_NZ, iy = (c / CELL_NZ) % CELL_NY, ix = c / (CELL_NZ * CELL_NY);
+        const f3 p = rand3from3((float)(tile.ox + ix), (float)(tile.oy + iy), (float)(tile.oz + iz));
+        s_cells[3 * c] = p.x; s_cells[3 * c + 1] = p.y; s_cells[3 * c + 2] = p.z;
+    }
+    if (y < 3 * MMGEN_MAX_CAVE_LAYERS_PER_COLUMN) s_layers[y] = ((y % 3) == 2) ? 0 : 384;   // {384, 384, biomes = 0}
+    __syncthreads();
+
+    const int topSolid = imax((int)maxHeight, MMGEN_SEA_LEVEL);
+    bool cave;
+    if (y == 0) cave = false;
+    else if (y > topSolid) cave = true;
+    else {
+        const float fy = (float)y;
+        const float npy = fy * 0.0050f;
+        const float topRatio = smoothstep(142.f, 95.f, fy + obw * 50.f);
+        const float bottomRatio = smoothstep(5.f, 20.f, fy);
+        cave = false;
+        if (topRatio > 0.f) {    // threshold is a product with topRatio: 0 → "threshold > 0.04" is false
+            float thr = 0.24f + 0.12f * fbm3<4>(npx * 4.f, npy * 4.f, npz * 4.f);
+            const float huge = smoothstep(0.2f, 0.4f, fbm3<4>(npx * 0.0700f, npy * 0.0700f, npz * 0.0700f));
+            thr *= (1.f + 1.4f * huge);
+            thr *= topRatio * (0.3f + 0.7f * bottomRatio);
+            if (thr > 0.04f) {
+                const f3 o = fbm3from3<5>(npx * 0.8000f, npy * 0.8000f, npz * 0.8000f);
+                const float n = special_cave_noise(npx * 1.f + o.x * 1.8f, npy * 1.6f + o.y * 1.8f, npz * 1.f + o.z * 1.8f, tile);
+                cave = n < thr;
+            }
+        }
+        if (!cave) cave = fy > ravineY;
+    }
+
+    // solid bits of this wave's 64 voxels
+    const unsigned long long solid = __ballot(!cave);
+    const int wave = y >> 6, lane = y & 63;
+    if (lane == 0) s_mask[wave] = solid;
+    __syncthreads();
+
+    // flip at y when solid(y) != solid(y+1); y = 383 compares with "not solid"
+    const unsigned long long nextLow = (wave < 5) ? (s_mask[wave + 1] & 1ull) : 0ull;
+    int before = 0;
+    unsigned long long myFlips = 0;
+#pragma unroll
+    for (int w = 0; w < 6; ++w) {
+        const unsigned long long m = s_mask[w];
+        const unsigned long long nl = (w < 5) ? (s_mask[w + 1] & 1ull) : 0ull;
+        const unsigned long long f = m ^ ((m >> 1) | (nl << 63));
+        if (w < wave) before += __popcll(f);
+        if (w == wave) myFlips = f;
+    }
+    (void)nextLow;
+    if ((myFlips >> lane) & 1ull) {
+        const int rank = before + __popcll(myFlips & ((1ull << lane) - 1ull));
+        if (rank < 2 * MMGEN_MAX_CAVE_LAYERS_PER_COLUMN)       // canonical: runs beyond 32 layers are dropped
+            s_layers[3 * (rank >> 1) + (rank & 1)] = y;
+    }
+    __syncthreads();
+    if (y < 3 * MMGEN_MAX_CAVE_LAYERS_PER_COLUMN)
+        ((int*)(caveLayers + (size_t)MMGEN_MAX_CAVE_LAYERS_PER_COLUMN * col))[y] = s_layers[y];
+}
+
+__global__ void __launch_bounds__(256)
+k_cave_biomes(const float* __restrict__ hf, const int2* __restrict__ chunkPos, mmgen_cave_layer* __restrict__ caveLayers)
+{
+    const int chunk = blockIdx.x >> 5, k = blockIdx.x & 31;
+    const int t = threadIdx.x;
+    mmgen_cave_layer* L = caveLayers + ((size_t)256 * chunk + t) * MMGEN_MAX_CAVE_LAYERS_PER_COLUMN + k;
+    const int start = L->start;
+    if (start == 384) return;           // unused slot: biomes stay NONE (0)
+    const int end = L->end;
+    const int2 cp = chunkPos[chunk];
+    const int wx = cp.x + (t & 15), wz = cp.y + (t >> 4);
+    const float maxHeight = hf[(size_t)256 * chunk + t];
+    const int bottom = cave_biome(wx, start, wz, maxHeight, 329271348);
+    const int top = (end == 384) ? MMCB_NONE : cave_biome(wx, end + 1, wz, maxHeight, 4982921);
+    L->bottom_biome = (uint8_t)bottom;
+    L->top_biome = (uint8_t)top;
+}
+
+// =========================================================================================================
+// K6 — fill.  One workgroup (6 waves) per column, lane = y.  Column data staged in LDS.
+// =========================================================================================================
+MM_DEV uint8_t place_block(const float* s_bw, const float* s_lh, const mmgen_cave_layer* s_cl, int y, float height, int wx, int wz)
+{
+    if (y == 0) return MMB_BEDROCK;
+    const float fy = (float)y;
+    if (fy > height && y > MMGEN_SEA_LEVEL) return MMB_AIR;
+
+    bool isOcean = false;
+#pragma unroll
+    for (int b = 0; b < MMGEN_NUM_OCEAN_BIOMES; ++b) isOcean = isOcean || (s_bw[b] > 0.f);
+
+    MinStd rng = rng3(wx, y, wz);
+    const int randBiome = random_biome(s_bw, 1, rng.u01());
+    const bool isTop = fy >= height - 1.f;
+
+    uint8_t block = MMB_AIR;
+    if (fy > height && y <= MMGEN_SEA_LEVEL) {
+        block = MMB_WATER;
+        biome_block_post(block, randBiome, wx, y, wz, isTop);
+        if (isOcean) return block;
+    }
+
+    int bottomDepth = -384, topDepth = -384;
+    for (int k = 0; k < MMGEN_MAX_CAVE_LAYERS_PER_COLUMN; ++k) {
+        const int start = s_cl[k].start, end = s_cl[k].end;
+        if (start == 384) { bottomDepth = -384; break; }
+        bottomDepth = start - y;
+        if (y <= start) break;
+        if (y <= end) {
+            // inside a cave: air or lava.  caveBiomeBlockPostProcess never alters AIR/LAVA (every rule requires
+            // STONE/DEEPSLATE/BLACKSTONE), so the cave biome is not evaluated here.
+            return (y <= MMGEN_LAVA_LEVEL) ? MMB_LAVA : MMB_AIR;
+        }
+        topDepth = y - (end + 1);
+    }
+
+    if (fy > height) return block;
+
+    if (biome_block_pre(block, randBiome, wx, y, wz, height)) {
+        biome_block_post(block, randBiome, wx, y, wz, isTop);
+        return block;
+    }
+
+    const int l0 = (fy >= s_lh[MMGEN_NUM_FORWARD_MATERIALS]) ? MMGEN_NUM_FORWARD_MATERIALS : 0;
+    int layer = -1;
+    for (int l = l0; l < MMGEN_NUM_MATERIALS; ++l) {
+        if (s_lh[l] <= fy && fy < s_lh[l + 1]) { layer = l; break; }
+    }
+    block = (layer < 0) ? (uint8_t)MMB_STONE : kMaterialBlock[layer];   // canonical: no layer (y == height exactly) → STONE
+    if (isTop && block == MMB_DIRT) block = kGrassBlock[randBiome];
+
+    biome_block_post(block, randBiome, wx, y, wz, isTop);
+    if (cave_post_can_apply(block)) {
+        const int cb = cave_biome(wx, y, wz, height, 190249401);
+        cave_biome_block_post(block, cb, wx, y, wz, bottomDepth, topDepth);
+    }
+    return block;
+}
+
+__global__ void __launch_bounds__(384)
+k_fill(const float* __restrict__ hf, const float* __restrict__ bw, const float* __restrict__ layers,
+       const mmgen_cave_layer* __restrict__ caveLayers, const int2* __restrict__ chunkPos, uint8_t* __restrict__ blocks)
+{
+    __shared__ float s_bw[MMGEN_NUM_BIOMES];
+    __shared__ float s_lh[MMGEN_NUM_MATERIALS + 1];
+    __shared__ mmgen_cave_layer s_cl[MMGEN_MAX_CAVE_LAYERS_PER_COLUMN];
+
+    const int col = blockIdx.x;
+    const int chunk = col >> 8, idx2d = col & 255;
+    const int y = threadIdx.x;
+
+    if (y < MMGEN_NUM_BIOMES) s_bw[y] = bw[(size_t)MMGEN_BIOME_WEIGHTS_SIZE * chunk + 256 * y + idx2d];
+    else if (y < MMGEN_NUM_BIOMES + MMGEN_NUM_MATERIALS) s_lh[y - MMGEN_NUM_BIOMES] = layers[(size_t)MMGEN_LAYERS_SIZE * chunk + 256 * (y - MMGEN_NUM_BIOMES) + idx2d];
+    else if (y == MMGEN_NUM_BIOMES + MMGEN_NUM_MATERIALS) s_lh[MMGEN_NUM_MATERIALS] = hf[col];
+    else if (y >= 64 && y < 64 + 3 * MMGEN_MAX_CAVE_LAYERS_PER_COLUMN)
+        ((int*)s_cl)[y - 64] = ((const int*)(caveLayers + (size_t)MMGEN_MAX_CAVE_LAYERS_PER_COLUMN * col))[y - 64];
+    __syncthreads();
+
+    const int2 cp = chunkPos[chunk];
+    const int wx = cp.x + (idx2d & 15), wz = cp.y + (idx2d >> 4);
+    const uint8_t block = place_block(s_bw, s_lh, s_cl, y, s_lh[MMGEN_NUM_MATERIALS], wx, wz);
+    blocks[(size_t)MMGEN_BLOCKS_PER_CHUNK * chunk + 384 * idx2d + y] = block;
+}
+
+}  // namespace mm
+
+// =========================================================================================================
+// launchers (host)
+// =========================================================================================================
+namespace mmk {
+
+#define LAUNCH_CHECK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return (int)e_; } while (0)
+
+int launch_heightfield(const int32_t* pos, int n, float* hf, float* bw, float* gathered, hipStream_t s)
+{
+    if (n <= 0) return 0;
+    if (gathered) hipLaunchKernelGGL(mm::k_heightfield<true>, dim3(n), dim3(384), 0, s, (const int2*)pos, hf, bw, gathered);
+    else hipLaunchKernelGGL(mm::k_heightfield<false>, dim3(n), dim3(256), 0, s, (const int2*)pos, hf, bw, (float*)nullptr);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_layers(const float* gathered, const float* bw, const int32_t* pos, int n, float* layers, hipStream_t s)
+{
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(mm::k_layers, dim3(n), dim3(256), 0, s, gathered, bw, (const int2*)pos, layers);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_fix_backward(float* layers, int n, hipStream_t s)
+{
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(mm::k_fix_backward, dim3(n), dim3(256), 0, s, layers);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_caves(const float* hf, const float* bw, const int32_t* pos, int n, mmgen_cave_layer* caveLayers, float* colInfoScratch, hipStream_t s)
+{
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(mm::k_cave_columns, dim3(n), dim3(256), 0, s, bw, (const int2*)pos, (float2*)colInfoScratch);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(mm::k_cave_voxels, dim3(n * 256), dim3(384), 0, s, hf, (const float2*)colInfoScratch, (const int2*)pos, caveLayers);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(mm::k_cave_biomes, dim3(n * 32), dim3(256), 0, s, hf, (const int2*)pos, caveLayers);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_fill(const float* hf, const float* bw, const float* layers, const mmgen_cave_layer* caveLayers, const int32_t* pos, int n,
+                uint8_t* blocks, hipStream_t s)
+{
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(mm::k_fill, dim3(n * 256), dim3(384), 0, s, hf, bw, layers, caveLayers, (const int2*)pos, blocks);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace mmk

@@ -1,0 +1,121 @@
+"""ctypes binding of libmmgen.so (include/mmgen.h) + a thin torch-tensor convenience layer.
+
+Mirrors the static stage functions of the reference's ``Chunk`` class (src/terrain/chunk.hpp:99-172): same stage names,
+same per-chunk staging layouts, same error convention at this level (a failing stage raises; the C++ wrapper in host/
+prints and exits like src/cuda/cuda_utils.cpp:5-17).  There is NO CPU fallback: if the HIP library is missing or the
+device is not gfx950 every call fails loudly.
+"""
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmmgen.so")
+
+HF, GHF, BW, LAYERS, CAVE, BLOCKS = 256, 324, 6144, 5120, 8192, 98304
+
+
+def build(verbose=False):
+    """Compile csrc/ for gfx950 with hipcc (cross-compiles without a GPU)."""
+    r = subprocess.run(["make", "-C", os.path.join(_HERE, "csrc"), "-j8"], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("libmmgen build failed:\n" + r.stdout + r.stderr)
+    if verbose:
+        print(r.stdout)
+
+
+def load_library():
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} not found: build it with `make -C mega-minecraft_amd/csrc` (no CPU fallback exists)")
+    lib = ctypes.CDLL(LIB_PATH)
+    vp, i32 = ctypes.c_void_p, ctypes.c_int
+    lib.mmgen_init.argtypes = [i32]
+    lib.mmgen_error_string.restype = ctypes.c_char_p
+    lib.mmgen_error_string.argtypes = [i32]
+    lib.mmgen_reserve.argtypes = [i32]
+    lib.mmgen_generate_heightfields.argtypes = [vp, i32, vp, vp, vp]
+    lib.mmgen_generate_heightfields_gathered.argtypes = [vp, i32, vp, vp, vp, vp]
+    lib.mmgen_generate_layers.argtypes = [vp, vp, vp, i32, vp, vp]
+    lib.mmgen_fix_backward_layers.argtypes = [vp, i32, vp]
+    lib.mmgen_generate_caves.argtypes = [vp, vp, vp, i32, vp, vp]
+    lib.mmgen_fill.argtypes = [vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp]
+    return lib
+
+
+class MMGen:
+    """Stage-level access to libmmgen on one GPU.  All tensors are torch CUDA tensors in the reference's layouts."""
+
+    def __init__(self, device=0):
+        import torch
+        self.torch = torch
+        if not torch.cuda.is_available():
+            raise RuntimeError("mmgen needs a GPU (gfx950); no CPU path exists")
+        self.lib = load_library()
+        self.device = torch.device("cuda", device)
+        torch.cuda.set_device(self.device)
+        self._check(self.lib.mmgen_init(device), "mmgen_init")
+
+    # ------------------------------------------------------------------ helpers
+    def _check(self, code, what):
+        if code != 0:
+            raise RuntimeError(f"{what} failed: {self.lib.mmgen_error_string(code).decode()} ({code})")
+
+    def _stream(self):
+        return ctypes.c_void_p(self.torch.cuda.current_stream().cuda_stream)
+
+    def _empty(self, shape, dtype):
+        return self.torch.empty(shape, dtype=dtype, device=self.device)
+
+    @staticmethod
+    def _p(t):
+        return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+    def positions(self, chunk_coords):
+        """[(cx, cz)] chunk coordinates -> device int32 [n,2] world block positions (Chunk::worldBlockPos, chunk.cu:18-20)."""
+        t = self.torch.tensor([[c[0] * 16, c[1] * 16] for c in chunk_coords], dtype=self.torch.int32)
+        return t.to(self.device)
+
+    # ------------------------------------------------------------------ stages
+    def generate_heightfields(self, pos, gathered=False):
+        n = pos.shape[0]
+        f32 = self.torch.float32
+        hf, bw = self._empty((n, HF), f32), self._empty((n, 24, 256), f32)
+        if gathered:
+            g = self._empty((n, GHF), f32)
+            self._check(self.lib.mmgen_generate_heightfields_gathered(self._p(pos), n, self._p(hf), self._p(bw), self._p(g), self._stream()),
+                        "mmgen_generate_heightfields_gathered")
+            return hf, bw, g
+        self._check(self.lib.mmgen_generate_heightfields(self._p(pos), n, self._p(hf), self._p(bw), self._stream()), "mmgen_generate_heightfields")
+        return hf, bw
+
+    def generate_layers(self, gathered, bw, pos):
+        n = pos.shape[0]
+        layers = self._empty((n, 20, 256), self.torch.float32)
+        self._check(self.lib.mmgen_generate_layers(self._p(gathered), self._p(bw), self._p(pos), n, self._p(layers), self._stream()), "mmgen_generate_layers")
+        return layers
+
+    def fix_backward_layers(self, layers):
+        self._check(self.lib.mmgen_fix_backward_layers(self._p(layers), layers.shape[0], self._stream()), "mmgen_fix_backward_layers")
+        return layers
+
+    def generate_caves(self, hf, bw, pos):
+        n = pos.shape[0]
+        cave = self._empty((n, 256, 32, 3), self.torch.int32)      # 12-byte mmgen_cave_layer viewed as 3 int32
+        self._check(self.lib.mmgen_generate_caves(self._p(hf), self._p(bw), self._p(pos), n, self._p(cave), self._stream()), "mmgen_generate_caves")
+        return cave
+
+    def fill(self, hf, bw, layers, cave, pos, features=None, cave_features=None, bounds=None):
+        n = pos.shape[0]
+        blocks = self._empty((n, BLOCKS), self.torch.uint8)
+        self._check(self.lib.mmgen_fill(self._p(hf), self._p(bw), self._p(layers), self._p(cave), self._p(pos), n, self._p(features),
+                                        self._p(cave_features), self._p(bounds), self._p(blocks), self._stream()), "mmgen_fill")
+        return blocks
+
+    # ------------------------------------------------------------------ config-2 pipeline (no erosion, no features)
+    def generate_chunks_no_erosion(self, pos):
+        """K1 -> K2 -> E3 fix-up (DEBUG_SKIP_EROSION semantics, chunk.cu:713-720) -> K4 -> K6; everything stays in HBM."""
+        hf, bw, g = self.generate_heightfields(pos, gathered=True)
+        layers = self.fix_backward_layers(self.generate_layers(g, bw, pos))
+        cave = self.generate_caves(hf, bw, pos)
+        blocks = self.fill(hf, bw, layers, cave, pos)
+        return dict(hf=hf, bw=bw, gathered=g, layers=layers, cave=cave, blocks=blocks)

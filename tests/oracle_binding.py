@@ -1,0 +1,84 @@
+"""ctypes binding of the CPU oracle (oracle/libmmoracle.so).  TEST INFRASTRUCTURE ONLY — imported by tests/,
+__graft_entry__.smoke() and bench.py's cpu_baseline leg, never by the product package."""
+import ctypes
+import os
+import subprocess
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+LIB = os.path.join(ORACLE_DIR, "libmmoracle.so")
+
+
+def build():
+    r = subprocess.run(["make", "-C", ORACLE_DIR], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("oracle build failed:\n" + r.stdout + r.stderr)
+
+
+def _p(a):
+    return a.ctypes.data_as(ctypes.c_void_p) if a is not None else None
+
+
+class Oracle:
+    def __init__(self, nthreads=None):
+        if not os.path.exists(LIB):
+            build()
+        self.lib = ctypes.CDLL(LIB)
+        self.nthreads = nthreads or os.cpu_count() or 1
+
+    @staticmethod
+    def positions(chunk_coords):
+        return np.array([[c[0] * 16, c[1] * 16] for c in chunk_coords], dtype=np.int32)
+
+    def heightfields(self, pos):
+        n = len(pos)
+        hf = np.zeros((n, 256), np.float32); bw = np.zeros((n, 24, 256), np.float32)
+        self.lib.mmo_heightfields(n, _p(pos), _p(hf), _p(bw), self.nthreads)
+        return hf, bw
+
+    def gather_heightfields(self, pos, hf):
+        n = len(pos)
+        g = np.zeros((n, 324), np.float32)
+        self.lib.mmo_gather_heightfields(n, _p(pos), _p(hf), _p(g), self.nthreads)
+        return g
+
+    def layers(self, pos, gathered, bw):
+        n = len(pos)
+        out = np.zeros((n, 20, 256), np.float32)
+        self.lib.mmo_layers(n, _p(pos), _p(gathered), _p(bw), _p(out), self.nthreads)
+        return out
+
+    def fix_backward(self, layers):
+        self.lib.mmo_fix_backward_layers(len(layers), _p(layers))
+        return layers
+
+    def erode_zone_planes(self, planes):
+        return self.lib.mmo_erode_zone_planes(_p(planes))
+
+    def caves(self, pos, hf, bw):
+        n = len(pos)
+        cave = np.zeros((n, 256, 32, 3), np.int32)
+        self.lib.mmo_caves(n, _p(pos), _p(hf), _p(bw), _p(cave), self.nthreads)
+        return cave
+
+    def fill(self, pos, hf, bw, layers, cave, decorators=False):
+        n = len(pos)
+        blocks = np.zeros((n, 98304), np.uint8)
+        self.lib.mmo_fill(n, _p(pos), _p(hf), _p(bw), _p(layers), _p(cave), None, None, None, None, _p(blocks), int(decorators), self.nthreads)
+        return blocks
+
+    def generate_region(self, cx0, cz0, nx, nz, erosion=False, features=False, decorators=False, want=("blocks", "hf")):
+        n = nx * nz
+        blocks = np.zeros((n, 98304), np.uint8)
+        hf = np.zeros((n, 256), np.float32)
+        layers = np.zeros((n, 20, 256), np.float32)
+        cave = np.zeros((n, 256, 32, 3), np.int32)
+        flags = (1 if erosion else 0) | (2 if features else 0) | (4 if decorators else 0)
+        self.lib.mmo_generate_region(cx0, cz0, nx, nz, flags, _p(blocks), _p(hf), _p(layers), _p(cave), self.nthreads, None)
+        return dict(blocks=blocks, hf=hf, layers=layers, cave=cave)
+
+    def ub_counters(self, reset=False):
+        out = np.zeros(3, np.int64)
+        self.lib.mmo_ub_counters(_p(out), int(reset))
+        return dict(no_layer_found=int(out[0]), cave_layer_overflow=int(out[1]), decorator_out_of_range=int(out[2]))
