@@ -59,6 +59,18 @@ int mmgen_fill(const float* d_heightfields, const float* d_biome_weights, const 
                const int32_t* d_chunk_world_block_pos, int num_chunks, const mmgen_feature_placement* d_feature_placements,
                const mmgen_cave_feature_placement* d_cave_feature_placements, const int32_t* d_feature_bounds, uint8_t* d_blocks, void* stream);
 
+/* Measurement hooks (not part of the reference's interface): when enabled every kernel launch is bracketed by HIP events on its
+ * launch stream; mmgen_profile_collect() waits for them and returns total milliseconds and launch counts per kernel id
+ * (arrays of mmgen_profile_num_kernels() entries), then clears the records. */
+void mmgen_profile_enable(int on);
+int mmgen_profile_num_kernels(void);
+const char* mmgen_profile_kernel_name(int id);
+int mmgen_profile_collect(double* total_ms, long long* counts);
+
+/* Test-only: evaluates device math function `fn` (MMGEN_PROBE_*) on n packed fp32 items (ints bit-cast); used by the parity
+ * tests to pin the device math against golden vectors.  Not part of the reference's interface. */
+int mmgen_debug_probe(int fn, const float* d_in, int n, float* d_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

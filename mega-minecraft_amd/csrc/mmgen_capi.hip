@@ -87,4 +87,15 @@ int mmgen_fill(const float* d_hf, const float* d_bw, const float* d_layers, cons
     return mmk::launch_fill(d_hf, d_bw, d_layers, d_cl, d_pos, n, d_blocks, (hipStream_t)stream);
 }
 
+int mmgen_debug_probe(int fn, const float* d_in, int n, float* d_out, void* stream)
+{
+    if (n < 0 || (n > 0 && (!d_in || !d_out))) return (int)hipErrorInvalidValue;
+    return mmk::launch_probe(fn, d_in, n, d_out, (hipStream_t)stream);
+}
+
+void mmgen_profile_enable(int on) { mmk::profile_enable(on != 0); }
+int mmgen_profile_num_kernels(void) { return mmk::profile_num_kernels(); }
+const char* mmgen_profile_kernel_name(int id) { return mmk::profile_kernel_name(id); }
+int mmgen_profile_collect(double* total_ms, long long* counts) { return mmk::profile_collect(total_ms, counts); }
+
 }  // extern "C"

@@ -11,4 +11,9 @@ int launch_fix_backward(float* layers, int n, hipStream_t s);
 int launch_caves(const float* hf, const float* bw, const int32_t* pos, int n, mmgen_cave_layer* caveLayers, float* colInfoScratch, hipStream_t s);
 int launch_fill(const float* hf, const float* bw, const float* layers, const mmgen_cave_layer* caveLayers, const int32_t* pos, int n,
                 uint8_t* blocks, hipStream_t s);
+int launch_probe(int fn, const float* in, int n, float* out, hipStream_t s);
+void profile_enable(bool on);
+int profile_num_kernels();
+const char* profile_kernel_name(int id);
+int profile_collect(double* total_ms, long long* counts);
 }  // namespace mmk

@@ -8,6 +8,7 @@
 // shouldGenerateCaveAtBlock :755-810, kernGenerateCaves :812-937, chunkFillPlaceBlock :1202-1380, kernFill :1382-1510.
 #include "mm_biome.cuh"
 #include "mmgen_kernels.h"
+#include <vector>
 
 namespace mm {
 
@@ -385,6 +386,47 @@ k_fill(const float* __restrict__ hf, const float* __restrict__ bw, const float* 
     blocks[(size_t)MMGEN_BLOCKS_PER_CHUNK * chunk + 384 * idx2d + y] = block;
 }
 
+
+// =========================================================================================================
+// Debug probes: evaluate one device function per item so that tests can pin the device math against the golden
+// vectors (real glm simplex, frozen KATs) through the C ABI.  Inputs/outputs are packed fp32 (ints bit-cast).
+// =========================================================================================================
+__global__ void __launch_bounds__(256) k_probe(int fn, const float* __restrict__ in, int n, float* __restrict__ out)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    switch (fn) {
+    case MMGEN_PROBE_SIN: out[i] = sinf_(in[i]); break;
+    case MMGEN_PROBE_COS: out[i] = cosf_(in[i]); break;
+    case MMGEN_PROBE_POW: out[i] = powf_(in[2 * i], in[2 * i + 1]); break;
+    case MMGEN_PROBE_ATAN2: out[i] = atan2f_(in[2 * i], in[2 * i + 1]); break;
+    case MMGEN_PROBE_ACOS: out[i] = acosf_(in[i]); break;
+    case MMGEN_PROBE_SIMPLEX2: out[i] = simplex2(in[2 * i], in[2 * i + 1]); break;
+    case MMGEN_PROBE_SIMPLEX3: out[i] = simplex3(in[3 * i], in[3 * i + 1], in[3 * i + 2]); break;
+    case MMGEN_PROBE_FBM2_5: out[i] = fbm2<5>(in[2 * i], in[2 * i + 1]); break;
+    case MMGEN_PROBE_FBM3_4: out[i] = fbm3<4>(in[3 * i], in[3 * i + 1], in[3 * i + 2]); break;
+    case MMGEN_PROBE_RAND3FROM3: { const f3 r = rand3from3(in[3 * i], in[3 * i + 1], in[3 * i + 2]); out[3 * i] = r.x; out[3 * i + 1] = r.y; out[3 * i + 2] = r.z; break; }
+    case MMGEN_PROBE_WORLEY2: {
+        const Worley2 w = worley2(in[2 * i], in[2 * i + 1]); const f3 c = rand3from2(w.closest.x, w.closest.y);
+        float* o = out + 5 * i; o[0] = w.d1; o[1] = c.x; o[2] = c.y; o[3] = c.z; o[4] = (w.d2 - w.d1) * 0.5f; break; }
+    case MMGEN_PROBE_WORLEY3: {
+        const Worley3 w = worley3(in[3 * i], in[3 * i + 1], in[3 * i + 2], CellDirect()); const f3 c = rand3from3(w.closest.x, w.closest.y, w.closest.z);
+        float* o = out + 5 * i; o[0] = w.d1; o[1] = c.x; o[2] = c.y; o[3] = c.z; o[4] = (w.d2 - w.d1) * 0.5f; break; }
+    case MMGEN_PROBE_SPECIAL_CAVE_NOISE: out[i] = special_cave_noise(in[3 * i], in[3 * i + 1], in[3 * i + 2], CellDirect()); break;
+    case MMGEN_PROBE_BIOME_HEIGHT: out[i] = biome_height(__float_as_int(in[3 * i]), in[3 * i + 1], in[3 * i + 2]); break;
+    case MMGEN_PROBE_CAVE_BIOME:
+        out[i] = (float)cave_biome(__float_as_int(in[5 * i]), __float_as_int(in[5 * i + 1]), __float_as_int(in[5 * i + 2]), in[5 * i + 3], __float_as_int(in[5 * i + 4]));
+        break;
+    case MMGEN_PROBE_HASH: out[i] = __int_as_float((int)hash32((uint32_t)__float_as_int(in[i]))); break;
+    case MMGEN_PROBE_RNG4_U01: {   // in: x y z w (ints), out: 4 draws; w == INT_MIN selects the 3-argument seeding
+        const int x = __float_as_int(in[4 * i]), y = __float_as_int(in[4 * i + 1]), z = __float_as_int(in[4 * i + 2]), w = __float_as_int(in[4 * i + 3]);
+        MinStd r = (w == (int)0x80000000) ? rng3(x, y, z) : rng4(x, y, z, w);
+        for (int k = 0; k < 4; ++k) out[4 * i + k] = r.u01();
+        break; }
+    default: break;
+    }
+}
+
 }  // namespace mm
 
 // =========================================================================================================
@@ -392,42 +434,80 @@ k_fill(const float* __restrict__ hf, const float* __restrict__ bw, const float* 
 // =========================================================================================================
 namespace mmk {
 
-#define LAUNCH_CHECK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return (int)e_; } while (0)
+// ---------------------------------------------------------------------------------------------------------
+// Optional per-kernel timing with HIP events on the launch stream (used by bench.py for the roofline line; off by default).
+// ---------------------------------------------------------------------------------------------------------
+struct ProfRec { int id; hipEvent_t a, b; };
+static bool g_prof = false;
+static std::vector<ProfRec> g_recs;
+static std::vector<hipEvent_t> g_pool;
+static const char* const kKernelNames[] = {"k_heightfield", "k_layers", "k_fix_backward", "k_cave_columns", "k_cave_voxels", "k_cave_biomes", "k_fill", "k_probe"};
+enum { KID_HEIGHTFIELD, KID_LAYERS, KID_FIX_BACKWARD, KID_CAVE_COLUMNS, KID_CAVE_VOXELS, KID_CAVE_BIOMES, KID_FILL, KID_PROBE, KID_COUNT };
+
+static hipEvent_t get_event()
+{
+    if (!g_pool.empty()) { hipEvent_t e = g_pool.back(); g_pool.pop_back(); return e; }
+    hipEvent_t e; (void)hipEventCreate(&e); return e;
+}
+
+void profile_enable(bool on) { g_prof = on; }
+int profile_num_kernels() { return KID_COUNT; }
+const char* profile_kernel_name(int id) { return (id >= 0 && id < KID_COUNT) ? kKernelNames[id] : ""; }
+// Synchronises the recorded events, accumulates total milliseconds and launch counts per kernel id, and clears the records.
+int profile_collect(double* total_ms, long long* counts)
+{
+    for (int i = 0; i < KID_COUNT; ++i) { total_ms[i] = 0; counts[i] = 0; }
+    for (auto& r : g_recs) {
+        hipError_t e = hipEventSynchronize(r.b);
+        if (e != hipSuccess) return (int)e;
+        float ms = 0.f;
+        e = hipEventElapsedTime(&ms, r.a, r.b);
+        if (e != hipSuccess) return (int)e;
+        total_ms[r.id] += ms; counts[r.id] += 1;
+        g_pool.push_back(r.a); g_pool.push_back(r.b);
+    }
+    g_recs.clear();
+    return 0;
+}
+
+#define LAUNCH(KID, KERNEL, GRID, BLOCK, STREAM, ...)                                        \
+    do {                                                                                     \
+        ProfRec rec_; rec_.id = (KID);                                                       \
+        if (g_prof) { rec_.a = get_event(); rec_.b = get_event(); (void)hipEventRecord(rec_.a, (STREAM)); } \
+        hipLaunchKernelGGL(KERNEL, GRID, BLOCK, 0, (STREAM), __VA_ARGS__);                   \
+        if (g_prof) { (void)hipEventRecord(rec_.b, (STREAM)); g_recs.push_back(rec_); }      \
+        hipError_t e_ = hipGetLastError();                                                   \
+        if (e_ != hipSuccess) return (int)e_;                                                \
+    } while (0)
 
 int launch_heightfield(const int32_t* pos, int n, float* hf, float* bw, float* gathered, hipStream_t s)
 {
     if (n <= 0) return 0;
-    if (gathered) hipLaunchKernelGGL(mm::k_heightfield<true>, dim3(n), dim3(384), 0, s, (const int2*)pos, hf, bw, gathered);
-    else hipLaunchKernelGGL(mm::k_heightfield<false>, dim3(n), dim3(256), 0, s, (const int2*)pos, hf, bw, (float*)nullptr);
-    LAUNCH_CHECK();
+    if (gathered) LAUNCH(KID_HEIGHTFIELD, mm::k_heightfield<true>, dim3(n), dim3(384), s, (const int2*)pos, hf, bw, gathered);
+    else LAUNCH(KID_HEIGHTFIELD, mm::k_heightfield<false>, dim3(n), dim3(256), s, (const int2*)pos, hf, bw, (float*)nullptr);
     return 0;
 }
 
 int launch_layers(const float* gathered, const float* bw, const int32_t* pos, int n, float* layers, hipStream_t s)
 {
     if (n <= 0) return 0;
-    hipLaunchKernelGGL(mm::k_layers, dim3(n), dim3(256), 0, s, gathered, bw, (const int2*)pos, layers);
-    LAUNCH_CHECK();
+    LAUNCH(KID_LAYERS, mm::k_layers, dim3(n), dim3(256), s, gathered, bw, (const int2*)pos, layers);
     return 0;
 }
 
 int launch_fix_backward(float* layers, int n, hipStream_t s)
 {
     if (n <= 0) return 0;
-    hipLaunchKernelGGL(mm::k_fix_backward, dim3(n), dim3(256), 0, s, layers);
-    LAUNCH_CHECK();
+    LAUNCH(KID_FIX_BACKWARD, mm::k_fix_backward, dim3(n), dim3(256), s, layers);
     return 0;
 }
 
 int launch_caves(const float* hf, const float* bw, const int32_t* pos, int n, mmgen_cave_layer* caveLayers, float* colInfoScratch, hipStream_t s)
 {
     if (n <= 0) return 0;
-    hipLaunchKernelGGL(mm::k_cave_columns, dim3(n), dim3(256), 0, s, bw, (const int2*)pos, (float2*)colInfoScratch);
-    LAUNCH_CHECK();
-    hipLaunchKernelGGL(mm::k_cave_voxels, dim3(n * 256), dim3(384), 0, s, hf, (const float2*)colInfoScratch, (const int2*)pos, caveLayers);
-    LAUNCH_CHECK();
-    hipLaunchKernelGGL(mm::k_cave_biomes, dim3(n * 32), dim3(256), 0, s, hf, (const int2*)pos, caveLayers);
-    LAUNCH_CHECK();
+    LAUNCH(KID_CAVE_COLUMNS, mm::k_cave_columns, dim3(n), dim3(256), s, bw, (const int2*)pos, (float2*)colInfoScratch);
+    LAUNCH(KID_CAVE_VOXELS, mm::k_cave_voxels, dim3(n * 256), dim3(384), s, hf, (const float2*)colInfoScratch, (const int2*)pos, caveLayers);
+    LAUNCH(KID_CAVE_BIOMES, mm::k_cave_biomes, dim3(n * 32), dim3(256), s, hf, (const int2*)pos, caveLayers);
     return 0;
 }
 
@@ -435,8 +515,14 @@ int launch_fill(const float* hf, const float* bw, const float* layers, const mmg
                 uint8_t* blocks, hipStream_t s)
 {
     if (n <= 0) return 0;
-    hipLaunchKernelGGL(mm::k_fill, dim3(n * 256), dim3(384), 0, s, hf, bw, layers, caveLayers, (const int2*)pos, blocks);
-    LAUNCH_CHECK();
+    LAUNCH(KID_FILL, mm::k_fill, dim3(n * 256), dim3(384), s, hf, bw, layers, caveLayers, (const int2*)pos, blocks);
+    return 0;
+}
+
+int launch_probe(int fn, const float* in, int n, float* out, hipStream_t s)
+{
+    if (n <= 0) return 0;
+    LAUNCH(KID_PROBE, mm::k_probe, dim3((n + 255) / 256), dim3(256), s, fn, in, n, out);
     return 0;
 }
 

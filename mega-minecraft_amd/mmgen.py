@@ -119,3 +119,16 @@ class MMGen:
         cave = self.generate_caves(hf, bw, pos)
         blocks = self.fill(hf, bw, layers, cave, pos)
         return dict(hf=hf, bw=bw, gathered=g, layers=layers, cave=cave, blocks=blocks)
+
+    # ------------------------------------------------------------------ test-only device math probe
+    PROBES = dict(sin=0, cos=1, pow=2, atan2=3, acos=4, simplex2=5, simplex3=6, fbm2_5=7, fbm3_4=8, rand3from3=9, worley2=10, worley3=11,
+                  special_cave_noise=12, biome_height=13, cave_biome=14, hash=15, rng4_u01=16)
+
+    def debug_probe(self, name, packed_in, n, out_per_item=1):
+        """packed_in: numpy float32/int32/uint32 array (ints are bit-cast); returns numpy float32 [n, out_per_item]."""
+        import numpy as np
+        t = self.torch.from_numpy(np.ascontiguousarray(packed_in).view(np.float32).copy()).to(self.device)
+        out = self._empty((n, out_per_item), self.torch.float32)
+        self.lib.mmgen_debug_probe.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+        self._check(self.lib.mmgen_debug_probe(self.PROBES[name], self._p(t), n, self._p(out), self._stream()), "mmgen_debug_probe")
+        return out.cpu().numpy()

@@ -1,0 +1,143 @@
+"""GPU parity tests (pytest -m gpu, run on the MI355X box): the HIP path through the C ABI against the CPU oracle on
+the same inputs, against the committed golden vectors, and — at BASELINE's full batch size — through size-independent
+properties.  Bar: bit-exact for block ids, cave layers and (stronger than the 1e-5 north-star tolerance) heightfields."""
+import hashlib
+
+import numpy as np
+import pytest
+from conftest import assert_bit_equal
+
+pytestmark = pytest.mark.gpu
+HEIGHT_TOL = 1e-5      # north_star: heightfield floats within 1e-5 of the reference (we additionally assert bit equality)
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def np_(t):
+    return t.cpu().numpy()
+
+
+# ------------------------------------------------------------------------------------------------ device math
+def test_device_simplex_matches_real_glm(gen, golden):
+    g = golden["glm_probe"]
+    assert_bit_equal(gen.debug_probe("simplex2", g["xy"], len(g["xy"]))[:, 0], g["simplex2"], "device simplex2 vs glm")
+    assert_bit_equal(gen.debug_probe("simplex3", g["xyz"], len(g["xyz"]))[:, 0], g["simplex3"], "device simplex3 vs glm")
+
+
+def test_device_math_matches_kat(gen, golden):
+    k = golden["oracle_kat"]
+    n = len(k["trig_in"])
+    assert_bit_equal(gen.debug_probe("sin", k["trig_in"], n)[:, 0], k["sin"], "sin")
+    assert_bit_equal(gen.debug_probe("cos", k["trig_in"], n)[:, 0], k["cos"], "cos")
+    assert_bit_equal(gen.debug_probe("pow", np.stack([k["pow_x"], k["pow_y"]], 1), 1024)[:, 0], k["pow"], "pow")
+    assert_bit_equal(gen.debug_probe("atan2", np.stack([k["atan2_y"], k["atan2_x"]], 1), 1024)[:, 0], k["atan2"], "atan2")
+    assert_bit_equal(gen.debug_probe("acos", k["acos_x"], 1024)[:, 0], k["acos"], "acos")
+    assert_bit_equal(gen.debug_probe("hash", k["hash_in"], 1024)[:, 0].view(np.uint32), k["hash_out"], "hash")
+    seeds = k["rng_seeds"].copy()
+    assert_bit_equal(gen.debug_probe("rng4_u01", seeds, 512, 4), k["u01_w1"], "u01 (4-arg seed)")
+    s3 = seeds.copy(); s3[:, 3] = np.int32(-2**31)
+    assert_bit_equal(gen.debug_probe("rng4_u01", s3, 512, 4), k["u01_w0"], "u01 (3-arg seed)")
+    assert_bit_equal(gen.debug_probe("fbm2_5", k["fbm2_in"], 1024)[:, 0], k["fbm2_5"], "fbm2<5>")
+    assert_bit_equal(gen.debug_probe("fbm3_4", k["fbm3_in"], 1024)[:, 0], k["fbm3_4"], "fbm3<4>")
+    assert_bit_equal(gen.debug_probe("rand3from3", k["cells"], 1024, 3), k["rand3from3"], "rand3From3")
+    assert_bit_equal(gen.debug_probe("worley2", k["fbm2_in"], 1024, 5), k["worley2"], "worley2")
+    assert_bit_equal(gen.debug_probe("worley3", k["fbm3_in"], 1024, 5), k["worley3"], "worley3")
+    assert_bit_equal(gen.debug_probe("special_cave_noise", k["fbm3_in"], 1024)[:, 0], k["special_cave_noise"], "specialCaveNoise")
+    for b in range(24):
+        packed = np.zeros((64, 3), np.float32); packed[:, 0] = np.int32(b).view(np.float32); packed[:, 1:] = k["biome_height_pos"]
+        assert_bit_equal(gen.debug_probe("biome_height", packed, 64)[:, 0], k["biome_height"][b], f"getHeight biome {b}")
+    packed = np.zeros((2048, 5), np.float32)
+    packed[:, :3] = k["cb_vox"].view(np.float32); packed[:, 3] = k["cb_maxheight"]; packed[:, 4] = np.int32(190249401).view(np.float32)
+    assert (gen.debug_probe("cave_biome", packed, 2048)[:, 0].astype(np.uint8) == k["cave_biome"]).all()
+
+
+# ------------------------------------------------------------------------------------------------ stage parity
+def _coords(golden):
+    return [tuple(c) for c in golden["stages"]["coords"].tolist()]
+
+
+def test_stages_match_oracle_and_golden(gen, oracle, golden):
+    """Every stage output of the HIP path on 32 chunks (all 24 biomes + mixed + negative coordinates) == oracle, == golden."""
+    s = golden["stages"]
+    coords = _coords(golden)
+    out = gen.generate_chunks_no_erosion(gen.positions(coords))
+    pos = oracle.positions(coords)
+    hf, bw = oracle.heightfields(pos)
+    g = oracle.gather_heightfields(pos, hf)
+    layers = oracle.fix_backward(oracle.layers(pos, g, bw))
+    cave = oracle.caves(pos, hf, bw)
+    blocks = oracle.fill(pos, hf, bw, layers, cave)
+    assert np.abs(np_(out["hf"]) - hf).max() <= HEIGHT_TOL
+    for name, ref in (("hf", hf), ("bw", bw), ("gathered", g), ("layers", layers), ("cave", cave), ("blocks", blocks)):
+        got = np_(out[name]).reshape(ref.shape)
+        assert_bit_equal(got, ref, f"{name} vs oracle")
+        for i in range(len(coords)):
+            assert sha(got[i]) == str(s["sha_" + name][i]), f"{name} golden sha, chunk {coords[i]}"
+    assert_bit_equal(np_(out["blocks"])[coords.index((0, 0))], s["blocks_0_0"], "golden blocks (0,0)")
+
+
+def test_abi_variants_agree(gen, oracle):
+    """mmgen_generate_heightfields (reference kernel shape) == the gathered variant; caller-gathered input == fused gather."""
+    coords = [(5, 5), (-9, 2), (300, -300)]
+    pos = gen.positions(coords)
+    hf1, bw1 = gen.generate_heightfields(pos)
+    hf2, bw2, g2 = gen.generate_heightfields(pos, gathered=True)
+    assert_bit_equal(np_(hf1), np_(hf2), "hf variants"); assert_bit_equal(np_(bw1), np_(bw2), "bw variants")
+    g_host = oracle.gather_heightfields(oracle.positions(coords), np_(hf1))
+    assert_bit_equal(np_(g2), g_host, "gathered")
+
+
+def test_empty_and_single(gen):
+    import torch
+    pos0 = torch.zeros((0, 2), dtype=torch.int32, device=gen.device)
+    out = gen.generate_chunks_no_erosion(pos0)
+    assert out["blocks"].shape[0] == 0
+    one = gen.generate_chunks_no_erosion(gen.positions([(7, -7)]))
+    assert one["blocks"].shape == (1, 98304)
+
+
+def test_error_behaviour(gen):
+    """Null device pointers are rejected with hipErrorInvalidValue (=1), like a failed CUDA call in the reference."""
+    assert gen.lib.mmgen_generate_heightfields(None, 4, None, None, None) == 1
+    assert gen.lib.mmgen_generate_caves(None, None, None, -1, None, None) == 1
+    assert b"invalid" in gen.lib.mmgen_error_string(1).lower()
+
+
+# ------------------------------------------------------------------------------------------------ full-size properties (config 2: 256 chunks)
+def test_full_batch_properties(gen, oracle):
+    import torch
+    coords = [(x, z) for z in range(16) for x in range(16)]
+    pos = gen.positions(coords)
+    a = gen.generate_chunks_no_erosion(pos)
+    torch.cuda.synchronize()
+    # determinism: second run identical
+    b = gen.generate_chunks_no_erosion(pos)
+    for k in ("hf", "layers", "cave", "blocks"):
+        assert torch.equal(a[k], b[k]), k
+    # batch-split and permutation invariance (chunks are independent given position)
+    perm = torch.randperm(256, generator=torch.Generator().manual_seed(1)).to(gen.device)
+    c = gen.generate_chunks_no_erosion(pos[perm][:100])
+    assert torch.equal(c["blocks"], a["blocks"][perm][:100])
+    assert torch.equal(c["cave"], a["cave"][perm][:100])
+    # structure: bedrock floor, air above max(height, sea level), gathered ring == neighbour chunk heights
+    blocks = a["blocks"].view(256, 256, 384)
+    assert bool((blocks[:, :, 0] == 56).all())
+    top = torch.clamp(a["hf"].to(torch.int32), min=128)
+    ys = torch.arange(384, device=gen.device).view(1, 1, 384)
+    assert bool((blocks[ys.expand(256, 256, 384) > top.unsqueeze(-1)] == 0).all())
+    hf = a["hf"].view(16, 16, 16, 16)          # [cz][cx][z][x]
+    g = a["gathered"].view(16, 16, 18, 18)
+    assert torch.equal(g[3, 4, 1:17, 17], hf[3, 5, :, 0]) and torch.equal(g[3, 4, 0, 1:17], hf[2, 4, 15, :]) and g[3, 4, 17, 17] == hf[4, 5, 0, 0]
+    # spot parity with the oracle on 6 random chunks of the batch
+    sel = [3, 77, 130, 201, 255, 16]
+    sub = [coords[i] for i in sel]
+    opos = oracle.positions(sub)
+    ohf, obw = oracle.heightfields(opos)
+    og = oracle.gather_heightfields(opos, ohf)
+    ol = oracle.fix_backward(oracle.layers(opos, og, obw))
+    oc = oracle.caves(opos, ohf, obw)
+    ob = oracle.fill(opos, ohf, obw, ol, oc)
+    assert_bit_equal(np_(a["blocks"])[sel], ob, "blocks sample of the 256-chunk batch")
+    assert_bit_equal(np_(a["cave"])[sel], oc, "cave layers sample")

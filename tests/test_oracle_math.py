@@ -1,0 +1,124 @@
+"""CPU tests: the oracle's math layer against the REAL glm golden vectors, frozen KATs and libm accuracy bounds."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+from conftest import assert_bit_equal, ROOT
+from oracle_binding import _p
+
+
+def test_simplex_matches_real_glm_golden(oracle, golden):
+    g = golden["glm_probe"]
+    s2 = np.zeros(len(g["xy"]), np.float32); oracle.lib.mmo_simplex2(len(s2), _p(np.ascontiguousarray(g["xy"])), _p(s2))
+    s3 = np.zeros(len(g["xyz"]), np.float32); oracle.lib.mmo_simplex3(len(s3), _p(np.ascontiguousarray(g["xyz"])), _p(s3))
+    assert_bit_equal(s2, g["simplex2"], "simplex2 vs glm")
+    assert_bit_equal(s3, g["simplex3"], "simplex3 vs glm")
+
+
+def test_simplex_matches_live_glm_probe_if_present(oracle):
+    """In the build container the real-glm probe is rebuilt from /root/reference; compare on fresh random points."""
+    path = os.path.join(ROOT, "oracle", "_ref", "libglmprobe.so")
+    if not os.path.exists(path):
+        pytest.skip("oracle/_ref not built here (no /root/reference)")
+    ref = ctypes.CDLL(path)
+    rng = np.random.default_rng(99)
+    for scale in (1.0, 300.0, 2e5):
+        xy = (rng.uniform(-1, 1, (50000, 2)) * scale).astype(np.float32)
+        xyz = (rng.uniform(-1, 1, (50000, 3)) * scale).astype(np.float32)
+        a = np.zeros(50000, np.float32); b = np.zeros(50000, np.float32)
+        oracle.lib.mmo_simplex2(50000, _p(xy), _p(a)); ref.ref_simplex2(50000, _p(xy), _p(b)); assert_bit_equal(a, b, "simplex2 live")
+        oracle.lib.mmo_simplex3(50000, _p(xyz), _p(a)); ref.ref_simplex3(50000, _p(xyz), _p(b)); assert_bit_equal(a, b, "simplex3 live")
+
+
+def test_glm_helpers_match_golden(golden):
+    """smoothstep / mix / mod / normalize / length of glm restated in numpy fp32 with glm's operation order."""
+    g = golden["glm_probe"]
+    f = np.float32
+    e0, e1, x = g["e0e1x"][:, 0], g["e0e1x"][:, 1], g["e0e1x"][:, 2]
+    with np.errstate(all="ignore"):
+        t = np.minimum(np.maximum((x - e0) / (e1 - e0), f(0)), f(1))
+        ss = t * t * (f(3) - f(2) * t)
+    ok = np.isfinite(g["smoothstep"])
+    assert_bit_equal(ss[ok], g["smoothstep"][ok], "smoothstep")
+    mx = e0 * (f(1) - x) + e1 * x
+    assert_bit_equal(mx, g["mix"], "mix")
+    a, b = g["ab"][:, 0], g["ab"][:, 1]
+    assert_bit_equal(a - b * np.floor(a / b), g["mod"], "mod")
+    v = g["v3"]
+    d = (v[:, 0] * v[:, 0] + v[:, 1] * v[:, 1]) + v[:, 2] * v[:, 2]
+    assert_bit_equal(np.sqrt(d), g["length"], "length")
+    assert_bit_equal(v * (f(1) / np.sqrt(d))[:, None], g["normalize"], "normalize")
+
+
+def test_kat_frozen(oracle, golden):
+    """The oracle still produces the frozen known-answer vectors (contract drift detector)."""
+    k = golden["oracle_kat"]
+    L = oracle.lib
+    out = np.zeros_like(k["hash_out"]); L.mmo_hash(len(out), _p(np.ascontiguousarray(k["hash_in"])), _p(out)); assert_bit_equal(out, k["hash_out"], "hash")
+    seeds = np.ascontiguousarray(k["rng_seeds"])
+    for use_w in (0, 1):
+        u = np.zeros((len(seeds), 4), np.float32); L.mmo_rng_u01(len(seeds), _p(seeds), use_w, 4, _p(u)); assert_bit_equal(u, k[f"u01_w{use_w}"], "u01")
+    x = np.ascontiguousarray(k["trig_in"]); s = np.zeros_like(x); L.mmo_sinf(len(x), _p(x), _p(s)); assert_bit_equal(s, k["sin"], "sin")
+    xyz = np.ascontiguousarray(k["fbm3_in"]); sc = np.zeros(len(xyz), np.float32)
+    L.mmo_special_cave_noise(len(xyz), _p(xyz), _p(sc)); assert_bit_equal(sc, k["special_cave_noise"], "specialCaveNoise")
+
+
+def test_hash_and_minstd_known_answers(oracle):
+    """hash() of rng.hpp:69-78 and thrust minstd_rand re-derived independently in Python integers."""
+    def h(a):
+        M = 0xFFFFFFFF
+        a = ((a + 0x7ed55d16) + (a << 12)) & M; a = ((a ^ 0xc761c23c) ^ (a >> 19)) & M; a = ((a + 0x165667b1) + (a << 5)) & M
+        a = ((a + 0xd3a2646c) ^ (a << 9)) & M; a = ((a + 0xfd7046c5) + (a << 3)) & M; a = ((a ^ 0xb55a4f09) ^ (a >> 16)) & M
+        return a
+    xs = np.array([0, 1, 12345, 0x80000000, 0xFFFFFFFF, 0x7ed55d16], np.uint32)
+    out = np.zeros_like(xs); oracle.lib.mmo_hash(len(xs), _p(xs), _p(out))
+    assert [int(v) for v in out] == [h(int(v)) for v in xs]
+    # minstd: seed -> x = 48271 x mod (2^31-1); u01 = float(x-1)/2^31 ; 4-argument seeding with negative coordinates
+    seeds = np.array([[3, 4, 5, 6], [-7, 200, -9, 190249401]], np.int32)
+    u = np.zeros((2, 3), np.float32); oracle.lib.mmo_rng_u01(2, _p(seeds), 1, 3, _p(u))
+    for row, (x, y, z, w) in zip(u, seeds.tolist()):
+        M = 0xFFFFFFFF
+        s = (h((0x80000000 | ((x << 22) & M) | ((y << 11) & M) | (w & M)) & M) ^ h(z & M)) % 2147483647 or 1
+        for got in row:
+            s = (s * 48271) % 2147483647
+            assert np.float32(got) == np.float32(np.float32(s - 1) / np.float32(2147483648.0))
+
+
+def _ulps(a, b):
+    ai = a.view(np.int32).astype(np.int64); bi = b.view(np.int32).astype(np.int64)
+    ai = np.where(ai < 0, -(ai & 0x7fffffff), ai); bi = np.where(bi < 0, -(bi & 0x7fffffff), bi)
+    return np.abs(ai - bi)
+
+
+def test_deterministic_libm_accuracy(oracle):
+    """The contract libm is within 2 ulp of the correctly rounded result (numpy fp64 -> fp32) on the argument ranges the
+    path uses: sin/cos up to 1e11 (sin-hash dot products), pow on [0,2]^[0.1,4], atan2, acos."""
+    rng = np.random.default_rng(5)
+    L = oracle.lib
+    for scale in (1, 1e3, 1e7, 1e11):
+        x = (rng.uniform(-1, 1, 200000) * scale).astype(np.float32)
+        s = np.zeros_like(x); c = np.zeros_like(x); L.mmo_sinf(len(x), _p(x), _p(s)); L.mmo_cosf(len(x), _p(x), _p(c))
+        assert np.abs(s.astype(np.float64) - np.sin(x.astype(np.float64))).max() < 1.3e-7
+        assert np.abs(c.astype(np.float64) - np.cos(x.astype(np.float64))).max() < 1.3e-7
+    x = rng.uniform(0, 2, 100000).astype(np.float32); y = rng.uniform(0.1, 4, 100000).astype(np.float32)
+    p = np.zeros_like(x); L.mmo_powf(len(x), _p(x), _p(y), _p(p))
+    assert _ulps(p, np.power(x.astype(np.float64), y.astype(np.float64)).astype(np.float32)).max() <= 1
+    yy = rng.uniform(-5, 5, 100000).astype(np.float32); xx = rng.uniform(-5, 5, 100000).astype(np.float32)
+    a = np.zeros_like(yy); L.mmo_atan2f(len(yy), _p(yy), _p(xx), _p(a))
+    assert _ulps(a, np.arctan2(yy.astype(np.float64), xx.astype(np.float64)).astype(np.float32)).max() <= 1
+    xc = rng.uniform(-1, 1, 100000).astype(np.float32); ac = np.zeros_like(xc); L.mmo_acosf(len(xc), _p(xc), _p(ac))
+    assert _ulps(ac, np.arccos(xc.astype(np.float64)).astype(np.float32)).max() <= 1
+
+
+def test_tables(oracle, golden):
+    """Frozen tan(angle of repose) constants are the correctly rounded fp64 values; weights tables match the fixture."""
+    k = golden["oracle_kat"]
+    mi = np.zeros((20, 4), np.float32); oracle.lib.mmo_tables_material_infos(_p(mi))
+    assert_bit_equal(mi, k["material_infos"], "material infos")
+    for row, deg in zip(mi[12:], (55, 40, 45, 40, 30, 35, 65, 45)):
+        rad = np.float32(deg) * np.float32(0.01745329251994329576923690768489)
+        assert row[2] == np.float32(np.tan(np.float64(rad)))
+    bm = np.zeros((24, 20), np.float32); oracle.lib.mmo_tables_biome_material_weights(_p(bm))
+    assert_bit_equal(bm, k["biome_material_weights"], "biome material weights")
+    assert bm[8, 7] == np.float32(3.2) and bm[0, 15] == 0 and bm[23, 12] == 1    # SAVANNA/TERRACOTTA, CORAL_REEF/DIRT, MOUNTAINS/GRAVEL

@@ -1,0 +1,99 @@
+"""CPU tests: oracle stages against the committed stage goldens + structural properties of the outputs."""
+import hashlib
+
+import numpy as np
+from conftest import assert_bit_equal
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def _run(oracle, coords):
+    pos = oracle.positions(coords)
+    hf, bw = oracle.heightfields(pos)
+    g = oracle.gather_heightfields(pos, hf)
+    layers = oracle.fix_backward(oracle.layers(pos, g, bw))
+    cave = oracle.caves(pos, hf, bw)
+    blocks = oracle.fill(pos, hf, bw, layers, cave)
+    return dict(hf=hf, bw=bw, gathered=g, layers=layers, cave=cave, blocks=blocks)
+
+
+def test_config1_chunk00_heightfield(oracle, golden):
+    """BASELINE config 1: single 16x16 chunk heightfield + surface-biome noise at the origin, host CPU."""
+    s = golden["stages"]
+    i = [tuple(c) for c in s["coords"].tolist()].index((0, 0))
+    hf, bw = oracle.heightfields(oracle.positions([(0, 0)]))
+    assert_bit_equal(hf[0], s["hf"][i], "chunk (0,0) heightfield")
+    assert_bit_equal(bw[0], s["bw_0_0"], "chunk (0,0) biome weights")
+    assert np.allclose(bw[0].sum(axis=0), 1.0, atol=1e-5)          # weights partition unity (biomeFuncs.hpp:158-185)
+    assert 60 < hf.min() and hf.max() < 300
+
+
+def test_stage_goldens(oracle, golden):
+    s = golden["stages"]
+    coords = [tuple(c) for c in s["coords"].tolist()]
+    sel = [0, 3, 9, 15, 19, 23, 24, 27]         # ocean, icebergs, mesa, tianzi, crystals, mountains, origin, mixed
+    out = _run(oracle, [coords[i] for i in sel])
+    for j, i in enumerate(sel):
+        for name in ("hf", "bw", "gathered", "layers", "cave", "blocks"):
+            assert sha(out[name][j]) == str(s["sha_" + name][i]), f"{name} of chunk {coords[i]}"
+    j = sel.index(24)
+    assert_bit_equal(out["blocks"][j], s["blocks_0_0"], "blocks (0,0)")
+    assert_bit_equal(out["cave"][j], s["cave_0_0"], "cave layers (0,0)")
+
+
+def test_structure(oracle):
+    out = _run(oracle, [(2609, -3227), (-175, 36)])
+    b = out["blocks"].reshape(2, 256, 384)
+    assert (b[:, :, 0] == 56).all()                                   # bedrock at y = 0 (chunk.cu:1212-1216)
+    hf = out["hf"]
+    top = np.maximum(hf.astype(np.int32), 128)
+    for c in range(2):
+        for col in range(0, 256, 17):
+            assert (b[c, col, top[c, col] + 1:] == 0).all()           # air above max(height, sea level)
+    cave = out["cave"]
+    start, end = cave[..., 0], cave[..., 1]
+    used = start != 384
+    assert (end[used] > start[used]).all()
+    # layers are sorted, disjoint, and the unused tail is the default {384, 384, NONE, NONE}
+    assert (np.diff(np.where(used, start, 10**6), axis=2) >= 0).all()
+    assert (cave[..., 2][~used] == 0).all() and (end[~used] == 384).all()
+    # every column's last used layer is open to the sky with topBiome NONE
+    last = used.sum(axis=2) - 1
+    cc, ii = np.meshgrid(np.arange(2), np.arange(256), indexing="ij")
+    assert (end[cc, ii, last] == 384).all()
+    assert ((cave[cc, ii, last, 2] >> 8) & 0xFF == 0).all()
+
+
+def test_gather_is_pure_function_of_position(oracle):
+    """The 18x18 gathered heightfield equals the neighbours' own heightfields (reference gather chunk.cu:237-293)."""
+    coords = [(10 + dx, -20 + dz) for dz in (-1, 0, 1) for dx in (-1, 0, 1)]
+    pos = oracle.positions(coords)
+    hf, _ = oracle.heightfields(pos)
+    g = oracle.gather_heightfields(pos[4:5], hf[4:5])[0].reshape(18, 18)
+    tiles = hf.reshape(3, 3, 16, 16)                                   # [cz][cx][z][x]
+    big = np.block([[tiles[r, c] for c in range(3)] for r in range(3)])
+    assert_bit_equal(g, big[15:33, 15:33], "gathered ring")
+
+
+def test_erosion_properties(oracle):
+    """Erosion on synthetic planes: idempotent at the fixed point, never lowers a layer start below its input
+    (first pass adds accumulated lift only), converges."""
+    rng = np.random.default_rng(3)
+    n = 384 * 384
+    hf = (140 + 20 * rng.random((384, 384))).astype(np.float32)
+    planes = np.zeros((9, n), np.float32)
+    planes[8] = hf.ravel()
+    thick = rng.random((8, n)).astype(np.float32) * np.float32(1.5)
+    cur = planes[8].copy()
+    for l in range(7, -1, -1):
+        cur = cur - thick[l]
+        planes[l] = cur
+    before = planes.copy()
+    passes = oracle.erode_zone_planes(planes)
+    assert 8 <= passes < 2000
+    assert (planes[8] == before[8]).all()                              # the heightfield plane is never written
+    again = planes.copy()
+    p2 = oracle.erode_zone_planes(again)
+    assert p2 >= 8
