@@ -46,6 +46,16 @@ int mmgen_generate_layers(const float* d_gathered_heightfields, const float* d_b
 /* Chunk::fixBackwardStratifiedLayers (chunk.cu:725-749), run by Chunk::erodeZone after (or instead of) erosion. */
 int mmgen_fix_backward_layers(float* d_layers, int num_chunks, void* stream);
 
+/* Chunk::erodeZone, device part (chunk.cu:477-601 kernDoErosion + the relaxation loop :672-705).
+ * d_gathered_layers: the packed zone buffer of copyLayers(..., true) (chunk.cu:603-656): 8 eroded-layer start planes + the heightfield
+ * plane over the 384x384 zone grid (+1 trailing flag word, unused here), MMGEN_GATHERED_LAYERS_SIZE floats; eroded IN PLACE.
+ * d_accumulated_heights: 147456 floats, overwritten with the accumulated lift (may be NULL).  Synchronous on return, like the reference.
+ * Canonical semantics: synchronous Jacobi passes; the reference's in-place update races between thread blocks. */
+int mmgen_erode_zone(float* d_gathered_layers, float* d_accumulated_heights, void* stream);
+/* Batched form: num_zones buffers of MMGEN_GATHERED_LAYERS_SIZE floats back to back (one launch per pass for all zones);
+ * *max_passes (nullable) receives the largest number of relaxation passes any zone needed. */
+int mmgen_erode_zones(float* d_gathered_layers, int num_zones, float* d_accumulated_heights, int* max_passes, void* stream);
+
 /* Chunk::generateCaves, device part (chunk.cu:755-937,970-981): default-fill + kernGenerateCaves.
  * out: d_cave_layers [n][256][32] mmgen_cave_layer */
 int mmgen_generate_caves(const float* d_heightfields, const float* d_biome_weights, const int32_t* d_chunk_world_block_pos, int num_chunks,

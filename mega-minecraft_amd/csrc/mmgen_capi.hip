@@ -1,6 +1,7 @@
 // libmmgen C ABI (include/mmgen.h): argument checks, scratch ownership, stream plumbing.  No torch, no C++ types across.
 #include "../../include/mmgen.h"
 #include "mmgen_kernels.h"
+#include "mmgen_erosion.h"
 #include <mutex>
 #include <cstring>
 #include <cstdio>
@@ -10,6 +11,24 @@ std::mutex g_mu;
 float* g_colInfo = nullptr;      // [chunks][256] float2 per-column cave info
 size_t g_colInfoChunks = 0;
 int g_device = -1;
+float* g_erodeWork = nullptr;     // erosion ping-pong planes + accumulators for g_erodeZones zones
+mm::ErosionState* g_erodeState = nullptr;
+int g_erodeZones = 0;
+
+int ensure_erosion(int zones)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (zones <= g_erodeZones) return 0;
+    if (g_erodeWork) (void)hipFree(g_erodeWork);
+    if (g_erodeState) (void)hipFree(g_erodeState);
+    g_erodeWork = nullptr; g_erodeState = nullptr; g_erodeZones = 0;
+    hipError_t e = hipMalloc((void**)&g_erodeWork, mmk::erosion_work_bytes(zones));
+    if (e != hipSuccess) return (int)e;
+    e = hipMalloc((void**)&g_erodeState, mmk::erosion_state_bytes(zones));
+    if (e != hipSuccess) return (int)e;
+    g_erodeZones = zones;
+    return 0;
+}
 
 int ensure_scratch(int n)
 {
@@ -67,6 +86,18 @@ int mmgen_fix_backward_layers(float* d_layers, int n, void* stream)
     if (n < 0 || (n > 0 && !d_layers)) return (int)hipErrorInvalidValue;
     return mmk::launch_fix_backward(d_layers, n, (hipStream_t)stream);
 }
+
+int mmgen_erode_zones(float* d_gathered, int num_zones, float* d_acc, int* max_passes, void* stream)
+{
+    if (num_zones < 0 || (num_zones > 0 && !d_gathered)) return (int)hipErrorInvalidValue;
+    if (num_zones == 0) return 0;
+    int e = ensure_erosion(num_zones);
+    if (e) return e;
+    return mmk::erode_zones(d_gathered, (size_t)MMGEN_GATHERED_LAYERS_SIZE, num_zones, g_erodeWork, g_erodeState, d_acc,
+                            (size_t)MMGEN_EROSION_GRID_NUM_COLS, (hipStream_t)stream, max_passes, nullptr);
+}
+
+int mmgen_erode_zone(float* d_gathered, float* d_acc, void* stream) { return mmgen_erode_zones(d_gathered, 1, d_acc, nullptr, stream); }
 
 int mmgen_generate_caves(const float* d_hf, const float* d_bw, const int32_t* d_pos, int n, mmgen_cave_layer* d_cl, void* stream)
 {

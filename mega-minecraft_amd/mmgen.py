@@ -98,6 +98,31 @@ class MMGen:
         self._check(self.lib.mmgen_fix_backward_layers(self._p(layers), layers.shape[0], self._stream()), "mmgen_fix_backward_layers")
         return layers
 
+    def erode_zones(self, gathered, want_acc=False):
+        """gathered: [zones, MMGEN_GATHERED_LAYERS_SIZE] f32 packed zone planes (copyLayers(to), chunk.cu:603-656), eroded in place.
+        Returns (gathered, max_passes[, accumulated])."""
+        zones = gathered.shape[0]
+        assert gathered.shape[1] == 1327105 and gathered.is_contiguous()
+        acc = self._empty((zones, 147456), self.torch.float32) if want_acc else None
+        mp = ctypes.c_int(0)
+        self.lib.mmgen_erode_zones.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_int), ctypes.c_void_p]
+        self._check(self.lib.mmgen_erode_zones(self._p(gathered), zones, self._p(acc), ctypes.byref(mp), self._stream()), "mmgen_erode_zones")
+        return (gathered, mp.value, acc) if want_acc else (gathered, mp.value)
+
+    @staticmethod
+    def zone_area_coords(zone_cx, zone_cz):
+        """The 24x24 chunks a zone gathers for erosion: own 12x12 + 6-chunk padding (terrain.cpp:471-522), z-major."""
+        return [(zone_cx - 6 + x, zone_cz - 6 + z) for z in range(24) for x in range(24)]
+
+    def pack_zone_planes(self, layers, hf):
+        """copyLayers(..., true) on device tensors: layers [576,20,256], hf [576,256] of zone_area_coords order -> [1, 1327105]."""
+        t = self.torch
+        planes = t.cat([layers[:, 12:20, :], hf.unsqueeze(1)], dim=1)              # [576, 9, 256]
+        planes = planes.view(24, 24, 9, 16, 16).permute(2, 0, 3, 1, 4).reshape(9, 384 * 384)   # [plane][cz,z][cx,x]
+        out = t.zeros((1, 1327105), dtype=t.float32, device=self.device)
+        out[0, : 9 * 147456] = planes.reshape(-1)
+        return out
+
     def generate_caves(self, hf, bw, pos):
         n = pos.shape[0]
         cave = self._empty((n, 256, 32, 3), self.torch.int32)      # 12-byte mmgen_cave_layer viewed as 3 int32
