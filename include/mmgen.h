@@ -61,6 +61,30 @@ int mmgen_erode_zones(float* d_gathered_layers, int num_zones, float* d_accumula
 int mmgen_generate_caves(const float* d_heightfields, const float* d_biome_weights, const int32_t* d_chunk_world_block_pos, int num_chunks,
                          mmgen_cave_layer* d_cave_layers, void* stream);
 
+/* Chunk::generateFeaturePlacements (chunk.cu:999-1156; CPU in the reference, a device kernel here) for a batch of chunks.
+ * in : heightfields, biome weights, (eroded, fixed-up) layers, cave layers, positions
+ * out: d_feature_placements [n][MMGEN_FP_CAP], d_cave_feature_placements [n][MMGEN_CFP_CAP] in the reference's emission order
+ *      (columns z-major, then emission order inside a column), d_counts [n][2] int32 = list lengths (cave count may exceed the cap:
+ *      the surplus is dropped and reported by the count). */
+int mmgen_generate_feature_placements(const float* d_heightfields, const float* d_biome_weights, const float* d_layers,
+                                      const mmgen_cave_layer* d_cave_layers, const int32_t* d_chunk_world_block_pos, int num_chunks,
+                                      mmgen_feature_placement* d_feature_placements, mmgen_cave_feature_placement* d_cave_feature_placements,
+                                      int32_t* d_counts, void* stream);
+
+/* Chunk::gatherFeaturePlacements (chunk.cu:1158-1196) + the host part of Chunk::fill (chunk.cu:1555-1601) on a rectangular chunk grid:
+ * the per-chunk lists above are indexed by grid cell (cell = cx + grid_w * cz); for each of the num_targets cells named by
+ * d_target_cells the 49 neighbour lists are concatenated in the reference's fixed offset order, truncated to 2048 / 4096 entries and
+ * NONE-terminated; d_feature_bounds [num_targets][4] receives {allFeaturesHeightBounds, allCaveFeaturesHeightBounds} of the
+ * un-truncated lists.  Neighbours outside the grid contribute nothing (the reference never fills such a chunk). */
+int mmgen_gather_feature_placements(const mmgen_feature_placement* d_feature_placements, const mmgen_cave_feature_placement* d_cave_feature_placements,
+                                    const int32_t* d_counts, const int32_t* d_target_cells, int num_targets, int grid_w, int grid_h,
+                                    mmgen_feature_placement* d_gathered, mmgen_cave_feature_placement* d_gathered_cave, int32_t* d_feature_bounds,
+                                    void* stream);
+
+/* Chunk::placeDecorators (chunk.cu:1634-1747; CPU in the reference, after the D2H of the blocks), in place on d_blocks. */
+int mmgen_place_decorators(uint8_t* d_blocks, const float* d_heightfields, const float* d_biome_weights, const mmgen_cave_layer* d_cave_layers,
+                           const int32_t* d_chunk_world_block_pos, int num_chunks, void* stream);
+
 /* Chunk::fill, device part (chunk.cu:1202-1510,1603-1616): kernFill for every chunk of the batch in ONE launch.
  * d_feature_placements / d_cave_feature_placements: [n][2048] / [n][4096] NONE-terminated gathered lists (may be NULL = empty),
  * d_feature_bounds [n][4] int32 = {allFeaturesHeightBounds.xy, allCaveFeaturesHeightBounds.xy} (chunk.cu:1555-1570; NULL with NULL lists).
@@ -68,6 +92,32 @@ int mmgen_generate_caves(const float* d_heightfields, const float* d_biome_weigh
 int mmgen_fill(const float* d_heightfields, const float* d_biome_weights, const float* d_layers, const mmgen_cave_layer* d_cave_layers,
                const int32_t* d_chunk_world_block_pos, int num_chunks, const mmgen_feature_placement* d_feature_placements,
                const mmgen_cave_feature_placement* d_cave_feature_placements, const int32_t* d_feature_bounds, uint8_t* d_blocks, void* stream);
+
+/* ---- Region fast path: a rectangle of chunks through ALL stages without leaving the device between stages -------------------
+ * Replaces, for a batch world, the per-tick stage dispatch of Terrain::tick (src/terrain/terrain.cpp:643-937) and its host round
+ * trips.  The region owns its scratch (grow-only device buffers); results go to caller-owned device buffers.
+ * Chunks are ordered z-major: index = (cx - cx0) + nx * (cz - cz0).  flags select the stages that are optional in the reference
+ * (DEBUG_SKIP_EROSION chunk.cu:12,665-715; features / decorators).  Canonical region semantics: DESIGN.md. */
+#define MMGEN_REGION_EROSION 1u
+#define MMGEN_REGION_FEATURES 2u
+#define MMGEN_REGION_DECORATORS 4u
+typedef struct mmgen_region mmgen_region;
+int mmgen_region_create(mmgen_region** out);
+void mmgen_region_destroy(mmgen_region* region);
+/* one call: begin + finish */
+int mmgen_region_generate(mmgen_region* region, int cx0, int cz0, int nx, int nz, unsigned flags, uint8_t* d_blocks /*[nx*nz][98304]*/,
+                          float* d_heightfields /*[nx*nz][256], nullable*/, void* stream);
+/* two-phase form for spatial multi-GPU tiling: begin runs heightfield .. feature placements on the tile plus its 3-chunk ring;
+ * h_local_mask (host, [(nx+6)*(nz+6)] bytes over the ring-extended grid, nullable = all) marks the ring cells whose placements this
+ * GPU must compute itself (world border); the other ring cells are expected to be written into the placement buffers by the caller
+ * (RCCL halo exchange with the neighbouring tiles) before finish. */
+int mmgen_region_begin(mmgen_region* region, int cx0, int cz0, int nx, int nz, unsigned flags, const uint8_t* h_local_mask, void* stream);
+int mmgen_region_placement_buffers(mmgen_region* region, mmgen_feature_placement** d_fp /*[grid][MMGEN_FP_CAP]*/,
+                                   mmgen_cave_feature_placement** d_cfp /*[grid][MMGEN_CFP_CAP]*/, int32_t** d_counts /*[grid][2]*/,
+                                   int* grid_cx0, int* grid_cz0, int* grid_w, int* grid_h);
+int mmgen_region_finish(mmgen_region* region, uint8_t* d_blocks, float* d_heightfields /*nullable*/, float* d_layers /*[n][20][256], nullable*/,
+                        mmgen_cave_layer* d_cave_layers /*[n][256][32], nullable*/, void* stream);
+int mmgen_region_last_erosion_passes(const mmgen_region* region);
 
 /* Measurement hooks (not part of the reference's interface): when enabled every kernel launch is bracketed by HIP events on its
  * launch stream; mmgen_profile_collect() waits for them and returns total milliseconds and launch counts per kernel id
@@ -80,6 +130,10 @@ int mmgen_profile_collect(double* total_ms, long long* counts);
 /* Test-only: evaluates device math function `fn` (MMGEN_PROBE_*) on n packed fp32 items (ints bit-cast); used by the parity
  * tests to pin the device math against golden vectors.  Not part of the reference's interface. */
 int mmgen_debug_probe(int fn, const float* d_in, int n, float* d_out, void* stream);
+/* Test-only: rasterises ONE (cave) feature placement into a box of voxels (placeFeature / placeCaveFeature per voxel,
+ * featurePlacement.hpp:147,1110); d_out[box_size x*y*z] in z, x, y order (y fastest), 255 = voxel not claimed. */
+int mmgen_debug_feature_box(int is_cave, int feature, const int32_t* h_feature_pos, int layer_height, const int32_t* h_box_min,
+                            const int32_t* h_box_size, uint8_t* d_out, void* stream);
 
 #ifdef __cplusplus
 }

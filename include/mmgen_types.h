@@ -35,6 +35,8 @@ extern "C" {
 #define MMGEN_CAVE_LAYERS_SIZE 8192          /* devCaveLayersSize = 256 * 32, column-major  (terrain.hpp:45)       */
 #define MMGEN_MAX_GATHERED_FEATURES_PER_CHUNK 2048        /* biome.hpp:7 */
 #define MMGEN_MAX_GATHERED_CAVE_FEATURES_PER_CHUNK 4096   /* biome.hpp:8 */
+#define MMGEN_FP_CAP 256                     /* per-chunk surface placements: at most one per column (chunk.cu:1136-1141) */
+#define MMGEN_CFP_CAP 1024                   /* per-chunk cave placements kept on device (typ. < 80, biome.hpp:8 comment)  */
 #define MMGEN_SEA_LEVEL 128
 #define MMGEN_LAVA_LEVEL 8
 #define MMGEN_ZONE_SIZE 12                   /* chunks per zone side                         (terrain.hpp:17)       */

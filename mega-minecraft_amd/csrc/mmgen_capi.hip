@@ -2,6 +2,7 @@
 #include "../../include/mmgen.h"
 #include "mmgen_kernels.h"
 #include "mmgen_erosion.h"
+#include "mmgen_features.h"
 #include <mutex>
 #include <cstring>
 #include <cstdio>
@@ -105,7 +106,7 @@ int mmgen_generate_caves(const float* d_hf, const float* d_bw, const int32_t* d_
     if (n == 0) return 0;
     int e = ensure_scratch(n);
     if (e) return e;
-    return mmk::launch_caves(d_hf, d_bw, d_pos, n, d_cl, g_colInfo, (hipStream_t)stream);
+    return mmk::launch_caves(d_hf, d_bw, d_pos, n, d_cl, g_colInfo, nullptr, (hipStream_t)stream);
 }
 
 int mmgen_fill(const float* d_hf, const float* d_bw, const float* d_layers, const mmgen_cave_layer* d_cl, const int32_t* d_pos, int n,
@@ -114,8 +115,39 @@ int mmgen_fill(const float* d_hf, const float* d_bw, const float* d_layers, cons
 {
     if (n < 0 || (n > 0 && (!d_hf || !d_bw || !d_layers || !d_cl || !d_pos || !d_blocks))) return (int)hipErrorInvalidValue;
     if ((d_fp || d_cfp) && !d_bounds) return (int)hipErrorInvalidValue;
-    if (d_fp || d_cfp) return (int)hipErrorNotSupported;   // feature evaluation: see fill with features milestone
-    return mmk::launch_fill(d_hf, d_bw, d_layers, d_cl, d_pos, n, d_blocks, (hipStream_t)stream);
+    int e = mmk::launch_fill(d_hf, d_bw, d_layers, d_cl, d_pos, n, d_blocks, nullptr, (hipStream_t)stream);
+    if (e || !(d_fp || d_cfp)) return e;
+    return mmk::launch_apply_features(d_blocks, d_pos, n, d_fp, d_cfp, d_bounds, nullptr, (hipStream_t)stream);
+}
+
+int mmgen_generate_feature_placements(const float* d_hf, const float* d_bw, const float* d_layers, const mmgen_cave_layer* d_cl, const int32_t* d_pos,
+                                      int n, mmgen_feature_placement* d_fp, mmgen_cave_feature_placement* d_cfp, int32_t* d_counts, void* stream)
+{
+    if (n < 0 || (n > 0 && (!d_hf || !d_bw || !d_layers || !d_cl || !d_pos || !d_fp || !d_cfp || !d_counts))) return (int)hipErrorInvalidValue;
+    return mmk::launch_feature_placements(d_hf, d_bw, d_layers, d_cl, d_pos, n, d_fp, d_cfp, d_counts, nullptr, (hipStream_t)stream);
+}
+
+int mmgen_gather_feature_placements(const mmgen_feature_placement* d_fp, const mmgen_cave_feature_placement* d_cfp, const int32_t* d_counts,
+                                    const int32_t* d_targets, int num_targets, int grid_w, int grid_h, mmgen_feature_placement* d_gfp,
+                                    mmgen_cave_feature_placement* d_gcfp, int32_t* d_bounds, void* stream)
+{
+    if (num_targets < 0 || grid_w <= 0 || grid_h <= 0) return (int)hipErrorInvalidValue;
+    if (num_targets > 0 && (!d_fp || !d_cfp || !d_counts || !d_targets || !d_gfp || !d_gcfp || !d_bounds)) return (int)hipErrorInvalidValue;
+    return mmk::launch_gather_placements(d_fp, d_cfp, d_counts, d_targets, num_targets, grid_w, grid_h, d_gfp, d_gcfp, d_bounds, (hipStream_t)stream);
+}
+
+int mmgen_place_decorators(uint8_t* d_blocks, const float* d_hf, const float* d_bw, const mmgen_cave_layer* d_cl, const int32_t* d_pos, int n,
+                           void* stream)
+{
+    if (n < 0 || (n > 0 && (!d_blocks || !d_hf || !d_bw || !d_cl || !d_pos))) return (int)hipErrorInvalidValue;
+    return mmk::launch_decorators(d_blocks, d_hf, d_bw, d_cl, d_pos, n, nullptr, (hipStream_t)stream);
+}
+
+int mmgen_debug_feature_box(int is_cave, int feature, const int32_t* h_feature_pos, int layer_height, const int32_t* h_box_min,
+                            const int32_t* h_box_size, uint8_t* d_out, void* stream)
+{
+    if (!h_feature_pos || !h_box_min || !h_box_size || !d_out) return (int)hipErrorInvalidValue;
+    return mmk::launch_feature_box(is_cave, feature, h_feature_pos, layer_height, h_box_min, h_box_size, d_out, (hipStream_t)stream);
 }
 
 int mmgen_debug_probe(int fn, const float* d_in, int n, float* d_out, void* stream)

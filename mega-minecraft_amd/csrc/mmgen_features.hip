@@ -1,0 +1,486 @@
+// mmgen feature stages for gfx950:
+//   k_feature_placements  (F1)  per-column placement generation, stable block-wide compaction into per-chunk lists
+//   k_gather_placements   (F2)  concatenation of the 49 neighbour lists in the reference's fixed offset order + height bounds
+//   k_apply_features      (K6b) first-match scan of the gathered lists per voxel (the second half of kernFill)
+//   k_decorators          (D1)  per-chunk decorator pass, parallel over columns by jumping the chunk's minstd stream ahead
+// Behavioural spec: chunk.cu:999-1196 (placements, gather), :1438-1509 (list scan in kernFill), :1555-1601 (host bounds /
+// truncation), :1634-1747 (decorators); gen tables biomeFuncs.hpp:974-1252.
+//
+// In the reference F1 and D1 run on the CPU between GPU stages (host round trips); here they are device kernels so that the
+// whole chunk pipeline stays resident in HBM.  Ordering is part of the output (first match wins in fill): lists are emitted
+// in column order (idx2d ascending = z outer, x inner, chunk.cu:1149-1155) and, within a column, in emission order.
+#include <hip/hip_runtime.h>
+#include "mm_features.cuh"
+#include "mmgen_features.h"
+
+namespace mm {
+
+// ---------------------------------------------------------------------------------------------------------
+// gen tables (biomeFuncs.hpp:974-1040, 1188-1208, 1078-1178, 1228-1252)
+// ---------------------------------------------------------------------------------------------------------
+struct SurfGen { uint8_t feature; uint8_t cell; uint8_t pad; uint8_t canReplace; float chance; uint8_t nTop; uint8_t topMat[2]; float topMin[2]; };
+struct CaveGen { uint8_t feature; uint8_t cell; uint8_t pad; uint8_t minLayerHeight; float chance; uint8_t canReplace; uint8_t fromCeiling; uint8_t canLava; };
+struct DecoGen { uint8_t block; float chance; uint8_t nUnder; uint8_t under[3]; uint8_t replace; uint8_t second; uint8_t fromCeiling; };
+
+#define SG(f, cell, pad, chance, rep, n, m0, t0, m1, t1) {f, cell, pad, rep, chance, n, {m0, m1}, {t0, t1}}
+__device__ constexpr int kSurfGenCount[MMGEN_NUM_BIOMES] = {2, 0, 0, 1, 0, 0, 1, 0, 1, 0, 0, 1, 2, 0, 1, 2, 4, 2, 2, 2, 2, 2, 0, 0};
+__device__ constexpr SurfGen kSurfGens[MMGEN_NUM_BIOMES][4] = {
+    /* CORAL_REEF */ {SG(MMF_CORAL, 5, 0, 0.65f, 1, 2, MMM_SMOOTH_SAND, 0.3f, MMM_SAND, 0.3f), SG(MMF_KELP, 8, 0, 0.50f, 1, 2, MMM_SMOOTH_SAND, 0.3f, MMM_SAND, 0.3f)},
+    /* ARCHIPELAGO */ {}, /* WARM_OCEAN */ {},
+    /* ICEBERGS */ {SG(MMF_ICEBERG, 112, 6, 0.70f, 1, 0, 0, 0.f, 0, 0.f)},
+    /* COOL_OCEAN */ {}, /* ROCKY_BEACH */ {},
+    /* TROPICAL_BEACH */ {SG(MMF_PALM_TREE, 48, 3, 0.35f, 1, 1, MMM_SMOOTH_SAND, 0.3f, 0, 0.f)},
+    /* BEACH */ {},
+    /* SAVANNA */ {SG(MMF_ACACIA_TREE, 36, 4, 0.3f, 1, 1, MMM_DIRT, 0.5f, 0, 0.f)},
+    /* MESA */ {}, /* FROZEN_WASTELAND */ {},
+    /* REDWOOD_FOREST */ {SG(MMF_REDWOOD_TREE, 16, 2, 0.70f, 1, 1, MMM_DIRT, 0.5f, 0, 0.f)},
+    /* SHREKS_SWAMP */ {SG(MMF_CYPRESS_TREE, 18, 3, 0.6f, 1, 2, MMM_DIRT, 0.5f, MMM_MUD, 0.5f), SG(MMF_BIRCH_TREE, 16, 2, 0.15f, 1, 1, MMM_DIRT, 0.4f, 0, 0.f)},
+    /* SPARSE_DESERT */ {},
+    /* LUSH_BIRCH_FOREST */ {SG(MMF_BIRCH_TREE, 9, 2, 0.7f, 1, 1, MMM_DIRT, 0.5f, 0, 0.f)},
+    /* TIANZI_MOUNTAINS */ {SG(MMF_PINE_TREE, 7, 1, 0.80f, 0, 0, 0, 0.f, 0, 0.f), SG(MMF_PINE_SHRUB, 6, 1, 0.80f, 0, 0, 0, 0.f, 0, 0.f)},
+    /* JUNGLE */ {SG(MMF_RAFFLESIA, 54, 6, 0.50f, 1, 1, MMM_DIRT, 0.5f, 0, 0.f), SG(MMF_LARGE_JUNGLE_TREE, 28, 3, 0.70f, 1, 1, MMM_DIRT, 0.5f, 0, 0.f),
+                   SG(MMF_SMALL_JUNGLE_TREE, 10, 2, 0.82f, 1, 1, MMM_DIRT, 0.5f, 0, 0.f), SG(MMF_TINY_JUNGLE_TREE, 6, 1, 0.28f, 1, 1, MMM_DIRT, 0.5f, 0, 0.f)},
+    /* RED_DESERT */ {SG(MMF_PALM_TREE, 40, 3, 0.20f, 1, 1, MMM_RED_SAND, 0.3f, 0, 0.f), SG(MMF_CACTUS, 16, 2, 0.20f, 1, 1, MMM_RED_SAND, 0.5f, 0, 0.f)},
+    /* PURPLE_MUSHROOMS */ {SG(MMF_MEDIUM_PURPLE_MUSHROOM, 10, 2, 0.50f, 1, 1, MMM_DIRT, 0.3f, 0, 0.f), SG(MMF_PURPLE_MUSHROOM, 11, 3, 0.45f, 1, 1, MMM_DIRT, 0.5f, 0, 0.f)},
+    /* CRYSTALS */ {SG(MMF_MEDIUM_CRYSTAL, 28, 6, 0.9f, 1, 0, 0, 0.f, 0, 0.f), SG(MMF_CRYSTAL, 52, 10, 0.8f, 1, 0, 0, 0.f, 0, 0.f)},
+    /* OASIS */ {SG(MMF_PALM_TREE, 24, 3, 0.35f, 1, 1, MMM_SAND, 0.3f, 0, 0.f), SG(MMF_CACTUS, 16, 2, 0.40f, 1, 1, MMM_SAND, 0.5f, 0, 0.f)},
+    /* DESERT */ {SG(MMF_PALM_TREE, 64, 3, 0.30f, 1, 1, MMM_SAND, 0.3f, 0, 0.f), SG(MMF_CACTUS, 16, 2, 0.70f, 1, 1, MMM_SAND, 0.5f, 0, 0.f)},
+    /* PLAINS */ {}, /* MOUNTAINS */ {}};
+
+// caveFeature, cell, pad, minLayerHeight, chance, canReplace, fromCeiling, canLava
+__device__ constexpr int kCaveGenCount[MMGEN_NUM_CAVE_BIOMES] = {0, 3, 2, 2, 2};
+__device__ constexpr CaveGen kCaveGens[MMGEN_NUM_CAVE_BIOMES][3] = {
+    {},
+    {{MMCF_STORMLIGHT_SPHERE, 32, 4, 4, 0.80f, 1, 0, 0}, {MMCF_CEILING_STORMLIGHT_SPHERE, 32, 4, 4, 0.80f, 1, 1, 0}, {MMCF_CRYSTAL_PILLAR, 28, 5, 10, 0.60f, 0, 1, 0}},
+    {{MMCF_GLOWSTONE_CLUSTER, 24, 3, 16, 0.60f, 0, 1, 0}, {MMCF_CAVE_VINE, 4, 0, 4, 0.40f, 0, 1, 0}},
+    {{MMCF_GLOWSTONE_CLUSTER, 16, 3, 16, 0.80f, 0, 1, 0}, {MMCF_WARPED_FUNGUS, 7, 1, 6, 0.75f, 0, 0, 0}},
+    {{MMCF_GLOWSTONE_CLUSTER, 18, 3, 16, 0.75f, 0, 1, 0}, {MMCF_AMBER_FUNGUS, 5, 1, 9, 0.60f, 0, 0, 0}}};
+
+// feature height bounds (biomeFuncs.hpp:1042-1074, 1210-1223)
+__device__ constexpr int kFeatureBounds[MMGEN_NUM_FEATURES][2] = {
+    {0, 0}, {-6, 6}, {-3, 12}, {0, 20}, {0, 110}, {0, 15}, {-5, 75}, {-3, 50}, {0, 30}, {0, 15}, {0, 8}, {0, 10}, {0, 38}, {0, 17}, {0, 5},
+    {0, 6}, {0, 120}, {-3, 32}, {-6, 64}, {0, 28}, {0, 15}};
+__device__ constexpr int kCaveFeatureBounds[MMGEN_NUM_CAVE_FEATURES][2] = {
+    {0, 0}, {-3, 3}, {-3, 3}, {0, 0}, {0, 6}, {-12, 12}, {-12, 12}, {-8, 8}, {-2, 3}, {-2, 5}};
+
+// decorators: block, chance, nUnder, under[3], replace (AIR default / WATER), second block (AIR = none), fromCeiling
+#define DG(b, ch, n, u0, u1, u2, rep, sec, ceil) {b, ch, n, {u0, u1, u2}, rep, sec, ceil}
+#define GB MMB_GRASS_BLOCK
+#define JGB MMB_JUNGLE_GRASS_BLOCK
+__device__ constexpr int kDecoCount[MMGEN_NUM_BIOMES] = {7, 2, 0, 0, 0, 0, 1, 0, 1, 0, 0, 5, 5, 0, 4, 0, 5, 1, 4, 4, 2, 1, 7, 2};
+__device__ constexpr DecoGen kDecoGens[MMGEN_NUM_BIOMES][7] = {
+    /* CORAL_REEF */ {DG(MMB_SEAGRASS, 0.200f, 2, MMB_SAND, MMB_SMOOTH_SAND, 0, MMB_WATER, MMB_AIR, 0),
+                      DG(MMB_TALL_SEAGRASS_BOTTOM, 0.040f, 2, MMB_SAND, MMB_SMOOTH_SAND, 0, MMB_WATER, MMB_TALL_SEAGRASS_TOP, 0),
+                      DG(MMB_BRAIN_CORAL, 0.030f, 2, MMB_SAND, MMB_SMOOTH_SAND, 0, MMB_WATER, MMB_WATER, 0),
+                      DG(MMB_BUBBLE_CORAL, 0.030f, 2, MMB_SAND, MMB_SMOOTH_SAND, 0, MMB_WATER, MMB_WATER, 0),
+                      DG(MMB_FIRE_CORAL, 0.030f, 2, MMB_SAND, MMB_SMOOTH_SAND, 0, MMB_WATER, MMB_WATER, 0),
+                      DG(MMB_HORN_CORAL, 0.030f, 2, MMB_SAND, MMB_SMOOTH_SAND, 0, MMB_WATER, MMB_WATER, 0),
+                      DG(MMB_TUBE_CORAL, 0.030f, 2, MMB_SAND, MMB_SMOOTH_SAND, 0, MMB_WATER, MMB_WATER, 0)},
+    /* ARCHIPELAGO */ {DG(MMB_GRASS, 0.200f, 1, GB, 0, 0, MMB_AIR, MMB_AIR, 0), DG(MMB_LILY_OF_THE_VALLEY, 0.025f, 1, GB, 0, 0, MMB_AIR, MMB_AIR, 0)},
+    {}, {}, {}, {},
+    /* TROPICAL_BEACH */ {DG(MMB_JUNGLE_GRASS, 0.1f, 1, JGB, 0, 0, MMB_AIR, MMB_AIR, 0)},
+    {},
+    /* SAVANNA */ {DG(MMB_SAVANNA_GRASS, 0.1f, 1, MMB_SAVANNA_GRASS_BLOCK, 0, 0, MMB_AIR, MMB_AIR, 0)},
+    {}, {},
+    /* REDWOOD_FOREST */ {DG(MMB_GRASS, 0.200f, 1, GB, 0, 0, MMB_AIR, MMB_AIR, 0), DG(MMB_TALL_GRASS_BOTTOM, 0.080f, 1, GB, 0, 0, MMB_AIR, MMB_TALL_GRASS_TOP, 0),
+                          DG(MMB_OXEYE_DAISY, 0.040f, 1, GB, 0, 0, MMB_AIR, MMB_AIR, 0), DG(MMB_LILY_OF_THE_VALLEY, 0.040f, 1, GB, 0, 0, MMB_AIR, MMB_AIR, 0),
+                          DG(MMB_PEONY_BOTTOM, 0.020f, 1, GB, 0, 0, MMB_AIR, MMB_PEONY_TOP, 0)},
+    /* SHREKS_SWAMP */ {DG(MMB_JUNGLE_GRASS, 0.300f, 1, JGB, 0, 0, MMB_AIR, MMB_AIR, 0), DG(MMB_JUNGLE_FERN, 0.050f, 1, JGB, 0, 0, MMB_AIR, MMB_AIR, 0),
+                        DG(MMB_CORNFLOWER, 0.030f, 1, JGB, 0, 0, MMB_AIR, MMB_AIR, 0), DG(MMB_BLUE_ORCHID, 0.030f, 1, JGB, 0, 0, MMB_AIR, MMB_AIR, 0),
+                        DG(MMB_ALLIUM, 0.030f, 1, JGB, 0, 0, MMB_AIR, MMB_AIR, 0)},
+    {},
+    /* LUSH_BIRCH_FOREST */ {DG(MMB_GRASS, 0.300f, 1, GB, 0, 0, MMB_AIR, MMB_AIR, 0), DG(MMB_PEONY_BOTTOM, 0.020f, 1, GB, 0, 0, MMB_AIR, MMB_PEONY_TOP, 0),
+                             DG(MMB_LILAC_BOTTOM, 0.020f, 1, GB, 0, 0, MMB_AIR, MMB_LILAC_TOP, 0), DG(MMB_DANDELION, 0.040f, 1, GB, 0, 0, MMB_AIR, MMB_AIR, 0)},
+    {},
+    /* JUNGLE */ {DG(MMB_JUNGLE_GRASS, 0.400f, 1, JGB, 0, 0, MMB_AIR, MMB_AIR, 0), DG(MMB_TALL_JUNGLE_GRASS_BOTTOM, 0.200f, 1, JGB, 0, 0, MMB_AIR, MMB_TALL_JUNGLE_GRASS_TOP, 0),
+                  DG(MMB_PITCHER_BOTTOM, 0.030f, 1, JGB, 0, 0, MMB_AIR, MMB_PITCHER_TOP, 0), DG(MMB_JUNGLE_FERN, 0.120f, 1, JGB, 0, 0, MMB_AIR, MMB_AIR, 0),
+                  DG(MMB_BLUE_ORCHID, 0.040f, 1, JGB, 0, 0, MMB_AIR, MMB_AIR, 0)},
+    /* RED_DESERT */ {DG(MMB_DEAD_BUSH, 0.020f, 1, MMB_RED_SAND, 0, 0, MMB_AIR, MMB_AIR, 0)},
+    /* PURPLE_MUSHROOMS */ {DG(MMB_SMALL_PURPLE_MUSHROOM, 0.100f, 1, MMB_MYCELIUM, 0, 0, MMB_AIR, MMB_AIR, 0),
+                            DG(MMB_SMALL_MAGENTA_CRYSTAL, 0.005f, 3, MMB_STONE, MMB_TUFF, MMB_CALCITE, MMB_AIR, MMB_AIR, 0),
+                            DG(MMB_SMALL_CYAN_CRYSTAL, 0.005f, 3, MMB_STONE, MMB_TUFF, MMB_CALCITE, MMB_AIR, MMB_AIR, 0),
+                            DG(MMB_SMALL_GREEN_CRYSTAL, 0.005f, 3, MMB_STONE, MMB_TUFF, MMB_CALCITE, MMB_AIR, MMB_AIR, 0)},
+    /* CRYSTALS */ {DG(MMB_SMALL_PURPLE_MUSHROOM, 0.020f, 1, MMB_MYCELIUM, 0, 0, MMB_AIR, MMB_AIR, 0),
+                    DG(MMB_SMALL_MAGENTA_CRYSTAL, 0.025f, 3, MMB_STONE, MMB_TUFF, MMB_CALCITE, MMB_AIR, MMB_AIR, 0),
+                    DG(MMB_SMALL_CYAN_CRYSTAL, 0.025f, 3, MMB_STONE, MMB_TUFF, MMB_CALCITE, MMB_AIR, MMB_AIR, 0),
+                    DG(MMB_SMALL_GREEN_CRYSTAL, 0.025f, 3, MMB_STONE, MMB_TUFF, MMB_CALCITE, MMB_AIR, MMB_AIR, 0)},
+    /* OASIS */ {DG(MMB_JUNGLE_GRASS, 0.200f, 1, JGB, 0, 0, MMB_AIR, MMB_AIR, 0), DG(MMB_CORNFLOWER, 0.020f, 1, JGB, 0, 0, MMB_AIR, MMB_AIR, 0)},
+    /* DESERT */ {DG(MMB_DEAD_BUSH, 0.030f, 1, MMB_RED_SAND, 0, 0, MMB_AIR, MMB_AIR, 0)},
+    /* PLAINS */ {DG(MMB_GRASS, 0.200f, 1, GB, 0, 0, MMB_AIR, MMB_AIR, 0), DG(MMB_RED_TULIP, 0.010f, 1, GB, 0, 0, MMB_AIR, MMB_AIR, 0),
+                  DG(MMB_ORANGE_TULIP, 0.010f, 1, GB, 0, 0, MMB_AIR, MMB_AIR, 0), DG(MMB_WHITE_TULIP, 0.010f, 1, GB, 0, 0, MMB_AIR, MMB_AIR, 0),
+                  DG(MMB_PINK_TULIP, 0.010f, 1, GB, 0, 0, MMB_AIR, MMB_AIR, 0), DG(MMB_DANDELION, 0.030f, 1, GB, 0, 0, MMB_AIR, MMB_AIR, 0),
+                  DG(MMB_POPPY, 0.030f, 1, GB, 0, 0, MMB_AIR, MMB_AIR, 0)},
+    /* MOUNTAINS */ {DG(MMB_GRASS, 0.050f, 1, GB, 0, 0, MMB_AIR, MMB_AIR, 0), DG(MMB_LILY_OF_THE_VALLEY, 0.015f, 1, GB, 0, 0, MMB_AIR, MMB_AIR, 0)}};
+
+__device__ constexpr int kCaveDecoCount[MMGEN_NUM_CAVE_BIOMES] = {0, 6, 3, 3, 2};
+__device__ constexpr DecoGen kCaveDecoGens[MMGEN_NUM_CAVE_BIOMES][6] = {
+    {},
+    {DG(MMB_SMALL_MAGENTA_CRYSTAL, 0.015f, 0, 0, 0, 0, MMB_AIR, MMB_AIR, 0), DG(MMB_SMALL_CYAN_CRYSTAL, 0.015f, 0, 0, 0, 0, MMB_AIR, MMB_AIR, 0),
+     DG(MMB_SMALL_GREEN_CRYSTAL, 0.015f, 0, 0, 0, 0, MMB_AIR, MMB_AIR, 0), DG(MMB_HANGING_SMALL_MAGENTA_CRYSTAL, 0.015f, 0, 0, 0, 0, MMB_AIR, MMB_AIR, 1),
+     DG(MMB_HANGING_SMALL_CYAN_CRYSTAL, 0.015f, 0, 0, 0, 0, MMB_AIR, MMB_AIR, 1), DG(MMB_HANGING_SMALL_GREEN_CRYSTAL, 0.015f, 0, 0, 0, 0, MMB_AIR, MMB_AIR, 1)},
+    {DG(MMB_GRASS, 0.100f, 1, MMB_MOSS, 0, 0, MMB_AIR, MMB_AIR, 0), DG(MMB_TALL_GRASS_BOTTOM, 0.030f, 1, MMB_MOSS, 0, 0, MMB_AIR, MMB_TALL_GRASS_TOP, 0),
+     DG(MMB_TORCHFLOWER, 0.020f, 1, MMB_MOSS, 0, 0, MMB_AIR, MMB_AIR, 0)},
+    {DG(MMB_WARPED_MUSHROOM, 0.020f, 2, MMB_WARPED_DEEPSLATE, MMB_WARPED_BLACKSTONE, 0, MMB_AIR, MMB_AIR, 0),
+     DG(MMB_WARPED_ROOTS, 0.060f, 2, MMB_WARPED_DEEPSLATE, MMB_WARPED_BLACKSTONE, 0, MMB_AIR, MMB_AIR, 0),
+     DG(MMB_NETHER_SPROUTS, 0.040f, 2, MMB_WARPED_DEEPSLATE, MMB_WARPED_BLACKSTONE, 0, MMB_AIR, MMB_AIR, 0)},
+    {DG(MMB_INFECTED_MUSHROOM, 0.020f, 2, MMB_AMBER_DEEPSLATE, MMB_AMBER_BLACKSTONE, 0, MMB_AIR, MMB_AIR, 0),
+     DG(MMB_AMBER_ROOTS, 0.060f, 2, MMB_AMBER_DEEPSLATE, MMB_AMBER_BLACKSTONE, 0, MMB_AIR, MMB_AIR, 0)}};
+
+// ---------------------------------------------------------------------------------------------------------
+// F1 — placement generation (chunk.cu:999-1156)
+// ---------------------------------------------------------------------------------------------------------
+MM_DEV bool is_feature_pos(int wx, int wz, int cell, int pad, int seed)      // chunk.cu:999-1008
+{
+    const float fc = (float)cell;
+    const int cornerX = (int)(__builtin_floorf((float)wx / fc) * fc), cornerZ = (int)(__builtin_floorf((float)wz / fc) * fc);
+    const int inner = cell - 2 * pad;
+    const f2 r = rand2from3((float)cornerX, (float)cornerZ, (float)seed);
+    const int px = cornerX + pad + (int)__builtin_floorf(r.x * (float)inner);
+    const int pz = cornerZ + pad + (int)__builtin_floorf(r.y * (float)inner);
+    return wx == px && wz == pz;
+}
+
+// Walks one column exactly like generateColumnFeaturePlacements (chunk.cu:1041-1145).  WRITE=false only counts.
+template <bool WRITE>
+MM_DEV void column_placements(int wx, int wz, float height, const float* cbw /*stride 256*/, const float* clayers /*stride 256*/,
+                              const mmgen_cave_layer* ccl, int& nSurf, int& nCave, mmgen_feature_placement* surfOut,
+                              mmgen_cave_feature_placement* caveOut, int caveCap)
+{
+    nSurf = 0; nCave = 0;
+    const int ground = (int)height;
+    MinStd rng = rng3(wx, wz, 329828101);
+
+    bool surfaceIsCave = false;
+    for (int k = 0; k < MMGEN_MAX_CAVE_LAYERS_PER_COLUMN; ++k) {
+        const int start = ccl[k].start, end = ccl[k].end;
+        if (start == 384 || ground <= start) break;
+        const int layerHeight = end - start;
+        for (int pass = 0; pass < 2; ++pass) {           // pass 0: bottom biome gens (floor), pass 1: top biome gens (ceiling)
+            if (pass == 1 && end == 384) break;
+            const int cb = pass == 0 ? ccl[k].bottom_biome : ccl[k].top_biome;
+            const bool top = pass == 1;
+            for (int g = 0; g < kCaveGenCount[cb]; ++g) {
+                const CaveGen& gen = kCaveGens[cb][g];
+                const int seed = (int)gen.feature * (top ? 58321 : 98239) + k * (top ? 871503 : 191702);
+                const float rand = rng.u01();             // every gen consumes one draw, accepted or not
+                if (rand >= gen.chance || (top != (gen.fromCeiling != 0)) || (!gen.canLava && (top ? end : (start + 1)) <= MMGEN_LAVA_LEVEL)
+                    || layerHeight < (int)gen.minLayerHeight)
+                    continue;
+                if (is_feature_pos(wx, wz, gen.cell, gen.pad, seed)) {
+                    if (WRITE && nCave < caveCap) {
+                        mmgen_cave_feature_placement p = {};
+                        p.feature = gen.feature; p.pos[0] = wx; p.pos[1] = start + 1; p.pos[2] = wz; p.layer_height = layerHeight;
+                        p.can_replace_blocks = gen.canReplace;
+                        caveOut[nCave] = p;
+                    }
+                    ++nCave;
+                    break;
+                }
+            }
+        }
+        if (ground > start && ground <= end) { surfaceIsCave = true; break; }
+    }
+
+    if (!surfaceIsCave) {
+        const int biome = random_biome(cbw, 256, rng.u01());
+        for (int g = 0; g < kSurfGenCount[biome]; ++g) {
+            const SurfGen& gen = kSurfGens[biome][g];
+            if (rng.u01() >= gen.chance) continue;
+            if (gen.nTop > 0) {
+                bool canPlace = false;
+                for (int t = 0; t < gen.nTop; ++t) {
+                    const int l = gen.topMat[t];
+                    const float ls = clayers[256 * l];
+                    const float le = clayers[256 * (l + 1)];
+                    if (ls > height || le < height || gmin(le, height) - ls < gen.topMin[t]) continue;
+                    canPlace = true;
+                    break;
+                }
+                if (!canPlace) continue;
+            }
+            if (is_feature_pos(wx, wz, gen.cell, gen.pad, (int)gen.feature * 518721)) {
+                if (WRITE) {
+                    mmgen_feature_placement p = {};
+                    p.feature = gen.feature; p.pos[0] = wx; p.pos[1] = ground + 1; p.pos[2] = wz; p.can_replace_blocks = gen.canReplace;
+                    surfOut[0] = p;
+                }
+                nSurf = 1;
+                break;
+            }
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256)
+k_feature_placements(const float* __restrict__ hf, const float* __restrict__ bw, const float* __restrict__ layers,
+                     const mmgen_cave_layer* __restrict__ caveLayers, const int2* __restrict__ chunkPos,
+                     mmgen_feature_placement* __restrict__ fpOut, mmgen_cave_feature_placement* __restrict__ cfpOut, int* __restrict__ counts,
+                     const int* __restrict__ chunkList)
+{
+    __shared__ int s_ns[256], s_nc[256];
+    const int chunk = chunkList ? chunkList[blockIdx.x] : blockIdx.x, t = threadIdx.x;
+    const int2 cp = chunkPos[chunk];
+    const int wx = cp.x + (t & 15), wz = cp.y + (t >> 4);
+    const float height = hf[(size_t)256 * chunk + t];
+    const float* cbw = bw + (size_t)MMGEN_BIOME_WEIGHTS_SIZE * chunk + t;
+    const float* cl = layers + (size_t)MMGEN_LAYERS_SIZE * chunk + t;
+    const mmgen_cave_layer* ccl = caveLayers + ((size_t)256 * chunk + t) * MMGEN_MAX_CAVE_LAYERS_PER_COLUMN;
+
+    int ns, nc;
+    column_placements<false>(wx, wz, height, cbw, cl, ccl, ns, nc, nullptr, nullptr, 0);
+    s_ns[t] = ns; s_nc[t] = nc;
+    __syncthreads();
+    int offS = 0, offC = 0;
+    for (int i = 0; i < t; ++i) { offS += s_ns[i]; offC += s_nc[i]; }
+    if (t == 255) { counts[2 * chunk] = offS + ns; counts[2 * chunk + 1] = offC + nc; }
+    if (ns + nc == 0) return;
+    mmgen_feature_placement* so = fpOut + (size_t)MMGEN_FP_CAP * chunk + offS;
+    mmgen_cave_feature_placement* co = cfpOut + (size_t)MMGEN_CFP_CAP * chunk + offC;
+    const int capLeft = imax(0, MMGEN_CFP_CAP - offC);
+    column_placements<true>(wx, wz, height, cbw, cl, ccl, ns, nc, so, co, capLeft);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// F2 — gather in the reference's fixed offset order (chunk.cu:1158-1187) + host part of Chunk::fill (chunk.cu:1555-1601):
+// union of height bounds over the un-truncated lists, truncation to 2048 / 4096, NONE sentinel.
+// ---------------------------------------------------------------------------------------------------------
+__device__ constexpr int kGatherDX[49] = {0, 0, 1, 1, 1, 0, -1, -1, -1, 2, 2, 2, 1, 0, -1, -2, -2, -2, -2, -2, -1, 0, 1, 2, 2,
+                                          -3, -2, -1, 0, 1, 2, 3, 3, 3, 3, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -3, -3, -3};
+__device__ constexpr int kGatherDZ[49] = {0, 1, 1, 0, -1, -1, -1, 0, 1, 0, 1, 2, 2, 2, 2, 2, 1, 0, -1, -2, -2, -2, -2, -2, -1,
+                                          -3, -3, -3, -3, -3, -3, -3, -2, -1, 0, 1, 2, 3, 3, 3, 3, 3, 3, 3, 2, 1, 0, -1, -2};
+
+__global__ void __launch_bounds__(256)
+k_gather_placements(const mmgen_feature_placement* __restrict__ fp, const mmgen_cave_feature_placement* __restrict__ cfp,
+                    const int* __restrict__ counts, const int* __restrict__ targetChunk /*[nOut] index into source grid*/,
+                    int gridW, int gridH, mmgen_feature_placement* __restrict__ gfp, mmgen_cave_feature_placement* __restrict__ gcfp,
+                    int* __restrict__ bounds)
+{
+    __shared__ int s_offS[50], s_offC[50], s_src[49];
+    __shared__ int s_b[4];
+    const int o = blockIdx.x, t = threadIdx.x;
+    const int c = targetChunk[o];
+    const int cx = c % gridW, cz = c / gridW;
+    if (t == 0) {
+        int aS = 0, aC = 0;
+        for (int k = 0; k < 49; ++k) {
+            const int nx = cx + kGatherDX[k], nz = cz + kGatherDZ[k];
+            const bool ok = nx >= 0 && nx < gridW && nz >= 0 && nz < gridH;
+            const int n = ok ? nx + gridW * nz : -1;
+            s_src[k] = n;
+            s_offS[k] = aS; s_offC[k] = aC;
+            if (ok) { aS += counts[2 * n]; aC += imin(counts[2 * n + 1], MMGEN_CFP_CAP); }
+        }
+        s_offS[49] = aS; s_offC[49] = aC;
+        s_b[0] = 384; s_b[1] = -1; s_b[2] = 384; s_b[3] = -1;
+    }
+    __syncthreads();
+    const int totS = s_offS[49], totC = s_offC[49];
+    mmgen_feature_placement* go = gfp + (size_t)MMGEN_MAX_GATHERED_FEATURES_PER_CHUNK * o;
+    mmgen_cave_feature_placement* gc = gcfp + (size_t)MMGEN_MAX_GATHERED_CAVE_FEATURES_PER_CHUNK * o;
+    int lo0 = 384, hi0 = -1, lo1 = 384, hi1 = -1;
+    for (int i = t; i < totS; i += 256) {
+        int k = 0;
+        while (s_offS[k + 1] <= i) ++k;
+        const mmgen_feature_placement p = fp[(size_t)MMGEN_FP_CAP * s_src[k] + (i - s_offS[k])];
+        lo0 = imin(lo0, p.pos[1] + kFeatureBounds[p.feature][0]);
+        hi0 = imax(hi0, p.pos[1] + kFeatureBounds[p.feature][1]);
+        if (i < MMGEN_MAX_GATHERED_FEATURES_PER_CHUNK) go[i] = p;
+    }
+    for (int i = t; i < totC; i += 256) {
+        int k = 0;
+        while (s_offC[k + 1] <= i) ++k;
+        const mmgen_cave_feature_placement p = cfp[(size_t)MMGEN_CFP_CAP * s_src[k] + (i - s_offC[k])];
+        lo1 = imin(lo1, p.pos[1] + kCaveFeatureBounds[p.feature][0]);
+        hi1 = imax(hi1, p.pos[1] + p.layer_height + kCaveFeatureBounds[p.feature][1]);
+        if (i < MMGEN_MAX_GATHERED_CAVE_FEATURES_PER_CHUNK) gc[i] = p;
+    }
+    atomicMin(&s_b[0], lo0); atomicMax(&s_b[1], hi0); atomicMin(&s_b[2], lo1); atomicMax(&s_b[3], hi1);
+    __syncthreads();
+    if (t == 0) {
+        if (totS < MMGEN_MAX_GATHERED_FEATURES_PER_CHUNK) { mmgen_feature_placement z = {}; go[totS] = z; }          // NONE sentinel
+        if (totC < MMGEN_MAX_GATHERED_CAVE_FEATURES_PER_CHUNK) { mmgen_cave_feature_placement z = {}; gc[totC] = z; }
+        bounds[4 * o] = s_b[0]; bounds[4 * o + 1] = s_b[1]; bounds[4 * o + 2] = s_b[2]; bounds[4 * o + 3] = s_b[3];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// K6b — feature evaluation per voxel (second half of kernFill, chunk.cu:1438-1509).  One workgroup per column, lane = y.
+// ---------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(384)
+k_apply_features(uint8_t* __restrict__ blocks, const int2* __restrict__ chunkPos, const mmgen_feature_placement* __restrict__ gfp,
+                 const mmgen_cave_feature_placement* __restrict__ gcfp, const int* __restrict__ bounds, const int* __restrict__ srcIdx)
+{
+    const int col = blockIdx.x;
+    const int chunk = col >> 8, idx2d = col & 255;      // dense output / list index; positions are read at srcIdx[chunk]
+    const int y = threadIdx.x;
+    const int b0 = bounds[4 * chunk], b1 = bounds[4 * chunk + 1], b2 = bounds[4 * chunk + 2], b3 = bounds[4 * chunk + 3];
+    const bool inF = gfp && y >= b0 && y <= b1;
+    const bool inC = gcfp && y >= b2 && y <= b3;
+    if (!inF && !inC) return;
+
+    const int2 cp = chunkPos[srcIdx ? srcIdx[chunk] : chunk];
+    const int wx = cp.x + (idx2d & 15), wz = cp.y + (idx2d >> 4);
+    uint8_t* bp = blocks + (size_t)MMGEN_BLOCKS_PER_CHUNK * chunk + 384 * idx2d + y;
+    const uint8_t block = *bp;
+    uint8_t fb = 0;
+    bool placed = false;
+    if (inF) {
+        const mmgen_feature_placement* list = gfp + (size_t)MMGEN_MAX_GATHERED_FEATURES_PER_CHUNK * chunk;
+        for (int i = 0; i < MMGEN_MAX_GATHERED_FEATURES_PER_CHUNK; ++i) {
+            const int feature = list[i].feature;
+            if (feature == MMF_NONE) break;
+            if (block != MMB_AIR && !list[i].can_replace_blocks) continue;
+            const int fy = list[i].pos[1];
+            if (y < fy + kFeatureBounds[feature][0] || y > fy + kFeatureBounds[feature][1]) continue;
+            if (place_feature(feature, list[i].pos[0], fy, list[i].pos[2], wx, y, wz, fb)) { placed = true; break; }
+        }
+    }
+    if (inC && !placed) {
+        const mmgen_cave_feature_placement* list = gcfp + (size_t)MMGEN_MAX_GATHERED_CAVE_FEATURES_PER_CHUNK * chunk;
+        for (int i = 0; i < MMGEN_MAX_GATHERED_CAVE_FEATURES_PER_CHUNK; ++i) {
+            const int feature = list[i].feature;
+            if (feature == MMCF_NONE) break;
+            if (block != MMB_AIR && !list[i].can_replace_blocks) continue;
+            const int fy = list[i].pos[1], lh = list[i].layer_height;
+            if (y < fy + kCaveFeatureBounds[feature][0] || y > fy + lh + kCaveFeatureBounds[feature][1]) continue;
+            if (place_cave_feature(feature, list[i].pos[0], fy, list[i].pos[2], lh, wx, y, wz, fb)) { placed = true; break; }
+        }
+    }
+    if (placed) *bp = fb;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// D1 — decorators (chunk.cu:1634-1747).  The reference consumes ONE minstd stream per chunk sequentially over the columns:
+// 2 draws per column + 2 per used cave layer.  minstd has no increment, so x_{n+k} = a^k x_n mod m: every lane jumps the
+// stream to its column's first draw and all 256 columns run in parallel (decorators only touch their own column).
+// ---------------------------------------------------------------------------------------------------------
+MM_DEV uint32_t mulmod(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * b) % 2147483647ull); }
+
+MM_DEV void try_place_decorator(uint8_t* col, int y, const DecoGen& g)     // tryPlaceSingleDecorator chunk.cu:1634-1677
+{
+    if (y < 0 || y > 383) return;       // canonical: out-of-column positions are no-ops (open-to-sky ceiling decorators, y == 384)
+    const uint8_t cur = col[y];
+    if (cur != g.replace) return;
+    const int uo = g.fromCeiling ? 1 : -1;
+    if (y + uo < 0 || y + uo > 383) return;
+    const uint8_t under = col[y + uo];
+    if (under < MMB_NUM_NON_SOLID_BLOCKS) return;
+    if (g.nUnder > 0) {
+        bool ok = false;
+        for (int i = 0; i < g.nUnder; ++i) ok = ok || under == g.under[i];
+        if (!ok) return;
+    }
+    if (g.second != MMB_AIR) {
+        const int oo = -uo;
+        if (y + oo < 0 || y + oo > 383) return;
+        if (col[y + oo] != g.replace) return;
+        col[y + oo] = g.second;
+    }
+    col[y] = g.block;
+}
+
+__global__ void __launch_bounds__(256)
+k_decorators(uint8_t* __restrict__ blocks, const float* __restrict__ hf, const float* __restrict__ bw,
+             const mmgen_cave_layer* __restrict__ caveLayers, const int2* __restrict__ chunkPos, const int* __restrict__ srcIdx)
+{
+    __shared__ int s_draws[256];
+    const int outChunk = blockIdx.x, t = threadIdx.x;
+    const int chunk = srcIdx ? srcIdx[outChunk] : outChunk;
+    const mmgen_cave_layer* ccl = caveLayers + ((size_t)256 * chunk + t) * MMGEN_MAX_CAVE_LAYERS_PER_COLUMN;
+    int used = 0;
+    while (used < MMGEN_MAX_CAVE_LAYERS_PER_COLUMN && ccl[used].start != 384) ++used;
+    s_draws[t] = 2 + 2 * used;
+    __syncthreads();
+    int skip = 0;
+    for (int i = 0; i < t; ++i) skip += s_draws[i];
+
+    const int2 cp = chunkPos[chunk];
+    MinStd rng = rng4(cp.x, 0, cp.y, 7589341);
+    // jump ahead by `skip` draws: x <- a^skip * x mod m
+    uint32_t mult = 1u, base = 48271u;
+    for (int e = skip; e > 0; e >>= 1) { if (e & 1) mult = mulmod(mult, base); base = mulmod(base, base); }
+    rng.x = mulmod(rng.x, mult);
+
+    uint8_t* col = blocks + (size_t)MMGEN_BLOCKS_PER_CHUNK * outChunk + 384 * t;
+    const float* cbw = bw + (size_t)MMGEN_BIOME_WEIGHTS_SIZE * chunk + t;
+    const int biome = random_biome(cbw, 256, rng.u01());
+    float rand = rng.u01();
+    for (int g = 0; g < kDecoCount[biome]; ++g) {
+        const DecoGen& gen = kDecoGens[biome][g];
+        if ((rand -= gen.chance) < 0.f) {
+            try_place_decorator(col, (int)hf[(size_t)256 * chunk + t] + 1, gen);
+            break;
+        }
+    }
+    for (int k = 0; k < used; ++k) {
+        float bottomRand = rng.u01();
+        float topRand = rng.u01();
+        const int cb = ccl[k].bottom_biome;
+        // placedBottom / placedTop are never set in the reference: every gen whose cumulative chance is passed fires
+        for (int g = 0; g < kCaveDecoCount[cb]; ++g) {
+            const DecoGen& gen = kCaveDecoGens[cb][g];
+            if (gen.fromCeiling) { if ((topRand -= gen.chance) < 0.f) try_place_decorator(col, ccl[k].end, gen); }
+            else { if ((bottomRand -= gen.chance) < 0.f) try_place_decorator(col, ccl[k].start + 1, gen); }
+        }
+    }
+}
+
+// Test probe: rasterise ONE placement into a box (255 = not claimed), order z, x, y (y fastest).
+__global__ void __launch_bounds__(256)
+k_feature_box(int isCave, int feature, int fx, int fy, int fz, int layerHeight, int bx, int by, int bz, int sx, int sy, int sz, uint8_t* __restrict__ out)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= sx * sy * sz) return;
+    const int y = i % sy, x = (i / sy) % sx, z = i / (sy * sx);
+    uint8_t b = 0;
+    const bool placed = isCave ? place_cave_feature(feature, fx, fy, fz, layerHeight, bx + x, by + y, bz + z, b)
+                               : place_feature(feature, fx, fy, fz, bx + x, by + y, bz + z, b);
+    out[i] = placed ? b : 255;
+}
+
+}  // namespace mm
+
+namespace mmk {
+
+int launch_feature_box(int isCave, int feature, const int* fpos, int layerHeight, const int* boxMin, const int* boxSize, uint8_t* out, hipStream_t s)
+{
+    const int n = boxSize[0] * boxSize[1] * boxSize[2];
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(mm::k_feature_box, dim3((n + 255) / 256), dim3(256), 0, s, isCave, feature, fpos[0], fpos[1], fpos[2], layerHeight,
+                       boxMin[0], boxMin[1], boxMin[2], boxSize[0], boxSize[1], boxSize[2], out);
+    return (int)hipGetLastError();
+}
+
+int launch_feature_placements(const float* hf, const float* bw, const float* layers, const mmgen_cave_layer* cl, const int32_t* pos, int n,
+                              mmgen_feature_placement* fp, mmgen_cave_feature_placement* cfp, int* counts, const int* chunkList, hipStream_t s)
+{
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(mm::k_feature_placements, dim3(n), dim3(256), 0, s, hf, bw, layers, cl, (const int2*)pos, fp, cfp, counts, chunkList);
+    return (int)hipGetLastError();
+}
+
+int launch_gather_placements(const mmgen_feature_placement* fp, const mmgen_cave_feature_placement* cfp, const int* counts, const int* target,
+                             int nOut, int gridW, int gridH, mmgen_feature_placement* gfp, mmgen_cave_feature_placement* gcfp, int* bounds,
+                             hipStream_t s)
+{
+    if (nOut <= 0) return 0;
+    hipLaunchKernelGGL(mm::k_gather_placements, dim3(nOut), dim3(256), 0, s, fp, cfp, counts, target, gridW, gridH, gfp, gcfp, bounds);
+    return (int)hipGetLastError();
+}
+
+int launch_apply_features(uint8_t* blocks, const int32_t* pos, int n, const mmgen_feature_placement* gfp, const mmgen_cave_feature_placement* gcfp,
+                          const int* bounds, const int* srcIdx, hipStream_t s)
+{
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(mm::k_apply_features, dim3(n * 256), dim3(384), 0, s, blocks, (const int2*)pos, gfp, gcfp, bounds, srcIdx);
+    return (int)hipGetLastError();
+}
+
+int launch_decorators(uint8_t* blocks, const float* hf, const float* bw, const mmgen_cave_layer* cl, const int32_t* pos, int n, const int* srcIdx, hipStream_t s)
+{
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(mm::k_decorators, dim3(n), dim3(256), 0, s, blocks, hf, bw, cl, (const int2*)pos, srcIdx);
+    return (int)hipGetLastError();
+}
+
+}  // namespace mmk

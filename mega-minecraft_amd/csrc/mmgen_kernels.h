@@ -8,9 +8,10 @@ namespace mmk {
 int launch_heightfield(const int32_t* pos, int n, float* hf, float* bw, float* gathered /*nullable*/, hipStream_t s);
 int launch_layers(const float* gathered, const float* bw, const int32_t* pos, int n, float* layers, hipStream_t s);
 int launch_fix_backward(float* layers, int n, hipStream_t s);
-int launch_caves(const float* hf, const float* bw, const int32_t* pos, int n, mmgen_cave_layer* caveLayers, float* colInfoScratch, hipStream_t s);
+int launch_caves(const float* hf, const float* bw, const int32_t* pos, int n, mmgen_cave_layer* caveLayers, float* colInfoScratch,
+                 const int* chunkList /*nullable: chunks to process*/, hipStream_t s);
 int launch_fill(const float* hf, const float* bw, const float* layers, const mmgen_cave_layer* caveLayers, const int32_t* pos, int n,
-                uint8_t* blocks, hipStream_t s);
+                uint8_t* blocks, const int* srcIdx /*nullable: input chunk of each output chunk*/, hipStream_t s);
 int launch_probe(int fn, const float* in, int n, float* out, hipStream_t s);
 void profile_enable(bool on);
 int profile_num_kernels();

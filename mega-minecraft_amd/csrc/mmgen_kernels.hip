@@ -147,9 +147,9 @@ __global__ void __launch_bounds__(256) k_fix_backward(float* __restrict__ layers
 //   k_cave_biomes  : per (layer slot, column) cave-biome pair, lanes = columns so that occupied slots pack densely
 // =========================================================================================================
 __global__ void __launch_bounds__(256)
-k_cave_columns(const float* __restrict__ bw, const int2* __restrict__ chunkPos, float2* __restrict__ colInfo)
+k_cave_columns(const float* __restrict__ bw, const int2* __restrict__ chunkPos, float2* __restrict__ colInfo, const int* __restrict__ chunkList)
 {
-    const int chunk = blockIdx.x, t = threadIdx.x;
+    const int chunk = chunkList ? chunkList[blockIdx.x] : blockIdx.x, t = threadIdx.x;
     const int2 cp = chunkPos[chunk];
     const int wx = cp.x + (t & 15), wz = cp.y + (t >> 4);
 
@@ -199,14 +199,14 @@ struct CellTile {
 
 __global__ void __launch_bounds__(384)
 k_cave_voxels(const float* __restrict__ hf, const float2* __restrict__ colInfo, const int2* __restrict__ chunkPos,
-              mmgen_cave_layer* __restrict__ caveLayers)
+              mmgen_cave_layer* __restrict__ caveLayers, const int* __restrict__ chunkList)
 {
     __shared__ float s_cells[3 * CELL_N];
     __shared__ unsigned long long s_mask[6];
     __shared__ int s_layers[3 * MMGEN_MAX_CAVE_LAYERS_PER_COLUMN];
 
-    const int col = blockIdx.x;            // chunk * 256 + idx2d
-    const int chunk = col >> 8, idx2d = col & 255;
+    const int chunk = chunkList ? chunkList[blockIdx.x >> 8] : (int)(blockIdx.x >> 8), idx2d = blockIdx.x & 255;
+    const int col = chunk * 256 + idx2d;
     const int y = threadIdx.x;
     const int2 cp = chunkPos[chunk];
     const int wx = cp.x + (idx2d & 15), wz = cp.y + (idx2d >> 4);
@@ -283,9 +283,10 @@ k_cave_voxels(const float* __restrict__ hf, const float2* __restrict__ colInfo, 
 }
 
 __global__ void __launch_bounds__(256)
-k_cave_biomes(const float* __restrict__ hf, const int2* __restrict__ chunkPos, mmgen_cave_layer* __restrict__ caveLayers)
+k_cave_biomes(const float* __restrict__ hf, const int2* __restrict__ chunkPos, mmgen_cave_layer* __restrict__ caveLayers,
+              const int* __restrict__ chunkList)
 {
-    const int chunk = blockIdx.x >> 5, k = blockIdx.x & 31;
+    const int chunk = chunkList ? chunkList[blockIdx.x >> 5] : (int)(blockIdx.x >> 5), k = blockIdx.x & 31;
     const int t = threadIdx.x;
     mmgen_cave_layer* L = caveLayers + ((size_t)256 * chunk + t) * MMGEN_MAX_CAVE_LAYERS_PER_COLUMN + k;
     const int start = L->start;
@@ -363,14 +364,16 @@ MM_DEV uint8_t place_block(const float* s_bw, const float* s_lh, const mmgen_cav
 
 __global__ void __launch_bounds__(384)
 k_fill(const float* __restrict__ hf, const float* __restrict__ bw, const float* __restrict__ layers,
-       const mmgen_cave_layer* __restrict__ caveLayers, const int2* __restrict__ chunkPos, uint8_t* __restrict__ blocks)
+       const mmgen_cave_layer* __restrict__ caveLayers, const int2* __restrict__ chunkPos, uint8_t* __restrict__ blocks,
+       const int* __restrict__ srcIdx)
 {
     __shared__ float s_bw[MMGEN_NUM_BIOMES];
     __shared__ float s_lh[MMGEN_NUM_MATERIALS + 1];
     __shared__ mmgen_cave_layer s_cl[MMGEN_MAX_CAVE_LAYERS_PER_COLUMN];
 
-    const int col = blockIdx.x;
-    const int chunk = col >> 8, idx2d = col & 255;
+    const int outChunk = blockIdx.x >> 8, idx2d = blockIdx.x & 255;
+    const int chunk = srcIdx ? srcIdx[outChunk] : outChunk;        // inputs are read at `chunk`, blocks are written densely at outChunk
+    const int col = chunk * 256 + idx2d;
     const int y = threadIdx.x;
 
     if (y < MMGEN_NUM_BIOMES) s_bw[y] = bw[(size_t)MMGEN_BIOME_WEIGHTS_SIZE * chunk + 256 * y + idx2d];
@@ -383,7 +386,7 @@ k_fill(const float* __restrict__ hf, const float* __restrict__ bw, const float* 
     const int2 cp = chunkPos[chunk];
     const int wx = cp.x + (idx2d & 15), wz = cp.y + (idx2d >> 4);
     const uint8_t block = place_block(s_bw, s_lh, s_cl, y, s_lh[MMGEN_NUM_MATERIALS], wx, wz);
-    blocks[(size_t)MMGEN_BLOCKS_PER_CHUNK * chunk + 384 * idx2d + y] = block;
+    blocks[(size_t)MMGEN_BLOCKS_PER_CHUNK * outChunk + 384 * idx2d + y] = block;
 }
 
 
@@ -502,20 +505,21 @@ int launch_fix_backward(float* layers, int n, hipStream_t s)
     return 0;
 }
 
-int launch_caves(const float* hf, const float* bw, const int32_t* pos, int n, mmgen_cave_layer* caveLayers, float* colInfoScratch, hipStream_t s)
+int launch_caves(const float* hf, const float* bw, const int32_t* pos, int n, mmgen_cave_layer* caveLayers, float* colInfoScratch,
+                 const int* chunkList, hipStream_t s)
 {
     if (n <= 0) return 0;
-    LAUNCH(KID_CAVE_COLUMNS, mm::k_cave_columns, dim3(n), dim3(256), s, bw, (const int2*)pos, (float2*)colInfoScratch);
-    LAUNCH(KID_CAVE_VOXELS, mm::k_cave_voxels, dim3(n * 256), dim3(384), s, hf, (const float2*)colInfoScratch, (const int2*)pos, caveLayers);
-    LAUNCH(KID_CAVE_BIOMES, mm::k_cave_biomes, dim3(n * 32), dim3(256), s, hf, (const int2*)pos, caveLayers);
+    LAUNCH(KID_CAVE_COLUMNS, mm::k_cave_columns, dim3(n), dim3(256), s, bw, (const int2*)pos, (float2*)colInfoScratch, chunkList);
+    LAUNCH(KID_CAVE_VOXELS, mm::k_cave_voxels, dim3(n * 256), dim3(384), s, hf, (const float2*)colInfoScratch, (const int2*)pos, caveLayers, chunkList);
+    LAUNCH(KID_CAVE_BIOMES, mm::k_cave_biomes, dim3(n * 32), dim3(256), s, hf, (const int2*)pos, caveLayers, chunkList);
     return 0;
 }
 
 int launch_fill(const float* hf, const float* bw, const float* layers, const mmgen_cave_layer* caveLayers, const int32_t* pos, int n,
-                uint8_t* blocks, hipStream_t s)
+                uint8_t* blocks, const int* srcIdx, hipStream_t s)
 {
     if (n <= 0) return 0;
-    LAUNCH(KID_FILL, mm::k_fill, dim3(n * 256), dim3(384), s, hf, bw, layers, caveLayers, (const int2*)pos, blocks);
+    LAUNCH(KID_FILL, mm::k_fill, dim3(n * 256), dim3(384), s, hf, bw, layers, caveLayers, (const int2*)pos, blocks, srcIdx);
     return 0;
 }
 

@@ -1,0 +1,267 @@
+// mmgen region pipeline (host orchestration, C++): generates a rectangle of chunks with every stage resident in HBM.
+//
+// This is the device-resident replacement of the reference's per-stage host round trips (Terrain::tick dispatch,
+// src/terrain/terrain.cpp:643-937 → Chunk::generateHeightfields / gatherHeightfield / generateLayers / erodeZone /
+// generateCaves / generateFeaturePlacements / gatherFeaturePlacements / fill, src/terrain/chunk.cu).  Same stages, same
+// order, same results; what changes is where the data lives between stages.
+//
+// Region semantics (canonical "world" definition): for the requested rectangle R of chunks
+//   P = R grown by the 3-chunk feature ring (chunk.cu:1158-1167) when features are on;
+//   Z = the 12-aligned zones intersecting P (zonePosFromChunkPos, terrain.cpp:259-262);
+//   A = union of the zones' 24x24 gathered areas (terrain.cpp:471-522) — heightfield + RAW layers are generated on A;
+//   each zone is eroded from RAW planes (never from a neighbour zone's eroded result), the centre 12x12 is kept;
+//   caves + placements are generated on P (or on the caller-selected subset when ring cells arrive from another GPU),
+//   gather / fill / features / decorators on R.
+#include <hip/hip_runtime.h>
+#include <vector>
+#include <cstdio>
+#include <cstring>
+#include "../../include/mmgen.h"
+#include "mmgen_kernels.h"
+#include "mmgen_erosion.h"
+#include "mmgen_features.h"
+
+namespace {
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes)
+    {
+        if (bytes <= cap) return 0;
+        if (p) { hipError_t e = hipFree(p); if (e != hipSuccess) return (int)e; p = nullptr; cap = 0; }
+        const size_t want = bytes + bytes / 8;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) return (int)e;
+        cap = want;
+        return 0;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    template <class T> T* as() const { return (T*)p; }
+};
+
+inline int floordiv(int a, int b) { int q = a / b; return (a % b != 0 && ((a < 0) != (b < 0))) ? q - 1 : q; }
+
+__global__ void __launch_bounds__(256) k_select(const float* __restrict__ src, const int* __restrict__ idx, float* __restrict__ dst, int floatsPerChunk)
+{
+    const int i = blockIdx.x;
+    const int o = blockIdx.y * 256 + threadIdx.x;
+    if (o < floatsPerChunk) dst[(size_t)floatsPerChunk * i + o] = src[(size_t)floatsPerChunk * idx[i] + o];
+}
+
+}  // namespace
+
+struct mmgen_region {
+    int cx0 = 0, cz0 = 0, nx = 0, nz = 0;
+    unsigned flags = 0;
+    int ring = 0, px0 = 0, pz0 = 0, pnx = 0, pnz = 0, np = 0;
+    int ax0 = 0, az0 = 0, anx = 0, anz = 0, na = 0;
+    int nCompute = 0, nZones = 0;
+    bool began = false;
+    DevBuf posA, hfA, bwA, gathA, layersA;
+    DevBuf posP, hfP, bwP, layersP, caveP, colInfo, fp, cfp, counts;
+    DevBuf selAP, zoneIdx, zoneIdxOut, gathered, erodeWork, erodeState, computeList, targets, gfp, gcfp, bounds;
+    int lastMaxPasses = 0;
+    ~mmgen_region()
+    {
+        DevBuf* all[] = {&posA, &hfA, &bwA, &gathA, &layersA, &posP, &hfP, &bwP, &layersP, &caveP, &colInfo, &fp, &cfp, &counts, &selAP, &zoneIdx,
+                         &zoneIdxOut, &gathered, &erodeWork, &erodeState, &computeList, &targets, &gfp, &gcfp, &bounds};
+        for (DevBuf* b : all) b->release();
+    }
+};
+
+#define CK(expr) do { int e_ = (int)(expr); if (e_) return e_; } while (0)
+
+extern "C" {
+
+int mmgen_region_create(mmgen_region** out)
+{
+    if (!out) return (int)hipErrorInvalidValue;
+    *out = new mmgen_region();
+    return 0;
+}
+
+void mmgen_region_destroy(mmgen_region* r) { delete r; }
+
+int mmgen_region_begin(mmgen_region* r, int cx0, int cz0, int nx, int nz, unsigned flags, const uint8_t* h_local_mask, void* stream)
+{
+    if (!r || nx <= 0 || nz <= 0) return (int)hipErrorInvalidValue;
+    hipStream_t s = (hipStream_t)stream;
+    const bool erosion = flags & MMGEN_REGION_EROSION, features = flags & MMGEN_REGION_FEATURES;
+    r->cx0 = cx0; r->cz0 = cz0; r->nx = nx; r->nz = nz; r->flags = flags;
+    r->ring = features ? 3 : 0;
+    r->px0 = cx0 - r->ring; r->pz0 = cz0 - r->ring; r->pnx = nx + 2 * r->ring; r->pnz = nz + 2 * r->ring; r->np = r->pnx * r->pnz;
+    const int np = r->np;
+
+    std::vector<int> zonesX, zonesZ;
+    if (erosion) {
+        const int zx0 = floordiv(r->px0, MMGEN_ZONE_SIZE) * MMGEN_ZONE_SIZE, zz0 = floordiv(r->pz0, MMGEN_ZONE_SIZE) * MMGEN_ZONE_SIZE;
+        const int zx1 = floordiv(r->px0 + r->pnx - 1, MMGEN_ZONE_SIZE) * MMGEN_ZONE_SIZE, zz1 = floordiv(r->pz0 + r->pnz - 1, MMGEN_ZONE_SIZE) * MMGEN_ZONE_SIZE;
+        r->ax0 = zx0 - 6; r->az0 = zz0 - 6; r->anx = (zx1 - zx0) + 24; r->anz = (zz1 - zz0) + 24;
+        for (int zz = zz0; zz <= zz1; zz += MMGEN_ZONE_SIZE) for (int zx = zx0; zx <= zx1; zx += MMGEN_ZONE_SIZE) { zonesX.push_back(zx); zonesZ.push_back(zz); }
+    } else {
+        r->ax0 = r->px0; r->az0 = r->pz0; r->anx = r->pnx; r->anz = r->pnz;
+    }
+    r->na = r->anx * r->anz;
+    r->nZones = (int)zonesX.size();
+    const int na = r->na;
+
+    // ---- host-built index tables
+    std::vector<int32_t> posA(2 * (size_t)na), selAP(np), computeList;
+    for (int z = 0; z < r->anz; ++z) for (int x = 0; x < r->anx; ++x) { posA[2 * (x + r->anx * z)] = (r->ax0 + x) * 16; posA[2 * (x + r->anx * z) + 1] = (r->az0 + z) * 16; }
+    for (int z = 0; z < r->pnz; ++z) for (int x = 0; x < r->pnx; ++x) selAP[x + r->pnx * z] = (r->px0 + x - r->ax0) + r->anx * (r->pz0 + z - r->az0);
+    for (int i = 0; i < np; ++i) {
+        const int x = i % r->pnx - r->ring, z = i / r->pnx - r->ring;
+        const bool inR = x >= 0 && x < nx && z >= 0 && z < nz;
+        if (inR || !h_local_mask || h_local_mask[i]) computeList.push_back(i);
+    }
+    r->nCompute = (int)computeList.size();
+
+    CK(r->posA.ensure(sizeof(int32_t) * 2 * na));
+    CK(r->hfA.ensure(sizeof(float) * 256 * (size_t)na));
+    CK(r->bwA.ensure(sizeof(float) * MMGEN_BIOME_WEIGHTS_SIZE * (size_t)na));
+    CK(r->gathA.ensure(sizeof(float) * MMGEN_GATHERED_HEIGHTFIELD_SIZE * (size_t)na));
+    CK(r->layersA.ensure(sizeof(float) * MMGEN_LAYERS_SIZE * (size_t)na));
+    CK(r->selAP.ensure(sizeof(int) * np));
+    CK(r->computeList.ensure(sizeof(int) * np));
+    CK(r->caveP.ensure(sizeof(mmgen_cave_layer) * MMGEN_CAVE_LAYERS_SIZE * (size_t)np));
+    CK(r->colInfo.ensure(sizeof(float) * 2 * 256 * (size_t)np));
+    CK(hipMemcpyAsync(r->posA.p, posA.data(), sizeof(int32_t) * 2 * na, hipMemcpyHostToDevice, s));
+    CK(hipMemcpyAsync(r->selAP.p, selAP.data(), sizeof(int) * np, hipMemcpyHostToDevice, s));
+    CK(hipMemcpyAsync(r->computeList.p, computeList.data(), sizeof(int) * r->nCompute, hipMemcpyHostToDevice, s));
+    CK(hipStreamSynchronize(s));     // host vectors go out of scope
+
+    // ---- K1 + K2 on the raw area A
+    CK(mmk::launch_heightfield(r->posA.as<int32_t>(), na, r->hfA.as<float>(), r->bwA.as<float>(), r->gathA.as<float>(), s));
+    CK(mmk::launch_layers(r->gathA.as<float>(), r->bwA.as<float>(), r->posA.as<int32_t>(), na, r->layersA.as<float>(), s));
+
+    float *hfP, *bwP, *layersP;
+    int32_t* posP;
+    if (erosion) {
+        // P-grid copies (eroded planes are scattered into layersP; layersA stays raw for the other zones' padding)
+        CK(r->posP.ensure(sizeof(int32_t) * 2 * np));
+        CK(r->hfP.ensure(sizeof(float) * 256 * (size_t)np));
+        CK(r->bwP.ensure(sizeof(float) * MMGEN_BIOME_WEIGHTS_SIZE * (size_t)np));
+        CK(r->layersP.ensure(sizeof(float) * MMGEN_LAYERS_SIZE * (size_t)np));
+        hfP = r->hfP.as<float>(); bwP = r->bwP.as<float>(); layersP = r->layersP.as<float>(); posP = r->posP.as<int32_t>();
+        const int* sel = r->selAP.as<int>();
+        hipLaunchKernelGGL(k_select, dim3(np, 1), dim3(256), 0, s, (const float*)r->posA.p, sel, (float*)posP, 2);
+        hipLaunchKernelGGL(k_select, dim3(np, 1), dim3(256), 0, s, r->hfA.as<float>(), sel, hfP, 256);
+        hipLaunchKernelGGL(k_select, dim3(np, MMGEN_BIOME_WEIGHTS_SIZE / 256), dim3(256), 0, s, r->bwA.as<float>(), sel, bwP, MMGEN_BIOME_WEIGHTS_SIZE);
+        hipLaunchKernelGGL(k_select, dim3(np, MMGEN_LAYERS_SIZE / 256), dim3(256), 0, s, r->layersA.as<float>(), sel, layersP, MMGEN_LAYERS_SIZE);
+        CK(hipGetLastError());
+
+        // ---- E1 / K3 / E3 per zone batch
+        const int Z = r->nZones;
+        const int batch = Z < 32 ? Z : 32;
+        std::vector<int> zi((size_t)Z * 576), zo((size_t)Z * 144);
+        for (int z = 0; z < Z; ++z) {
+            for (int cz = 0; cz < 24; ++cz) for (int cx = 0; cx < 24; ++cx)
+                zi[(size_t)z * 576 + cx + 24 * cz] = (zonesX[z] - 6 + cx - r->ax0) + r->anx * (zonesZ[z] - 6 + cz - r->az0);
+            for (int cz = 0; cz < 12; ++cz) for (int cx = 0; cx < 12; ++cx) {
+                const int gx = zonesX[z] + cx - r->px0, gz = zonesZ[z] + cz - r->pz0;
+                zo[(size_t)z * 144 + cx + 12 * cz] = (gx >= 0 && gx < r->pnx && gz >= 0 && gz < r->pnz) ? gx + r->pnx * gz : -1;
+            }
+        }
+        CK(r->zoneIdx.ensure(sizeof(int) * zi.size()));
+        CK(r->zoneIdxOut.ensure(sizeof(int) * zo.size()));
+        CK(r->gathered.ensure(sizeof(float) * (size_t)MMGEN_GATHERED_LAYERS_SIZE * batch));
+        CK(r->erodeWork.ensure(mmk::erosion_work_bytes(batch)));
+        CK(r->erodeState.ensure(mmk::erosion_state_bytes(batch)));
+        CK(hipMemcpyAsync(r->zoneIdx.p, zi.data(), sizeof(int) * zi.size(), hipMemcpyHostToDevice, s));
+        CK(hipMemcpyAsync(r->zoneIdxOut.p, zo.data(), sizeof(int) * zo.size(), hipMemcpyHostToDevice, s));
+        CK(hipStreamSynchronize(s));
+        r->lastMaxPasses = 0;
+        for (int z0 = 0; z0 < Z; z0 += batch) {
+            const int nb = (Z - z0) < batch ? (Z - z0) : batch;
+            CK(mmk::erosion_gather(r->layersA.as<float>(), r->hfA.as<float>(), r->zoneIdx.as<int>() + (size_t)z0 * 576, nb, r->gathered.as<float>(),
+                                   (size_t)MMGEN_GATHERED_LAYERS_SIZE, s));
+            int mp = 0;
+            CK(mmk::erode_zones(r->gathered.as<float>(), (size_t)MMGEN_GATHERED_LAYERS_SIZE, nb, r->erodeWork.as<float>(),
+                                r->erodeState.as<mm::ErosionState>(), nullptr, 0, s, &mp, nullptr));
+            if (mp > r->lastMaxPasses) r->lastMaxPasses = mp;
+            CK(mmk::erosion_scatter(r->gathered.as<float>(), (size_t)MMGEN_GATHERED_LAYERS_SIZE, r->zoneIdxOut.as<int>() + (size_t)z0 * 144, nb, layersP, s));
+        }
+    } else {
+        hfP = r->hfA.as<float>(); bwP = r->bwA.as<float>(); layersP = r->layersA.as<float>(); posP = r->posA.as<int32_t>();
+    }
+
+    // ---- E3 fix-up, K4 caves, F1 placements
+    CK(mmk::launch_fix_backward(layersP, np, s));
+    const int* list = r->computeList.as<int>();
+    CK(mmk::launch_caves(hfP, bwP, posP, r->nCompute, r->caveP.as<mmgen_cave_layer>(), r->colInfo.as<float>(), list, s));
+    if (features) {
+        CK(r->fp.ensure(sizeof(mmgen_feature_placement) * MMGEN_FP_CAP * (size_t)np));
+        CK(r->cfp.ensure(sizeof(mmgen_cave_feature_placement) * MMGEN_CFP_CAP * (size_t)np));
+        CK(r->counts.ensure(sizeof(int) * 2 * np));
+        CK(hipMemsetAsync(r->counts.p, 0, sizeof(int) * 2 * np, s));
+        CK(mmk::launch_feature_placements(hfP, bwP, layersP, r->caveP.as<mmgen_cave_layer>(), posP, r->nCompute, r->fp.as<mmgen_feature_placement>(),
+                                          r->cfp.as<mmgen_cave_feature_placement>(), r->counts.as<int>(), list, s));
+    }
+    r->began = true;
+    return 0;
+}
+
+int mmgen_region_placement_buffers(mmgen_region* r, mmgen_feature_placement** d_fp, mmgen_cave_feature_placement** d_cfp, int32_t** d_counts,
+                                   int* grid_x0, int* grid_z0, int* grid_w, int* grid_h)
+{
+    if (!r || !r->began || !(r->flags & MMGEN_REGION_FEATURES)) return (int)hipErrorInvalidValue;
+    if (d_fp) *d_fp = r->fp.as<mmgen_feature_placement>();
+    if (d_cfp) *d_cfp = r->cfp.as<mmgen_cave_feature_placement>();
+    if (d_counts) *d_counts = r->counts.as<int32_t>();
+    if (grid_x0) *grid_x0 = r->px0;
+    if (grid_z0) *grid_z0 = r->pz0;
+    if (grid_w) *grid_w = r->pnx;
+    if (grid_h) *grid_h = r->pnz;
+    return 0;
+}
+
+int mmgen_region_finish(mmgen_region* r, uint8_t* d_blocks, float* d_heightfields, float* d_layers, mmgen_cave_layer* d_cave_layers, void* stream)
+{
+    if (!r || !r->began || !d_blocks) return (int)hipErrorInvalidValue;
+    hipStream_t s = (hipStream_t)stream;
+    const bool erosion = r->flags & MMGEN_REGION_EROSION, features = r->flags & MMGEN_REGION_FEATURES, decor = r->flags & MMGEN_REGION_DECORATORS;
+    const int nr = r->nx * r->nz;
+    float* hfP = erosion ? r->hfP.as<float>() : r->hfA.as<float>();
+    float* bwP = erosion ? r->bwP.as<float>() : r->bwA.as<float>();
+    float* layersP = erosion ? r->layersP.as<float>() : r->layersA.as<float>();
+    int32_t* posP = erosion ? r->posP.as<int32_t>() : r->posA.as<int32_t>();
+
+    std::vector<int> targets(nr);
+    for (int z = 0; z < r->nz; ++z) for (int x = 0; x < r->nx; ++x) targets[x + r->nx * z] = (x + r->ring) + r->pnx * (z + r->ring);
+    CK(r->targets.ensure(sizeof(int) * nr));
+    CK(hipMemcpyAsync(r->targets.p, targets.data(), sizeof(int) * nr, hipMemcpyHostToDevice, s));
+    CK(hipStreamSynchronize(s));
+    const int* tgt = r->targets.as<int>();
+
+    CK(mmk::launch_fill(hfP, bwP, layersP, r->caveP.as<mmgen_cave_layer>(), posP, nr, d_blocks, tgt, s));
+    if (features) {
+        CK(r->gfp.ensure(sizeof(mmgen_feature_placement) * MMGEN_MAX_GATHERED_FEATURES_PER_CHUNK * (size_t)nr));
+        CK(r->gcfp.ensure(sizeof(mmgen_cave_feature_placement) * MMGEN_MAX_GATHERED_CAVE_FEATURES_PER_CHUNK * (size_t)nr));
+        CK(r->bounds.ensure(sizeof(int) * 4 * nr));
+        CK(mmk::launch_gather_placements(r->fp.as<mmgen_feature_placement>(), r->cfp.as<mmgen_cave_feature_placement>(), r->counts.as<int>(), tgt, nr,
+                                         r->pnx, r->pnz, r->gfp.as<mmgen_feature_placement>(), r->gcfp.as<mmgen_cave_feature_placement>(),
+                                         r->bounds.as<int>(), s));
+        CK(mmk::launch_apply_features(d_blocks, posP, nr, r->gfp.as<mmgen_feature_placement>(), r->gcfp.as<mmgen_cave_feature_placement>(),
+                                      r->bounds.as<int>(), tgt, s));
+    }
+    if (decor) CK(mmk::launch_decorators(d_blocks, hfP, bwP, r->caveP.as<mmgen_cave_layer>(), posP, nr, tgt, s));
+
+    if (d_heightfields) { hipLaunchKernelGGL(k_select, dim3(nr, 1), dim3(256), 0, s, hfP, tgt, d_heightfields, 256); }
+    if (d_layers) { hipLaunchKernelGGL(k_select, dim3(nr, MMGEN_LAYERS_SIZE / 256), dim3(256), 0, s, layersP, tgt, d_layers, MMGEN_LAYERS_SIZE); }
+    if (d_cave_layers) {
+        hipLaunchKernelGGL(k_select, dim3(nr, (3 * MMGEN_CAVE_LAYERS_SIZE) / 256), dim3(256), 0, s, (const float*)r->caveP.p, tgt, (float*)d_cave_layers,
+                           3 * MMGEN_CAVE_LAYERS_SIZE);
+    }
+    return (int)hipGetLastError();
+}
+
+int mmgen_region_generate(mmgen_region* r, int cx0, int cz0, int nx, int nz, unsigned flags, uint8_t* d_blocks, float* d_heightfields, void* stream)
+{
+    CK(mmgen_region_begin(r, cx0, cz0, nx, nz, flags, nullptr, stream));
+    return mmgen_region_finish(r, d_blocks, d_heightfields, nullptr, nullptr, stream);
+}
+
+int mmgen_region_last_erosion_passes(const mmgen_region* r) { return r ? r->lastMaxPasses : -1; }
+
+}  // extern "C"

@@ -136,6 +136,103 @@ class MMGen:
                                         self._p(cave_features), self._p(bounds), self._p(blocks), self._stream()), "mmgen_fill")
         return blocks
 
+    # ------------------------------------------------------------------ feature stages
+    def generate_feature_placements(self, hf, bw, layers, cave, pos):
+        """-> (fp [n,256,5] int32 view of 20-byte records, cfp [n,1024,6] int32 view of 24-byte records, counts [n,2])."""
+        n = pos.shape[0]
+        i32 = self.torch.int32
+        fp = self.torch.zeros((n, 256, 5), dtype=i32, device=self.device)
+        cfp = self.torch.zeros((n, 1024, 6), dtype=i32, device=self.device)
+        counts = self.torch.zeros((n, 2), dtype=i32, device=self.device)
+        self.lib.mmgen_generate_feature_placements.argtypes = [ctypes.c_void_p] * 5 + [ctypes.c_int] + [ctypes.c_void_p] * 4
+        self._check(self.lib.mmgen_generate_feature_placements(self._p(hf), self._p(bw), self._p(layers), self._p(cave), self._p(pos), n,
+                                                               self._p(fp), self._p(cfp), self._p(counts), self._stream()),
+                    "mmgen_generate_feature_placements")
+        return fp, cfp, counts
+
+    def gather_feature_placements(self, fp, cfp, counts, targets, grid_w, grid_h):
+        nt = targets.shape[0]
+        i32 = self.torch.int32
+        gfp = self.torch.zeros((nt, 2048, 5), dtype=i32, device=self.device)
+        gcfp = self.torch.zeros((nt, 4096, 6), dtype=i32, device=self.device)
+        bounds = self.torch.zeros((nt, 4), dtype=i32, device=self.device)
+        self.lib.mmgen_gather_feature_placements.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int] * 3 + [ctypes.c_void_p] * 4
+        self._check(self.lib.mmgen_gather_feature_placements(self._p(fp), self._p(cfp), self._p(counts), self._p(targets), nt, grid_w, grid_h,
+                                                             self._p(gfp), self._p(gcfp), self._p(bounds), self._stream()),
+                    "mmgen_gather_feature_placements")
+        return gfp, gcfp, bounds
+
+    def place_decorators(self, blocks, hf, bw, cave, pos):
+        self.lib.mmgen_place_decorators.argtypes = [ctypes.c_void_p] * 5 + [ctypes.c_int, ctypes.c_void_p]
+        self._check(self.lib.mmgen_place_decorators(self._p(blocks), self._p(hf), self._p(bw), self._p(cave), self._p(pos), pos.shape[0],
+                                                    self._stream()), "mmgen_place_decorators")
+        return blocks
+
+    # ------------------------------------------------------------------ region fast path (all stages, device resident)
+    EROSION, FEATURES, DECORATORS = 1, 2, 4
+
+    def _region(self):
+        if getattr(self, "_region_handle", None) is None:
+            h = ctypes.c_void_p()
+            self.lib.mmgen_region_create.argtypes = [ctypes.POINTER(ctypes.c_void_p)]
+            self._check(self.lib.mmgen_region_create(ctypes.byref(h)), "mmgen_region_create")
+            self._region_handle = h
+            vp, i32 = ctypes.c_void_p, ctypes.c_int
+            self.lib.mmgen_region_begin.argtypes = [vp, i32, i32, i32, i32, ctypes.c_uint, vp, vp]
+            self.lib.mmgen_region_finish.argtypes = [vp, vp, vp, vp, vp, vp]
+            self.lib.mmgen_region_placement_buffers.argtypes = [vp] + [ctypes.POINTER(vp)] * 3 + [ctypes.POINTER(i32)] * 4
+            self.lib.mmgen_region_last_erosion_passes.argtypes = [vp]
+        return self._region_handle
+
+    def region_begin(self, cx0, cz0, nx, nz, flags, local_mask=None):
+        mask = None
+        if local_mask is not None:
+            mask = (ctypes.c_uint8 * len(local_mask))(*[1 if m else 0 for m in local_mask])
+        self._check(self.lib.mmgen_region_begin(self._region(), cx0, cz0, nx, nz, flags, mask, self._stream()), "mmgen_region_begin")
+
+    def region_placement_buffers(self):
+        """Torch views (no copy) of the region's ring-extended placement grid: fp [cells,256,5], cfp [cells,1024,6], counts [cells,2]."""
+        vp, i32 = ctypes.c_void_p, ctypes.c_int
+        fp, cfp, cnt = vp(), vp(), vp()
+        x0, z0, w, h = i32(), i32(), i32(), i32()
+        self._check(self.lib.mmgen_region_placement_buffers(self._region(), ctypes.byref(fp), ctypes.byref(cfp), ctypes.byref(cnt), ctypes.byref(x0),
+                                                            ctypes.byref(z0), ctypes.byref(w), ctypes.byref(h)), "mmgen_region_placement_buffers")
+        cells = w.value * h.value
+        return dict(fp=self._view(fp.value, (cells, 256, 5)), cfp=self._view(cfp.value, (cells, 1024, 6)), counts=self._view(cnt.value, (cells, 2)),
+                    x0=x0.value, z0=z0.value, w=w.value, h=h.value)
+
+    def _view(self, ptr, shape):
+        """int32 torch tensor aliasing device memory owned by the library (valid until the next region_begin)."""
+        import numpy as np
+        n = int(np.prod(shape))
+
+        class _Holder:
+            __cuda_array_interface__ = {"shape": (n,), "typestr": "<i4", "data": (ptr, False), "version": 2}
+        return self.torch.as_tensor(_Holder(), device=self.device).view(*shape)
+
+    def region_finish(self, nx, nz, want=()):
+        n = nx * nz
+        t = self.torch
+        blocks = self._empty((n, BLOCKS), t.uint8)
+        hf = self._empty((n, HF), t.float32)
+        layers = self._empty((n, 20, 256), t.float32) if "layers" in want else None
+        cave = self._empty((n, 256, 32, 3), t.int32) if "cave" in want else None
+        self._check(self.lib.mmgen_region_finish(self._region(), self._p(blocks), self._p(hf), self._p(layers), self._p(cave), self._stream()),
+                    "mmgen_region_finish")
+        out = dict(blocks=blocks, hf=hf)
+        if layers is not None:
+            out["layers"] = layers
+        if cave is not None:
+            out["cave"] = cave
+        return out
+
+    def generate_region(self, cx0, cz0, nx, nz, erosion=True, features=True, decorators=True, want=()):
+        flags = (self.EROSION if erosion else 0) | (self.FEATURES if features else 0) | (self.DECORATORS if decorators else 0)
+        self.region_begin(cx0, cz0, nx, nz, flags)
+        out = self.region_finish(nx, nz, want)
+        out["erosion_passes"] = self.lib.mmgen_region_last_erosion_passes(self._region())
+        return out
+
     # ------------------------------------------------------------------ config-2 pipeline (no erosion, no features)
     def generate_chunks_no_erosion(self, pos):
         """K1 -> K2 -> E3 fix-up (DEBUG_SKIP_EROSION semantics, chunk.cu:713-720) -> K4 -> K6; everything stays in HBM."""
@@ -156,4 +253,14 @@ class MMGen:
         out = self._empty((n, out_per_item), self.torch.float32)
         self.lib.mmgen_debug_probe.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
         self._check(self.lib.mmgen_debug_probe(self.PROBES[name], self._p(t), n, self._p(out), self._stream()), "mmgen_debug_probe")
+        return out.cpu().numpy()
+
+    def debug_feature_box(self, is_cave, feature, fpos, layer_height, box_min, box_size):
+        i3 = ctypes.c_int32 * 3
+        n = box_size[0] * box_size[1] * box_size[2]
+        out = self._empty((n,), self.torch.uint8)
+        self.lib.mmgen_debug_feature_box.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                                     ctypes.c_void_p, ctypes.c_void_p]
+        self._check(self.lib.mmgen_debug_feature_box(int(is_cave), feature, i3(*fpos), layer_height, i3(*box_min), i3(*box_size), self._p(out),
+                                                     self._stream()), "mmgen_debug_feature_box")
         return out.cpu().numpy()

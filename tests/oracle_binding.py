@@ -82,3 +82,14 @@ class Oracle:
         out = np.zeros(3, np.int64)
         self.lib.mmo_ub_counters(_p(out), int(reset))
         return dict(no_layer_found=int(out[0]), cave_layer_overflow=int(out[1]), decorator_out_of_range=int(out[2]))
+
+
+def feature_box(oracle, is_cave, feature, fpos, layer_height, box_min, box_size, can_replace=True):
+    i3 = ctypes.c_int * 3
+    n = box_size[0] * box_size[1] * box_size[2]
+    out = np.zeros(n, np.uint8)
+    if is_cave:
+        oracle.lib.mmo_place_cave_feature_box(feature, i3(*fpos), layer_height, int(can_replace), i3(*box_min), i3(*box_size), _p(out))
+    else:
+        oracle.lib.mmo_place_feature_box(feature, i3(*fpos), int(can_replace), i3(*box_min), i3(*box_size), _p(out))
+    return out

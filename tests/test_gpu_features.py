@@ -1,0 +1,97 @@
+"""GPU parity tests for the feature stages (F1 placements, F2 gather, L2 rasterisers, D1 decorators) and the full region
+pipeline (all stages, device resident) against the CPU oracle.  Bit-exact block ids is the bar."""
+import numpy as np
+import pytest
+from conftest import assert_bit_equal
+from oracle_binding import feature_box
+
+pytestmark = pytest.mark.gpu
+
+SURFACE_FEATURES = list(range(1, 21))     # SPHERE .. CACTUS (biome.hpp:117-158)
+CAVE_FEATURES = list(range(1, 10))        # TEST_GLOWSTONE_PILLAR .. AMBER_FUNGUS (biome.hpp:162-177)
+
+
+def np_(t):
+    return t.cpu().numpy()
+
+
+@pytest.mark.parametrize("feature", SURFACE_FEATURES)
+def test_surface_feature_rasteriser(gen, oracle, feature):
+    """Every surface feature rasterised alone in an empty volume at fixed placements (SURVEY §8c fixture 11): the box of
+    claimed voxels and their block ids equal the oracle's for several placement positions (different per-feature RNG streams)."""
+    total = 0
+    for fpos in [(10, 100, -7), (-1234, 90, 777), (40001, 140, -39999), (5, 70, 5)]:
+        box_min = (fpos[0] - 28, fpos[1] - 8, fpos[2] - 28)
+        size = (57, 130, 57)
+        ref = feature_box(oracle, False, feature, fpos, 0, box_min, size)
+        got = gen.debug_feature_box(False, feature, fpos, 0, box_min, size)
+        assert_bit_equal(got, ref, f"feature {feature} at {fpos}")
+        total += int((ref != 255).sum())
+    assert total > 0, f"feature {feature} never placed a block in any probe: probe volume is wrong"
+
+
+@pytest.mark.parametrize("feature", CAVE_FEATURES)
+def test_cave_feature_rasteriser(gen, oracle, feature):
+    total = 0
+    for fpos, lh in [((3, 40, 9), 12), ((-500, 20, 321), 25), ((7777, 60, -8888), 17)]:
+        box_min = (fpos[0] - 16, fpos[1] - 16, fpos[2] - 16)
+        size = (33, lh + 40, 33)
+        ref = feature_box(oracle, True, feature, fpos, lh, box_min, size)
+        got = gen.debug_feature_box(True, feature, fpos, lh, box_min, size)
+        assert_bit_equal(got, ref, f"cave feature {feature} at {fpos}")
+        total += int((ref != 255).sum())
+    assert total > 0
+
+
+REGIONS = [
+    # (cx0, cz0, nx, nz): birch forest, jungle, redwood, crystals, coral reef, origin (tianzi pines), swamp, desert, icebergs, mushrooms
+    (3654, -2794, 1, 1), (1488, -1110, 2, 1), (3518, 2777, 1, 1), (2669, -2199, 1, 2), (-1268, -1773, 1, 1), (0, 0, 2, 2),
+    (1767, -1044, 1, 1), (3227, 152, 1, 1), (1602, 977, 1, 1), (3946, -3906, 1, 1), (-2105, -2470, 1, 1), (-88, -3971, 1, 1),
+]
+
+
+@pytest.mark.parametrize("region", REGIONS)
+def test_full_pipeline_region_matches_oracle(gen, oracle, region):
+    """All stages incl. erosion, feature placement + gather, feature rasterisation and decorators, device resident: block ids,
+    heightfields, eroded layers and cave layers of the region are bit-exact vs the oracle's region pipeline."""
+    cx0, cz0, nx, nz = region
+    ref = oracle.generate_region(cx0, cz0, nx, nz, erosion=True, features=True, decorators=True)
+    out = gen.generate_region(cx0, cz0, nx, nz, want=("layers", "cave"))
+    assert_bit_equal(np_(out["hf"]), ref["hf"], "heightfield")
+    assert_bit_equal(np_(out["layers"]), ref["layers"], "eroded layers")
+    assert_bit_equal(np_(out["cave"]), ref["cave"], "cave layers")
+    got = np_(out["blocks"])
+    if not np.array_equal(got, ref["blocks"]):
+        bad = np.argwhere(got != ref["blocks"])
+        c, i = bad[0]
+        raise AssertionError(f"{len(bad)} block ids differ; first: chunk {c} column {i // 384} y {i % 384}: got {got[c, i]} want {ref['blocks'][c, i]}")
+
+
+@pytest.mark.parametrize("flags", [(False, False, False), (True, False, False), (False, True, False), (False, False, True), (True, True, False)])
+def test_region_flag_combinations(gen, oracle, flags):
+    erosion, features, decorators = flags
+    ref = oracle.generate_region(1488, -1110, 1, 1, erosion=erosion, features=features, decorators=decorators)
+    out = gen.generate_region(1488, -1110, 1, 1, erosion=erosion, features=features, decorators=decorators)
+    assert_bit_equal(np_(out["blocks"]), ref["blocks"], f"blocks flags={flags}")
+
+
+def test_stage_level_features_match_region(gen, oracle):
+    """The per-stage C ABI (placements -> gather -> fill with lists -> decorators) on a 7x7 chunk grid gives the same centre chunk
+    as the oracle's region pipeline without erosion (stage-level drop-in path == region fast path)."""
+    import torch
+    cx, cz = 1488, -1110
+    coords = [(cx - 3 + x, cz - 3 + z) for z in range(7) for x in range(7)]
+    pos = gen.positions(coords)
+    hf, bw, g = gen.generate_heightfields(pos, gathered=True)
+    layers = gen.fix_backward_layers(gen.generate_layers(g, bw, pos))
+    cave = gen.generate_caves(hf, bw, pos)
+    fp, cfp, counts = gen.generate_feature_placements(hf, bw, layers, cave, pos)
+    target = torch.tensor([24], dtype=torch.int32, device=gen.device)
+    gfp, gcfp, bounds = gen.gather_feature_placements(fp, cfp, counts, target, 7, 7)
+    sel = slice(24, 25)
+    blocks = gen.fill(hf[sel].contiguous(), bw[sel].contiguous(), layers[sel].contiguous(), cave[sel].contiguous(), pos[sel].contiguous(),
+                      gfp, gcfp, bounds)
+    gen.place_decorators(blocks, hf[sel].contiguous(), bw[sel].contiguous(), cave[sel].contiguous(), pos[sel].contiguous())
+    ref = oracle.generate_region(cx, cz, 1, 1, erosion=False, features=True, decorators=True)
+    assert int(counts.sum()) > 0
+    assert_bit_equal(np_(blocks), ref["blocks"], "stage-level feature path")
