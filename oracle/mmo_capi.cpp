@@ -220,21 +220,41 @@ void mmo_ub_counters(long long* out3, int reset)
 // ---------------------------------------------------------------- region pipeline (the canonical "world" definition)
 // Generates chunks [cx0, cx0+nx) x [cz0, cz0+nz) (chunk coordinates), chunk-major output in z-major order (i = cx + nx*cz).
 // flags: bit0 erosion, bit1 features, bit2 decorators.  Without erosion only E3's fix-up runs (DEBUG_SKIP_EROSION semantics,
-// chunk.cu:713-720).  out_hf / out_layers / out_cave may be null.
+// chunk.cu:713-720).
 // Canonical region semantics: a zone's 6-chunk erosion padding always uses RAW (pre-erosion) layers; feature
 // placements of the 3-chunk ring around the region are generated from that ring's own eroded layers.
-void mmo_generate_region(int cx0, int cz0, int nx, int nz, int flags, uint8_t* out_blocks, float* out_hf, float* out_layers,
-                         void* out_cave, int nthreads, double* stage_seconds /*nullable, 8*/)
-{
-    const bool doErosion = flags & 1, doFeatures = flags & 2, doDecor = flags & 4;
-    const int ring = doFeatures ? 3 : 0;
-    const int px0 = cx0 - ring, pz0 = cz0 - ring, pnx = nx + 2 * ring, pnz = nz + 2 * ring;   // placement region P
-    const int np = pnx * pnz;
+//
+// Two phases so that the multi-process tiling tests can exchange ring placements between the phases:
+//   mmo_region_begin   heightfield .. placements on the ring-extended grid P (ring cells with local_mask == 0 are skipped)
+//   mmo_region_finish  gather + fill + decorators on the region, from the (possibly externally completed) placement arrays
+struct RegionCtx {
+    int cx0, cz0, nx, nz, flags, ring, px0, pz0, pnx, pnz, np;
+    std::vector<int> ppos;
+    std::vector<float> hf, bw, layers;
+    std::vector<CaveLayer> cave;
+};
 
-    std::vector<int> ppos(2 * np);
+void* mmo_region_create() { return new RegionCtx(); }
+void mmo_region_destroy(void* c) { delete (RegionCtx*)c; }
+
+// fp/cfp/counts: flat placement arrays over the P grid, capacities fpCap / cfpCap entries per cell (20 / 24 byte records)
+void mmo_region_begin(void* ctx, int cx0, int cz0, int nx, int nz, int flags, const uint8_t* local_mask, void* fp_out, void* cfp_out,
+                      int* counts_out, int fpCap, int cfpCap, int nthreads)
+{
+    RegionCtx& r = *(RegionCtx*)ctx;
+    const bool doErosion = flags & 1, doFeatures = flags & 2;
+    r.cx0 = cx0; r.cz0 = cz0; r.nx = nx; r.nz = nz; r.flags = flags;
+    r.ring = doFeatures ? 3 : 0;
+    const int ring = r.ring;
+    const int px0 = r.px0 = cx0 - ring, pz0 = r.pz0 = cz0 - ring, pnx = r.pnx = nx + 2 * ring, pnz = r.pnz = nz + 2 * ring;
+    const int np = r.np = pnx * pnz;
+
+    std::vector<int>& ppos = r.ppos;
+    ppos.assign(2 * np, 0);
     for (int z = 0; z < pnz; ++z) for (int x = 0; x < pnx; ++x) { ppos[2 * (x + pnx * z)] = (px0 + x) * 16; ppos[2 * (x + pnx * z) + 1] = (pz0 + z) * 16; }
-    std::vector<float> hf((size_t)256 * np), bw((size_t)6144 * np), layers((size_t)5120 * np);
-    std::vector<CaveLayer> cave((size_t)8192 * np);
+    std::vector<float>&hf = r.hf, &bw = r.bw, &layers = r.layers;
+    hf.assign((size_t)256 * np, 0.f); bw.assign((size_t)6144 * np, 0.f); layers.assign((size_t)5120 * np, 0.f);
+    r.cave.assign((size_t)8192 * np, CaveLayer{});
 
     if (!doErosion) {
         std::vector<float> gathered((size_t)324 * np);
@@ -286,16 +306,38 @@ void mmo_generate_region(int cx0, int cz0, int nx, int nz, int flags, uint8_t* o
         }
     }
     mmo_fix_backward_layers(np, layers.data());
-    mmo_caves(np, ppos.data(), hf.data(), bw.data(), cave.data(), nthreads);
 
-    std::vector<std::vector<FeaturePlacement>> fps(np);
-    std::vector<std::vector<CaveFeaturePlacement>> cfps(np);
-    if (doFeatures)
-        parallel_for(np, nthreads, [&](int i) {
+    // cells to compute locally: the region itself + ring cells selected by the mask (null = all)
+    std::vector<int> compute;
+    for (int i = 0; i < np; ++i) {
+        const int x = i % pnx - ring, z = i / pnx - ring;
+        const bool inR = x >= 0 && x < nx && z >= 0 && z < nz;
+        if (inR || !local_mask || local_mask[i]) compute.push_back(i);
+    }
+    parallel_for((int)compute.size(), nthreads, [&](int k) {
+        const int i = compute[k];
+        generateCaves(ivec2{ppos[2 * i], ppos[2 * i + 1]}, hf.data() + (size_t)256 * i, bw.data() + (size_t)6144 * i, r.cave.data() + (size_t)8192 * i);
+    });
+    if (doFeatures && counts_out) {
+        std::memset(counts_out, 0, sizeof(int) * 2 * np);
+        parallel_for((int)compute.size(), nthreads, [&](int k) {
+            const int i = compute[k];
+            std::vector<FeaturePlacement> a; std::vector<CaveFeaturePlacement> b;
             generateFeaturePlacements(ivec2{ppos[2 * i], ppos[2 * i + 1]}, hf.data() + (size_t)256 * i, bw.data() + (size_t)6144 * i,
-                                      layers.data() + (size_t)5120 * i, cave.data() + (size_t)8192 * i, fps[i], cfps[i]);
+                                      layers.data() + (size_t)5120 * i, r.cave.data() + (size_t)8192 * i, a, b);
+            counts_out[2 * i] = (int)a.size(); counts_out[2 * i + 1] = (int)b.size();
+            std::memcpy((FeaturePlacement*)fp_out + (size_t)fpCap * i, a.data(), sizeof(FeaturePlacement) * std::min((int)a.size(), fpCap));
+            std::memcpy((CaveFeaturePlacement*)cfp_out + (size_t)cfpCap * i, b.data(), sizeof(CaveFeaturePlacement) * std::min((int)b.size(), cfpCap));
         });
+    }
+}
 
+void mmo_region_finish(void* ctx, const void* fp_in, const void* cfp_in, const int* counts_in, int fpCap, int cfpCap, uint8_t* out_blocks,
+                       float* out_hf, float* out_layers, void* out_cave, int nthreads)
+{
+    RegionCtx& r = *(RegionCtx*)ctx;
+    const bool doFeatures = r.flags & 2, doDecor = r.flags & 4;
+    const int nx = r.nx, nz = r.nz, ring = r.ring, pnx = r.pnx;
     parallel_for(nx * nz, nthreads, [&](int i) {
         const int x = i % nx, z = i / nx;
         const int pi = (x + ring) + pnx * (z + ring);
@@ -303,19 +345,35 @@ void mmo_generate_region(int cx0, int cz0, int nx, int nz, int flags, uint8_t* o
         if (doFeatures)
             for (const ivec2& off : gatherFeaturePlacementsChunkOffsets) {
                 const int ni = (x + ring + off.x) + pnx * (z + ring + off.y);
-                gf.insert(gf.end(), fps[ni].begin(), fps[ni].end());
-                gc.insert(gc.end(), cfps[ni].begin(), cfps[ni].end());
+                const FeaturePlacement* a = (const FeaturePlacement*)fp_in + (size_t)fpCap * ni;
+                const CaveFeaturePlacement* b = (const CaveFeaturePlacement*)cfp_in + (size_t)cfpCap * ni;
+                gf.insert(gf.end(), a, a + std::min(counts_in[2 * ni], fpCap));
+                gc.insert(gc.end(), b, b + std::min(counts_in[2 * ni + 1], cfpCap));
             }
         Block* b = (Block*)out_blocks + (size_t)98304 * i;
-        ivec3 wp = {ppos[2 * pi], 0, ppos[2 * pi + 1]};
-        fillChunk(wp, hf.data() + (size_t)256 * pi, bw.data() + (size_t)6144 * pi, layers.data() + (size_t)5120 * pi, cave.data() + (size_t)8192 * pi,
+        ivec3 wp = {r.ppos[2 * pi], 0, r.ppos[2 * pi + 1]};
+        fillChunk(wp, r.hf.data() + (size_t)256 * pi, r.bw.data() + (size_t)6144 * pi, r.layers.data() + (size_t)5120 * pi, r.cave.data() + (size_t)8192 * pi,
                   gf.data(), (int)gf.size(), gc.data(), (int)gc.size(), b);
-        if (doDecor) placeDecorators(wp, hf.data() + (size_t)256 * pi, bw.data() + (size_t)6144 * pi, cave.data() + (size_t)8192 * pi, b);
-        if (out_hf) std::memcpy(out_hf + (size_t)256 * i, hf.data() + (size_t)256 * pi, 256 * sizeof(float));
-        if (out_layers) std::memcpy(out_layers + (size_t)5120 * i, layers.data() + (size_t)5120 * pi, 5120 * sizeof(float));
-        if (out_cave) std::memcpy((CaveLayer*)out_cave + (size_t)8192 * i, cave.data() + (size_t)8192 * pi, 8192 * sizeof(CaveLayer));
+        if (doDecor) placeDecorators(wp, r.hf.data() + (size_t)256 * pi, r.bw.data() + (size_t)6144 * pi, r.cave.data() + (size_t)8192 * pi, b);
+        if (out_hf) std::memcpy(out_hf + (size_t)256 * i, r.hf.data() + (size_t)256 * pi, 256 * sizeof(float));
+        if (out_layers) std::memcpy(out_layers + (size_t)5120 * i, r.layers.data() + (size_t)5120 * pi, 5120 * sizeof(float));
+        if (out_cave) std::memcpy((CaveLayer*)out_cave + (size_t)8192 * i, r.cave.data() + (size_t)8192 * pi, 8192 * sizeof(CaveLayer));
     });
+}
+
+void mmo_generate_region(int cx0, int cz0, int nx, int nz, int flags, uint8_t* out_blocks, float* out_hf, float* out_layers,
+                         void* out_cave, int nthreads, double* stage_seconds /*unused*/)
+{
     (void)stage_seconds;
+    RegionCtx r;
+    const int ring = (flags & 2) ? 3 : 0;
+    const size_t np = (size_t)(nx + 2 * ring) * (nz + 2 * ring);
+    const int fpCap = 256, cfpCap = 4096;
+    std::vector<FeaturePlacement> fp(flags & 2 ? np * fpCap : 0);
+    std::vector<CaveFeaturePlacement> cfp(flags & 2 ? np * cfpCap : 0);
+    std::vector<int> counts(2 * np, 0);
+    mmo_region_begin(&r, cx0, cz0, nx, nz, flags, nullptr, fp.data(), cfp.data(), counts.data(), fpCap, cfpCap, nthreads);
+    mmo_region_finish(&r, fp.data(), cfp.data(), counts.data(), fpCap, cfpCap, out_blocks, out_hf, out_layers, out_cave, nthreads);
 }
 
 }  // extern "C"

@@ -93,3 +93,42 @@ def feature_box(oracle, is_cave, feature, fpos, layer_height, box_min, box_size,
     else:
         oracle.lib.mmo_place_feature_box(feature, i3(*fpos), int(can_replace), i3(*box_min), i3(*box_size), _p(out))
     return out
+
+
+class OracleBackend:
+    """CPU stand-in for MMGen's region API (region_begin / region_placement_buffers / region_finish), backed by the oracle.
+    Used ONLY by the multi-process gloo tests of mega-minecraft_amd/distributed.py (the orchestration under test is the product's;
+    the per-stage compute here is the checker's)."""
+    FP_CAP, CFP_CAP = 256, 1024
+
+    def __init__(self, nthreads=4):
+        import torch
+        self.torch = torch
+        self.o = Oracle(nthreads)
+        self.ctx = ctypes.c_void_p(self.o.lib.mmo_region_create()) if False else None
+        self.o.lib.mmo_region_create.restype = ctypes.c_void_p
+        self.ctx = ctypes.c_void_p(self.o.lib.mmo_region_create())
+
+    def region_begin(self, cx0, cz0, nx, nz, flags, local_mask=None):
+        ring = 3 if flags & 2 else 0
+        self.cells = (nx + 2 * ring) * (nz + 2 * ring)
+        self.dims = (cx0 - ring, cz0 - ring, nx + 2 * ring, nz + 2 * ring)
+        t = self.torch
+        self.fp = t.zeros((self.cells, self.FP_CAP, 5), dtype=t.int32)
+        self.cfp = t.zeros((self.cells, self.CFP_CAP, 6), dtype=t.int32)
+        self.counts = t.zeros((self.cells, 2), dtype=t.int32)
+        mask = (ctypes.c_uint8 * len(local_mask))(*local_mask) if local_mask is not None else None
+        vp = ctypes.c_void_p
+        self.o.lib.mmo_region_begin(self.ctx, cx0, cz0, nx, nz, flags, mask, vp(self.fp.data_ptr()), vp(self.cfp.data_ptr()),
+                                    vp(self.counts.data_ptr()), self.FP_CAP, self.CFP_CAP, self.o.nthreads)
+
+    def region_placement_buffers(self):
+        return dict(fp=self.fp, cfp=self.cfp, counts=self.counts, x0=self.dims[0], z0=self.dims[1], w=self.dims[2], h=self.dims[3])
+
+    def region_finish(self, nx, nz, want=()):
+        n = nx * nz
+        blocks = np.zeros((n, 98304), np.uint8); hf = np.zeros((n, 256), np.float32)
+        vp = ctypes.c_void_p
+        self.o.lib.mmo_region_finish(self.ctx, vp(self.fp.data_ptr()), vp(self.cfp.data_ptr()), vp(self.counts.data_ptr()), self.FP_CAP, self.CFP_CAP,
+                                     _p(blocks), _p(hf), None, None, self.o.nthreads)
+        return dict(blocks=blocks, hf=hf)

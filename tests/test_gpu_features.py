@@ -95,3 +95,36 @@ def test_stage_level_features_match_region(gen, oracle):
     ref = oracle.generate_region(cx, cz, 1, 1, erosion=False, features=True, decorators=True)
     assert int(counts.sum()) > 0
     assert_bit_equal(np_(blocks), ref["blocks"], "stage-level feature path")
+
+
+def test_tiled_generation_with_halo_exchange_on_one_gpu(mmgen_pkg, oracle):
+    """The multi-GPU tiling path (masks: ring cells owned by a peer are NOT computed locally; placements arrive by exchange) on one
+    device: two regions play ranks 0 and 1 of a 2x1 layout, the exchange is done by hand with the product's exchange_plan, and the
+    stitched result equals the oracle's region.  (The RCCL transport itself is covered by the driver's multi-GPU bench run and, for the
+    protocol, by the gloo tests on CPU.)"""
+    import importlib
+    import torch
+    d = importlib.import_module("mega-minecraft_amd.distributed")
+    layout = d.TileLayout(1487, -1111, 2, 1, 2, 2)
+    gens = [mmgen_pkg.MMGen(0), mmgen_pkg.MMGen(0)]
+    bufs = []
+    for r in range(2):
+        cx0, cz0, nx, nz = layout.region(r)
+        mask = layout.local_mask(r)
+        assert 0 in mask
+        gens[r].region_begin(cx0, cz0, nx, nz, 7, mask)
+        bufs.append(gens[r].region_placement_buffers())
+    for r in range(2):
+        for peer, (recv_cells, _) in layout.exchange_plan(r).items():
+            send_cells = layout.exchange_plan(peer)[r][1]
+            ri = torch.tensor(recv_cells, dtype=torch.long, device="cuda"); si = torch.tensor(send_cells, dtype=torch.long, device="cuda")
+            for k in ("fp", "cfp", "counts"):
+                bufs[r][k][ri] = bufs[peer][k][si]
+    tiles = [np_(gens[r].region_finish(2, 2)["blocks"]) for r in range(2)]
+    ref = oracle.generate_region(1487, -1111, 4, 2, erosion=True, features=True, decorators=True)["blocks"]
+    world = np.zeros_like(ref)
+    for r in range(2):
+        for z in range(2):
+            for x in range(2):
+                world[(2 * r + x) + 4 * z] = tiles[r][x + 2 * z]
+    assert np.array_equal(world, ref)
