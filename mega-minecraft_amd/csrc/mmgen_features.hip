@@ -305,45 +305,116 @@ k_gather_placements(const mmgen_feature_placement* __restrict__ fp, const mmgen_
 
 // ---------------------------------------------------------------------------------------------------------
 // K6b — feature evaluation per voxel (second half of kernFill, chunk.cu:1438-1509).  One workgroup per column, lane = y.
+//
+// The reference makes every voxel walk the whole gathered list (up to 2048 + 4096 entries).  Here the workgroup first
+// filters the list for ITS column: a placement can only claim voxels within a fixed horizontal reach of its position
+// (every rasteriser starts with, or implies, such a bound — table below, validated against the oracle in
+// tests/test_oracle_stages.py::test_feature_reach_table), so the six waves compact the indices of the reachable entries
+// into LDS in list order (wave ballots + popcount prefix: a stable compaction, first match still wins) and the voxels then
+// scan a handful of candidates instead of hundreds of entries.  Entries skipped by the filter would have returned false.
 // ---------------------------------------------------------------------------------------------------------
+// Chebyshev reach max(|dx|, |dz|) in blocks beyond which placeFeature / placeCaveFeature cannot return true
+__device__ constexpr int kFeatureReach[MMGEN_NUM_FEATURES] = {
+    /*NONE*/ 0, /*SPHERE*/ 5, /*CORAL*/ 8, /*KELP*/ 0, /*ICEBERG*/ 40, /*ACACIA*/ 15, /*REDWOOD*/ 20, /*CYPRESS*/ 12, /*BIRCH*/ 8,
+    /*PINE_TREE*/ 6, /*PINE_SHRUB*/ 6, /*RAFFLESIA*/ 15, /*LARGE_JUNGLE*/ 15, /*SMALL_JUNGLE*/ 8, /*TINY_JUNGLE*/ 1,
+    /*MEDIUM_PURPLE_MUSHROOM*/ 8, /*PURPLE_MUSHROOM*/ 127, /*MEDIUM_CRYSTAL*/ 25, /*CRYSTAL*/ 25, /*PALM*/ 24, /*CACTUS*/ 5};
+__device__ constexpr int kCaveFeatureReach[MMGEN_NUM_CAVE_FEATURES] = {
+    /*NONE*/ 0, /*TEST pillars*/ 0, 0, /*CAVE_VINE*/ 0, /*GLOWSTONE_CLUSTER*/ 6, /*STORMLIGHT*/ 8, /*CEILING_STORMLIGHT*/ 8,
+    /*CRYSTAL_PILLAR*/ 7, /*WARPED_FUNGUS*/ 6, /*AMBER_FUNGUS*/ 4};
+
+#define CAND_CAP 1024
+
+// Stable block-wide compaction of the list entries that can reach column (wx, wz).  Returns the number of candidates, or -1
+// when they do not fit CAND_CAP (caller falls back to the full scan).  All 384 threads must call it.
+template <class Entry, int LIST_CAP, bool CAVE>
+MM_DEV int filter_column(const Entry* __restrict__ list, int wx, int wz, uint16_t* s_cand, int* s_wave /*[16]*/)
+{
+    const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+    int base = 0;
+    bool overflow = false;
+    for (int r0 = 0; r0 < LIST_CAP; r0 += 384) {
+        const int i = r0 + t;
+        int feat = 0, fx = 0, fz = 0;
+        if (i < LIST_CAP) { feat = list[i].feature; fx = list[i].pos[0]; fz = list[i].pos[2]; }
+        const bool isNone = feat == 0;
+        const unsigned long long noneMask = __ballot(isNone);
+        if (lane == 0) s_wave[8 + wave] = noneMask ? 64 * wave + (int)__builtin_ctzll(noneMask) : 1 << 20;
+        __syncthreads();
+        int firstNone = 1 << 20;
+#pragma unroll
+        for (int w = 0; w < 6; ++w) firstNone = imin(firstNone, s_wave[8 + w]);
+        const int reach = CAVE ? kCaveFeatureReach[feat] : kFeatureReach[feat];
+        const bool cand = t < firstNone && iabs(wx - fx) <= reach && iabs(wz - fz) <= reach;
+        const unsigned long long cm = __ballot(cand);
+        if (lane == 0) s_wave[wave] = __popcll(cm);
+        __syncthreads();
+        int before = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < 6; ++w) { const int c = s_wave[w]; if (w < wave) before += c; total += c; }
+        if (cand) {
+            const int slot = base + before + __popcll(cm & ((1ull << lane) - 1ull));
+            if (slot < CAND_CAP) s_cand[slot] = (uint16_t)i;
+        }
+        base += total;
+        if (base > CAND_CAP) overflow = true;
+        __syncthreads();                       // s_wave is reused by the next round
+        if (firstNone < 384) break;
+    }
+    return overflow ? -1 : base;
+}
+
 __global__ void __launch_bounds__(384)
 k_apply_features(uint8_t* __restrict__ blocks, const int2* __restrict__ chunkPos, const mmgen_feature_placement* __restrict__ gfp,
                  const mmgen_cave_feature_placement* __restrict__ gcfp, const int* __restrict__ bounds, const int* __restrict__ srcIdx)
 {
+    __shared__ uint16_t s_candS[CAND_CAP], s_candC[CAND_CAP];
+    __shared__ int s_wave[16];
     const int col = blockIdx.x;
     const int chunk = col >> 8, idx2d = col & 255;      // dense output / list index; positions are read at srcIdx[chunk]
     const int y = threadIdx.x;
     const int b0 = bounds[4 * chunk], b1 = bounds[4 * chunk + 1], b2 = bounds[4 * chunk + 2], b3 = bounds[4 * chunk + 3];
-    const bool inF = gfp && y >= b0 && y <= b1;
-    const bool inC = gcfp && y >= b2 && y <= b3;
-    if (!inF && !inC) return;
+    const bool doS = gfp && b0 <= b1, doC = gcfp && b2 <= b3;      // workgroup-uniform
+    if (!doS && !doC) return;
 
     const int2 cp = chunkPos[srcIdx ? srcIdx[chunk] : chunk];
     const int wx = cp.x + (idx2d & 15), wz = cp.y + (idx2d >> 4);
+    const mmgen_feature_placement* listS = gfp + (size_t)MMGEN_MAX_GATHERED_FEATURES_PER_CHUNK * chunk;
+    const mmgen_cave_feature_placement* listC = gcfp + (size_t)MMGEN_MAX_GATHERED_CAVE_FEATURES_PER_CHUNK * chunk;
+    int nS = 0, nC = 0;
+    if (doS) nS = filter_column<mmgen_feature_placement, MMGEN_MAX_GATHERED_FEATURES_PER_CHUNK, false>(listS, wx, wz, s_candS, s_wave);
+    if (doC) nC = filter_column<mmgen_cave_feature_placement, MMGEN_MAX_GATHERED_CAVE_FEATURES_PER_CHUNK, true>(listC, wx, wz, s_candC, s_wave);
+    if (nS == 0 && nC == 0) return;
+
+    const bool inF = doS && y >= b0 && y <= b1;
+    const bool inC = doC && y >= b2 && y <= b3;
+    if (!inF && !inC) return;
+
     uint8_t* bp = blocks + (size_t)MMGEN_BLOCKS_PER_CHUNK * chunk + 384 * idx2d + y;
     const uint8_t block = *bp;
     uint8_t fb = 0;
     bool placed = false;
     if (inF) {
-        const mmgen_feature_placement* list = gfp + (size_t)MMGEN_MAX_GATHERED_FEATURES_PER_CHUNK * chunk;
-        for (int i = 0; i < MMGEN_MAX_GATHERED_FEATURES_PER_CHUNK; ++i) {
-            const int feature = list[i].feature;
+        const int n = nS < 0 ? MMGEN_MAX_GATHERED_FEATURES_PER_CHUNK : nS;
+        for (int c = 0; c < n; ++c) {
+            const int i = nS < 0 ? c : (int)s_candS[c];
+            const int feature = listS[i].feature;
             if (feature == MMF_NONE) break;
-            if (block != MMB_AIR && !list[i].can_replace_blocks) continue;
-            const int fy = list[i].pos[1];
+            if (block != MMB_AIR && !listS[i].can_replace_blocks) continue;
+            const int fy = listS[i].pos[1];
             if (y < fy + kFeatureBounds[feature][0] || y > fy + kFeatureBounds[feature][1]) continue;
-            if (place_feature(feature, list[i].pos[0], fy, list[i].pos[2], wx, y, wz, fb)) { placed = true; break; }
+            if (place_feature(feature, listS[i].pos[0], fy, listS[i].pos[2], wx, y, wz, fb)) { placed = true; break; }
         }
     }
     if (inC && !placed) {
-        const mmgen_cave_feature_placement* list = gcfp + (size_t)MMGEN_MAX_GATHERED_CAVE_FEATURES_PER_CHUNK * chunk;
-        for (int i = 0; i < MMGEN_MAX_GATHERED_CAVE_FEATURES_PER_CHUNK; ++i) {
-            const int feature = list[i].feature;
+        const int n = nC < 0 ? MMGEN_MAX_GATHERED_CAVE_FEATURES_PER_CHUNK : nC;
+        for (int c = 0; c < n; ++c) {
+            const int i = nC < 0 ? c : (int)s_candC[c];
+            const int feature = listC[i].feature;
             if (feature == MMCF_NONE) break;
-            if (block != MMB_AIR && !list[i].can_replace_blocks) continue;
-            const int fy = list[i].pos[1], lh = list[i].layer_height;
+            if (block != MMB_AIR && !listC[i].can_replace_blocks) continue;
+            const int fy = listC[i].pos[1], lh = listC[i].layer_height;
             if (y < fy + kCaveFeatureBounds[feature][0] || y > fy + lh + kCaveFeatureBounds[feature][1]) continue;
-            if (place_cave_feature(feature, list[i].pos[0], fy, list[i].pos[2], lh, wx, y, wz, fb)) { placed = true; break; }
+            if (place_cave_feature(feature, listC[i].pos[0], fy, listC[i].pos[2], lh, wx, y, wz, fb)) { placed = true; break; }
         }
     }
     if (placed) *bp = fb;

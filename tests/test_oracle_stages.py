@@ -97,3 +97,38 @@ def test_erosion_properties(oracle):
     again = planes.copy()
     p2 = oracle.erode_zone_planes(again)
     assert p2 >= 8
+
+
+def test_feature_reach_table(oracle):
+    """The horizontal reach bounds the HIP fill uses to pre-filter placements per column (kFeatureReach / kCaveFeatureReach in
+    mmgen_features.hip) are upper bounds of what the rasterisers can claim: rasterise every feature for many placements in a box
+    wider than the reach and check nothing is claimed outside it."""
+    from oracle_binding import feature_box
+    reach = [0, 5, 8, 0, 40, 15, 20, 12, 8, 6, 6, 15, 15, 8, 1, 8, 127, 25, 25, 24, 5]
+    cave_reach = [0, 0, 0, 0, 6, 8, 8, 7, 6, 4]
+    src = open(__import__("os").path.join(__import__("conftest").ROOT, "mega-minecraft_amd", "csrc", "mmgen_features.hip")).read()
+    import re
+    nums = [int(v) for v in re.findall(r"\*/\s*(\d+)", src[src.index("kFeatureReach[MMGEN_NUM_FEATURES]"):src.index("kCaveFeatureReach[")])]
+    assert nums == reach, "test copy of the reach table is out of date"
+    rng = np.random.default_rng(11)
+    for f in range(1, 21):
+        if reach[f] >= 64:
+            continue
+        half = reach[f] + 6
+        for _ in range(6):
+            fpos = (int(rng.integers(-30000, 30000)), int(rng.integers(60, 125 if f in (2, 3) else 96 if f == 4 else 170)), int(rng.integers(-30000, 30000)))
+            size = (2 * half + 1, 150, 2 * half + 1)
+            box = feature_box(oracle, False, f, fpos, 0, (fpos[0] - half, fpos[1] - 10, fpos[2] - half), size).reshape(size[2], size[0], size[1])
+            zz, xx, _ = np.nonzero(box != 255)
+            if len(xx):
+                assert max(np.abs(xx - half).max(), np.abs(zz - half).max()) <= reach[f], f"feature {f} exceeds its reach"
+    for f in range(1, 10):
+        half = cave_reach[f] + 5
+        for _ in range(6):
+            fpos = (int(rng.integers(-30000, 30000)), int(rng.integers(10, 100)), int(rng.integers(-30000, 30000)))
+            lh = int(rng.integers(4, 30))
+            size = (2 * half + 1, lh + 40, 2 * half + 1)
+            box = feature_box(oracle, True, f, fpos, lh, (fpos[0] - half, fpos[1] - 20, fpos[2] - half), size).reshape(size[2], size[0], size[1])
+            zz, xx, _ = np.nonzero(box != 255)
+            if len(xx):
+                assert max(np.abs(xx - half).max(), np.abs(zz - half).max()) <= cave_reach[f], f"cave feature {f} exceeds its reach"
