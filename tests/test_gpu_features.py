@@ -128,3 +128,17 @@ def test_tiled_generation_with_halo_exchange_on_one_gpu(mmgen_pkg, oracle):
             for x in range(2):
                 world[(2 * r + x) + 4 * z] = tiles[r][x + 2 * z]
     assert np.array_equal(world, ref)
+
+
+def test_cpp_chunk_api_matches_region_path(mmgen_pkg):
+    """The C++ mirror of the reference's Chunk stage API (host/chunk.hpp: generateHeightfields, gatherHeightfield, generateLayers,
+    erodeZone, generateCaves, generateFeaturePlacements, gatherFeaturePlacements, fill) driven like Terrain::tick for one zone gives
+    the same blocks as the device-resident region path (the headless driver compares in-process; exit code 0 = identical)."""
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(mmgen_pkg.LIB_PATH), "mmgen_headless")
+    assert os.path.exists(exe), "build it with make -C mega-minecraft_amd/csrc"
+    for zone in (("0", "0"), ("1488", "-1116")):
+        r = subprocess.run([exe, *zone], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert "0 chunks differ" in r.stdout
