@@ -8,6 +8,12 @@
 
 namespace mm {
 
+// Code-size control: the voxel kernels evaluate simplex noise at 20-40 call sites; fully inlined that is 80-110 KB of straight-line
+// code per kernel, larger than the instruction cache.  MM_SIMPLEX_ATTR selects one shared (non-inlined) body per translation unit.
+#ifndef MM_SIMPLEX_ATTR
+#define MM_SIMPLEX_ATTR static __device__ __attribute__((noinline))
+#endif
+
 struct f2 { float x, y; };
 struct f3 { float x, y, z; };
 
@@ -20,7 +26,7 @@ MM_DEV f3 mk3(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; retu
 MM_DEV float mod289(float x) { return x - __builtin_floorf(x * (1.f / 289.f)) * 289.f; }
 MM_DEV float permute(float x) { return mod289(((x * 34.f) + 1.f) * x); }
 
-MM_DEV float simplex2(float vx, float vy)
+MM_SIMPLEX_ATTR float simplex2(float vx, float vy)
 {
     const float C0 = (float)0.211324865405187, C1 = (float)0.366025403784439;
     const float C2 = (float)-0.577350269189626, C3 = (float)0.024390243902439;
@@ -62,7 +68,7 @@ MM_DEV float simplex2(float vx, float vy)
     return 130.f * ((m0 * g0 + m1 * g1) + m2 * g2);
 }
 
-MM_DEV float simplex3(float vx, float vy, float vz)
+MM_SIMPLEX_ATTR float simplex3(float vx, float vy, float vz)
 {
     const float Cx = (float)(1.0 / 6.0), Cy = (float)(1.0 / 3.0);
 
@@ -177,7 +183,7 @@ MM_DEV f2 simplex2from2(float x, float y) { return mk2(simplex2(x, y), simplex2(
 // ---------------------------------------------------------------------------------------------------------
 // sin hashes (rng.hpp:102-155)
 // ---------------------------------------------------------------------------------------------------------
-MM_DEV float hash_unit(float t) { return fract(sinf_(t) * 39021.426f); }
+MM_SIMPLEX_ATTR float hash_unit(float t) { return fract(sinf_(t) * 39021.426f); }
 MM_DEV float rand1from2(float x, float y) { return hash_unit(x * 238.68f + y * 491.28f); }
 MM_DEV float rand1from3(float x, float y, float z) { return hash_unit((x * 238.68f + y * 491.28f) + z * 640.88f); }
 MM_DEV f2 rand2from2(float x, float y) { return mk2(hash_unit(x * 238.68f + y * 491.28f), hash_unit(x * 654.37f + y * 560.45f)); }

@@ -178,10 +178,13 @@ k_cave_columns(const float* __restrict__ bw, const int2* __restrict__ chunkPos, 
     colInfo[(size_t)256 * chunk + t] = make_float2(obw, ravineY);
 }
 
-#define CELL_NX 7
+#define CELL_NX 8          // 4 adjacent columns share one tile: +1 cell in x over the single-column reach
 #define CELL_NY 8
 #define CELL_NZ 7
 #define CELL_N (CELL_NX * CELL_NY * CELL_NZ)
+#define CAVE_COLS 4        // columns per workgroup (same z row of the chunk, x = 4g .. 4g+3)
+#define CAVE_YEVAL 144     // voxels y < 144 may need the noise (threshold is 0 once y + 50*obw >= 142); 144 = 2.25 waves
+#define CAVE_THREADS (CAVE_COLS * CAVE_YEVAL)     // 576 = 9 full waves: no partially filled wave
 
 struct CellTile {
     const float* pts;     // LDS, 3 floats per cell
@@ -197,17 +200,24 @@ struct CellTile {
     }
 };
 
-__global__ void __launch_bounds__(384)
+// One workgroup = 4 neighbouring columns.  Lane e evaluates voxel (column e / 144, y = e % 144): 576 lanes = 9 FULL waves (a
+// 384-lane-per-column mapping pays 3 waves for 142 useful lanes).  Voxels y >= 144 never need noise: solid iff
+// y <= min(max((int)h, 128), ravine cut), so their bits are built analytically.  The air/solid bits of all 4 x 384 voxels go to
+// LDS as 64-bit words; runs are extracted with popcount prefixes over those words.
+__global__ void __launch_bounds__(CAVE_THREADS)
 k_cave_voxels(const float* __restrict__ hf, const float2* __restrict__ colInfo, const int2* __restrict__ chunkPos,
               mmgen_cave_layer* __restrict__ caveLayers, const int* __restrict__ chunkList)
 {
     __shared__ float s_cells[3 * CELL_N];
-    __shared__ unsigned long long s_mask[6];
-    __shared__ int s_layers[3 * MMGEN_MAX_CAVE_LAYERS_PER_COLUMN];
+    __shared__ unsigned long long s_solid[CAVE_COLS][6];      // solid bit of voxel y at word y / 64, bit y % 64
+    __shared__ int s_layers[CAVE_COLS][3 * MMGEN_MAX_CAVE_LAYERS_PER_COLUMN];
 
-    const int chunk = chunkList ? chunkList[blockIdx.x >> 8] : (int)(blockIdx.x >> 8), idx2d = blockIdx.x & 255;
+    const int t = threadIdx.x;
+    const int chunk = chunkList ? chunkList[blockIdx.x >> 6] : (int)(blockIdx.x >> 6);
+    const int group = blockIdx.x & 63;                         // 64 groups of 4 columns per chunk
+    const int c = t / CAVE_YEVAL, y = t - c * CAVE_YEVAL;
+    const int idx2d = 4 * group + c;                           // x = 4 (group % 4) + c, z = group / 4
     const int col = chunk * 256 + idx2d;
-    const int y = threadIdx.x;
     const int2 cp = chunkPos[chunk];
     const int wx = cp.x + (idx2d & 15), wz = cp.y + (idx2d >> 4);
     const float maxHeight = hf[col];
@@ -215,18 +225,19 @@ k_cave_voxels(const float* __restrict__ hf, const float2* __restrict__ colInfo, 
     const float obw = ci.x, ravineY = ci.y;
 
     const float npx = (float)wx * 0.0050f, npz = (float)wz * 0.0050f;
-    // cell box origin: sample position = noisePos * (1, 1.6, 1) + offset with |offset| < 1.8
+    // cell tile: sample position = noisePos * (1, 1.6, 1) + offset with |offset| < 1.8; origin from the group's first column
     CellTile tile;
     tile.pts = s_cells;
-    tile.ox = (int)__builtin_floorf(npx * 1.f) - 3;
+    tile.ox = (int)__builtin_floorf(((float)(cp.x + ((4 * group) & 15)) * 0.0050f) * 1.f) - 3;
     tile.oy = -3;
     tile.oz = (int)__builtin_floorf(npz * 1.f) - 3;
-    for (int c = y; c < CELL_N; c += 384) {
-        const int iz = c % CELL_NZ, iy = (c / CELL_NZ) % CELL_NY, ix = c / (CELL_NZ * CELL_NY);
+    if (t < CELL_N) {
+        const int iz = t % CELL_NZ, iy = (t / CELL_NZ) % CELL_NY, ix = t / (CELL_NZ * CELL_NY);
         const f3 p = rand3from3((float)(tile.ox + ix), (float)(tile.oy + iy), (float)(tile.oz + iz));
-        s_cells[3 * c] = p.x; s_cells[3 * c + 1] = p.y; s_cells[3 * c + 2] = p.z;
+        s_cells[3 * t] = p.x; s_cells[3 * t + 1] = p.y; s_cells[3 * t + 2] = p.z;
     }
-    if (y < 3 * MMGEN_MAX_CAVE_LAYERS_PER_COLUMN) s_layers[y] = ((y % 3) == 2) ? 0 : 384;   // {384, 384, biomes = 0}
+    if (t < CAVE_COLS * 6) s_solid[t / 6][t % 6] = 0ull;
+    if (t < CAVE_COLS * 3 * MMGEN_MAX_CAVE_LAYERS_PER_COLUMN) (&s_layers[0][0])[t] = ((t % 3) == 2) ? 0 : 384;   // {384, 384, biomes = 0}
     __syncthreads();
 
     const int topSolid = imax((int)maxHeight, MMGEN_SEA_LEVEL);
@@ -252,34 +263,45 @@ k_cave_voxels(const float* __restrict__ hf, const float2* __restrict__ colInfo, 
         }
         if (!cave) cave = fy > ravineY;
     }
-
-    // solid bits of this wave's 64 voxels
-    const unsigned long long solid = __ballot(!cave);
-    const int wave = y >> 6, lane = y & 63;
-    if (lane == 0) s_mask[wave] = solid;
+    // the wave's 64 lanes may straddle two columns / two 64-bit words: OR each lane's bit into its word
+    if (!cave) atomicOr(&s_solid[c][y >> 6], 1ull << (y & 63));
+    // analytic part, y in [144, 384): solid iff y <= topSolid and not (y > ravineY)   (topRatio == 0 there)
+    if (y < 4) {               // 4 lanes per column fill words 2..5 (word 2 holds y 128..191: bits >= 16 only)
+        const int w = 2 + y;
+        unsigned long long m = 0ull;
+        for (int b = 0; b < 64; ++b) {
+            const int yy = 64 * w + b;
+            if (yy >= CAVE_YEVAL && yy <= topSolid && !((float)yy > ravineY)) m |= 1ull << b;
+        }
+        if (m) atomicOr(&s_solid[c][w], m);
+    }
     __syncthreads();
 
-    // flip at y when solid(y) != solid(y+1); y = 383 compares with "not solid"
-    const unsigned long long nextLow = (wave < 5) ? (s_mask[wave + 1] & 1ull) : 0ull;
-    int before = 0;
-    unsigned long long myFlips = 0;
+    // flips: solid(y) != solid(y+1), y = 383 compares with "not solid"; rank by popcount prefix; 4 x 384 voxels over 576 lanes
+    for (int v = t; v < CAVE_COLS * 384; v += CAVE_THREADS) {
+        const int cc = v / 384, yy = v - cc * 384;
+        const int w = yy >> 6, b = yy & 63;
+        int before = 0;
+        unsigned long long mine = 0ull;
 #pragma unroll
-    for (int w = 0; w < 6; ++w) {
-        const unsigned long long m = s_mask[w];
-        const unsigned long long nl = (w < 5) ? (s_mask[w + 1] & 1ull) : 0ull;
-        const unsigned long long f = m ^ ((m >> 1) | (nl << 63));
-        if (w < wave) before += __popcll(f);
-        if (w == wave) myFlips = f;
-    }
-    (void)nextLow;
-    if ((myFlips >> lane) & 1ull) {
-        const int rank = before + __popcll(myFlips & ((1ull << lane) - 1ull));
-        if (rank < 2 * MMGEN_MAX_CAVE_LAYERS_PER_COLUMN)       // canonical: runs beyond 32 layers are dropped
-            s_layers[3 * (rank >> 1) + (rank & 1)] = y;
+        for (int k = 0; k < 6; ++k) {
+            const unsigned long long m = s_solid[cc][k];
+            const unsigned long long nl = (k < 5) ? (s_solid[cc][k + 1] & 1ull) : 0ull;
+            const unsigned long long f = m ^ ((m >> 1) | (nl << 63));
+            if (k < w) before += __popcll(f);
+            if (k == w) mine = f;
+        }
+        if ((mine >> b) & 1ull) {
+            const int rank = before + __popcll(mine & ((1ull << b) - 1ull));
+            if (rank < 2 * MMGEN_MAX_CAVE_LAYERS_PER_COLUMN)       // canonical: runs beyond 32 layers are dropped
+                s_layers[cc][3 * (rank >> 1) + (rank & 1)] = yy;
+        }
     }
     __syncthreads();
-    if (y < 3 * MMGEN_MAX_CAVE_LAYERS_PER_COLUMN)
-        ((int*)(caveLayers + (size_t)MMGEN_MAX_CAVE_LAYERS_PER_COLUMN * col))[y] = s_layers[y];
+    if (t < CAVE_COLS * 3 * MMGEN_MAX_CAVE_LAYERS_PER_COLUMN) {
+        const int cc = t / (3 * MMGEN_MAX_CAVE_LAYERS_PER_COLUMN), k = t % (3 * MMGEN_MAX_CAVE_LAYERS_PER_COLUMN);
+        ((int*)(caveLayers + (size_t)MMGEN_MAX_CAVE_LAYERS_PER_COLUMN * (chunk * 256 + 4 * group + cc)))[k] = s_layers[cc][k];
+    }
 }
 
 __global__ void __launch_bounds__(256)
@@ -510,7 +532,7 @@ int launch_caves(const float* hf, const float* bw, const int32_t* pos, int n, mm
 {
     if (n <= 0) return 0;
     LAUNCH(KID_CAVE_COLUMNS, mm::k_cave_columns, dim3(n), dim3(256), s, bw, (const int2*)pos, (float2*)colInfoScratch, chunkList);
-    LAUNCH(KID_CAVE_VOXELS, mm::k_cave_voxels, dim3(n * 256), dim3(384), s, hf, (const float2*)colInfoScratch, (const int2*)pos, caveLayers, chunkList);
+    LAUNCH(KID_CAVE_VOXELS, mm::k_cave_voxels, dim3(n * 64), dim3(CAVE_THREADS), s, hf, (const float2*)colInfoScratch, (const int2*)pos, caveLayers, chunkList);
     LAUNCH(KID_CAVE_BIOMES, mm::k_cave_biomes, dim3(n * 32), dim3(256), s, hf, (const int2*)pos, caveLayers, chunkList);
     return 0;
 }

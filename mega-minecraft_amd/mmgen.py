@@ -10,7 +10,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmmgen.so")
+LIB_PATH = os.environ.get("MMGEN_LIB", os.path.join(_HERE, "libmmgen.so"))   # MMGEN_LIB: A/B builds of the same ABI
 
 HF, GHF, BW, LAYERS, CAVE, BLOCKS = 256, 324, 6144, 5120, 8192, 98304
 
