@@ -324,13 +324,21 @@ k_cave_biomes(const float* __restrict__ hf, const int2* __restrict__ chunkPos, m
 }
 
 // =========================================================================================================
-// K6 — fill.  One workgroup (6 waves) per column, lane = y.  Column data staged in LDS.
+// K6 — fill.  One workgroup = 4 neighbouring columns (12 waves).  Two phases inside the workgroup:
+//   1. every voxel gets its base block (bedrock / air / water / cave air / layer material + surface-biome rules): cheap, lane = y;
+//   2. the voxels whose block a cave biome could still alter (STONE / DEEPSLATE / BLACKSTONE below ground — the only blocks
+//      caveBiomeBlockPostProcess touches) are compacted into an LDS list and processed densely: the cave-biome evaluation
+//      (9 simplex3D + 12 simplex2D) is the expensive part of fill, and a dense list keeps every lane of every wave on it instead
+//      of interleaving it with lanes that returned "air" long ago.  Order inside the list is irrelevant (voxels are independent).
 // =========================================================================================================
-MM_DEV uint8_t place_block(const float* s_bw, const float* s_lh, const mmgen_cave_layer* s_cl, int y, float height, int wx, int wz)
+struct BaseBlock { uint8_t block; bool needCave; int bottomDepth, topDepth; };
+
+MM_DEV BaseBlock place_block_base(const float* s_bw, const float* s_lh, const mmgen_cave_layer* s_cl, int y, float height, int wx, int wz)
 {
-    if (y == 0) return MMB_BEDROCK;
+    BaseBlock r; r.needCave = false; r.bottomDepth = -384; r.topDepth = -384;
+    if (y == 0) { r.block = MMB_BEDROCK; return r; }
     const float fy = (float)y;
-    if (fy > height && y > MMGEN_SEA_LEVEL) return MMB_AIR;
+    if (fy > height && y > MMGEN_SEA_LEVEL) { r.block = MMB_AIR; return r; }
 
     bool isOcean = false;
 #pragma unroll
@@ -344,7 +352,7 @@ MM_DEV uint8_t place_block(const float* s_bw, const float* s_lh, const mmgen_cav
     if (fy > height && y <= MMGEN_SEA_LEVEL) {
         block = MMB_WATER;
         biome_block_post(block, randBiome, wx, y, wz, isTop);
-        if (isOcean) return block;
+        if (isOcean) { r.block = block; return r; }
     }
 
     int bottomDepth = -384, topDepth = -384;
@@ -356,16 +364,18 @@ MM_DEV uint8_t place_block(const float* s_bw, const float* s_lh, const mmgen_cav
         if (y <= end) {
             // inside a cave: air or lava.  caveBiomeBlockPostProcess never alters AIR/LAVA (every rule requires
             // STONE/DEEPSLATE/BLACKSTONE), so the cave biome is not evaluated here.
-            return (y <= MMGEN_LAVA_LEVEL) ? MMB_LAVA : MMB_AIR;
+            r.block = (y <= MMGEN_LAVA_LEVEL) ? MMB_LAVA : MMB_AIR;
+            return r;
         }
         topDepth = y - (end + 1);
     }
 
-    if (fy > height) return block;
+    if (fy > height) { r.block = block; return r; }
 
     if (biome_block_pre(block, randBiome, wx, y, wz, height)) {
         biome_block_post(block, randBiome, wx, y, wz, isTop);
-        return block;
+        r.block = block;
+        return r;
     }
 
     const int l0 = (fy >= s_lh[MMGEN_NUM_FORWARD_MATERIALS]) ? MMGEN_NUM_FORWARD_MATERIALS : 0;
@@ -377,40 +387,80 @@ MM_DEV uint8_t place_block(const float* s_bw, const float* s_lh, const mmgen_cav
     if (isTop && block == MMB_DIRT) block = kGrassBlock[randBiome];
 
     biome_block_post(block, randBiome, wx, y, wz, isTop);
-    if (cave_post_can_apply(block)) {
-        const int cb = cave_biome(wx, y, wz, height, 190249401);
-        cave_biome_block_post(block, cb, wx, y, wz, bottomDepth, topDepth);
-    }
-    return block;
+    r.block = block;
+    r.needCave = cave_post_can_apply(block);
+    r.bottomDepth = bottomDepth;
+    r.topDepth = topDepth;
+    return r;
 }
 
-__global__ void __launch_bounds__(384)
+#define FILL_COLS 4
+#define FILL_THREADS 768
+
+__global__ void __launch_bounds__(FILL_THREADS)
 k_fill(const float* __restrict__ hf, const float* __restrict__ bw, const float* __restrict__ layers,
        const mmgen_cave_layer* __restrict__ caveLayers, const int2* __restrict__ chunkPos, uint8_t* __restrict__ blocks,
        const int* __restrict__ srcIdx)
 {
-    __shared__ float s_bw[MMGEN_NUM_BIOMES];
-    __shared__ float s_lh[MMGEN_NUM_MATERIALS + 1];
-    __shared__ mmgen_cave_layer s_cl[MMGEN_MAX_CAVE_LAYERS_PER_COLUMN];
+    __shared__ float s_bw[FILL_COLS][MMGEN_NUM_BIOMES];
+    __shared__ float s_lh[FILL_COLS][MMGEN_NUM_MATERIALS + 1];
+    __shared__ mmgen_cave_layer s_cl[FILL_COLS][MMGEN_MAX_CAVE_LAYERS_PER_COLUMN];
+    __shared__ unsigned int s_list[FILL_COLS * 384];          // voxel (11 bits) | block (8) | 13 spare
+    __shared__ int s_depth[FILL_COLS * 384];                  // bottomDepth (low 16, signed) | topDepth (high 16, signed)
+    __shared__ int s_count;
 
-    const int outChunk = blockIdx.x >> 8, idx2d = blockIdx.x & 255;
+    const int t = threadIdx.x;
+    const int outChunk = blockIdx.x >> 6, group = blockIdx.x & 63;
     const int chunk = srcIdx ? srcIdx[outChunk] : outChunk;        // inputs are read at `chunk`, blocks are written densely at outChunk
-    const int col = chunk * 256 + idx2d;
-    const int y = threadIdx.x;
+    const int idxBase = 4 * group;
 
-    if (y < MMGEN_NUM_BIOMES) s_bw[y] = bw[(size_t)MMGEN_BIOME_WEIGHTS_SIZE * chunk + 256 * y + idx2d];
-    else if (y < MMGEN_NUM_BIOMES + MMGEN_NUM_MATERIALS) s_lh[y - MMGEN_NUM_BIOMES] = layers[(size_t)MMGEN_LAYERS_SIZE * chunk + 256 * (y - MMGEN_NUM_BIOMES) + idx2d];
-    else if (y == MMGEN_NUM_BIOMES + MMGEN_NUM_MATERIALS) s_lh[MMGEN_NUM_MATERIALS] = hf[col];
-    else if (y >= 64 && y < 64 + 3 * MMGEN_MAX_CAVE_LAYERS_PER_COLUMN)
-        ((int*)s_cl)[y - 64] = ((const int*)(caveLayers + (size_t)MMGEN_MAX_CAVE_LAYERS_PER_COLUMN * col))[y - 64];
+    // stage the 4 columns: 24 weights + 20 layer starts + height + 96 cave-layer words each = 141 words per column
+    if (t < FILL_COLS * 141) {
+        const int c = t / 141, k = t % 141;
+        const int idx2d = idxBase + c;
+        if (k < MMGEN_NUM_BIOMES) s_bw[c][k] = bw[(size_t)MMGEN_BIOME_WEIGHTS_SIZE * chunk + 256 * k + idx2d];
+        else if (k < MMGEN_NUM_BIOMES + MMGEN_NUM_MATERIALS) s_lh[c][k - MMGEN_NUM_BIOMES] = layers[(size_t)MMGEN_LAYERS_SIZE * chunk + 256 * (k - MMGEN_NUM_BIOMES) + idx2d];
+        else if (k == MMGEN_NUM_BIOMES + MMGEN_NUM_MATERIALS) s_lh[c][MMGEN_NUM_MATERIALS] = hf[chunk * 256 + idx2d];
+        else ((int*)s_cl[c])[k - 45] = ((const int*)(caveLayers + (size_t)MMGEN_MAX_CAVE_LAYERS_PER_COLUMN * (chunk * 256 + idx2d)))[k - 45];
+    }
+    if (t == 0) s_count = 0;
     __syncthreads();
 
     const int2 cp = chunkPos[chunk];
-    const int wx = cp.x + (idx2d & 15), wz = cp.y + (idx2d >> 4);
-    const uint8_t block = place_block(s_bw, s_lh, s_cl, y, s_lh[MMGEN_NUM_MATERIALS], wx, wz);
-    blocks[(size_t)MMGEN_BLOCKS_PER_CHUNK * outChunk + 384 * idx2d + y] = block;
-}
+    uint8_t* outBase = blocks + (size_t)MMGEN_BLOCKS_PER_CHUNK * outChunk + 384 * idxBase;     // the 4 columns are contiguous: 1536 bytes
 
+    // phase 1: base blocks
+    for (int v = t; v < FILL_COLS * 384; v += FILL_THREADS) {
+        const int c = v / 384, y = v - 384 * c;
+        const int idx2d = idxBase + c;
+        const int wx = cp.x + (idx2d & 15), wz = cp.y + (idx2d >> 4);
+        const BaseBlock r = place_block_base(s_bw[c], s_lh[c], s_cl[c], y, s_lh[c][MMGEN_NUM_MATERIALS], wx, wz);
+        if (r.needCave) {
+            const int slot = atomicAdd(&s_count, 1);
+            s_list[slot] = (unsigned)v | ((unsigned)r.block << 11);
+            s_depth[slot] = (r.bottomDepth & 0xffff) | (r.topDepth << 16);
+        } else {
+            outBase[v] = r.block;
+        }
+    }
+    __syncthreads();
+
+    // phase 2: cave-biome rules on the compacted stone voxels
+    const int count = s_count;
+    for (int i = t; i < count; i += FILL_THREADS) {
+        const unsigned e = s_list[i];
+        const int v = e & 2047;
+        uint8_t block = (uint8_t)(e >> 11);
+        const int d = s_depth[i];
+        const int bottomDepth = (int)(short)(d & 0xffff), topDepth = d >> 16;
+        const int c = v / 384, y = v - 384 * c;
+        const int idx2d = idxBase + c;
+        const int wx = cp.x + (idx2d & 15), wz = cp.y + (idx2d >> 4);
+        const int cb = cave_biome(wx, y, wz, s_lh[c][MMGEN_NUM_MATERIALS], 190249401);
+        cave_biome_block_post(block, cb, wx, y, wz, bottomDepth, topDepth);
+        outBase[v] = block;
+    }
+}
 
 // =========================================================================================================
 // Debug probes: evaluate one device function per item so that tests can pin the device math against the golden
@@ -541,7 +591,7 @@ int launch_fill(const float* hf, const float* bw, const float* layers, const mmg
                 uint8_t* blocks, const int* srcIdx, hipStream_t s)
 {
     if (n <= 0) return 0;
-    LAUNCH(KID_FILL, mm::k_fill, dim3(n * 256), dim3(384), s, hf, bw, layers, caveLayers, (const int2*)pos, blocks, srcIdx);
+    LAUNCH(KID_FILL, mm::k_fill, dim3(n * 64), dim3(FILL_THREADS), s, hf, bw, layers, caveLayers, (const int2*)pos, blocks, srcIdx);
     return 0;
 }
 
