@@ -164,7 +164,10 @@ void Chunk::generateLayers(std::vector<Chunk*>& chunks, float* host_hf, float* d
     MM_CALL(mmgen_generate_layers(dev_hf, dev_bw, (const int32_t*)dev_pos, n, dev_layers, stream), "Chunk::generateLayers() failed");
     MM_CALL(hipMemcpyAsync(host_layers, dev_layers, (size_t)n * devLayersSize * sizeof(float), hipMemcpyDeviceToHost, stream), "D2H layers");
     MM_CALL(hipStreamSynchronize(stream), "Chunk::generateLayers() failed");
-    for (int i = 0; i < n; ++i) std::memcpy(chunks[i]->layers.data(), host_layers + (size_t)i * devLayersSize, devLayersSize * sizeof(float));
+    for (int i = 0; i < n; ++i) {
+        std::memcpy(chunks[i]->layers.data(), host_layers + (size_t)i * devLayersSize, devLayersSize * sizeof(float));
+        std::memcpy(chunks[i]->rawErodedLayers.data(), chunks[i]->layers.data() + 256 * numStratifiedMaterials, 256 * numErodedMaterials * sizeof(float));
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -180,7 +183,9 @@ static void copyLayers(Zone* zone, float* packed, bool toPacked)
             const int bx = (toPacked ? cx : cx + ZONE_SIZE / 2) * 16, bz = (toPacked ? cz : cz + ZONE_SIZE / 2) * 16;
             for (int p = 0; p < planes; ++p) {
                 for (int z = 0; z < 16; ++z) {
-                    float* chunkRow = (p == numErodedMaterials) ? c->heightfield.data() + 16 * z : c->layers.data() + 256 * (numStratifiedMaterials + p) + 16 * z;
+                    float* chunkRow = (p == numErodedMaterials) ? c->heightfield.data() + 16 * z
+                                      : toPacked    ? c->rawErodedLayers.data() + 256 * p + 16 * z          // padding AND centre start from raw planes
+                                                    : c->layers.data() + 256 * (numStratifiedMaterials + p) + 16 * z;
                     float* packedRow = packed + (size_t)EROSION_GRID_NUM_COLS * p + (size_t)EROSION_GRID_SIDE_LENGTH_BLOCKS * (bz + z) + bx;
                     if (toPacked) std::memcpy(packedRow, chunkRow, 16 * sizeof(float));
                     else std::memcpy(chunkRow, packedRow, 16 * sizeof(float));

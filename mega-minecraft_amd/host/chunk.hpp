@@ -85,6 +85,10 @@ public:
     std::array<float, 256> heightfield;                                   // iteration order z, x
     std::vector<float> gatheredHeightfield;
     std::array<float, 256 * numMaterials> layers;                         // y, z, x
+    // RAW (pre-erosion) copy of the 8 eroded-layer planes, kept so that a neighbouring zone's erosion padding never sees this
+    // chunk's eroded result (canonical raw-padding semantics; the reference reads `layers`, chunk.cu:638, and is
+    // therefore dependent on the order in which the player's movement erodes zones)
+    std::array<float, 256 * numErodedMaterials> rawErodedLayers;
     std::array<CaveLayer, 256 * MMGEN_MAX_CAVE_LAYERS_PER_COLUMN> caveLayers;   // z, x, y
     std::array<float, 256 * numBiomes> biomeWeights;                      // y, z, x
     std::array<Block, 98304> blocks;                                      // z, x, y

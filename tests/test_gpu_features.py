@@ -142,3 +142,16 @@ def test_cpp_chunk_api_matches_region_path(mmgen_pkg):
         r = subprocess.run([exe, *zone], capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stdout + r.stderr
         assert "0 chunks differ" in r.stdout
+
+
+def test_cpp_terrain_scheduler_streams_a_world(mmgen_pkg):
+    """The C++ mirror of the reference's Terrain scheduler (host/terrain.hpp: action-time budget, nine queues, zones, spiral) ticked
+    headlessly until all queues drain: all (2*16+1)^2 chunks around the player become DRAWABLE and sampled chunks equal the region
+    path bit for bit (canonical raw-padding erosion makes the result independent of the order zones get eroded in)."""
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(mmgen_pkg.LIB_PATH), "mmgen_terrain_demo")
+    assert os.path.exists(exe), "build it with make -C mega-minecraft_amd/csrc"
+    r = subprocess.run([exe, "-40", "25"], capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "1089 drawable" in r.stdout and ", 0 bad" in r.stdout
