@@ -137,7 +137,8 @@ enum {
 enum {
     MMGEN_PROBE_SIN, MMGEN_PROBE_COS, MMGEN_PROBE_POW, MMGEN_PROBE_ATAN2, MMGEN_PROBE_ACOS, MMGEN_PROBE_SIMPLEX2, MMGEN_PROBE_SIMPLEX3,
     MMGEN_PROBE_FBM2_5, MMGEN_PROBE_FBM3_4, MMGEN_PROBE_RAND3FROM3, MMGEN_PROBE_WORLEY2, MMGEN_PROBE_WORLEY3,
-    MMGEN_PROBE_SPECIAL_CAVE_NOISE, MMGEN_PROBE_BIOME_HEIGHT, MMGEN_PROBE_CAVE_BIOME, MMGEN_PROBE_HASH, MMGEN_PROBE_RNG4_U01
+    MMGEN_PROBE_SPECIAL_CAVE_NOISE, MMGEN_PROBE_BIOME_HEIGHT, MMGEN_PROBE_CAVE_BIOME, MMGEN_PROBE_HASH, MMGEN_PROBE_RNG4_U01,
+    MMGEN_PROBE_SIMPLEX3_SPLIT   /* simplex3 regrouped at the lattice (part1 -> corner gradients -> part3), as k_cave_voxels evaluates it */
 };
 
 #ifdef __cplusplus

@@ -141,6 +141,80 @@ MM_SIMPLEX_ATTR float simplex3(float vx, float vy, float vz)
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// simplex3 split at the lattice: part1 (skewed cell + offsets inside it) -> gradients of the cell's 4 simplex corners
+// -> part3 (falloff * gradient . offset).  The gradients are a function of (cell, corner ordering) ONLY, so voxels that
+// share a cell can share them through LDS (k_cave_voxels).  simplex3_part3(part1(v), grad(part1(v))) == simplex3(v)
+// bit for bit: the same operations in the same order, merely regrouped (checked by the probe tests against real glm).
+// ---------------------------------------------------------------------------------------------------------
+struct Sx3Cell { float ix, iy, iz; float x0x, x0y, x0z; int order; };      // order bits: gx | gy << 1 | gz << 2
+
+MM_DEV Sx3Cell simplex3_part1(float vx, float vy, float vz)
+{
+    const float Cx = (float)(1.0 / 6.0), Cy = (float)(1.0 / 3.0);
+    Sx3Cell c;
+    const float d = (vx * Cy + vy * Cy) + vz * Cy;
+    c.ix = __builtin_floorf(vx + d); c.iy = __builtin_floorf(vy + d); c.iz = __builtin_floorf(vz + d);
+    const float e = (c.ix * Cx + c.iy * Cx) + c.iz * Cx;
+    c.x0x = (vx - c.ix) + e; c.x0y = (vy - c.iy) + e; c.x0z = (vz - c.iz) + e;
+    c.order = ((c.x0x < c.x0y) ? 0 : 1) | ((c.x0y < c.x0z) ? 0 : 2) | ((c.x0z < c.x0x) ? 0 : 4);
+    return c;
+}
+
+// 12 floats: (qx, qy, qz) of the 4 corners, already scaled by taylorInvSqrt
+MM_DEV void simplex3_gradients(float ix, float iy, float iz, int order, float* __restrict__ q)
+{
+    const float gx = (order & 1) ? 1.f : 0.f, gy = (order & 2) ? 1.f : 0.f, gz = (order & 4) ? 1.f : 0.f;
+    const float lx = 1.f - gx, ly = 1.f - gy, lz = 1.f - gz;
+    const float i1x = gmin(gx, lz), i1y = gmin(gy, lx), i1z = gmin(gz, ly);
+    const float i2x = gmax(gx, lz), i2y = gmax(gy, lx), i2z = gmax(gz, ly);
+    ix = mod289(ix); iy = mod289(iy); iz = mod289(iz);
+    const float oz[4] = {0.f, i1z, i2z, 1.f}, oy[4] = {0.f, i1y, i2y, 1.f}, ox[4] = {0.f, i1x, i2x, 1.f};
+    const float n_ = (float)0.142857142857;
+    const float nsx = n_ * 2.f - 0.f, nsy = n_ * 0.5f - 1.f, nsz = n_ * 1.f - 0.f;
+    const float K1 = (float)1.79284291400159, K2 = (float)0.85373472095314;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float a = permute(iz + oz[k]);
+        const float b = permute((a + iy) + oy[k]);
+        const float p = permute((b + ix) + ox[k]);
+        const float j = p - 49.f * __builtin_floorf((p * nsz) * nsz);
+        const float x_ = __builtin_floorf(j * nsz);
+        const float y_ = __builtin_floorf(j - 7.f * x_);
+        const float px = x_ * nsx + nsy;
+        const float py = y_ * nsx + nsy;
+        const float hh = (1.f - __builtin_fabsf(px)) - __builtin_fabsf(py);
+        const float sh = -((0.f < hh) ? 0.f : 1.f);
+        const float sx = __builtin_floorf(px) * 2.f + 1.f;
+        const float sy = __builtin_floorf(py) * 2.f + 1.f;
+        const float g0 = px + sx * sh;
+        const float g1 = py + sy * sh;
+        const float nrm = K1 - K2 * ((g0 * g0 + g1 * g1) + hh * hh);
+        q[3 * k] = g0 * nrm; q[3 * k + 1] = g1 * nrm; q[3 * k + 2] = hh * nrm;
+    }
+}
+
+MM_DEV float simplex3_part3(const Sx3Cell& c, const float* __restrict__ q)
+{
+    const float Cx = (float)(1.0 / 6.0), Cy = (float)(1.0 / 3.0);
+    const float gx = (c.order & 1) ? 1.f : 0.f, gy = (c.order & 2) ? 1.f : 0.f, gz = (c.order & 4) ? 1.f : 0.f;
+    const float lx = 1.f - gx, ly = 1.f - gy, lz = 1.f - gz;
+    const float i1x = gmin(gx, lz), i1y = gmin(gy, lx), i1z = gmin(gz, ly);
+    const float i2x = gmax(gx, lz), i2y = gmax(gy, lx), i2z = gmax(gz, ly);
+    const float cx[4] = {c.x0x, (c.x0x - i1x) + Cx, (c.x0x - i2x) + Cy, c.x0x - 0.5f};
+    const float cy[4] = {c.x0y, (c.x0y - i1y) + Cx, (c.x0y - i2y) + Cy, c.x0y - 0.5f};
+    const float cz[4] = {c.x0z, (c.x0z - i1z) + Cx, (c.x0z - i2z) + Cy, c.x0z - 0.5f};
+    float mm4[4], pd[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        float m = gmax(0.6f - ((cx[k] * cx[k] + cy[k] * cy[k]) + cz[k] * cz[k]), 0.f);
+        m = m * m;
+        mm4[k] = m * m;
+        pd[k] = (q[3 * k] * cx[k] + q[3 * k + 1] * cy[k]) + q[3 * k + 2] * cz[k];
+    }
+    return 42.f * ((mm4[0] * pd[0] + mm4[1] * pd[1]) + (mm4[2] * pd[2] + mm4[3] * pd[3]));
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // fbm stacks (rng.hpp:166-191): amplitude halves, frequency doubles, octaves summed in order
 // ---------------------------------------------------------------------------------------------------------
 template <int OCT>

@@ -200,16 +200,127 @@ struct CellTile {
     }
 };
 
+#ifndef MM_CAVE_LATTICE
+#define MM_CAVE_LATTICE 1
+#endif
+#define LAT_CAP 64
+// per-wave LDS staging of simplex lattice gradients: keys of the distinct (cell, corner ordering) pairs met by the wave's 64 voxels
+// and the 4 corner gradients (12 floats) of each
+typedef float f4v __attribute__((ext_vector_type(4)));
+struct alignas(16) LatticeWave { f4v key[LAT_CAP]; f4v q[LAT_CAP][3]; };
+typedef __attribute__((address_space(3))) LatticeWave* LatticePtr;      // LDS pointer: ds_read/ds_write instead of flat_*
+
+// Wave-local LDS hand-off: LDS operations of one wave are executed in issue order, so lanes of the same wave see each other's
+// writes without a workgroup barrier; only the compiler has to be kept from reordering across the hand-off.
+MM_DEV void wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// value of the previous lane (lane 0 gets its own): one DPP move (wave_shr:1)
+#ifndef MM_PREV_LANE
+#define MM_PREV_LANE 1
+#endif
+#if MM_PREV_LANE == 0
+MM_DEV int prev_lane_i(int v) { return __shfl_up(v, 1); }
+#elif MM_PREV_LANE == 1
+MM_DEV int prev_lane_i(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x138, 0xf, 0xf, false); }
+#else
+MM_DEV int prev_lane_i(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x111, 0xf, 0xf, false); }   // row_shr:1, rows of 16
+#endif
+MM_DEV float prev_lane_f(float v) { return __int_as_float(prev_lane_i(__float_as_int(v))); }
+
+// one lane per queued (cell, ordering) pair computes the 4 corner gradients
+static __device__ __attribute__((noinline)) void lattice_build(LatticePtr Lp, int n, int lane)
+{
+    wave_lds_sync();
+    if (lane < n) {
+        float q[12];
+        const f4v k = Lp->key[lane];
+        simplex3_gradients(k.x, k.y, k.z, __float_as_int(k.w), q);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) Lp->q[lane][i] = f4v{q[4 * i], q[4 * i + 1], q[4 * i + 2], q[4 * i + 3]};
+    }
+    wave_lds_sync();
+}
+
+static __device__ __attribute__((noinline)) float lattice_eval(LatticePtr Lp, int slot, float ix, float iy, float iz, float x0x, float x0y,
+                                                                 float x0z, int order)
+{
+    Sx3Cell c; c.ix = ix; c.iy = iy; c.iz = iz; c.x0x = x0x; c.x0y = x0y; c.x0z = x0z; c.order = order;
+    float q[12];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const f4v v = Lp->q[slot][i];
+        q[4 * i] = v.x; q[4 * i + 1] = v.y; q[4 * i + 2] = v.z; q[4 * i + 3] = v.w;
+    }
+    return simplex3_part3(c, q);
+}
+
+// Evaluates NS simplex3 samples per lane.  Along a column the samples of one site fall into few lattice cells, so instead of
+// every lane recomputing the 12 permutation hashes + gradient decode of its cell (≈ 2/3 of simplex3), the wave (1) finds the
+// change points of (cell, ordering) along its lanes, (2) lets ONE lane per distinct pair compute the gradients — pairs of
+// SEVERAL sites in different lanes of the same pass, flushed whenever the 64-entry table would overflow — and (3) every lane
+// fetches its cell's gradients from LDS.  Bit-exact: the gradients are the same function of the same arguments.
+// Wave-local (no workgroup barrier): must be called wave-uniformly; waves may take different numbers of flushes.
+template <int NS>
+MM_DEV void simplex3_sites(const float* sx, const float* sy, const float* sz, float* out, LatticeWave& L, int lane)
+{
+    Sx3Cell c[NS];
+    int slot[NS];
+    int base = 0, first = 0;
+    const LatticePtr Lp = (LatticePtr)&L;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        c[s] = simplex3_part1(sx[s], sy[s], sz[s]);
+        // cross-lane reads first, unconditionally (a short-circuited || would run them under a partial EXEC mask)
+        const float pix = prev_lane_f(c[s].ix), piy = prev_lane_f(c[s].iy), piz = prev_lane_f(c[s].iz);
+        const int po = prev_lane_i(c[s].order);
+        const bool leader = (int)(MM_PREV_LANE == 2 ? (lane & 15) == 0 : lane == 0) | (int)(pix != c[s].ix) | (int)(piy != c[s].iy) |
+                            (int)(piz != c[s].iz) | (int)(po != c[s].order);
+        const unsigned long long m = __ballot(leader);
+        const int cnt = __popcll(m);
+        if (base + cnt > LAT_CAP) {            // wave-uniform: flush the queued sites first
+            lattice_build(Lp, base, lane);
+#pragma unroll
+            for (int u = 0; u < NS; ++u)
+                if (u >= first && u < s) out[u] = lattice_eval(Lp, slot[u], c[u].ix, c[u].iy, c[u].iz, c[u].x0x, c[u].x0y, c[u].x0z, c[u].order);
+            wave_lds_sync();
+            first = s;
+            base = 0;
+        }
+        slot[s] = base + __popcll(m & ((2ull << lane) - 1ull)) - 1;
+        if (leader) {
+            Lp->key[slot[s]] = f4v{c[s].ix, c[s].iy, c[s].iz, __int_as_float(c[s].order)};
+        }
+        base += cnt;
+    }
+    lattice_build(Lp, base, lane);
+#pragma unroll
+    for (int u = 0; u < NS; ++u)
+        if (u >= first) out[u] = lattice_eval(Lp, slot[u], c[u].ix, c[u].iy, c[u].iz, c[u].x0x, c[u].x0y, c[u].x0z, c[u].order);
+    wave_lds_sync();      // L is reused by the next call
+}
+
 // One workgroup = 4 neighbouring columns.  Lane e evaluates voxel (column e / 144, y = e % 144): 576 lanes = 9 FULL waves (a
 // 384-lane-per-column mapping pays 3 waves for 142 useful lanes).  Voxels y >= 144 never need noise: solid iff
 // y <= min(max((int)h, 128), ravine cut), so their bits are built analytically.  The air/solid bits of all 4 x 384 voxels go to
 // LDS as 64-bit words; runs are extracted with popcount prefixes over those words.
+#ifndef MM_CAVE_WAVES
+#define MM_CAVE_WAVES 6          // 80 VGPRs: 2 workgroups of 9 waves per CU (the default allocation, 98 VGPRs, fits only one)
+#endif
+__attribute__((amdgpu_waves_per_eu(MM_CAVE_WAVES, MM_CAVE_WAVES)))
 __global__ void __launch_bounds__(CAVE_THREADS)
 k_cave_voxels(const float* __restrict__ hf, const float2* __restrict__ colInfo, const int2* __restrict__ chunkPos,
               mmgen_cave_layer* __restrict__ caveLayers, const int* __restrict__ chunkList)
 {
     __shared__ float s_cells[3 * CELL_N];
     __shared__ unsigned long long s_solid[CAVE_COLS][6];      // solid bit of voxel y at word y / 64, bit y % 64
+#if MM_CAVE_LATTICE
+    __shared__ LatticeWave s_lat[CAVE_THREADS / 64];
+#endif
     __shared__ int s_layers[CAVE_COLS][3 * MMGEN_MAX_CAVE_LAYERS_PER_COLUMN];
 
     const int t = threadIdx.x;
@@ -241,28 +352,70 @@ k_cave_voxels(const float* __restrict__ hf, const float2* __restrict__ colInfo, 
     __syncthreads();
 
     const int topSolid = imax((int)maxHeight, MMGEN_SEA_LEVEL);
-    bool cave;
-    if (y == 0) cave = false;
-    else if (y > topSolid) cave = true;
-    else {
-        const float fy = (float)y;
-        const float npy = fy * 0.0050f;
-        const float topRatio = smoothstep(142.f, 95.f, fy + obw * 50.f);
-        const float bottomRatio = smoothstep(5.f, 20.f, fy);
-        cave = false;
-        if (topRatio > 0.f) {    // threshold is a product with topRatio: 0 → "threshold > 0.04" is false
-            float thr = 0.24f + 0.12f * fbm3<4>(npx * 4.f, npy * 4.f, npz * 4.f);
-            const float huge = smoothstep(0.2f, 0.4f, fbm3<4>(npx * 0.0700f, npy * 0.0700f, npz * 0.0700f));
-            thr *= (1.f + 1.4f * huge);
-            thr *= topRatio * (0.3f + 0.7f * bottomRatio);
-            if (thr > 0.04f) {
-                const f3 o = fbm3from3<5>(npx * 0.8000f, npy * 0.8000f, npz * 0.8000f);
-                const float n = special_cave_noise(npx * 1.f + o.x * 1.8f, npy * 1.6f + o.y * 1.8f, npz * 1.f + o.z * 1.8f, tile);
-                cave = n < thr;
-            }
-        }
-        if (!cave) cave = fy > ravineY;
+    const float fy = (float)y;
+    const float npy = fy * 0.0050f;
+    const bool inBand = (y != 0) && (y <= topSolid);
+    const float topRatio = smoothstep(142.f, 95.f, fy + obw * 50.f);
+    const float bottomRatio = smoothstep(5.f, 20.f, fy);
+    const bool needThr = inBand && topRatio > 0.f;      // threshold is a product with topRatio: 0 → "threshold > 0.04" is false
+    bool cave = (y != 0) && !inBand;                    // y == 0 solid, y > topSolid air
+#if MM_CAVE_LATTICE
+    // All 23 simplex3 evaluations of a voxel go through simplex3_sites: every wave shares the lattice gradients of the cells its
+    // 64 voxels fall into (stage structure is uniform over the workgroup; lanes that do not need a value simply ignore it).
+    LatticeWave& L = s_lat[t >> 6];
+    const int lane = t & 63;
+    float thr = 0.f;
+    if (__ballot(needThr) != 0ull) {       // wave-uniform
+        float sx[4], sy[4], sz[4], v[4];
+        float ax = npx * 4.f, ay = npy * 4.f, az = npz * 4.f;
+#pragma unroll
+        for (int o = 0; o < 4; ++o) { sx[o] = ax; sy[o] = ay; sz[o] = az; ax *= 2.f; ay *= 2.f; az *= 2.f; }
+        simplex3_sites<4>(sx, sy, sz, v, L, lane);
+        const float fa = (((0.f + 0.5f * v[0]) + 0.25f * v[1]) + 0.125f * v[2]) + 0.0625f * v[3];
+        float bx = npx * 0.0700f, by = npy * 0.0700f, bz = npz * 0.0700f;
+#pragma unroll
+        for (int o = 0; o < 4; ++o) { sx[o] = bx; sy[o] = by; sz[o] = bz; bx *= 2.f; by *= 2.f; bz *= 2.f; }
+        simplex3_sites<4>(sx, sy, sz, v, L, lane);
+        const float fb = (((0.f + 0.5f * v[0]) + 0.25f * v[1]) + 0.125f * v[2]) + 0.0625f * v[3];
+        thr = 0.24f + 0.12f * fa;
+        const float huge = smoothstep(0.2f, 0.4f, fb);
+        thr *= (1.f + 1.4f * huge);
+        thr *= topRatio * (0.3f + 0.7f * bottomRatio);
     }
+    const bool needWarp = needThr && thr > 0.04f;
+    float warp[3] = {0.f, 0.f, 0.f};
+    if (__ballot(needWarp) != 0ull) {      // wave-uniform
+        const float offx[3] = {0.f, 5923.45f, 1765.68f}, offy[3] = {0.f, 4129.42f, 4704.36f}, offz[3] = {0.f, 5790.48f, 5692.12f};
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            float sx[5], sy[5], sz[5], v[5];
+            float wx0 = npx * 0.8000f, wy0 = npy * 0.8000f, wz0 = npz * 0.8000f;
+            if (k > 0) { wx0 += offx[k]; wy0 += offy[k]; wz0 += offz[k]; }
+#pragma unroll
+            for (int o = 0; o < 5; ++o) { sx[o] = wx0; sy[o] = wy0; sz[o] = wz0; wx0 *= 2.f; wy0 *= 2.f; wz0 *= 2.f; }
+            simplex3_sites<5>(sx, sy, sz, v, L, lane);
+            warp[k] = ((((0.f + 0.5f * v[0]) + 0.25f * v[1]) + 0.125f * v[2]) + 0.0625f * v[3]) + 0.03125f * v[4];
+        }
+    }
+    if (needWarp) {
+        const float n = special_cave_noise(npx * 1.f + warp[0] * 1.8f, npy * 1.6f + warp[1] * 1.8f, npz * 1.f + warp[2] * 1.8f, tile);
+        cave = n < thr;
+    }
+    if (inBand && !cave) cave = fy > ravineY;
+#else
+    if (needThr) {
+        float thr = 0.24f + 0.12f * fbm3<4>(npx * 4.f, npy * 4.f, npz * 4.f);
+        const float huge = smoothstep(0.2f, 0.4f, fbm3<4>(npx * 0.0700f, npy * 0.0700f, npz * 0.0700f));
+        thr *= (1.f + 1.4f * huge);
+        thr *= topRatio * (0.3f + 0.7f * bottomRatio);
+        if (thr > 0.04f) {
+            const f3 o = fbm3from3<5>(npx * 0.8000f, npy * 0.8000f, npz * 0.8000f);
+            const float n = special_cave_noise(npx * 1.f + o.x * 1.8f, npy * 1.6f + o.y * 1.8f, npz * 1.f + o.z * 1.8f, tile);
+            cave = n < thr;
+        }
+    }
+    if (inBand && !cave) cave = fy > ravineY;
+#endif
     // the wave's 64 lanes may straddle two columns / two 64-bit words: OR each lane's bit into its word
     if (!cave) atomicOr(&s_solid[c][y >> 6], 1ull << (y & 63));
     // analytic part, y in [144, 384): solid iff y <= topSolid and not (y > ravineY)   (topRatio == 0 there)
@@ -497,6 +650,12 @@ __global__ void __launch_bounds__(256) k_probe(int fn, const float* __restrict__
         const int x = __float_as_int(in[4 * i]), y = __float_as_int(in[4 * i + 1]), z = __float_as_int(in[4 * i + 2]), w = __float_as_int(in[4 * i + 3]);
         MinStd r = (w == (int)0x80000000) ? rng3(x, y, z) : rng4(x, y, z, w);
         for (int k = 0; k < 4; ++k) out[4 * i + k] = r.u01();
+        break; }
+    case MMGEN_PROBE_SIMPLEX3_SPLIT: {
+        const Sx3Cell c = simplex3_part1(in[3 * i], in[3 * i + 1], in[3 * i + 2]);
+        float q[12];
+        simplex3_gradients(c.ix, c.iy, c.iz, c.order, q);
+        out[i] = simplex3_part3(c, q);
         break; }
     default: break;
     }

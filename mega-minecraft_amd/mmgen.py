@@ -244,7 +244,7 @@ class MMGen:
 
     # ------------------------------------------------------------------ test-only device math probe
     PROBES = dict(sin=0, cos=1, pow=2, atan2=3, acos=4, simplex2=5, simplex3=6, fbm2_5=7, fbm3_4=8, rand3from3=9, worley2=10, worley3=11,
-                  special_cave_noise=12, biome_height=13, cave_biome=14, hash=15, rng4_u01=16)
+                  special_cave_noise=12, biome_height=13, cave_biome=14, hash=15, rng4_u01=16, simplex3_split=17)
 
     def debug_probe(self, name, packed_in, n, out_per_item=1):
         """packed_in: numpy float32/int32/uint32 array (ints are bit-cast); returns numpy float32 [n, out_per_item]."""

@@ -24,6 +24,8 @@ def test_device_simplex_matches_real_glm(gen, golden):
     g = golden["glm_probe"]
     assert_bit_equal(gen.debug_probe("simplex2", g["xy"], len(g["xy"]))[:, 0], g["simplex2"], "device simplex2 vs glm")
     assert_bit_equal(gen.debug_probe("simplex3", g["xyz"], len(g["xyz"]))[:, 0], g["simplex3"], "device simplex3 vs glm")
+    # the lattice-split form k_cave_voxels uses (gradients shared per wave through LDS) is the same function
+    assert_bit_equal(gen.debug_probe("simplex3_split", g["xyz"], len(g["xyz"]))[:, 0], g["simplex3"], "device split simplex3 vs glm")
 
 
 def test_device_math_matches_kat(gen, golden):
