@@ -272,18 +272,25 @@ MM_DEV int cave_biome(int wx, int wy, int wz, float maxHeight, int seed)
     const float s2dStart = (top - 72.f) + 18.f * fbm2<3>(qx + -4921.34f, qz + 8402.13f);
     const float s2dEnd = (s2dStart - 10.f) + 7.f * fbm2<3>(qx + 9411.32f, qz + -3921.34f);
     const float shallow = smoothstep(s2dEnd, s2dStart, py);
-    const float rocky = smoothstep(-0.05f, 0.05f, simplex3(px * 0.0022f + -9193.23f, py * 0.0022f + -6813.39f, pz * 0.0022f + (float)-2171.23));
 
-    rand -= ((1.f - none) * shallow) * rocky;       // CRYSTAL_CAVES
-    if (rand <= 0.f) return MMCB_CRYSTAL_CAVES;
-    rand -= ((1.f - none) * shallow) * (1.f - rocky);   // LUSH_CAVES
-    if (rand <= 0.f) return MMCB_LUSH_CAVES;
-
-    const float warped = smoothstep(-0.05f, 0.05f, simplex3(px * 0.0030f + 5821.32f, py * 0.0030f + 4920.12f, pz * 0.0030f + 7931.59f));
-    rand -= (1.f - shallow) * warped;               // WARPED_FOREST
-    if (rand <= 0.f) return MMCB_WARPED_FOREST;
-    rand -= (1.f - shallow) * (1.f - warped);       // AMBER_FOREST
-    if (rand <= 0.f) return MMCB_AMBER_FOREST;
+    // rand > 0 here.  A weight that is exactly 0 (rocky, warped are in [0, 1]) subtracts +0 and cannot select its biome, so
+    // the simplex3 behind it is only evaluated when its factor is non-zero (outside the transition bands one of the two is 0).
+    const float shallowW = (1.f - none) * shallow;
+    if (shallowW != 0.f) {
+        const float rocky = smoothstep(-0.05f, 0.05f, simplex3(px * 0.0022f + -9193.23f, py * 0.0022f + -6813.39f, pz * 0.0022f + (float)-2171.23));
+        rand -= shallowW * rocky;                   // CRYSTAL_CAVES
+        if (rand <= 0.f) return MMCB_CRYSTAL_CAVES;
+        rand -= shallowW * (1.f - rocky);           // LUSH_CAVES
+        if (rand <= 0.f) return MMCB_LUSH_CAVES;
+    }
+    const float deepW = 1.f - shallow;
+    if (deepW != 0.f) {
+        const float warped = smoothstep(-0.05f, 0.05f, simplex3(px * 0.0030f + 5821.32f, py * 0.0030f + 4920.12f, pz * 0.0030f + 7931.59f));
+        rand -= deepW * warped;                     // WARPED_FOREST
+        if (rand <= 0.f) return MMCB_WARPED_FOREST;
+        rand -= deepW * (1.f - warped);             // AMBER_FOREST
+        if (rand <= 0.f) return MMCB_AMBER_FOREST;
+    }
     return MMCB_NONE;
 }
 

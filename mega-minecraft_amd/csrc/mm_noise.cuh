@@ -1,8 +1,19 @@
 // mmgen device noise library for gfx950: permutation-polynomial simplex 2D/3D with glm 0.9.9.8's exact fp32
 // operation order (reference math spec: external/include/glm/gtc/noise.inl:591-721, detail/_noise.hpp:8-60),
 // fbm stacks, sin-hash cell points and Worley distance searches (reference: src/util/rng.hpp:102-320).
-// Scalar formulation: every lane carries one sample; no vector temporaries, no lookup tables (the simplex
-// variant used by the reference has none), Worley cell points optionally served from an LDS tile.
+// Scalar formulation: every lane carries one sample; no vector temporaries.
+//
+// LDS tables.  The path is VALU-issue bound and the LDS pipe is idle, so the integer-valued part of simplex noise is served
+// from LDS: glm's permute() only ever sees small integer-valued floats (lattice coordinates mod 289 plus earlier permute
+// results), and the gradient of a lattice corner is a function of the final permute value alone.  Every workgroup builds
+//   perm4[i]  = 4 * permute(i - 8)               (byte offset of the next lookup), i - 8 in [-8, 600)
+//   grad3[p]  = simplex3 corner gradient * taylorInvSqrt          grad2[p] = simplex2 (a0, h, norm factor)
+// at kernel entry with the SAME fp32 instruction sequences the direct evaluation uses (noise_tables_init), so a lookup returns
+// bit for bit what the arithmetic would have produced.  A simplex3 then costs 16 LDS reads + ~170 VALU instead of 325 VALU, a
+// simplex2 9 reads + ~80 instead of 151.  Domain: mod289 of an integer-valued |x| < 2^24 lies in [-1, 289] and permute of
+// [-16, 700) in [0, 288] (tests/test_oracle_math.py::test_noise_table_domains); anything else (never met inside the
+// world's coordinate range) takes the direct arithmetic path.  EVERY kernel that can reach simplex2/simplex3 calls
+// noise_tables_init() before its first use.
 #pragma once
 #include "mm_math.cuh"
 
@@ -16,20 +27,81 @@ namespace mm {
 
 struct f2 { float x, y; };
 struct f3 { float x, y, z; };
+typedef float f4v __attribute__((ext_vector_type(4)));
 
 MM_DEV f2 mk2(float x, float y) { f2 r; r.x = x; r.y = y; return r; }
 MM_DEV f3 mk3(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
 
 // ---------------------------------------------------------------------------------------------------------
-// simplex
+// simplex: arithmetic pieces (glm order) and the LDS tables built from them
 // ---------------------------------------------------------------------------------------------------------
 MM_DEV float mod289(float x) { return x - __builtin_floorf(x * (1.f / 289.f)) * 289.f; }
 MM_DEV float permute(float x) { return mod289(((x * 34.f) + 1.f) * x); }
 
+// simplex2: gradient terms of a corner from its permute value p: (a0, h, 1.79284291400159 - 0.85373472095314 * (a0^2 + h^2))
+MM_DEV f3 simplex2_corner(float p)
+{
+    const float C3 = (float)0.024390243902439;
+    const float K1 = (float)1.79284291400159, K2 = (float)0.85373472095314;
+    const float X = 2.f * fract(p * C3) - 1.f;
+    const float h = __builtin_fabsf(X) - 0.5f;
+    const float a = X - __builtin_floorf(X + 0.5f);
+    return mk3(a, h, K1 - K2 * (a * a + h * h));
+}
+
+// simplex3: gradient of a corner from its permute value p, already scaled by taylorInvSqrt
+MM_DEV f3 simplex3_corner(float p)
+{
+    const float n_ = (float)0.142857142857;
+    const float nsx = n_ * 2.f - 0.f, nsy = n_ * 0.5f - 1.f, nsz = n_ * 1.f - 0.f;
+    const float K1 = (float)1.79284291400159, K2 = (float)0.85373472095314;
+    const float j = p - 49.f * __builtin_floorf((p * nsz) * nsz);
+    const float x_ = __builtin_floorf(j * nsz);
+    const float y_ = __builtin_floorf(j - 7.f * x_);
+    const float px = x_ * nsx + nsy;
+    const float py = y_ * nsx + nsy;
+    const float hh = (1.f - __builtin_fabsf(px)) - __builtin_fabsf(py);
+    // b0 = (x.x, x.y, y.x, y.y), b1 = (x.z, x.w, y.z, y.w); s = floor(b)*2+1; sh = -step(h, 0); a = b + s * sh
+    const float sh = -((0.f < hh) ? 0.f : 1.f);
+    const float sx = __builtin_floorf(px) * 2.f + 1.f;
+    const float sy = __builtin_floorf(py) * 2.f + 1.f;
+    const float g0 = px + sx * sh;
+    const float g1 = py + sy * sh;
+    const float nrm = K1 - K2 * ((g0 * g0 + g1 * g1) + hh * hh);
+    return mk3(g0 * nrm, g1 * nrm, hh * nrm);
+}
+
+#define MM_PERM_LO 8
+#define MM_PERM_N 608
+#define MM_GRAD_N 296
+// one object, so that non-inlined callees address every table with an immediate offset from a single known LDS base
+struct alignas(16) NoiseTables { f4v grad3[MM_GRAD_N]; f4v grad2[MM_GRAD_N]; int perm4[MM_PERM_N]; };
+static __shared__ NoiseTables s_noise;
+
+typedef __attribute__((address_space(3))) const char* lds_bytes;
+MM_DEV int perm4(int off) { return *(__attribute__((address_space(3))) const int*)((lds_bytes)s_noise.perm4 + 4 * MM_PERM_LO + off); }
+MM_DEV f4v grad3_at(int p4) { return *(__attribute__((address_space(3))) const f4v*)((lds_bytes)s_noise.grad3 + (p4 << 2)); }
+MM_DEV f4v grad2_at(int p4) { return *(__attribute__((address_space(3))) const f4v*)((lds_bytes)s_noise.grad2 + (p4 << 2)); }
+
+// Called by every thread of the workgroup at kernel entry (ends with a workgroup barrier).
+MM_DEV void noise_tables_init()
+{
+    const int nt = blockDim.x * blockDim.y * blockDim.z;
+    const int t = threadIdx.x + blockDim.x * (threadIdx.y + blockDim.y * threadIdx.z);
+    for (int i = t; i < MM_PERM_N; i += nt) s_noise.perm4[i] = 4 * (int)permute((float)(i - MM_PERM_LO));
+    for (int i = t; i < MM_GRAD_N; i += nt) {
+        const f3 g3 = simplex3_corner((float)i);
+        const f3 g2 = simplex2_corner((float)i);
+        s_noise.grad3[i] = f4v{g3.x, g3.y, g3.z, 0.f};
+        s_noise.grad2[i] = f4v{g2.x, g2.y, g2.z, 0.f};
+    }
+    __syncthreads();
+}
+
 MM_SIMPLEX_ATTR float simplex2(float vx, float vy)
 {
     const float C0 = (float)0.211324865405187, C1 = (float)0.366025403784439;
-    const float C2 = (float)-0.577350269189626, C3 = (float)0.024390243902439;
+    const float C2 = (float)-0.577350269189626;
 
     const float d = vx * C1 + vy * C1;
     float ix = __builtin_floorf(vx + d), iy = __builtin_floorf(vy + d);
@@ -43,9 +115,6 @@ MM_SIMPLEX_ATTR float simplex2(float vx, float vy)
 
     ix = gmod(ix, 289.f);
     iy = gmod(iy, 289.f);
-    const float p0 = permute((permute(iy + 0.f) + ix) + 0.f);
-    const float p1 = permute((permute(iy + i1y) + ix) + i1x);
-    const float p2 = permute((permute(iy + 1.f) + ix) + 1.f);
 
     float m0 = gmax(0.5f - (x0x * x0x + x0y * x0y), 0.f);
     float m1 = gmax(0.5f - (ax * ax + ay * ay), 0.f);
@@ -53,98 +122,33 @@ MM_SIMPLEX_ATTR float simplex2(float vx, float vy)
     m0 = m0 * m0; m1 = m1 * m1; m2 = m2 * m2;
     m0 = m0 * m0; m1 = m1 * m1; m2 = m2 * m2;
 
-    const float X0 = 2.f * fract(p0 * C3) - 1.f, X1 = 2.f * fract(p1 * C3) - 1.f, X2 = 2.f * fract(p2 * C3) - 1.f;
-    const float h0 = __builtin_fabsf(X0) - 0.5f, h1 = __builtin_fabsf(X1) - 0.5f, h2 = __builtin_fabsf(X2) - 0.5f;
-    const float a0 = X0 - __builtin_floorf(X0 + 0.5f), a1 = X1 - __builtin_floorf(X1 + 0.5f), a2 = X2 - __builtin_floorf(X2 + 0.5f);
-
-    const float K1 = (float)1.79284291400159, K2 = (float)0.85373472095314;
-    m0 = m0 * (K1 - K2 * (a0 * a0 + h0 * h0));
-    m1 = m1 * (K1 - K2 * (a1 * a1 + h1 * h1));
-    m2 = m2 * (K1 - K2 * (a2 * a2 + h2 * h2));
-
-    const float g0 = a0 * x0x + h0 * x0y;
-    const float g1 = a1 * ax + h1 * ay;
-    const float g2 = a2 * bx + h2 * by;
+    f3 c0, c1, c2;
+    if (ix >= -1.f && ix <= 289.f && iy >= -1.f && iy <= 289.f) {
+        const int x4 = 4 * (int)ix, y4 = 4 * (int)iy;
+        const int o1x = gt ? 4 : 0, o1y = gt ? 0 : 4;
+        const f4v t0 = grad2_at(perm4(perm4(y4) + x4));
+        const f4v t1 = grad2_at(perm4((perm4(y4 + o1y) + x4) + o1x));
+        const f4v t2 = grad2_at(perm4((perm4(y4 + 4) + x4) + 4));
+        c0 = mk3(t0.x, t0.y, t0.z); c1 = mk3(t1.x, t1.y, t1.z); c2 = mk3(t2.x, t2.y, t2.z);
+    } else {
+        c0 = simplex2_corner(permute((permute(iy + 0.f) + ix) + 0.f));
+        c1 = simplex2_corner(permute((permute(iy + i1y) + ix) + i1x));
+        c2 = simplex2_corner(permute((permute(iy + 1.f) + ix) + 1.f));
+    }
+    m0 = m0 * c0.z;
+    m1 = m1 * c1.z;
+    m2 = m2 * c2.z;
+    const float g0 = c0.x * x0x + c0.y * x0y;
+    const float g1 = c1.x * ax + c1.y * ay;
+    const float g2 = c2.x * bx + c2.y * by;
     return 130.f * ((m0 * g0 + m1 * g1) + m2 * g2);
-}
-
-MM_SIMPLEX_ATTR float simplex3(float vx, float vy, float vz)
-{
-    const float Cx = (float)(1.0 / 6.0), Cy = (float)(1.0 / 3.0);
-
-    const float d = (vx * Cy + vy * Cy) + vz * Cy;
-    float ix = __builtin_floorf(vx + d), iy = __builtin_floorf(vy + d), iz = __builtin_floorf(vz + d);
-    const float e = (ix * Cx + iy * Cx) + iz * Cx;
-    const float x0x = (vx - ix) + e, x0y = (vy - iy) + e, x0z = (vz - iz) + e;
-
-    // g = step(x0.yzx, x0); l = 1 - g; i1 = min(g, l.zxy); i2 = max(g, l.zxy)
-    const float gx = (x0x < x0y) ? 0.f : 1.f, gy = (x0y < x0z) ? 0.f : 1.f, gz = (x0z < x0x) ? 0.f : 1.f;
-    const float lx = 1.f - gx, ly = 1.f - gy, lz = 1.f - gz;
-    const float i1x = gmin(gx, lz), i1y = gmin(gy, lx), i1z = gmin(gz, ly);
-    const float i2x = gmax(gx, lz), i2y = gmax(gy, lx), i2z = gmax(gz, ly);
-
-    const float x1x = (x0x - i1x) + Cx, x1y = (x0y - i1y) + Cx, x1z = (x0z - i1z) + Cx;
-    const float x2x = (x0x - i2x) + Cy, x2y = (x0y - i2y) + Cy, x2z = (x0z - i2z) + Cy;
-    const float x3x = x0x - 0.5f, x3y = x0y - 0.5f, x3z = x0z - 0.5f;
-
-    ix = mod289(ix); iy = mod289(iy); iz = mod289(iz);
-
-    float p[4];
-    {
-        const float oz[4] = {0.f, i1z, i2z, 1.f}, oy[4] = {0.f, i1y, i2y, 1.f}, ox[4] = {0.f, i1x, i2x, 1.f};
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const float a = permute(iz + oz[k]);
-            const float b = permute((a + iy) + oy[k]);
-            p[k] = permute((b + ix) + ox[k]);
-        }
-    }
-
-    const float n_ = (float)0.142857142857;
-    const float nsx = n_ * 2.f - 0.f, nsy = n_ * 0.5f - 1.f, nsz = n_ * 1.f - 0.f;
-
-    float px[4], py[4], hh[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const float j = p[k] - 49.f * __builtin_floorf((p[k] * nsz) * nsz);
-        const float x_ = __builtin_floorf(j * nsz);
-        const float y_ = __builtin_floorf(j - 7.f * x_);
-        px[k] = x_ * nsx + nsy;
-        py[k] = y_ * nsx + nsy;
-        hh[k] = (1.f - __builtin_fabsf(px[k])) - __builtin_fabsf(py[k]);
-    }
-    // b0 = (x.x, x.y, y.x, y.y), b1 = (x.z, x.w, y.z, y.w); s = floor(b)*2+1; sh = -step(h, 0)
-    // a0 = b0.xzyw + s0.xzyw * sh.xxyy ; a1 = b1.xzyw + s1.xzyw * sh.zzww
-    float gx_[4], gy_[4];   // gradient xy per corner: corner k uses (x[k], y[k]) with sh[k]
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const float sh = -((0.f < hh[k]) ? 0.f : 1.f);
-        const float sx = __builtin_floorf(px[k]) * 2.f + 1.f;
-        const float sy = __builtin_floorf(py[k]) * 2.f + 1.f;
-        gx_[k] = px[k] + sx * sh;
-        gy_[k] = py[k] + sy * sh;
-    }
-
-    const float K1 = (float)1.79284291400159, K2 = (float)0.85373472095314;
-    float cx[4] = {x0x, x1x, x2x, x3x}, cy[4] = {x0y, x1y, x2y, x3y}, cz[4] = {x0z, x1z, x2z, x3z};
-    float mm4[4], pd[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const float nrm = K1 - K2 * ((gx_[k] * gx_[k] + gy_[k] * gy_[k]) + hh[k] * hh[k]);
-        const float qx = gx_[k] * nrm, qy = gy_[k] * nrm, qz = hh[k] * nrm;
-        float m = gmax(0.6f - ((cx[k] * cx[k] + cy[k] * cy[k]) + cz[k] * cz[k]), 0.f);
-        m = m * m;
-        mm4[k] = m * m;
-        pd[k] = (qx * cx[k] + qy * cy[k]) + qz * cz[k];
-    }
-    return 42.f * ((mm4[0] * pd[0] + mm4[1] * pd[1]) + (mm4[2] * pd[2] + mm4[3] * pd[3]));
 }
 
 // ---------------------------------------------------------------------------------------------------------
 // simplex3 split at the lattice: part1 (skewed cell + offsets inside it) -> gradients of the cell's 4 simplex corners
-// -> part3 (falloff * gradient . offset).  The gradients are a function of (cell, corner ordering) ONLY, so voxels that
-// share a cell can share them through LDS (k_cave_voxels).  simplex3_part3(part1(v), grad(part1(v))) == simplex3(v)
-// bit for bit: the same operations in the same order, merely regrouped (checked by the probe tests against real glm).
+// -> part3 (falloff * gradient . offset).  The gradients are a function of (cell, corner ordering) ONLY and come from the
+// LDS tables.  simplex3 = part3(part1(v), gradients(part1(v))): glm's operations in glm's order, merely regrouped (checked by
+// the probe tests against real glm).
 // ---------------------------------------------------------------------------------------------------------
 struct Sx3Cell { float ix, iy, iz; float x0x, x0y, x0z; int order; };      // order bits: gx | gy << 1 | gz << 2
 
@@ -156,40 +160,47 @@ MM_DEV Sx3Cell simplex3_part1(float vx, float vy, float vz)
     c.ix = __builtin_floorf(vx + d); c.iy = __builtin_floorf(vy + d); c.iz = __builtin_floorf(vz + d);
     const float e = (c.ix * Cx + c.iy * Cx) + c.iz * Cx;
     c.x0x = (vx - c.ix) + e; c.x0y = (vy - c.iy) + e; c.x0z = (vz - c.iz) + e;
+    // g = step(x0.yzx, x0)
     c.order = ((c.x0x < c.x0y) ? 0 : 1) | ((c.x0y < c.x0z) ? 0 : 2) | ((c.x0z < c.x0x) ? 0 : 4);
     return c;
 }
 
-// 12 floats: (qx, qy, qz) of the 4 corners, already scaled by taylorInvSqrt
-MM_DEV void simplex3_gradients(float ix, float iy, float iz, int order, float* __restrict__ q)
+// 12 floats: (qx, qy, qz) of the 4 corners, already scaled by taylorInvSqrt.  Arithmetic form; ix, iy, iz already mod289'd.
+MM_DEV void simplex3_gradients_direct(float ix, float iy, float iz, int order, float* __restrict__ q)
 {
-    const float gx = (order & 1) ? 1.f : 0.f, gy = (order & 2) ? 1.f : 0.f, gz = (order & 4) ? 1.f : 0.f;
-    const float lx = 1.f - gx, ly = 1.f - gy, lz = 1.f - gz;
-    const float i1x = gmin(gx, lz), i1y = gmin(gy, lx), i1z = gmin(gz, ly);
-    const float i2x = gmax(gx, lz), i2y = gmax(gy, lx), i2z = gmax(gz, ly);
-    ix = mod289(ix); iy = mod289(iy); iz = mod289(iz);
-    const float oz[4] = {0.f, i1z, i2z, 1.f}, oy[4] = {0.f, i1y, i2y, 1.f}, ox[4] = {0.f, i1x, i2x, 1.f};
-    const float n_ = (float)0.142857142857;
-    const float nsx = n_ * 2.f - 0.f, nsy = n_ * 0.5f - 1.f, nsz = n_ * 1.f - 0.f;
-    const float K1 = (float)1.79284291400159, K2 = (float)0.85373472095314;
+    // l = 1 - g; i1 = min(g, l.zxy); i2 = max(g, l.zxy)
+    const int gx = order & 1, gy = (order >> 1) & 1, gz = (order >> 2) & 1;
+    const int i1x = gx & (gz ^ 1), i1y = gy & (gx ^ 1), i1z = gz & (gy ^ 1);
+    const int i2x = gx | (gz ^ 1), i2y = gy | (gx ^ 1), i2z = gz | (gy ^ 1);
+    const float oz[4] = {0.f, (float)i1z, (float)i2z, 1.f}, oy[4] = {0.f, (float)i1y, (float)i2y, 1.f}, ox[4] = {0.f, (float)i1x, (float)i2x, 1.f};
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const float a = permute(iz + oz[k]);
         const float b = permute((a + iy) + oy[k]);
-        const float p = permute((b + ix) + ox[k]);
-        const float j = p - 49.f * __builtin_floorf((p * nsz) * nsz);
-        const float x_ = __builtin_floorf(j * nsz);
-        const float y_ = __builtin_floorf(j - 7.f * x_);
-        const float px = x_ * nsx + nsy;
-        const float py = y_ * nsx + nsy;
-        const float hh = (1.f - __builtin_fabsf(px)) - __builtin_fabsf(py);
-        const float sh = -((0.f < hh) ? 0.f : 1.f);
-        const float sx = __builtin_floorf(px) * 2.f + 1.f;
-        const float sy = __builtin_floorf(py) * 2.f + 1.f;
-        const float g0 = px + sx * sh;
-        const float g1 = py + sy * sh;
-        const float nrm = K1 - K2 * ((g0 * g0 + g1 * g1) + hh * hh);
-        q[3 * k] = g0 * nrm; q[3 * k + 1] = g1 * nrm; q[3 * k + 2] = hh * nrm;
+        const f3 g = simplex3_corner(permute((b + ix) + ox[k]));
+        q[3 * k] = g.x; q[3 * k + 1] = g.y; q[3 * k + 2] = g.z;
+    }
+}
+
+// Same values through the LDS tables (see the header); falls back to the arithmetic outside the tables' domain.
+MM_DEV void simplex3_gradients(float ix, float iy, float iz, int order, float* __restrict__ q)
+{
+    ix = mod289(ix); iy = mod289(iy); iz = mod289(iz);
+    if (ix >= -1.f && ix <= 289.f && iy >= -1.f && iy <= 289.f && iz >= -1.f && iz <= 289.f) {
+        const int gx = order & 1, gy = (order >> 1) & 1, gz = (order >> 2) & 1;
+        const int i1x = gx & (gz ^ 1), i1y = gy & (gx ^ 1), i1z = gz & (gy ^ 1);
+        const int i2x = gx | (gz ^ 1), i2y = gy | (gx ^ 1), i2z = gz | (gy ^ 1);
+        const int x4 = 4 * (int)ix, y4 = 4 * (int)iy, z4 = 4 * (int)iz;
+        const int oz[4] = {0, 4 * i1z, 4 * i2z, 4}, oy[4] = {0, 4 * i1y, 4 * i2y, 4}, ox[4] = {0, 4 * i1x, 4 * i2x, 4};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int a = perm4(z4 + oz[k]);
+            const int b = perm4((a + y4) + oy[k]);
+            const f4v g = grad3_at(perm4((b + x4) + ox[k]));
+            q[3 * k] = g.x; q[3 * k + 1] = g.y; q[3 * k + 2] = g.z;
+        }
+    } else {
+        simplex3_gradients_direct(ix, iy, iz, order, q);
     }
 }
 
@@ -212,6 +223,14 @@ MM_DEV float simplex3_part3(const Sx3Cell& c, const float* __restrict__ q)
         pd[k] = (q[3 * k] * cx[k] + q[3 * k + 1] * cy[k]) + q[3 * k + 2] * cz[k];
     }
     return 42.f * ((mm4[0] * pd[0] + mm4[1] * pd[1]) + (mm4[2] * pd[2] + mm4[3] * pd[3]));
+}
+
+MM_SIMPLEX_ATTR float simplex3(float vx, float vy, float vz)
+{
+    const Sx3Cell c = simplex3_part1(vx, vy, vz);
+    float q[12];
+    simplex3_gradients(c.ix, c.iy, c.iz, c.order, q);
+    return simplex3_part3(c, q);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -330,11 +349,30 @@ MM_DEV Worley3 worley3(float px, float py, float pz, const Cells& cells)
     return w;
 }
 
+// specialCaveNoise (rng.hpp:300-320) only uses the VALUES of the first and third smallest distance.  sqrt is monotonic and
+// correctly rounded, so the three smallest sqrt(d2) are the sqrt of the three smallest d2 whatever the tie order: the search
+// runs on squared distances and takes 2 square roots instead of 27.
 template <class Cells>
 MM_DEV float special_cave_noise(float px, float py, float pz, const Cells& cells)
 {
-    const Worley3 w = worley3(px, py, pz, cells);
-    return w.d3 / w.d1 - 1.f;
+    const float flx = __builtin_floorf(px), fly = __builtin_floorf(py), flz = __builtin_floorf(pz);
+    const int ux = (int)flx, uy = (int)fly, uz = (int)flz;
+    const float fx = px - flx, fy = py - fly, fz = pz - flz;
+    float s1 = 3.402823466e+38f, s2 = 3.402823466e+38f, s3 = 3.402823466e+38f;
+    for (int x = -1; x <= 1; ++x) {
+        for (int y = -1; y <= 1; ++y) {
+            for (int z = -1; z <= 1; ++z) {
+                const f3 pt = cells(ux + x, uy + y, uz + z);
+                const float dx = ((float)x + pt.x) - fx, dy = ((float)y + pt.y) - fy, dz = ((float)z + pt.z) - fz;
+                const float d2 = (dx * dx + dy * dy) + dz * dz;
+                // keep the three smallest: s1 <= s2 <= s3
+                const float a = gmin(s1, d2), b = gmax(s1, d2);
+                const float c = gmin(s2, b), d = gmax(s2, b);
+                s1 = a; s2 = c; s3 = gmin(s3, d);
+            }
+        }
+    }
+    return __builtin_sqrtf(s3) / __builtin_sqrtf(s1) - 1.f;
 }
 
 }  // namespace mm

@@ -217,6 +217,7 @@ k_feature_placements(const float* __restrict__ hf, const float* __restrict__ bw,
                      mmgen_feature_placement* __restrict__ fpOut, mmgen_cave_feature_placement* __restrict__ cfpOut, int* __restrict__ counts,
                      const int* __restrict__ chunkList)
 {
+    noise_tables_init();
     __shared__ int s_ns[256], s_nc[256];
     const int chunk = chunkList ? chunkList[blockIdx.x] : blockIdx.x, t = threadIdx.x;
     const int2 cp = chunkPos[chunk];
@@ -367,6 +368,7 @@ __global__ void __launch_bounds__(384)
 k_apply_features(uint8_t* __restrict__ blocks, const int2* __restrict__ chunkPos, const mmgen_feature_placement* __restrict__ gfp,
                  const mmgen_cave_feature_placement* __restrict__ gcfp, const int* __restrict__ bounds, const int* __restrict__ srcIdx)
 {
+    noise_tables_init();
     __shared__ uint16_t s_candS[CAND_CAP], s_candC[CAND_CAP];
     __shared__ int s_wave[16];
     const int col = blockIdx.x;
@@ -454,6 +456,7 @@ __global__ void __launch_bounds__(256)
 k_decorators(uint8_t* __restrict__ blocks, const float* __restrict__ hf, const float* __restrict__ bw,
              const mmgen_cave_layer* __restrict__ caveLayers, const int2* __restrict__ chunkPos, const int* __restrict__ srcIdx)
 {
+    noise_tables_init();
     __shared__ int s_draws[256];
     const int outChunk = blockIdx.x, t = threadIdx.x;
     const int chunk = srcIdx ? srcIdx[outChunk] : outChunk;
@@ -500,6 +503,7 @@ k_decorators(uint8_t* __restrict__ blocks, const float* __restrict__ hf, const f
 __global__ void __launch_bounds__(256)
 k_feature_box(int isCave, int feature, int fx, int fy, int fz, int layerHeight, int bx, int by, int bz, int sx, int sy, int sz, uint8_t* __restrict__ out)
 {
+    noise_tables_init();
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= sx * sy * sz) return;
     const int y = i % sy, x = (i / sy) % sx, z = i / (sy * sx);

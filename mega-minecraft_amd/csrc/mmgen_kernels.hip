@@ -20,6 +20,7 @@ template <bool GATHERED>
 __global__ void __launch_bounds__(GATHERED ? 384 : 256)
 k_heightfield(const int2* __restrict__ chunkPos, float* __restrict__ hf, float* __restrict__ bw, float* __restrict__ gathered)
 {
+    noise_tables_init();
     const int chunk = blockIdx.x;
     const int t = threadIdx.x;
     int x, z;
@@ -65,6 +66,7 @@ MM_DEV float stratified_thickness(int layer, float weight, float wx, float wz)
 __global__ void __launch_bounds__(256)
 k_layers(const float* __restrict__ gathered, const float* __restrict__ bw, const int2* __restrict__ chunkPos, float* __restrict__ layers)
 {
+    noise_tables_init();
     __shared__ float s_h[MMGEN_GATHERED_HEIGHTFIELD_SIZE];
     const int chunk = blockIdx.x;
     const int t = threadIdx.x;
@@ -142,13 +144,14 @@ __global__ void __launch_bounds__(256) k_fix_backward(float* __restrict__ layers
 // K4 — caves.
 //   k_cave_columns : per column, everything of shouldGenerateCaveAtBlock that does not depend on y
 //                    (ocean+beach weight, the whole ravine branch → one y threshold)
-//   k_cave_voxels  : one workgroup (6 waves) per column, lane = y; Worley cell points of the column's reachable
-//                    7x8x7 cell box staged in LDS; solid/air bits → wave ballots → (start,end) runs
-//   k_cave_biomes  : per (layer slot, column) cave-biome pair, lanes = columns so that occupied slots pack densely
+//   k_cave_voxels  : one workgroup (3 waves, 3 passes) per 4 columns, lane = voxel; Worley cell points of the columns' reachable
+//                    8x8x7 cell box staged in LDS; solid/air bits → LDS bit words → popcount ranks → (start,end) runs
+//   k_cave_biomes  : the occupied layer slots' (bottom, top) cave-biome evaluations, compacted per 32 columns and walked densely
 // =========================================================================================================
 __global__ void __launch_bounds__(256)
 k_cave_columns(const float* __restrict__ bw, const int2* __restrict__ chunkPos, float2* __restrict__ colInfo, const int* __restrict__ chunkList)
 {
+    noise_tables_init();
     const int chunk = chunkList ? chunkList[blockIdx.x] : blockIdx.x, t = threadIdx.x;
     const int2 cp = chunkPos[chunk];
     const int wx = cp.x + (t & 15), wz = cp.y + (t >> 4);
@@ -184,7 +187,10 @@ k_cave_columns(const float* __restrict__ bw, const int2* __restrict__ chunkPos, 
 #define CELL_N (CELL_NX * CELL_NY * CELL_NZ)
 #define CAVE_COLS 4        // columns per workgroup (same z row of the chunk, x = 4g .. 4g+3)
 #define CAVE_YEVAL 144     // voxels y < 144 may need the noise (threshold is 0 once y + 50*obw >= 142); 144 = 2.25 waves
-#define CAVE_THREADS (CAVE_COLS * CAVE_YEVAL)     // 576 = 9 full waves: no partially filled wave
+#define CAVE_VOXELS (CAVE_COLS * CAVE_YEVAL)      // 576 = 9 full waves: no partially filled wave
+#ifndef CAVE_THREADS
+#define CAVE_THREADS 192                          // 3 waves x 3 passes
+#endif
 
 struct CellTile {
     const float* pts;     // LDS, 3 floats per cell
@@ -200,116 +206,13 @@ struct CellTile {
     }
 };
 
-#ifndef MM_CAVE_LATTICE
-#define MM_CAVE_LATTICE 1
-#endif
-#define LAT_CAP 64
-// per-wave LDS staging of simplex lattice gradients: keys of the distinct (cell, corner ordering) pairs met by the wave's 64 voxels
-// and the 4 corner gradients (12 floats) of each
-typedef float f4v __attribute__((ext_vector_type(4)));
-struct alignas(16) LatticeWave { f4v key[LAT_CAP]; f4v q[LAT_CAP][3]; };
-typedef __attribute__((address_space(3))) LatticeWave* LatticePtr;      // LDS pointer: ds_read/ds_write instead of flat_*
-
-// Wave-local LDS hand-off: LDS operations of one wave are executed in issue order, so lanes of the same wave see each other's
-// writes without a workgroup barrier; only the compiler has to be kept from reordering across the hand-off.
-MM_DEV void wave_lds_sync()
-{
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-// value of the previous lane (lane 0 gets its own): one DPP move (wave_shr:1)
-#ifndef MM_PREV_LANE
-#define MM_PREV_LANE 1
-#endif
-#if MM_PREV_LANE == 0
-MM_DEV int prev_lane_i(int v) { return __shfl_up(v, 1); }
-#elif MM_PREV_LANE == 1
-MM_DEV int prev_lane_i(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x138, 0xf, 0xf, false); }
-#else
-MM_DEV int prev_lane_i(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x111, 0xf, 0xf, false); }   // row_shr:1, rows of 16
-#endif
-MM_DEV float prev_lane_f(float v) { return __int_as_float(prev_lane_i(__float_as_int(v))); }
-
-// one lane per queued (cell, ordering) pair computes the 4 corner gradients
-static __device__ __attribute__((noinline)) void lattice_build(LatticePtr Lp, int n, int lane)
-{
-    wave_lds_sync();
-    if (lane < n) {
-        float q[12];
-        const f4v k = Lp->key[lane];
-        simplex3_gradients(k.x, k.y, k.z, __float_as_int(k.w), q);
-#pragma unroll
-        for (int i = 0; i < 3; ++i) Lp->q[lane][i] = f4v{q[4 * i], q[4 * i + 1], q[4 * i + 2], q[4 * i + 3]};
-    }
-    wave_lds_sync();
-}
-
-static __device__ __attribute__((noinline)) float lattice_eval(LatticePtr Lp, int slot, float ix, float iy, float iz, float x0x, float x0y,
-                                                                 float x0z, int order)
-{
-    Sx3Cell c; c.ix = ix; c.iy = iy; c.iz = iz; c.x0x = x0x; c.x0y = x0y; c.x0z = x0z; c.order = order;
-    float q[12];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        const f4v v = Lp->q[slot][i];
-        q[4 * i] = v.x; q[4 * i + 1] = v.y; q[4 * i + 2] = v.z; q[4 * i + 3] = v.w;
-    }
-    return simplex3_part3(c, q);
-}
-
-// Evaluates NS simplex3 samples per lane.  Along a column the samples of one site fall into few lattice cells, so instead of
-// every lane recomputing the 12 permutation hashes + gradient decode of its cell (≈ 2/3 of simplex3), the wave (1) finds the
-// change points of (cell, ordering) along its lanes, (2) lets ONE lane per distinct pair compute the gradients — pairs of
-// SEVERAL sites in different lanes of the same pass, flushed whenever the 64-entry table would overflow — and (3) every lane
-// fetches its cell's gradients from LDS.  Bit-exact: the gradients are the same function of the same arguments.
-// Wave-local (no workgroup barrier): must be called wave-uniformly; waves may take different numbers of flushes.
-template <int NS>
-MM_DEV void simplex3_sites(const float* sx, const float* sy, const float* sz, float* out, LatticeWave& L, int lane)
-{
-    Sx3Cell c[NS];
-    int slot[NS];
-    int base = 0, first = 0;
-    const LatticePtr Lp = (LatticePtr)&L;
-#pragma unroll
-    for (int s = 0; s < NS; ++s) {
-        c[s] = simplex3_part1(sx[s], sy[s], sz[s]);
-        // cross-lane reads first, unconditionally (a short-circuited || would run them under a partial EXEC mask)
-        const float pix = prev_lane_f(c[s].ix), piy = prev_lane_f(c[s].iy), piz = prev_lane_f(c[s].iz);
-        const int po = prev_lane_i(c[s].order);
-        const bool leader = (int)(MM_PREV_LANE == 2 ? (lane & 15) == 0 : lane == 0) | (int)(pix != c[s].ix) | (int)(piy != c[s].iy) |
-                            (int)(piz != c[s].iz) | (int)(po != c[s].order);
-        const unsigned long long m = __ballot(leader);
-        const int cnt = __popcll(m);
-        if (base + cnt > LAT_CAP) {            // wave-uniform: flush the queued sites first
-            lattice_build(Lp, base, lane);
-#pragma unroll
-            for (int u = 0; u < NS; ++u)
-                if (u >= first && u < s) out[u] = lattice_eval(Lp, slot[u], c[u].ix, c[u].iy, c[u].iz, c[u].x0x, c[u].x0y, c[u].x0z, c[u].order);
-            wave_lds_sync();
-            first = s;
-            base = 0;
-        }
-        slot[s] = base + __popcll(m & ((2ull << lane) - 1ull)) - 1;
-        if (leader) {
-            Lp->key[slot[s]] = f4v{c[s].ix, c[s].iy, c[s].iz, __int_as_float(c[s].order)};
-        }
-        base += cnt;
-    }
-    lattice_build(Lp, base, lane);
-#pragma unroll
-    for (int u = 0; u < NS; ++u)
-        if (u >= first) out[u] = lattice_eval(Lp, slot[u], c[u].ix, c[u].iy, c[u].iz, c[u].x0x, c[u].x0y, c[u].x0z, c[u].order);
-    wave_lds_sync();      // L is reused by the next call
-}
-
-// One workgroup = 4 neighbouring columns.  Lane e evaluates voxel (column e / 144, y = e % 144): 576 lanes = 9 FULL waves (a
-// 384-lane-per-column mapping pays 3 waves for 142 useful lanes).  Voxels y >= 144 never need noise: solid iff
-// y <= min(max((int)h, 128), ravine cut), so their bits are built analytically.  The air/solid bits of all 4 x 384 voxels go to
-// LDS as 64-bit words; runs are extracted with popcount prefixes over those words.
+// One workgroup = 4 neighbouring columns = 4 x 144 evaluated voxels (e -> column e / 144, y = e % 144), walked by CAVE_THREADS
+// lanes in CAVE_VOXELS / CAVE_THREADS passes of FULL waves (a 384-lane-per-column mapping pays 3 waves for 142 useful lanes).
+// Small workgroups (3 waves) pack the CU's wave slots tightly whatever SIMD the dispatcher starts a workgroup on.
+// Voxels y >= 144 never need noise: solid iff y <= min(max((int)h, 128), ravine cut), so their bits are built analytically.
+// The air/solid bits of all 4 x 384 voxels go to LDS as 64-bit words; runs are extracted with popcount prefixes over those words.
 #ifndef MM_CAVE_WAVES
-#define MM_CAVE_WAVES 6          // 80 VGPRs: 2 workgroups of 9 waves per CU (the default allocation, 98 VGPRs, fits only one)
+#define MM_CAVE_WAVES 6
 #endif
 __attribute__((amdgpu_waves_per_eu(MM_CAVE_WAVES, MM_CAVE_WAVES)))
 __global__ void __launch_bounds__(CAVE_THREADS)
@@ -318,109 +221,68 @@ k_cave_voxels(const float* __restrict__ hf, const float2* __restrict__ colInfo, 
 {
     __shared__ float s_cells[3 * CELL_N];
     __shared__ unsigned long long s_solid[CAVE_COLS][6];      // solid bit of voxel y at word y / 64, bit y % 64
-#if MM_CAVE_LATTICE
-    __shared__ LatticeWave s_lat[CAVE_THREADS / 64];
-#endif
     __shared__ int s_layers[CAVE_COLS][3 * MMGEN_MAX_CAVE_LAYERS_PER_COLUMN];
 
     const int t = threadIdx.x;
     const int chunk = chunkList ? chunkList[blockIdx.x >> 6] : (int)(blockIdx.x >> 6);
-    const int group = blockIdx.x & 63;                         // 64 groups of 4 columns per chunk
-    const int c = t / CAVE_YEVAL, y = t - c * CAVE_YEVAL;
-    const int idx2d = 4 * group + c;                           // x = 4 (group % 4) + c, z = group / 4
-    const int col = chunk * 256 + idx2d;
+    const int group = blockIdx.x & 63;                         // 64 groups of 4 columns per chunk: x = 4 (group % 4) + c, z = group / 4
     const int2 cp = chunkPos[chunk];
-    const int wx = cp.x + (idx2d & 15), wz = cp.y + (idx2d >> 4);
-    const float maxHeight = hf[col];
-    const float2 ci = colInfo[col];
-    const float obw = ci.x, ravineY = ci.y;
 
-    const float npx = (float)wx * 0.0050f, npz = (float)wz * 0.0050f;
     // cell tile: sample position = noisePos * (1, 1.6, 1) + offset with |offset| < 1.8; origin from the group's first column
     CellTile tile;
     tile.pts = s_cells;
     tile.ox = (int)__builtin_floorf(((float)(cp.x + ((4 * group) & 15)) * 0.0050f) * 1.f) - 3;
     tile.oy = -3;
-    tile.oz = (int)__builtin_floorf(npz * 1.f) - 3;
-    if (t < CELL_N) {
-        const int iz = t % CELL_NZ, iy = (t / CELL_NZ) % CELL_NY, ix = t / (CELL_NZ * CELL_NY);
+    tile.oz = (int)__builtin_floorf(((float)(cp.y + ((4 * group) >> 4)) * 0.0050f) * 1.f) - 3;
+    for (int i = t; i < CELL_N; i += CAVE_THREADS) {
+        const int iz = i % CELL_NZ, iy = (i / CELL_NZ) % CELL_NY, ix = i / (CELL_NZ * CELL_NY);
         const f3 p = rand3from3((float)(tile.ox + ix), (float)(tile.oy + iy), (float)(tile.oz + iz));
-        s_cells[3 * t] = p.x; s_cells[3 * t + 1] = p.y; s_cells[3 * t + 2] = p.z;
+        s_cells[3 * i] = p.x; s_cells[3 * i + 1] = p.y; s_cells[3 * i + 2] = p.z;
     }
     if (t < CAVE_COLS * 6) s_solid[t / 6][t % 6] = 0ull;
-    if (t < CAVE_COLS * 3 * MMGEN_MAX_CAVE_LAYERS_PER_COLUMN) (&s_layers[0][0])[t] = ((t % 3) == 2) ? 0 : 384;   // {384, 384, biomes = 0}
-    __syncthreads();
+    for (int i = t; i < CAVE_COLS * 3 * MMGEN_MAX_CAVE_LAYERS_PER_COLUMN; i += CAVE_THREADS)
+        (&s_layers[0][0])[i] = ((i % 3) == 2) ? 0 : 384;       // {384, 384, biomes = 0}
+    noise_tables_init();                                       // ends with the workgroup barrier
 
-    const int topSolid = imax((int)maxHeight, MMGEN_SEA_LEVEL);
-    const float fy = (float)y;
-    const float npy = fy * 0.0050f;
-    const bool inBand = (y != 0) && (y <= topSolid);
-    const float topRatio = smoothstep(142.f, 95.f, fy + obw * 50.f);
-    const float bottomRatio = smoothstep(5.f, 20.f, fy);
-    const bool needThr = inBand && topRatio > 0.f;      // threshold is a product with topRatio: 0 → "threshold > 0.04" is false
-    bool cave = (y != 0) && !inBand;                    // y == 0 solid, y > topSolid air
-#if MM_CAVE_LATTICE
-    // All 23 simplex3 evaluations of a voxel go through simplex3_sites: every wave shares the lattice gradients of the cells its
-    // 64 voxels fall into (stage structure is uniform over the workgroup; lanes that do not need a value simply ignore it).
-    LatticeWave& L = s_lat[t >> 6];
-    const int lane = t & 63;
-    float thr = 0.f;
-    if (__ballot(needThr) != 0ull) {       // wave-uniform
-        float sx[4], sy[4], sz[4], v[4];
-        float ax = npx * 4.f, ay = npy * 4.f, az = npz * 4.f;
-#pragma unroll
-        for (int o = 0; o < 4; ++o) { sx[o] = ax; sy[o] = ay; sz[o] = az; ax *= 2.f; ay *= 2.f; az *= 2.f; }
-        simplex3_sites<4>(sx, sy, sz, v, L, lane);
-        const float fa = (((0.f + 0.5f * v[0]) + 0.25f * v[1]) + 0.125f * v[2]) + 0.0625f * v[3];
-        float bx = npx * 0.0700f, by = npy * 0.0700f, bz = npz * 0.0700f;
-#pragma unroll
-        for (int o = 0; o < 4; ++o) { sx[o] = bx; sy[o] = by; sz[o] = bz; bx *= 2.f; by *= 2.f; bz *= 2.f; }
-        simplex3_sites<4>(sx, sy, sz, v, L, lane);
-        const float fb = (((0.f + 0.5f * v[0]) + 0.25f * v[1]) + 0.125f * v[2]) + 0.0625f * v[3];
-        thr = 0.24f + 0.12f * fa;
-        const float huge = smoothstep(0.2f, 0.4f, fb);
-        thr *= (1.f + 1.4f * huge);
-        thr *= topRatio * (0.3f + 0.7f * bottomRatio);
-    }
-    const bool needWarp = needThr && thr > 0.04f;
-    float warp[3] = {0.f, 0.f, 0.f};
-    if (__ballot(needWarp) != 0ull) {      // wave-uniform
-        const float offx[3] = {0.f, 5923.45f, 1765.68f}, offy[3] = {0.f, 4129.42f, 4704.36f}, offz[3] = {0.f, 5790.48f, 5692.12f};
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            float sx[5], sy[5], sz[5], v[5];
-            float wx0 = npx * 0.8000f, wy0 = npy * 0.8000f, wz0 = npz * 0.8000f;
-            if (k > 0) { wx0 += offx[k]; wy0 += offy[k]; wz0 += offz[k]; }
-#pragma unroll
-            for (int o = 0; o < 5; ++o) { sx[o] = wx0; sy[o] = wy0; sz[o] = wz0; wx0 *= 2.f; wy0 *= 2.f; wz0 *= 2.f; }
-            simplex3_sites<5>(sx, sy, sz, v, L, lane);
-            warp[k] = ((((0.f + 0.5f * v[0]) + 0.25f * v[1]) + 0.125f * v[2]) + 0.0625f * v[3]) + 0.03125f * v[4];
+    for (int e = t; e < CAVE_VOXELS; e += CAVE_THREADS) {
+        const int c = e / CAVE_YEVAL, y = e - c * CAVE_YEVAL;
+        const int idx2d = 4 * group + c;
+        const int col = chunk * 256 + idx2d;
+        const int wx = cp.x + (idx2d & 15), wz = cp.y + (idx2d >> 4);
+        const float maxHeight = hf[col];
+        const float2 ci = colInfo[col];
+        const float obw = ci.x, ravineY = ci.y;
+        const float npx = (float)wx * 0.0050f, npz = (float)wz * 0.0050f;
+
+        const int topSolid = imax((int)maxHeight, MMGEN_SEA_LEVEL);
+        const float fy = (float)y;
+        const float npy = fy * 0.0050f;
+        const bool inBand = (y != 0) && (y <= topSolid);
+        const float topRatio = smoothstep(142.f, 95.f, fy + obw * 50.f);
+        const float bottomRatio = smoothstep(5.f, 20.f, fy);
+        const bool needThr = inBand && topRatio > 0.f;      // threshold is a product with topRatio: 0 → "threshold > 0.04" is false
+        bool cave = (y != 0) && !inBand;                    // y == 0 solid, y > topSolid air
+        if (needThr) {
+            float thr = 0.24f + 0.12f * fbm3<4>(npx * 4.f, npy * 4.f, npz * 4.f);
+            const float huge = smoothstep(0.2f, 0.4f, fbm3<4>(npx * 0.0700f, npy * 0.0700f, npz * 0.0700f));
+            thr *= (1.f + 1.4f * huge);
+            thr *= topRatio * (0.3f + 0.7f * bottomRatio);
+            if (thr > 0.04f) {
+                const f3 o = fbm3from3<5>(npx * 0.8000f, npy * 0.8000f, npz * 0.8000f);
+                const float n = special_cave_noise(npx * 1.f + o.x * 1.8f, npy * 1.6f + o.y * 1.8f, npz * 1.f + o.z * 1.8f, tile);
+                cave = n < thr;
+            }
         }
+        if (inBand && !cave) cave = fy > ravineY;
+        // the wave's 64 lanes may straddle two columns / two 64-bit words: OR each lane's bit into its word
+        if (!cave) atomicOr(&s_solid[c][y >> 6], 1ull << (y & 63));
     }
-    if (needWarp) {
-        const float n = special_cave_noise(npx * 1.f + warp[0] * 1.8f, npy * 1.6f + warp[1] * 1.8f, npz * 1.f + warp[2] * 1.8f, tile);
-        cave = n < thr;
-    }
-    if (inBand && !cave) cave = fy > ravineY;
-#else
-    if (needThr) {
-        float thr = 0.24f + 0.12f * fbm3<4>(npx * 4.f, npy * 4.f, npz * 4.f);
-        const float huge = smoothstep(0.2f, 0.4f, fbm3<4>(npx * 0.0700f, npy * 0.0700f, npz * 0.0700f));
-        thr *= (1.f + 1.4f * huge);
-        thr *= topRatio * (0.3f + 0.7f * bottomRatio);
-        if (thr > 0.04f) {
-            const f3 o = fbm3from3<5>(npx * 0.8000f, npy * 0.8000f, npz * 0.8000f);
-            const float n = special_cave_noise(npx * 1.f + o.x * 1.8f, npy * 1.6f + o.y * 1.8f, npz * 1.f + o.z * 1.8f, tile);
-            cave = n < thr;
-        }
-    }
-    if (inBand && !cave) cave = fy > ravineY;
-#endif
-    // the wave's 64 lanes may straddle two columns / two 64-bit words: OR each lane's bit into its word
-    if (!cave) atomicOr(&s_solid[c][y >> 6], 1ull << (y & 63));
     // analytic part, y in [144, 384): solid iff y <= topSolid and not (y > ravineY)   (topRatio == 0 there)
-    if (y < 4) {               // 4 lanes per column fill words 2..5 (word 2 holds y 128..191: bits >= 16 only)
-        const int w = 2 + y;
+    if (t < CAVE_COLS * 4) {   // 4 lanes per column fill words 2..5 (word 2 holds y 128..191: bits >= 16 only)
+        const int c = t >> 2, w = 2 + (t & 3);
+        const int col = chunk * 256 + 4 * group + c;
+        const int topSolid = imax((int)hf[col], MMGEN_SEA_LEVEL);
+        const float ravineY = colInfo[col].y;
         unsigned long long m = 0ull;
         for (int b = 0; b < 64; ++b) {
             const int yy = 64 * w + b;
@@ -430,7 +292,7 @@ k_cave_voxels(const float* __restrict__ hf, const float2* __restrict__ colInfo, 
     }
     __syncthreads();
 
-    // flips: solid(y) != solid(y+1), y = 383 compares with "not solid"; rank by popcount prefix; 4 x 384 voxels over 576 lanes
+    // flips: solid(y) != solid(y+1), y = 383 compares with "not solid"; rank by popcount prefix over the 4 x 384 voxels
     for (int v = t; v < CAVE_COLS * 384; v += CAVE_THREADS) {
         const int cc = v / 384, yy = v - cc * 384;
         const int w = yy >> 6, b = yy & 63;
@@ -451,33 +313,59 @@ k_cave_voxels(const float* __restrict__ hf, const float2* __restrict__ colInfo, 
         }
     }
     __syncthreads();
-    if (t < CAVE_COLS * 3 * MMGEN_MAX_CAVE_LAYERS_PER_COLUMN) {
-        const int cc = t / (3 * MMGEN_MAX_CAVE_LAYERS_PER_COLUMN), k = t % (3 * MMGEN_MAX_CAVE_LAYERS_PER_COLUMN);
+    for (int i = t; i < CAVE_COLS * 3 * MMGEN_MAX_CAVE_LAYERS_PER_COLUMN; i += CAVE_THREADS) {
+        const int cc = i / (3 * MMGEN_MAX_CAVE_LAYERS_PER_COLUMN), k = i % (3 * MMGEN_MAX_CAVE_LAYERS_PER_COLUMN);
         ((int*)(caveLayers + (size_t)MMGEN_MAX_CAVE_LAYERS_PER_COLUMN * (chunk * 256 + 4 * group + cc)))[k] = s_layers[cc][k];
     }
 }
 
-__global__ void __launch_bounds__(256)
+// Cave biomes of the layers' end blocks: at most 2 getCaveBiome evaluations per occupied layer slot, and only a few of a column's
+// 32 slots are occupied.  One workgroup = CB_COLS columns of a chunk: the (column, slot, bottom | top) evaluations that exist are
+// compacted into an LDS list and walked densely, so that every lane of every pass carries one.
+#ifndef CB_COLS
+#define CB_COLS 32
+#endif
+#ifndef CB_THREADS
+#define CB_THREADS 128
+#endif
+__global__ void __launch_bounds__(CB_THREADS)
 k_cave_biomes(const float* __restrict__ hf, const int2* __restrict__ chunkPos, mmgen_cave_layer* __restrict__ caveLayers,
               const int* __restrict__ chunkList)
 {
-    const int chunk = chunkList ? chunkList[blockIdx.x >> 5] : (int)(blockIdx.x >> 5), k = blockIdx.x & 31;
+    __shared__ unsigned short s_items[CB_COLS * MMGEN_MAX_CAVE_LAYERS_PER_COLUMN * 2];    // (column * 32 + slot) << 1 | top
+    __shared__ int s_count;
+    constexpr int groupsPerChunk = 256 / CB_COLS;
+    const int chunk = chunkList ? chunkList[blockIdx.x / groupsPerChunk] : (int)(blockIdx.x / groupsPerChunk);
+    const int col0 = (blockIdx.x % groupsPerChunk) * CB_COLS;
     const int t = threadIdx.x;
-    mmgen_cave_layer* L = caveLayers + ((size_t)256 * chunk + t) * MMGEN_MAX_CAVE_LAYERS_PER_COLUMN + k;
-    const int start = L->start;
-    if (start == 384) return;           // unused slot: biomes stay NONE (0)
-    const int end = L->end;
+    mmgen_cave_layer* L0 = caveLayers + ((size_t)256 * chunk + col0) * MMGEN_MAX_CAVE_LAYERS_PER_COLUMN;
+    if (t == 0) s_count = 0;
+    noise_tables_init();                                       // ends with the workgroup barrier
+    for (int i = t; i < CB_COLS * MMGEN_MAX_CAVE_LAYERS_PER_COLUMN; i += CB_THREADS) {
+        const int start = L0[i].start, end = L0[i].end;
+        if (start == 384) continue;                            // unused slot: biomes stay NONE (0)
+        const int n = (end == 384) ? 1 : 2;                    // a layer open to the sky has no top block: top biome NONE
+        const int at = atomicAdd(&s_count, n);
+        s_items[at] = (unsigned short)(i << 1);
+        if (n == 2) s_items[at + 1] = (unsigned short)((i << 1) | 1);
+        else L0[i].top_biome = (uint8_t)MMCB_NONE;
+    }
+    __syncthreads();
+    const int count = s_count;
     const int2 cp = chunkPos[chunk];
-    const int wx = cp.x + (t & 15), wz = cp.y + (t >> 4);
-    const float maxHeight = hf[(size_t)256 * chunk + t];
-    const int bottom = cave_biome(wx, start, wz, maxHeight, 329271348);
-    const int top = (end == 384) ? MMCB_NONE : cave_biome(wx, end + 1, wz, maxHeight, 4982921);
-    L->bottom_biome = (uint8_t)bottom;
-    L->top_biome = (uint8_t)top;
+    for (int k = t; k < count; k += CB_THREADS) {
+        const int item = s_items[k];
+        const int i = item >> 1, top = item & 1;
+        const int col = col0 + i / MMGEN_MAX_CAVE_LAYERS_PER_COLUMN;
+        const int wx = cp.x + (col & 15), wz = cp.y + (col >> 4);
+        const float maxHeight = hf[(size_t)256 * chunk + col];
+        if (top) L0[i].top_biome = (uint8_t)cave_biome(wx, L0[i].end + 1, wz, maxHeight, 4982921);
+        else L0[i].bottom_biome = (uint8_t)cave_biome(wx, L0[i].start, wz, maxHeight, 329271348);
+    }
 }
 
 // =========================================================================================================
-// K6 — fill.  One workgroup = 4 neighbouring columns (12 waves).  Two phases inside the workgroup:
+// K6 — fill.  One workgroup (4 waves) = 4 neighbouring columns.  Two phases inside the workgroup:
 //   1. every voxel gets its base block (bedrock / air / water / cave air / layer material + surface-biome rules): cheap, lane = y;
 //   2. the voxels whose block a cave biome could still alter (STONE / DEEPSLATE / BLACKSTONE below ground — the only blocks
 //      caveBiomeBlockPostProcess touches) are compacted into an LDS list and processed densely: the cave-biome evaluation
@@ -548,13 +436,20 @@ MM_DEV BaseBlock place_block_base(const float* s_bw, const float* s_lh, const mm
 }
 
 #define FILL_COLS 4
-#define FILL_THREADS 768
+#ifndef FILL_THREADS
+#define FILL_THREADS 256      // phase 2 walks ~450 compacted voxels: 2 passes at 88 % lane use (768 lanes: 1 pass at 59 %)
+#endif
+#ifndef MM_FILL_WAVES
+#define MM_FILL_WAVES 6
+#endif
 
+__attribute__((amdgpu_waves_per_eu(MM_FILL_WAVES, MM_FILL_WAVES)))
 __global__ void __launch_bounds__(FILL_THREADS)
 k_fill(const float* __restrict__ hf, const float* __restrict__ bw, const float* __restrict__ layers,
        const mmgen_cave_layer* __restrict__ caveLayers, const int2* __restrict__ chunkPos, uint8_t* __restrict__ blocks,
        const int* __restrict__ srcIdx)
 {
+    noise_tables_init();
     __shared__ float s_bw[FILL_COLS][MMGEN_NUM_BIOMES];
     __shared__ float s_lh[FILL_COLS][MMGEN_NUM_MATERIALS + 1];
     __shared__ mmgen_cave_layer s_cl[FILL_COLS][MMGEN_MAX_CAVE_LAYERS_PER_COLUMN];
@@ -568,8 +463,8 @@ k_fill(const float* __restrict__ hf, const float* __restrict__ bw, const float* 
     const int idxBase = 4 * group;
 
     // stage the 4 columns: 24 weights + 20 layer starts + height + 96 cave-layer words each = 141 words per column
-    if (t < FILL_COLS * 141) {
-        const int c = t / 141, k = t % 141;
+    for (int i = t; i < FILL_COLS * 141; i += FILL_THREADS) {
+        const int c = i / 141, k = i % 141;
         const int idx2d = idxBase + c;
         if (k < MMGEN_NUM_BIOMES) s_bw[c][k] = bw[(size_t)MMGEN_BIOME_WEIGHTS_SIZE * chunk + 256 * k + idx2d];
         else if (k < MMGEN_NUM_BIOMES + MMGEN_NUM_MATERIALS) s_lh[c][k - MMGEN_NUM_BIOMES] = layers[(size_t)MMGEN_LAYERS_SIZE * chunk + 256 * (k - MMGEN_NUM_BIOMES) + idx2d];
@@ -621,6 +516,7 @@ k_fill(const float* __restrict__ hf, const float* __restrict__ bw, const float* 
 // =========================================================================================================
 __global__ void __launch_bounds__(256) k_probe(int fn, const float* __restrict__ in, int n, float* __restrict__ out)
 {
+    noise_tables_init();
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     switch (fn) {
@@ -742,7 +638,7 @@ int launch_caves(const float* hf, const float* bw, const int32_t* pos, int n, mm
     if (n <= 0) return 0;
     LAUNCH(KID_CAVE_COLUMNS, mm::k_cave_columns, dim3(n), dim3(256), s, bw, (const int2*)pos, (float2*)colInfoScratch, chunkList);
     LAUNCH(KID_CAVE_VOXELS, mm::k_cave_voxels, dim3(n * 64), dim3(CAVE_THREADS), s, hf, (const float2*)colInfoScratch, (const int2*)pos, caveLayers, chunkList);
-    LAUNCH(KID_CAVE_BIOMES, mm::k_cave_biomes, dim3(n * 32), dim3(256), s, hf, (const int2*)pos, caveLayers, chunkList);
+    LAUNCH(KID_CAVE_BIOMES, mm::k_cave_biomes, dim3(n * (256 / CB_COLS)), dim3(CB_THREADS), s, hf, (const int2*)pos, caveLayers, chunkList);
     return 0;
 }
 
