@@ -323,27 +323,36 @@ __device__ constexpr int kCaveFeatureReach[MMGEN_NUM_CAVE_FEATURES] = {
     /*NONE*/ 0, /*TEST pillars*/ 0, 0, /*CAVE_VINE*/ 0, /*GLOWSTONE_CLUSTER*/ 6, /*STORMLIGHT*/ 8, /*CEILING_STORMLIGHT*/ 8,
     /*CRYSTAL_PILLAR*/ 7, /*WARPED_FUNGUS*/ 6, /*AMBER_FUNGUS*/ 4};
 
-#define CAND_CAP 1024
+#ifndef CAND_CAP
+#define CAND_CAP 256
+#endif
+#ifndef APPLY_THREADS
+#define APPLY_THREADS 128
+#endif
+#define APPLY_WAVES (APPLY_THREADS / 64)
 
-// Stable block-wide compaction of the list entries that can reach column (wx, wz).  Returns the number of candidates, or -1
-// when they do not fit CAND_CAP (caller falls back to the full scan).  All 384 threads must call it.
+// Stable block-wide compaction of the list entries that can reach column (wx, wz), as packed copies
+// (x, y, z, feature | canReplace << 8 | layerHeight << 16) so that the voxel loop never goes back to global memory.
+// Returns the number of candidates, or -1 when they do not fit CAND_CAP (caller falls back to the full scan); ylo / yhi
+// receive the union of the candidates' vertical extents (every thread gets the same values).  All threads must call it.
 template <class Entry, int LIST_CAP, bool CAVE>
-MM_DEV int filter_column(const Entry* __restrict__ list, int wx, int wz, uint16_t* s_cand, int* s_wave /*[16]*/)
+MM_DEV int filter_column(const Entry* __restrict__ list, int wx, int wz, int4* s_cand, int* s_wave /*[2 * APPLY_WAVES + 2]*/, int& ylo, int& yhi)
 {
     const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
     int base = 0;
     bool overflow = false;
-    for (int r0 = 0; r0 < LIST_CAP; r0 += 384) {
+    int lo = 384, hi = -1;
+    for (int r0 = 0; r0 < LIST_CAP; r0 += APPLY_THREADS) {
         const int i = r0 + t;
         int feat = 0, fx = 0, fz = 0;
         if (i < LIST_CAP) { feat = list[i].feature; fx = list[i].pos[0]; fz = list[i].pos[2]; }
         const bool isNone = feat == 0;
         const unsigned long long noneMask = __ballot(isNone);
-        if (lane == 0) s_wave[8 + wave] = noneMask ? 64 * wave + (int)__builtin_ctzll(noneMask) : 1 << 20;
+        if (lane == 0) s_wave[APPLY_WAVES + wave] = noneMask ? 64 * wave + (int)__builtin_ctzll(noneMask) : 1 << 20;
         __syncthreads();
         int firstNone = 1 << 20;
 #pragma unroll
-        for (int w = 0; w < 6; ++w) firstNone = imin(firstNone, s_wave[8 + w]);
+        for (int w = 0; w < APPLY_WAVES; ++w) firstNone = imin(firstNone, s_wave[APPLY_WAVES + w]);
         const int reach = CAVE ? kCaveFeatureReach[feat] : kFeatureReach[feat];
         const bool cand = t < firstNone && iabs(wx - fx) <= reach && iabs(wz - fz) <= reach;
         const unsigned long long cm = __ballot(cand);
@@ -351,29 +360,49 @@ MM_DEV int filter_column(const Entry* __restrict__ list, int wx, int wz, uint16_
         __syncthreads();
         int before = 0, total = 0;
 #pragma unroll
-        for (int w = 0; w < 6; ++w) { const int c = s_wave[w]; if (w < wave) before += c; total += c; }
+        for (int w = 0; w < APPLY_WAVES; ++w) { const int c = s_wave[w]; if (w < wave) before += c; total += c; }
         if (cand) {
+            const int fy = list[i].pos[1];
+            int w = feat | ((int)list[i].can_replace_blocks << 8);
+            int top;
+            if constexpr (CAVE) {
+                const int lh = list[i].layer_height;
+                w |= lh << 16;
+                lo = imin(lo, fy + kCaveFeatureBounds[feat][0]); top = fy + lh + kCaveFeatureBounds[feat][1];
+            } else {
+                lo = imin(lo, fy + kFeatureBounds[feat][0]); top = fy + kFeatureBounds[feat][1];
+            }
+            hi = imax(hi, top);
             const int slot = base + before + __popcll(cm & ((1ull << lane) - 1ull));
-            if (slot < CAND_CAP) s_cand[slot] = (uint16_t)i;
+            if (slot < CAND_CAP) s_cand[slot] = make_int4(fx, fy, fz, w);
         }
         base += total;
         if (base > CAND_CAP) overflow = true;
         __syncthreads();                       // s_wave is reused by the next round
-        if (firstNone < 384) break;
+        if (firstNone < APPLY_THREADS) break;
     }
+    // block-wide union of the vertical extents
+    if (t == 0) { s_wave[2 * APPLY_WAVES] = 384; s_wave[2 * APPLY_WAVES + 1] = -1; }
+    __syncthreads();
+    if (hi >= lo) { atomicMin(&s_wave[2 * APPLY_WAVES], lo); atomicMax(&s_wave[2 * APPLY_WAVES + 1], hi); }
+    __syncthreads();
+    ylo = s_wave[2 * APPLY_WAVES]; yhi = s_wave[2 * APPLY_WAVES + 1];
+    __syncthreads();
     return overflow ? -1 : base;
 }
 
-__global__ void __launch_bounds__(384)
+#ifndef MM_APPLY_WAVES
+#define MM_APPLY_WAVES 4
+#endif
+__attribute__((amdgpu_waves_per_eu(MM_APPLY_WAVES, MM_APPLY_WAVES)))
+__global__ void __launch_bounds__(APPLY_THREADS)
 k_apply_features(uint8_t* __restrict__ blocks, const int2* __restrict__ chunkPos, const mmgen_feature_placement* __restrict__ gfp,
                  const mmgen_cave_feature_placement* __restrict__ gcfp, const int* __restrict__ bounds, const int* __restrict__ srcIdx)
 {
-    noise_tables_init();
-    __shared__ uint16_t s_candS[CAND_CAP], s_candC[CAND_CAP];
-    __shared__ int s_wave[16];
+    __shared__ int4 s_candS[CAND_CAP], s_candC[CAND_CAP];     // (x, y, z, feature | canReplace << 8 | layerHeight << 16)
+    __shared__ int s_wave[2 * APPLY_WAVES + 2];
     const int col = blockIdx.x;
     const int chunk = col >> 8, idx2d = col & 255;      // dense output / list index; positions are read at srcIdx[chunk]
-    const int y = threadIdx.x;
     const int b0 = bounds[4 * chunk], b1 = bounds[4 * chunk + 1], b2 = bounds[4 * chunk + 2], b3 = bounds[4 * chunk + 3];
     const bool doS = gfp && b0 <= b1, doC = gcfp && b2 <= b3;      // workgroup-uniform
     if (!doS && !doC) return;
@@ -383,43 +412,65 @@ k_apply_features(uint8_t* __restrict__ blocks, const int2* __restrict__ chunkPos
     const mmgen_feature_placement* listS = gfp + (size_t)MMGEN_MAX_GATHERED_FEATURES_PER_CHUNK * chunk;
     const mmgen_cave_feature_placement* listC = gcfp + (size_t)MMGEN_MAX_GATHERED_CAVE_FEATURES_PER_CHUNK * chunk;
     int nS = 0, nC = 0;
-    if (doS) nS = filter_column<mmgen_feature_placement, MMGEN_MAX_GATHERED_FEATURES_PER_CHUNK, false>(listS, wx, wz, s_candS, s_wave);
-    if (doC) nC = filter_column<mmgen_cave_feature_placement, MMGEN_MAX_GATHERED_CAVE_FEATURES_PER_CHUNK, true>(listC, wx, wz, s_candC, s_wave);
+    int loS = 384, hiS = -1, loC = 384, hiC = -1;       // the column's own vertical extents: subsets of the chunk's bounds
+    if (doS) nS = filter_column<mmgen_feature_placement, MMGEN_MAX_GATHERED_FEATURES_PER_CHUNK, false>(listS, wx, wz, s_candS, s_wave, loS, hiS);
+    if (doC) nC = filter_column<mmgen_cave_feature_placement, MMGEN_MAX_GATHERED_CAVE_FEATURES_PER_CHUNK, true>(listC, wx, wz, s_candC, s_wave, loC, hiC);
     if (nS == 0 && nC == 0) return;
+    noise_tables_init();          // after the workgroup-uniform exits: most columns have nothing to rasterise
+    loS = imax(loS, imax(b0, 0)); hiS = imin(hiS, imin(b1, 383));
+    loC = imax(loC, imax(b2, 0)); hiC = imin(hiC, imin(b3, 383));
+    const int ylo = imin(nS ? loS : 384, nC ? loC : 384), yhi = imax(nS ? hiS : -1, nC ? hiC : -1);
 
-    const bool inF = doS && y >= b0 && y <= b1;
-    const bool inC = doC && y >= b2 && y <= b3;
-    if (!inF && !inC) return;
-
-    uint8_t* bp = blocks + (size_t)MMGEN_BLOCKS_PER_CHUNK * chunk + 384 * idx2d + y;
-    const uint8_t block = *bp;
-    uint8_t fb = 0;
-    bool placed = false;
-    if (inF) {
-        const int n = nS < 0 ? MMGEN_MAX_GATHERED_FEATURES_PER_CHUNK : nS;
-        for (int c = 0; c < n; ++c) {
-            const int i = nS < 0 ? c : (int)s_candS[c];
-            const int feature = listS[i].feature;
-            if (feature == MMF_NONE) break;
-            if (block != MMB_AIR && !listS[i].can_replace_blocks) continue;
-            const int fy = listS[i].pos[1];
-            if (y < fy + kFeatureBounds[feature][0] || y > fy + kFeatureBounds[feature][1]) continue;
-            if (place_feature(feature, listS[i].pos[0], fy, listS[i].pos[2], wx, y, wz, fb)) { placed = true; break; }
+    uint8_t* colBlocks = blocks + (size_t)MMGEN_BLOCKS_PER_CHUNK * chunk + 384 * idx2d;
+    for (int y = ylo + (int)threadIdx.x; y <= yhi; y += APPLY_THREADS) {
+        const bool inF = nS && y >= loS && y <= hiS;
+        const bool inC = nC && y >= loC && y <= hiC;
+        if (!inF && !inC) continue;
+        const uint8_t block = colBlocks[y];
+        uint8_t fb = 0;
+        bool placed = false;
+        if (inF) {
+            if (nS >= 0) {
+                for (int c = 0; c < nS; ++c) {
+                    const int4 e = s_candS[c];
+                    const int feature = e.w & 255;
+                    if (block != MMB_AIR && !((e.w >> 8) & 1)) continue;
+                    if (y < e.y + kFeatureBounds[feature][0] || y > e.y + kFeatureBounds[feature][1]) continue;
+                    if (place_feature(feature, e.x, e.y, e.z, wx, y, wz, fb)) { placed = true; break; }
+                }
+            } else {                               // more reachable entries than CAND_CAP: scan the list itself
+                for (int i = 0; i < MMGEN_MAX_GATHERED_FEATURES_PER_CHUNK; ++i) {
+                    const int feature = listS[i].feature;
+                    if (feature == MMF_NONE) break;
+                    if (block != MMB_AIR && !listS[i].can_replace_blocks) continue;
+                    const int fy = listS[i].pos[1];
+                    if (y < fy + kFeatureBounds[feature][0] || y > fy + kFeatureBounds[feature][1]) continue;
+                    if (place_feature(feature, listS[i].pos[0], fy, listS[i].pos[2], wx, y, wz, fb)) { placed = true; break; }
+                }
+            }
         }
-    }
-    if (inC && !placed) {
-        const int n = nC < 0 ? MMGEN_MAX_GATHERED_CAVE_FEATURES_PER_CHUNK : nC;
-        for (int c = 0; c < n; ++c) {
-            const int i = nC < 0 ? c : (int)s_candC[c];
-            const int feature = listC[i].feature;
-            if (feature == MMCF_NONE) break;
-            if (block != MMB_AIR && !listC[i].can_replace_blocks) continue;
-            const int fy = listC[i].pos[1], lh = listC[i].layer_height;
-            if (y < fy + kCaveFeatureBounds[feature][0] || y > fy + lh + kCaveFeatureBounds[feature][1]) continue;
-            if (place_cave_feature(feature, listC[i].pos[0], fy, listC[i].pos[2], lh, wx, y, wz, fb)) { placed = true; break; }
+        if (inC && !placed) {
+            if (nC >= 0) {
+                for (int c = 0; c < nC; ++c) {
+                    const int4 e = s_candC[c];
+                    const int feature = e.w & 255, lh = e.w >> 16;
+                    if (block != MMB_AIR && !((e.w >> 8) & 1)) continue;
+                    if (y < e.y + kCaveFeatureBounds[feature][0] || y > e.y + lh + kCaveFeatureBounds[feature][1]) continue;
+                    if (place_cave_feature(feature, e.x, e.y, e.z, lh, wx, y, wz, fb)) { placed = true; break; }
+                }
+            } else {
+                for (int i = 0; i < MMGEN_MAX_GATHERED_CAVE_FEATURES_PER_CHUNK; ++i) {
+                    const int feature = listC[i].feature;
+                    if (feature == MMCF_NONE) break;
+                    if (block != MMB_AIR && !listC[i].can_replace_blocks) continue;
+                    const int fy = listC[i].pos[1], lh = listC[i].layer_height;
+                    if (y < fy + kCaveFeatureBounds[feature][0] || y > fy + lh + kCaveFeatureBounds[feature][1]) continue;
+                    if (place_cave_feature(feature, listC[i].pos[0], fy, listC[i].pos[2], lh, wx, y, wz, fb)) { placed = true; break; }
+                }
+            }
         }
+        if (placed) colBlocks[y] = fb;
     }
-    if (placed) *bp = fb;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -547,7 +598,7 @@ int launch_apply_features(uint8_t* blocks, const int32_t* pos, int n, const mmge
                           const int* bounds, const int* srcIdx, hipStream_t s)
 {
     if (n <= 0) return 0;
-    hipLaunchKernelGGL(mm::k_apply_features, dim3(n * 256), dim3(384), 0, s, blocks, (const int2*)pos, gfp, gcfp, bounds, srcIdx);
+    hipLaunchKernelGGL(mm::k_apply_features, dim3(n * 256), dim3(APPLY_THREADS), 0, s, blocks, (const int2*)pos, gfp, gcfp, bounds, srcIdx);
     return (int)hipGetLastError();
 }
 
