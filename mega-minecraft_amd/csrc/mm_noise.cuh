@@ -98,7 +98,7 @@ MM_DEV void noise_tables_init()
     __syncthreads();
 }
 
-MM_SIMPLEX_ATTR float simplex2(float vx, float vy)
+MM_DEV float simplex2_inl(float vx, float vy)
 {
     const float C0 = (float)0.211324865405187, C1 = (float)0.366025403784439;
     const float C2 = (float)-0.577350269189626;
@@ -225,13 +225,18 @@ MM_DEV float simplex3_part3(const Sx3Cell& c, const float* __restrict__ q)
     return 42.f * ((mm4[0] * pd[0] + mm4[1] * pd[1]) + (mm4[2] * pd[2] + mm4[3] * pd[3]));
 }
 
-MM_SIMPLEX_ATTR float simplex3(float vx, float vy, float vz)
+MM_DEV float simplex3_inl(float vx, float vy, float vz)
 {
     const Sx3Cell c = simplex3_part1(vx, vy, vz);
     float q[12];
     simplex3_gradients(c.ix, c.iy, c.iz, c.order, q);
     return simplex3_part3(c, q);
 }
+
+// One shared (non-inlined) body per translation unit for the scattered call sites (block rules, rasterisers); the fbm stacks
+// below inline the body ONCE inside a rolled octave loop instead: no call, no callee-saved register pressure around it.
+MM_SIMPLEX_ATTR float simplex2(float vx, float vy) { return simplex2_inl(vx, vy); }
+MM_SIMPLEX_ATTR float simplex3(float vx, float vy, float vz) { return simplex3_inl(vx, vy, vz); }
 
 // ---------------------------------------------------------------------------------------------------------
 // fbm stacks (rng.hpp:166-191): amplitude halves, frequency doubles, octaves summed in order
@@ -240,10 +245,10 @@ template <int OCT>
 MM_DEV float fbm2(float x, float y)
 {
     float acc = 0.f, amp = 1.f;
-#pragma unroll
+#pragma unroll 1
     for (int i = 0; i < OCT; ++i) {
         amp *= 0.5f;
-        acc += amp * simplex2(x, y);
+        acc += amp * simplex2_inl(x, y);
         x *= 2.f; y *= 2.f;
     }
     return acc;
@@ -253,10 +258,10 @@ template <int OCT>
 MM_DEV float fbm3(float x, float y, float z)
 {
     float acc = 0.f, amp = 1.f;
-#pragma unroll
+#pragma unroll 1
     for (int i = 0; i < OCT; ++i) {
         amp *= 0.5f;
-        acc += amp * simplex3(x, y, z);
+        acc += amp * simplex3_inl(x, y, z);
         x *= 2.f; y *= 2.f; z *= 2.f;
     }
     return acc;
@@ -268,7 +273,15 @@ MM_DEV f2 fbm2from2(float x, float y) { return mk2(fbm2<OCT>(x, y), fbm2<OCT>(x 
 template <int OCT>
 MM_DEV f3 fbm3from3(float x, float y, float z)
 {
-    return mk3(fbm3<OCT>(x, y, z), fbm3<OCT>(x + 5923.45f, y + 4129.42f, z + 5790.48f), fbm3<OCT>(x + 1765.68f, y + 4704.36f, z + 5692.12f));
+    // rolled over the three components as well: one inlined simplex body for all 3 * OCT samples
+    float r[3];
+#pragma unroll 1
+    for (int k = 0; k < 3; ++k) {
+        const float ox = k == 0 ? 0.f : (k == 1 ? 5923.45f : 1765.68f), oy = k == 0 ? 0.f : (k == 1 ? 4129.42f : 4704.36f),
+                    oz = k == 0 ? 0.f : (k == 1 ? 5790.48f : 5692.12f);
+        r[k] = k == 0 ? fbm3<OCT>(x, y, z) : fbm3<OCT>(x + ox, y + oy, z + oz);
+    }
+    return mk3(r[0], r[1], r[2]);
 }
 
 MM_DEV f2 simplex2from2(float x, float y) { return mk2(simplex2(x, y), simplex2(x + 5923.45f, y + 4129.42f)); }
@@ -359,8 +372,12 @@ MM_DEV float special_cave_noise(float px, float py, float pz, const Cells& cells
     const int ux = (int)flx, uy = (int)fly, uz = (int)flz;
     const float fx = px - flx, fy = py - fly, fz = pz - flz;
     float s1 = 3.402823466e+38f, s2 = 3.402823466e+38f, s3 = 3.402823466e+38f;
-    for (int x = -1; x <= 1; ++x) {
-        for (int y = -1; y <= 1; ++y) {
+    // 9 rolled (x, y) steps of 3 unrolled z cells: a fully unrolled search hoists all 81 cell-point loads and spills
+#pragma unroll 1
+    for (int xy = 0; xy < 9; ++xy) {
+        const int x = xy / 3 - 1, y = xy % 3 - 1;
+        {
+#pragma unroll
             for (int z = -1; z <= 1; ++z) {
                 const f3 pt = cells(ux + x, uy + y, uz + z);
                 const float dx = ((float)x + pt.x) - fx, dy = ((float)y + pt.y) - fy, dz = ((float)z + pt.z) - fz;
