@@ -12,6 +12,18 @@
 
 namespace mm {
 
+// XCD-aware workgroup order for the kernels that run 64 workgroups (4-column groups) per chunk.  The dispatcher deals consecutive
+// workgroup ids round-robin over the 8 XCDs, each with its own L2: neighbouring groups of a chunk read the same 128-byte lines of
+// the attribute planes (16 bytes each), so with the plain order every line is fetched by up to 8 L2s.  This map gives every XCD
+// whole chunks: of each run of 8 chunks (512 workgroup ids), XCD k takes the k-th.  MEASURED (profiles/README.md, r01h): k_fill
+// read traffic 117 MB -> 37 MB per launch (= algorithmic), but launch time 1.01 -> 1.11 ms; these kernels are VALU-issue bound at
+// < 2 % of HBM peak, so the plain order stays the default and the map is kept behind MM_XCD_SWIZZLE for HBM-bound variants.
+#ifndef MM_XCD_SWIZZLE
+#define MM_XCD_SWIZZLE 0
+#endif
+MM_DEV int xcd_block(int b, int n) { return (!MM_XCD_SWIZZLE || (n & 511)) ? b : (((b >> 9) * 8 + (b & 7)) << 6) + ((b >> 3) & 63); }
+
+
 // =========================================================================================================
 // K1 — heightfield + 24 biome weights.  GATHERED variant also produces the 18x18 ring the layer stage needs
 // (the ring heights are a pure function of position, so no neighbour chunk is read).
@@ -224,8 +236,9 @@ k_cave_voxels(const float* __restrict__ hf, const float2* __restrict__ colInfo, 
     __shared__ int s_layers[CAVE_COLS][3 * MMGEN_MAX_CAVE_LAYERS_PER_COLUMN];
 
     const int t = threadIdx.x;
-    const int chunk = chunkList ? chunkList[blockIdx.x >> 6] : (int)(blockIdx.x >> 6);
-    const int group = blockIdx.x & 63;                         // 64 groups of 4 columns per chunk: x = 4 (group % 4) + c, z = group / 4
+    const int bid = xcd_block(blockIdx.x, gridDim.x);
+    const int chunk = chunkList ? chunkList[bid >> 6] : (bid >> 6);
+    const int group = bid & 63;                                // 64 groups of 4 columns per chunk: x = 4 (group % 4) + c, z = group / 4
     const int2 cp = chunkPos[chunk];
 
     // cell tile: sample position = noisePos * (1, 1.6, 1) + offset with |offset| < 1.8; origin from the group's first column
@@ -458,7 +471,8 @@ k_fill(const float* __restrict__ hf, const float* __restrict__ bw, const float* 
     __shared__ int s_count;
 
     const int t = threadIdx.x;
-    const int outChunk = blockIdx.x >> 6, group = blockIdx.x & 63;
+    const int bid = xcd_block(blockIdx.x, gridDim.x);
+    const int outChunk = bid >> 6, group = bid & 63;
     const int chunk = srcIdx ? srcIdx[outChunk] : outChunk;        // inputs are read at `chunk`, blocks are written densely at outChunk
     const int idxBase = 4 * group;
 

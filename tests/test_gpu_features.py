@@ -130,6 +130,68 @@ def test_tiled_generation_with_halo_exchange_on_one_gpu(mmgen_pkg, oracle):
     assert np.array_equal(world, ref)
 
 
+def _tiled_world_on_one_gpu(mmgen_pkg, layout):
+    """All ranks of `layout` played one after the other on this GPU: region_begin with the peer-owned ring masked out, placement
+    lists exchanged by hand along the product's exchange_plan, region_finish; returns the stitched [nz_world * nx_world, 98304] blocks."""
+    import torch
+    n = layout.world_size
+    gens = [mmgen_pkg.MMGen(0) for _ in range(n)]
+    bufs = []
+    for r in range(n):
+        cx0, cz0, nx, nz = layout.region(r)
+        gens[r].region_begin(cx0, cz0, nx, nz, 7, layout.local_mask(r))
+        bufs.append(gens[r].region_placement_buffers())
+    for r in range(n):
+        for peer, (recv_cells, _) in layout.exchange_plan(r).items():
+            send_cells = layout.exchange_plan(peer)[r][1]
+            ri = torch.tensor(recv_cells, dtype=torch.long, device="cuda"); si = torch.tensor(send_cells, dtype=torch.long, device="cuda")
+            for k in ("fp", "cfp", "counts"):
+                bufs[r][k][ri] = bufs[peer][k][si]
+    wx0, wz0 = layout.region(0)[0], layout.region(0)[1]
+    regs = [layout.region(r) for r in range(n)]
+    W = max(c[0] + c[2] for c in regs) - wx0
+    H = max(c[1] + c[3] for c in regs) - wz0
+    world = torch.zeros((H, W, 98304), dtype=torch.uint8, device="cuda")
+    for r in range(n):
+        cx0, cz0, nx, nz = regs[r]
+        world[cz0 - wz0:cz0 - wz0 + nz, cx0 - wx0:cx0 - wx0 + nx] = gens[r].region_finish(nx, nz)["blocks"].view(nz, nx, 98304)
+        gens[r] = None
+    return world.view(H * W, 98304), (wx0, wz0, W, H)
+
+
+def test_config4_world_2x2_tiles_equals_single_region_and_oracle(mmgen_pkg, oracle):
+    """BASELINE config 4 at full size: the 4 096-chunk world [-32, 32)^2, all stages, as 2 x 2 tiles of 32 x 32 chunks with the
+    placement-ring exchange == the same world generated as ONE region (tiling invariance, every block of 4 096 chunks), and the
+    2 x 2 chunks around the four-tile corner == the CPU oracle."""
+    import importlib
+    import torch
+    d = importlib.import_module("mega-minecraft_amd.distributed")
+    layout = d.TileLayout(-32, -32, 2, 2, 32, 32)
+    world, (wx0, wz0, W, H) = _tiled_world_on_one_gpu(mmgen_pkg, layout)
+    single = mmgen_pkg.MMGen(0).generate_region(wx0, wz0, W, H)["blocks"]
+    assert torch.equal(world, single)
+    ref = oracle.generate_region(-1, -1, 2, 2, erosion=True, features=True, decorators=True)["blocks"]
+    got = world.view(H, W, 98304)[31:33, 31:33].reshape(4, 98304).cpu().numpy()
+    assert np.array_equal(got, ref)
+
+
+def test_config5_world_8_tiles_equals_single_region(mmgen_pkg):
+    """BASELINE config 5 at full size: the 65 536-chunk world [-128, 128)^2 as 4 x 2 tiles of 64 x 128 chunks (the 8-GPU layout,
+    played on one GPU) is block-for-block the world generated as one region: 6.4 GB of block ids compared on the device."""
+    import importlib
+    import torch
+    d = importlib.import_module("mega-minecraft_amd.distributed")
+    layout = d.TileLayout(-128, -128, 4, 2, 64, 128)
+    world, (wx0, wz0, W, H) = _tiled_world_on_one_gpu(mmgen_pkg, layout)
+    assert (W, H) == (256, 256)
+    g = mmgen_pkg.MMGen(0)
+    single = g.generate_region(wx0, wz0, W, H)["blocks"]
+    assert torch.equal(world, single)
+    # not a trivially empty world: bedrock floor everywhere, and a healthy mix of block ids
+    assert bool((single.view(-1, 384)[:, 0] == 56).all())
+    assert int(torch.unique(single[::97]).numel()) > 40
+
+
 def test_cpp_chunk_api_matches_region_path(mmgen_pkg):
     """The C++ mirror of the reference's Chunk stage API (host/chunk.hpp: generateHeightfields, gatherHeightfield, generateLayers,
     erodeZone, generateCaves, generateFeaturePlacements, gatherFeaturePlacements, fill) driven like Terrain::tick for one zone gives
