@@ -122,3 +122,23 @@ def test_tables(oracle, golden):
     bm = np.zeros((24, 20), np.float32); oracle.lib.mmo_tables_biome_material_weights(_p(bm))
     assert_bit_equal(bm, k["biome_material_weights"], "biome material weights")
     assert bm[8, 7] == np.float32(3.2) and bm[0, 15] == 0 and bm[23, 12] == 1    # SAVANNA/TERRACOTTA, CORAL_REEF/DIRT, MOUNTAINS/GRAVEL
+
+
+def test_noise_table_domains():
+    """The HIP path serves glm's permute() chain and the corner gradients of simplex noise from LDS tables built per workgroup
+    with the same fp32 operations (csrc/mm_noise.cuh).  Exactness needs only that every lookup index is inside the tables:
+      * mod289 (x - floor(x * (1/289)) * 289, fp32) of an integer-valued |x| < 2^24 lies in [-1, 289]   (the guard the device checks),
+      * glm::mod(x, 289) (x - 289 * floor(x / 289)) of the same lies in [0, 288]                           (simplex2),
+      * permute of every integer in [-16, 700) is an integer in [0, 288]: so chained indices stay in [-1, 578] within perm4[-8, 600)
+        and gradient indices in [0, 288] within grad[296]."""
+    f = np.float32
+    xs = np.arange(-2 ** 24 + 1, 2 ** 24, dtype=np.int64).astype(f)
+    m = (xs - np.floor(xs * (f(1.0) / f(289.0))) * f(289.0)).astype(f)
+    assert m.min() >= -1 and m.max() <= 289 and np.array_equal(m, np.floor(m))
+    g = (xs - f(289.0) * np.floor(xs / f(289.0))).astype(f)
+    assert g.min() >= 0 and g.max() <= 288
+    x = np.arange(-16, 700, dtype=f)
+    t = ((x * f(34.0)) + f(1.0)) * x
+    p = (t - np.floor(t * (f(1.0) / f(289.0))) * f(289.0)).astype(f)
+    assert p.min() >= 0 and p.max() <= 288 and np.array_equal(p, np.floor(p))
+    assert -1 + -1 + 0 >= -8 and 288 + 289 + 1 < 600 - 8 + 8       # chained index range vs table range [-8, 600)
