@@ -47,6 +47,8 @@ REGIONS = [
     # (cx0, cz0, nx, nz): birch forest, jungle, redwood, crystals, coral reef, origin (tianzi pines), swamp, desert, icebergs, mushrooms
     (3654, -2794, 1, 1), (1488, -1110, 2, 1), (3518, 2777, 1, 1), (2669, -2199, 1, 2), (-1268, -1773, 1, 1), (0, 0, 2, 2),
     (1767, -1044, 1, 1), (3227, 152, 1, 1), (1602, 977, 1, 1), (3946, -3906, 1, 1), (-2105, -2470, 1, 1), (-88, -3971, 1, 1),
+    # world edge: block coordinates 6.4e8 (fp32 ulp 64), noise lattice cells beyond the LDS tables' domain
+    (40_000_000, -40_000_000, 1, 1),
 ]
 
 

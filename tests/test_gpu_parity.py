@@ -80,6 +80,22 @@ def test_stages_match_oracle_and_golden(gen, oracle, golden):
     assert_bit_equal(np_(out["blocks"])[coords.index((0, 0))], s["blocks_0_0"], "golden blocks (0,0)")
 
 
+def test_far_coordinates_match_oracle(gen, oracle):
+    """World-edge coordinates: block coordinates up to 6.4e8 (fp32 ulp 64, several columns share one float) and simplex lattice
+    cells beyond 2^24, where the device's LDS noise tables are out of their domain and the arithmetic path takes over lane by lane.
+    Every stage output is still bit-exact vs the oracle."""
+    coords = [(2_000_000, -2_000_000), (40_000_000, 39_999_999), (-40_000_000, 123), (1_048_576, -1_048_577)]
+    out = gen.generate_chunks_no_erosion(gen.positions(coords))
+    pos = oracle.positions(coords)
+    hf, bw = oracle.heightfields(pos)
+    g = oracle.gather_heightfields(pos, hf)
+    layers = oracle.fix_backward(oracle.layers(pos, g, bw))
+    cave = oracle.caves(pos, hf, bw)
+    blocks = oracle.fill(pos, hf, bw, layers, cave)
+    for name, ref in (("hf", hf), ("bw", bw), ("gathered", g), ("layers", layers), ("cave", cave), ("blocks", blocks)):
+        assert_bit_equal(np_(out[name]).reshape(ref.shape), ref, f"{name} vs oracle at far coordinates")
+
+
 def test_abi_variants_agree(gen, oracle):
     """mmgen_generate_heightfields (reference kernel shape) == the gathered variant; caller-gathered input == fused gather."""
     coords = [(5, 5), (-9, 2), (300, -300)]
