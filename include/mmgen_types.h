@@ -52,6 +52,13 @@ typedef struct mmgen_cave_layer {            /* biome.hpp:106-115 */
     uint8_t padding[2];
 } mmgen_cave_layer;
 
+typedef struct mmgen_vertex {                /* Vertex, src/rendering/structs.hpp:25-31 (vec3, vec3, vec2, Mats : size_t) */
+    float pos[3];                            /* chunk-local block coordinates */
+    float nor[3];
+    float uv[2];                             /* texture-atlas coordinates, tile = 1/16 */
+    uint64_t material;                       /* Mats: 0 DIFFUSE, 1 WATER, 2 CRYSTAL, 3 SMOOTH_MICRO, 4 MICRO, 5 ROUGH_MICRO */
+} mmgen_vertex;
+
 typedef struct mmgen_feature_placement {     /* biome.hpp:195-200: feature@0, pos@4, canReplaceBlocks@16 */
     uint8_t feature;
     uint8_t pad0[3];

@@ -366,4 +366,43 @@ void Chunk::placeDecorators()
     MM_CALL(hipMemcpy(blocks.data(), d + oB, devBlocksSize, hipMemcpyDeviceToHost), "D2H");
 }
 
+// chunk.cu:1778-2003.  The reference walks the voxels on the host; here the chunk and its (up to) four neighbours' blocks go to the
+// device, the mesher counts, the buffers are sized exactly, and the vertices / indices come back in the reference's order.
+void Chunk::createVBOs()
+{
+    idx.clear();
+    verts.clear();
+    idxCount = 0;
+    const size_t oB = 0, oN = oB + (size_t)5 * devBlocksSize, oPos = oN + 16, oCol = oPos + 8, oCnt = oCol + 256 * 4, oOff = oCnt + 8, total = oOff + 8;
+    char* d = (char*)g_single.get(total);
+    int32_t nidx[4] = {-1, -1, -1, -1};
+    MM_CALL(hipMemcpy(d + oB, blocks.data(), devBlocksSize, hipMemcpyHostToDevice), "H2D");
+    int used = 1;
+    for (int k = 0; k < 4; ++k) {                 // neighbors: N (+z), E (+x), S (-z), W (-x), the order createVBOs indexes them in
+        if (!neighbors[k]) continue;
+        MM_CALL(hipMemcpy(d + oB + (size_t)used * devBlocksSize, neighbors[k]->blocks.data(), devBlocksSize, hipMemcpyHostToDevice), "H2D");
+        nidx[k] = used++;
+    }
+    const int32_t pos[2] = {worldBlockPos.x, worldBlockPos.z};
+    const uint64_t zero = 0;
+    MM_CALL(hipMemcpy(d + oN, nidx, 16, hipMemcpyHostToDevice), "H2D");
+    MM_CALL(hipMemcpy(d + oPos, pos, 8, hipMemcpyHostToDevice), "H2D");
+    MM_CALL(hipMemcpy(d + oOff, &zero, 8, hipMemcpyHostToDevice), "H2D");
+    MM_CALL(mmgen_mesh_count((uint8_t*)(d + oB), (int32_t*)(d + oN), 1, (uint32_t*)(d + oCol), (uint32_t*)(d + oCnt), nullptr), "Chunk::createVBOs() count failed");
+    uint32_t nv = 0;
+    MM_CALL(hipMemcpy(&nv, d + oCnt, 4, hipMemcpyDeviceToHost), "D2H");
+    if (nv == 0) return;
+    static Scratch out;
+    const size_t vb = (size_t)nv * sizeof(Vertex), ib = (size_t)nv / 4 * 6 * sizeof(unsigned int);
+    char* o = (char*)out.get(vb + ib);
+    MM_CALL(mmgen_mesh_fill((uint8_t*)(d + oB), (int32_t*)(d + oN), (int32_t*)(d + oPos), 1, (uint32_t*)(d + oCol), (uint64_t*)(d + oOff), (Vertex*)o,
+                            (uint32_t*)(o + vb), nullptr),
+            "Chunk::createVBOs() fill failed");
+    verts.resize(nv);
+    idx.resize((size_t)nv / 4 * 6);
+    MM_CALL(hipMemcpy(verts.data(), o, vb, hipMemcpyDeviceToHost), "D2H");
+    MM_CALL(hipMemcpy(idx.data(), o + vb, ib, hipMemcpyDeviceToHost), "D2H");
+    idxCount = (int)idx.size();
+}
+
 }  // namespace mmhost

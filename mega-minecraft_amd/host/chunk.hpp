@@ -5,7 +5,8 @@
 // meaning, same ownership (the CALLER owns every pinned-host and device staging buffer and the streams, exactly like
 // Terrain::initCuda, terrain.cpp:154-185), same synchronous-on-return behaviour, same error convention (print + exit,
 // src/cuda/cuda_utils.cpp:5-17).  Differences, all outside the generation path:
-//   * renderer coupling is dropped: no `Drawable` base, no `verts/idx`, no createVBOs/bufferVBOs (chunk.cu:1751-2021);
+//   * renderer coupling is dropped: no `Drawable` base and no GL buffers (bufferVBOs, chunk.cu:2005-2021); createVBOs() keeps its
+//     name, its `verts` / `idx` outputs and their exact contents, but is built on the GPU (mmgen_mesh_count / mmgen_mesh_fill);
 //   * stream type is hipStream_t; glm's ivec2/ivec3 are replaced by layout-identical PODs (glm is not a dependency);
 //   * generateFeaturePlacements() and placeDecorators() keep their member signatures but run as device kernels.
 #pragma once
@@ -28,6 +29,7 @@ using Block = uint8_t;                       // enum Block : unsigned char (bloc
 using CaveLayer = mmgen_cave_layer;          // biome.hpp:106-115
 using FeaturePlacement = mmgen_feature_placement;
 using CaveFeaturePlacement = mmgen_cave_feature_placement;
+using Vertex = mmgen_vertex;                 // rendering/structs.hpp:25-31
 
 constexpr int numMaterials = MMGEN_NUM_MATERIALS, numBiomes = MMGEN_NUM_BIOMES;
 constexpr int numStratifiedMaterials = MMGEN_NUM_STRATIFIED_MATERIALS, numForwardMaterials = MMGEN_NUM_FORWARD_MATERIALS;
@@ -130,6 +132,12 @@ public:
                      FeaturePlacement* dev_featurePlacements, CaveFeaturePlacement* dev_caveFeaturePlacements, Block* host_blocks, Block* dev_blocks,
                      hipStream_t stream);
     void placeDecorators();
+
+    // Drawable's buffers (rendering/drawable.hpp) as filled by createVBOs (chunk.cu:1778-2003): same order, same bytes
+    std::vector<Vertex> verts;
+    std::vector<unsigned int> idx;
+    int idxCount{0};
+    void createVBOs();
 
     // test hooks
     const std::vector<FeaturePlacement>& getFeaturePlacements() const { return featurePlacements; }

@@ -50,8 +50,15 @@ int main(int argc, char** argv)
         const bool same = std::memcmp(ref.data(), chunk->blocks.data(), devBlocksSize) == 0;
         ++checked;
         if (!same) { ++bad; std::printf("  chunk (%d,%d) differs from the region path\n", c.x, c.y); }
+        // createVBOs ran for every drawable chunk: a surface chunk has faces, 4 vertices and 6 indices per quad
+        if (chunk->verts.empty() || chunk->verts.size() % 4 != 0 || chunk->idx.size() != chunk->verts.size() / 4 * 6 || chunk->idxCount != (int)chunk->idx.size()) {
+            ++bad; std::printf("  chunk (%d,%d): bad mesh (%zu vertices, %zu indices)\n", c.x, c.y, chunk->verts.size(), chunk->idx.size());
+        }
     }
     mmgen_region_destroy(region);
+    size_t totalVerts = 0;
+    for (Chunk* c : terrain.getDrawableChunks()) totalVerts += c->verts.size();
+    std::printf("mmgen_terrain_demo: %zu mesh vertices over the drawable chunks (%.0f per chunk)\n", totalVerts, drawable ? (double)totalVerts / drawable : 0.0);
     std::printf("mmgen_terrain_demo: %d sampled chunks checked against the region path, %d bad\n", checked, bad);
     return (bad == 0 && (int)drawable == Terrain::getMaxNumDrawableChunks()) ? 0 : 1;
 }

@@ -227,7 +227,8 @@ void Terrain::tick(float deltaTime)
     while (!chunksToCreateAndBufferVbos.empty() && actionTimeLeft >= actionTimeCreateAndBufferVbos) {
         needsUpdateChunks = true;
         Chunk* c = chunksToCreateAndBufferVbos.front(); chunksToCreateAndBufferVbos.pop();
-        drawableChunks.insert(c);                       // createVBOs + buildChunkAccel in the reference: renderer side
+        c->createVBOs();                                // terrain.cpp:650; bufferVBOs / buildChunkAccel are the renderer's
+        drawableChunks.insert(c);
         c->setState(ChunkState::DRAWABLE);
         c->setNotReadyForQueue();
         actionTimeLeft -= actionTimeCreateAndBufferVbos;

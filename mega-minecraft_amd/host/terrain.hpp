@@ -3,7 +3,7 @@
 // getCurrentChunkPos / getDrawableChunks / getMaxNumDrawableChunks), same nine work queues drained latest-stage-first under the
 // same action-time budget and costs (terrain.cpp:65-82), same zone bookkeeping (12x12-chunk zones, 8 neighbour links, erosion
 // readiness with the 6-chunk padding), same staging-buffer ownership (initCuda, terrain.cpp:111-185 → initHip).  The renderer
-// hooks (OptixRenderer, draw, VBO destruction) are outside the generation path: createVBOs is a state transition only.
+// hooks (OptixRenderer, draw, GL buffer upload / destruction) are outside the path; createVBOs builds verts / idx on the GPU.
 #pragma once
 #include <map>
 #include <queue>

@@ -168,6 +168,36 @@ class MMGen:
                                                     self._stream()), "mmgen_place_decorators")
         return blocks
 
+    # ------------------------------------------------------------------ mesh build (Chunk::createVBOs, chunk.cu:1778-2003)
+    def create_vbos(self, blocks, world_block_pos, nx=None, nz=None, neighbor_idx=None):
+        """blocks: uint8 [n, 98304] on the device.  Either `neighbor_idx` (int32 [n, 4]: N(+z), E(+x), S(-z), W(-x) index into the
+        batch, -1 = absent) or a z-major nx x nz grid shape (neighbours = grid neighbours, absent beyond the grid) or neither (every
+        chunk alone).  world_block_pos: int32 [n, 2] (x, z) world block origins.  Returns dict(verts float32 view [V, 10] (pos 3, nor 3,
+        uv 2, material as 2 x 32-bit), idx int32 [3 V / 2], chunk_verts int32 [n], vert_offset int64 [n])."""
+        t = self.torch
+        n = blocks.shape[0]
+        vp, i32 = ctypes.c_void_p, ctypes.c_int
+        self.lib.mmgen_mesh_count.argtypes = [vp, vp, i32, vp, vp, vp]
+        self.lib.mmgen_mesh_fill.argtypes = [vp, vp, vp, i32, vp, vp, vp, vp, vp]
+        if neighbor_idx is None and nx is not None:
+            c = t.arange(n, dtype=t.int32, device=blocks.device)
+            x, z = c % nx, c // nx
+            neg = t.full_like(c, -1)
+            neighbor_idx = t.stack([t.where(z < nz - 1, c + nx, neg), t.where(x < nx - 1, c + 1, neg), t.where(z > 0, c - nx, neg),
+                                    t.where(x > 0, c - 1, neg)], dim=1).contiguous()
+        colv = self._empty((n, 256), t.int32)
+        chv = self._empty((n,), t.int32)
+        self._check(self.lib.mmgen_mesh_count(self._p(blocks), self._p(neighbor_idx), n, self._p(colv), self._p(chv), self._stream()), "mmgen_mesh_count")
+        incl = t.cumsum(chv.to(t.int64), 0)
+        off = (incl - chv).contiguous()
+        total = int(incl[-1].item()) if n else 0
+        verts = self._empty((max(total, 1), 10), t.float32)
+        idx = self._empty((max(total * 3 // 2, 1),), t.int32)
+        if total:
+            self._check(self.lib.mmgen_mesh_fill(self._p(blocks), self._p(neighbor_idx), self._p(world_block_pos), n, self._p(colv), self._p(off),
+                                                 self._p(verts), self._p(idx), self._stream()), "mmgen_mesh_fill")
+        return dict(verts=verts[:total], idx=idx[:total * 3 // 2], chunk_verts=chv, vert_offset=off)
+
     # ------------------------------------------------------------------ region fast path (all stages, device resident)
     EROSION, FEATURES, DECORATORS = 1, 2, 4
 

@@ -78,6 +78,22 @@ class Oracle:
         self.lib.mmo_generate_region(cx0, cz0, nx, nz, flags, _p(blocks), _p(hf), _p(layers), _p(cave), self.nthreads, None)
         return dict(blocks=blocks, hf=hf, layers=layers, cave=cave)
 
+    def create_vbos(self, blocks, neighbors, wbx, wbz):
+        """Chunk::createVBOs restatement for one chunk.  blocks uint8 [98304]; neighbors: 4 arrays or None (N, E, S, W).
+        Returns (verts uint8 [V, 40], idx uint32 [3V/2])."""
+        keep = [None if a is None else np.ascontiguousarray(a) for a in neighbors]
+        arr = (ctypes.c_void_p * 4)(*[None if a is None else a.ctypes.data for a in keep])
+        self.lib.mmo_create_vbos.restype = ctypes.c_long
+        self.lib.mmo_create_vbos.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                             ctypes.c_long, ctypes.c_long, ctypes.c_void_p]
+        blocks = np.ascontiguousarray(blocks)
+        ni = ctypes.c_long(0)
+        nv = self.lib.mmo_create_vbos(blocks.ctypes.data, arr, int(wbx), int(wbz), None, None, 0, 0, ctypes.byref(ni))
+        verts = np.zeros((nv, 40), np.uint8)
+        idx = np.zeros(ni.value, np.uint32)
+        self.lib.mmo_create_vbos(blocks.ctypes.data, arr, int(wbx), int(wbz), verts.ctypes.data, idx.ctypes.data, nv, ni.value, ctypes.byref(ni))
+        return verts, idx
+
     def ub_counters(self, reset=False):
         out = np.zeros(3, np.int64)
         self.lib.mmo_ub_counters(_p(out), int(reset))

@@ -1,0 +1,128 @@
+"""Mesh build that follows the generation path (Chunk::createVBOs, chunk.cu:1778-2003): oracle self-checks on CPU, HIP-vs-oracle
+parity on the GPU (vertex and index buffers byte for byte, in the reference's order)."""
+import numpy as np
+import pytest
+
+AIR, WATER, STONE, GRASS_BLOCK, GRASS_X, BIRCH_LEAVES, ICE = 0, 1, 57, 59, 7, None, None
+
+
+def _ids():
+    import re, os
+    txt = open(os.path.join(os.path.dirname(__file__), "..", "include", "mmgen_types.h")).read()
+    body = txt[txt.index("MMB_AIR"):txt.index("MMB_NUM_BLOCKS")]
+    names = [n.strip() for n in re.sub(r"/\*.*?\*/", "", body, flags=re.S).replace("\n", " ").split(",") if n.strip()]
+    return {n[4:]: i for i, n in enumerate(names)}
+
+
+def _verts(v):
+    """uint8 [V, 40] -> (pos [V,3], nor [V,3], uv [V,2], mat [V])"""
+    f = v[:, :32].copy().view(np.float32).reshape(-1, 8)
+    return f[:, 0:3], f[:, 3:6], f[:, 6:8], v[:, 32:40].copy().view(np.uint64).reshape(-1)
+
+
+def test_oracle_mesh_hand_cases(oracle):
+    ids = _ids()
+    assert ids["STONE"] == 57 and ids["GRASS"] == 7 and ids["GRASS_BLOCK"] == 59
+    none = [None] * 4
+    # 1. a lone opaque cube inside the chunk: 6 faces, dirVecs order (+z, +x, -z, -x, +y, -y), 24 vertices / 36 indices
+    b = np.zeros(98304, np.uint8)
+    b[100 + 384 * (5 + 16 * 6)] = ids["BEDROCK"]          # no random rotation / flip: uvs are the plain tile corners
+    v, i = oracle.create_vbos(b, none, 160, -320)
+    assert v.shape == (24, 40) and len(i) == 36
+    pos, nor, uv, mat = _verts(v)
+    assert [tuple(n) for n in nor[::4]] == [(0, 0, 1), (1, 0, 0), (0, 0, -1), (-1, 0, 0), (0, 1, 0), (0, -1, 0)]
+    assert pos.min(0).tolist() == [5, 100, 6] and pos.max(0).tolist() == [6, 101, 7]
+    assert np.array_equal(uv[:4], np.array([[0, 5], [1, 5], [1, 6], [0, 6]], np.float32) * np.float32(0.0625))      # BEDROCK tile (0, 5)
+    assert np.array_equal(i[:6], [0, 1, 2, 0, 2, 3]) and np.array_equal(i[6:12], [4, 5, 6, 4, 6, 7]) and (mat == 0).all()
+    # 2. two stacked opaque cubes hide the faces between them: 10 faces
+    b[101 + 384 * (5 + 16 * 6)] = ids["BEDROCK"]
+    v, i = oracle.create_vbos(b, none, 0, 0)
+    assert v.shape[0] == 40 and len(i) == 60
+    # 3. a cube on the chunk border: the face towards an ABSENT neighbour chunk is skipped, towards a present AIR one it shows
+    b = np.zeros(98304, np.uint8); b[50 + 384 * (15 + 16 * 3)] = ids["BEDROCK"]
+    assert oracle.create_vbos(b, none, 0, 0)[0].shape[0] == 20
+    assert oracle.create_vbos(b, [None, np.zeros(98304, np.uint8), None, None], 0, 0)[0].shape[0] == 24
+    full = np.full(98304, ids["STONE"], np.uint8)
+    assert oracle.create_vbos(b, [None, full, None, None], 0, 0)[0].shape[0] == 20          # opaque neighbour hides it
+    # 4. the world floor / ceiling faces always show (no neighbour lookup at y = -1 / 384)
+    b = np.zeros(98304, np.uint8); b[0 + 384 * (8 + 16 * 8)] = ids["BEDROCK"]; b[383 + 384 * (8 + 16 * 8)] = ids["BEDROCK"]
+    assert oracle.create_vbos(b, none, 0, 0)[0].shape[0] == 48
+    # 5. transparency rules: water shows only against AIR or SEMI_TRANSPARENT (leaves), not against stone or water
+    b = np.zeros(98304, np.uint8); c = 384 * (4 + 16 * 4)
+    b[c + 10] = ids["WATER"]; b[c + 11] = ids["WATER"]; b[c + 9] = ids["STONE"]
+    v, _ = oracle.create_vbos(b, none, 0, 0)
+    pos, nor, uv, mat = _verts(v)
+    assert (mat == 1).sum() == 4 * (4 + 4 + 1)           # 2 water cubes: 4 sides each + top of the upper one; nothing towards water / stone
+    # 6. an X-shaped plant: 8 vertices, 12 indices, jittered inside its cell, both diagonal normals
+    b = np.zeros(98304, np.uint8); b[64 + 384 * (2 + 16 * 9)] = ids["GRASS"]
+    v, i = oracle.create_vbos(b, none, 1600, 3200)
+    assert v.shape[0] == 8 and np.array_equal(i, [0, 1, 2, 0, 2, 3, 4, 5, 6, 4, 6, 7])
+    pos, nor, uv, mat = _verts(v)
+    k = np.float32(1) / np.sqrt(np.float32(2))
+    assert np.array_equal(nor[0], [k, 0, -k]) and np.array_equal(nor[4], [k, 0, k])
+    cx, cz = pos[:, 0].mean(), pos[:, 2].mean()
+    assert abs(cx - 2.5) <= 0.2001 and abs(cz - 9.5) <= 0.2001 and pos[:, 1].min() == 64 and pos[:, 1].max() == 65
+    # 7. random uv rotation / flip is a function of (world position, face) only: same block elsewhere in the world differs, same place agrees
+    b = np.zeros(98304, np.uint8); b[70 + 384 * (3 + 16 * 3)] = ids["STONE"]
+    a1, _ = oracle.create_vbos(b, none, 0, 0); a2, _ = oracle.create_vbos(b, none, 0, 0); a3, _ = oracle.create_vbos(b, none, 16, 32)
+    assert np.array_equal(a1, a2) and not np.array_equal(a1, a3)
+    u = _verts(a1)[2]
+    assert set(np.unique(u[:, 0] * 16)) <= {3.0, 4.0} and set(np.unique(u[:, 1] * 16)) <= {0.0, 1.0}          # STONE tile (3, 0)
+
+
+@pytest.mark.gpu
+def test_mesh_matches_oracle_on_generated_terrain(gen, oracle):
+    """A generated 3x3-chunk region (all stages, features: trees, plants, water) meshed by the HIP mesher as one grid: every chunk's
+    vertex and index bytes == the oracle's createVBOs with the same neighbours (absent beyond the grid)."""
+    import torch
+    for (cx0, cz0) in ((3654, -2794), (1488, -1110), (-1268, -1773)):          # birch forest, jungle, coral reef
+        nx = nz = 3
+        blocks = gen.generate_region(cx0, cz0, nx, nz)["blocks"]
+        coords = [(cx0 + x, cz0 + z) for z in range(nz) for x in range(nx)]
+        pos = gen.positions(coords)
+        m = gen.create_vbos(blocks, pos, nx, nz)
+        hb = blocks.cpu().numpy()
+        verts = m["verts"].cpu().numpy().view(np.uint8).reshape(-1, 40)
+        idx = m["idx"].cpu().numpy().view(np.uint32)
+        off = m["vert_offset"].cpu().numpy(); cnt = m["chunk_verts"].cpu().numpy()
+        total = 0
+        for c, (cx, cz) in enumerate(coords):
+            x, z = c % nx, c // nx
+            nb = [hb[c + nx] if z < nz - 1 else None, hb[c + 1] if x < nx - 1 else None, hb[c - nx] if z > 0 else None, hb[c - 1] if x > 0 else None]
+            rv, ri = oracle.create_vbos(hb[c], nb, 16 * cx, 16 * cz)
+            assert cnt[c] == len(rv), f"chunk {c}: vertex count {cnt[c]} vs {len(rv)}"
+            got_v = verts[off[c]:off[c] + cnt[c]]
+            if not np.array_equal(got_v, rv):
+                bad = np.argwhere((got_v != rv).any(1))[0][0]
+                raise AssertionError(f"chunk {c} vertex {bad}: {got_v[bad].view(np.float32)[:8]} vs {rv[bad].view(np.float32)[:8]}")
+            assert np.array_equal(idx[off[c] * 3 // 2:(off[c] + cnt[c]) * 3 // 2], ri), f"chunk {c} indices"
+            total += len(rv)
+        assert total == len(verts) and total > 20000
+
+
+@pytest.mark.gpu
+def test_mesh_edge_cases(gen, oracle):
+    """Empty batch, all-AIR chunk, lone chunks (no neighbours: NULL index array), explicit neighbour indices, full stone chunk."""
+    import torch
+    dev = gen.device
+    pos0 = torch.zeros((0, 2), dtype=torch.int32, device=dev)
+    assert gen.create_vbos(torch.zeros((0, 98304), dtype=torch.uint8, device=dev), pos0)["verts"].shape[0] == 0
+    b = torch.zeros((3, 98304), dtype=torch.uint8, device=dev)
+    b[1] = 57                                              # solid stone chunk
+    b[2].view(256, 384)[:, :64] = 58                       # dirt slab with random uv rotation
+    pos = torch.tensor([[0, 0], [16, 0], [-160, 4800]], dtype=torch.int32, device=dev)
+    m = gen.create_vbos(b, pos)                            # every chunk alone
+    cnt = m["chunk_verts"].cpu().numpy()
+    assert cnt[0] == 0 and cnt[1] == 4 * 2 * 256 and cnt[2] == 4 * 2 * 256      # only floor and ceiling faces show without neighbours
+    hb = b.cpu().numpy(); verts = m["verts"].cpu().numpy().view(np.uint8).reshape(-1, 40); off = m["vert_offset"].cpu().numpy()
+    for c in range(3):
+        rv, _ = oracle.create_vbos(hb[c], [None] * 4, int(pos[c, 0]), int(pos[c, 1]))
+        assert np.array_equal(verts[off[c]:off[c] + cnt[c]], rv)
+    # explicit neighbour indices: chunk 2's east neighbour is the AIR chunk 0 -> its east border faces appear
+    nidx = torch.tensor([[-1, -1, -1, -1], [-1, -1, -1, -1], [-1, 0, -1, -1]], dtype=torch.int32, device=dev)
+    m2 = gen.create_vbos(b, pos, neighbor_idx=nidx)
+    assert int(m2["chunk_verts"][2]) == 4 * (2 * 256 + 16 * 64)
+    rv, ri = oracle.create_vbos(hb[2], [None, hb[0], None, None], -160, 4800)
+    o2 = int(m2["vert_offset"][2])
+    assert np.array_equal(m2["verts"].cpu().numpy().view(np.uint8).reshape(-1, 40)[o2:], rv)
+    assert np.array_equal(m2["idx"].cpu().numpy().view(np.uint32)[o2 * 3 // 2:], ri)
