@@ -74,16 +74,21 @@ MM_DEV f3 simplex3_corner(float p)
 #define MM_PERM_LO 8
 #define MM_PERM_N 608
 #define MM_GRAD_N 296
-// one object, so that non-inlined callees address every table with an immediate offset from a single known LDS base
-struct alignas(16) NoiseTables { f4v grad3[MM_GRAD_N]; f4v grad2[MM_GRAD_N]; int perm4[MM_PERM_N]; };
-static __shared__ NoiseTables s_noise;
+// two objects (known LDS bases, immediate offsets in the non-inlined callees): a kernel that never reaches simplex2 does not
+// reference s_noise2 and does not pay its 4.6 KB
+struct alignas(16) NoiseTables3 { f4v grad3[MM_GRAD_N]; int perm4[MM_PERM_N]; };
+struct alignas(16) NoiseTables2 { f4v grad2[MM_GRAD_N]; };
+static __shared__ NoiseTables3 s_noise;
+static __shared__ NoiseTables2 s_noise2;
 
 typedef __attribute__((address_space(3))) const char* lds_bytes;
 MM_DEV int perm4(int off) { return *(__attribute__((address_space(3))) const int*)((lds_bytes)s_noise.perm4 + 4 * MM_PERM_LO + off); }
 MM_DEV f4v grad3_at(int p4) { return *(__attribute__((address_space(3))) const f4v*)((lds_bytes)s_noise.grad3 + (p4 << 2)); }
-MM_DEV f4v grad2_at(int p4) { return *(__attribute__((address_space(3))) const f4v*)((lds_bytes)s_noise.grad2 + (p4 << 2)); }
+MM_DEV f4v grad2_at(int p4) { return *(__attribute__((address_space(3))) const f4v*)((lds_bytes)s_noise2.grad2 + (p4 << 2)); }
 
-// Called by every thread of the workgroup at kernel entry (ends with a workgroup barrier).
+// Called by every thread of the workgroup at kernel entry (ends with a workgroup barrier).  NEED2 = false: the kernel never
+// evaluates simplex2 (it must not: the table is not built).
+template <bool NEED2 = true>
 MM_DEV void noise_tables_init()
 {
     const int nt = blockDim.x * blockDim.y * blockDim.z;
@@ -91,9 +96,11 @@ MM_DEV void noise_tables_init()
     for (int i = t; i < MM_PERM_N; i += nt) s_noise.perm4[i] = 4 * (int)permute((float)(i - MM_PERM_LO));
     for (int i = t; i < MM_GRAD_N; i += nt) {
         const f3 g3 = simplex3_corner((float)i);
-        const f3 g2 = simplex2_corner((float)i);
         s_noise.grad3[i] = f4v{g3.x, g3.y, g3.z, 0.f};
-        s_noise.grad2[i] = f4v{g2.x, g2.y, g2.z, 0.f};
+        if (NEED2) {
+            const f3 g2 = simplex2_corner((float)i);
+            s_noise2.grad2[i] = f4v{g2.x, g2.y, g2.z, 0.f};
+        }
     }
     __syncthreads();
 }

@@ -234,6 +234,9 @@ k_cave_voxels(const float* __restrict__ hf, const float2* __restrict__ colInfo, 
     __shared__ float s_cells[3 * CELL_N];
     __shared__ unsigned long long s_solid[CAVE_COLS][6];      // solid bit of voxel y at word y / 64, bit y % 64
     __shared__ int s_layers[CAVE_COLS][3 * MMGEN_MAX_CAVE_LAYERS_PER_COLUMN];
+    __shared__ unsigned short s_list1[CAVE_VOXELS], s_list2[CAVE_VOXELS];
+    __shared__ float s_thr[CAVE_VOXELS];
+    __shared__ int s_count[2];
 
     const int t = threadIdx.x;
     const int bid = xcd_block(blockIdx.x, gridDim.x);
@@ -253,42 +256,71 @@ k_cave_voxels(const float* __restrict__ hf, const float2* __restrict__ colInfo, 
         s_cells[3 * i] = p.x; s_cells[3 * i + 1] = p.y; s_cells[3 * i + 2] = p.z;
     }
     if (t < CAVE_COLS * 6) s_solid[t / 6][t % 6] = 0ull;
+    if (t < 2) s_count[t] = 0;
     for (int i = t; i < CAVE_COLS * 3 * MMGEN_MAX_CAVE_LAYERS_PER_COLUMN; i += CAVE_THREADS)
         (&s_layers[0][0])[i] = ((i % 3) == 2) ? 0 : 384;       // {384, 384, biomes = 0}
-    noise_tables_init();                                       // ends with the workgroup barrier
+    noise_tables_init<false>();                                // no simplex2 in this kernel; ends with the workgroup barrier
 
+    // Three dense phases over LDS-compacted voxel lists (order inside a list is irrelevant: voxels are independent).  Ocean columns
+    // need the noise only below y ~ 92 and most voxels that pass the first test pass the second, so without compaction 4 - 40 %
+    // of the lanes idle through the 23 simplex evaluations.
+    //   A  every voxel: everything that needs no noise; solid bit set as if the noise said "no cave"; voxels that need it -> list 1
+    //   B  list 1: threshold (2 x fbm3<4>); voxels whose threshold can carve (> 0.04) -> list 2 with their threshold
+    //   C  list 2: position warp (fbm3from3<5>) + Worley; "cave" clears the solid bit again
     for (int e = t; e < CAVE_VOXELS; e += CAVE_THREADS) {
         const int c = e / CAVE_YEVAL, y = e - c * CAVE_YEVAL;
-        const int idx2d = 4 * group + c;
-        const int col = chunk * 256 + idx2d;
-        const int wx = cp.x + (idx2d & 15), wz = cp.y + (idx2d >> 4);
+        const int col = chunk * 256 + 4 * group + c;
         const float maxHeight = hf[col];
         const float2 ci = colInfo[col];
         const float obw = ci.x, ravineY = ci.y;
-        const float npx = (float)wx * 0.0050f, npz = (float)wz * 0.0050f;
-
         const int topSolid = imax((int)maxHeight, MMGEN_SEA_LEVEL);
         const float fy = (float)y;
-        const float npy = fy * 0.0050f;
         const bool inBand = (y != 0) && (y <= topSolid);
         const float topRatio = smoothstep(142.f, 95.f, fy + obw * 50.f);
-        const float bottomRatio = smoothstep(5.f, 20.f, fy);
         const bool needThr = inBand && topRatio > 0.f;      // threshold is a product with topRatio: 0 → "threshold > 0.04" is false
-        bool cave = (y != 0) && !inBand;                    // y == 0 solid, y > topSolid air
-        if (needThr) {
-            float thr = 0.24f + 0.12f * fbm3<4>(npx * 4.f, npy * 4.f, npz * 4.f);
-            const float huge = smoothstep(0.2f, 0.4f, fbm3<4>(npx * 0.0700f, npy * 0.0700f, npz * 0.0700f));
-            thr *= (1.f + 1.4f * huge);
-            thr *= topRatio * (0.3f + 0.7f * bottomRatio);
-            if (thr > 0.04f) {
-                const f3 o = fbm3from3<5>(npx * 0.8000f, npy * 0.8000f, npz * 0.8000f);
-                const float n = special_cave_noise(npx * 1.f + o.x * 1.8f, npy * 1.6f + o.y * 1.8f, npz * 1.f + o.z * 1.8f, tile);
-                cave = n < thr;
-            }
-        }
-        if (inBand && !cave) cave = fy > ravineY;
+        // final cave = noise cave || (y != 0 && !inBand) || (inBand && fy > ravineY)   (y == 0 solid, y > topSolid air, ravine cut)
+        const bool cave0 = ((y != 0) && !inBand) || (inBand && fy > ravineY);
         // the wave's 64 lanes may straddle two columns / two 64-bit words: OR each lane's bit into its word
-        if (!cave) atomicOr(&s_solid[c][y >> 6], 1ull << (y & 63));
+        if (!cave0) {
+            atomicOr(&s_solid[c][y >> 6], 1ull << (y & 63));
+            if (needThr) s_list1[atomicAdd(&s_count[0], 1)] = (unsigned short)e;      // a voxel that is a cave anyway needs no noise
+        }
+    }
+    __syncthreads();
+    const int count1 = s_count[0];
+    for (int i = t; i < count1; i += CAVE_THREADS) {
+        const int e = s_list1[i];
+        const int c = e / CAVE_YEVAL, y = e - c * CAVE_YEVAL;
+        const int idx2d = 4 * group + c;
+        const float obw = colInfo[chunk * 256 + idx2d].x;
+        const int wx = cp.x + (idx2d & 15), wz = cp.y + (idx2d >> 4);
+        const float npx = (float)wx * 0.0050f, npz = (float)wz * 0.0050f;
+        const float fy = (float)y;
+        const float npy = fy * 0.0050f;
+        const float topRatio = smoothstep(142.f, 95.f, fy + obw * 50.f);
+        const float bottomRatio = smoothstep(5.f, 20.f, fy);
+        float thr = 0.24f + 0.12f * fbm3<4>(npx * 4.f, npy * 4.f, npz * 4.f);
+        const float huge = smoothstep(0.2f, 0.4f, fbm3<4>(npx * 0.0700f, npy * 0.0700f, npz * 0.0700f));
+        thr *= (1.f + 1.4f * huge);
+        thr *= topRatio * (0.3f + 0.7f * bottomRatio);
+        if (thr > 0.04f) {
+            const int k = atomicAdd(&s_count[1], 1);
+            s_list2[k] = (unsigned short)e;
+            s_thr[k] = thr;
+        }
+    }
+    __syncthreads();
+    const int count2 = s_count[1];
+    for (int i = t; i < count2; i += CAVE_THREADS) {
+        const int e = s_list2[i];
+        const float thr = s_thr[i];
+        const int c = e / CAVE_YEVAL, y = e - c * CAVE_YEVAL;
+        const int idx2d = 4 * group + c;
+        const int wx = cp.x + (idx2d & 15), wz = cp.y + (idx2d >> 4);
+        const float npx = (float)wx * 0.0050f, npz = (float)wz * 0.0050f, npy = (float)y * 0.0050f;
+        const f3 o = fbm3from3<5>(npx * 0.8000f, npy * 0.8000f, npz * 0.8000f);
+        const float n = special_cave_noise(npx * 1.f + o.x * 1.8f, npy * 1.6f + o.y * 1.8f, npz * 1.f + o.z * 1.8f, tile);
+        if (n < thr) atomicAnd(&s_solid[c][y >> 6], ~(1ull << (y & 63)));
     }
     // analytic part, y in [144, 384): solid iff y <= topSolid and not (y > ravineY)   (topRatio == 0 there)
     if (t < CAVE_COLS * 4) {   // 4 lanes per column fill words 2..5 (word 2 holds y 128..191: bits >= 16 only)
