@@ -129,16 +129,18 @@ int mmgen_profile_collect(double* total_ms, long long* counts);
 
 /* ---- mesh build that follows the path ------------------------------------------------------
  * Replaces Chunk::createVBOs (src/terrain/chunk.cu:1778-2003), the host loop over 98 304 voxels x 6 neighbours per chunk.
- * d_blocks: [n][98304] block ids (a batch or a whole region grid); d_neighbor_idx: [n][4] index into the same batch of the
- * N (+z), E (+x), S (-z), W (-x) neighbour chunk, -1 = absent (faces towards an absent chunk are not emitted, chunk.cu:1906),
- * NULL = all absent.  Vertices are the reference's Vertex (40 bytes), indices are local to their chunk, order is the reference's
+ * d_blocks: [*][98304] block ids (a batch, a whole region grid or a pool of chunk slots); d_chunk_idx: [n] which chunks of
+ * d_blocks to mesh (NULL = chunks 0 .. n-1); every other per-chunk array is indexed by the position in that work list.
+ * d_neighbor_idx: [n][4] index into d_blocks of the N (+z), E (+x), S (-z), W (-x) neighbour chunk, -1 = absent (faces towards an
+ * absent chunk are not emitted, chunk.cu:1906), NULL = all absent.  Vertices are the reference's Vertex (40 bytes), indices are local to their chunk, order is the reference's
  * (z, x, y; faces in DirectionEnums::dirVecs order); a chunk with V vertices has exactly 3 V / 2 indices.
  *   mmgen_mesh_count: d_column_verts [n][256] and d_chunk_verts [n] receive the vertex counts.
  *   mmgen_mesh_fill : writes chunk c's vertices at d_verts[d_vert_offset[c] ...] and its indices at d_idx[d_vert_offset[c] * 3 / 2 ...]
  *                     (d_vert_offset: exclusive prefix of d_chunk_verts, computed by the caller who also sizes the buffers);
  *                     d_chunk_world_block_pos [n][2] = (x, z) world block origin of each chunk (X-shaped jitter and uv rotation seeds). */
-int mmgen_mesh_count(const uint8_t* d_blocks, const int32_t* d_neighbor_idx, int n, uint32_t* d_column_verts, uint32_t* d_chunk_verts, void* stream);
-int mmgen_mesh_fill(const uint8_t* d_blocks, const int32_t* d_neighbor_idx, const int32_t* d_chunk_world_block_pos, int n,
+int mmgen_mesh_count(const uint8_t* d_blocks, const int32_t* d_chunk_idx, const int32_t* d_neighbor_idx, int n, uint32_t* d_column_verts,
+                     uint32_t* d_chunk_verts, void* stream);
+int mmgen_mesh_fill(const uint8_t* d_blocks, const int32_t* d_chunk_idx, const int32_t* d_neighbor_idx, const int32_t* d_chunk_world_block_pos, int n,
                     const uint32_t* d_column_verts, const uint64_t* d_vert_offset, mmgen_vertex* d_verts, uint32_t* d_idx, void* stream);
 
 /* Test-only: evaluates device math function `fn` (MMGEN_PROBE_*) on n packed fp32 items (ints bit-cast); used by the parity

@@ -131,12 +131,12 @@ MM_DEV uint32_t mesh_column(const uint8_t* __restrict__ col, const uint8_t* __re
 }
 
 // neighbour columns of column (x, z) of chunk `c`: inside the chunk, or the facing border column of the neighbouring chunk
-MM_DEV void mesh_neighbours(const uint8_t* __restrict__ blocks, const int32_t* __restrict__ neighborIdx, int c, int x, int z, const uint8_t*& colN,
-                            const uint8_t*& colE, const uint8_t*& colS, const uint8_t*& colW)
+MM_DEV void mesh_neighbours(const uint8_t* __restrict__ blocks, const int32_t* __restrict__ neighborIdx, int o, int c, int x, int z,
+                            const uint8_t*& colN, const uint8_t*& colE, const uint8_t*& colS, const uint8_t*& colW)
 {
     const uint8_t* base = blocks + (size_t)MMGEN_BLOCKS_PER_CHUNK * c;
     auto chunk_of = [&](int k) -> const uint8_t* {
-        const int n = neighborIdx ? neighborIdx[4 * c + k] : -1;
+        const int n = neighborIdx ? neighborIdx[4 * o + k] : -1;
         return n < 0 ? nullptr : blocks + (size_t)MMGEN_BLOCKS_PER_CHUNK * n;
     };
     const uint8_t* cN = z < 15 ? base : chunk_of(0);
@@ -150,23 +150,24 @@ MM_DEV void mesh_neighbours(const uint8_t* __restrict__ blocks, const int32_t* _
 }
 
 __global__ void __launch_bounds__(256)
-k_mesh_count(const uint8_t* __restrict__ blocks, const int32_t* __restrict__ neighborIdx, uint32_t* __restrict__ columnVerts,
-             uint32_t* __restrict__ chunkVerts)
+k_mesh_count(const uint8_t* __restrict__ blocks, const int32_t* __restrict__ chunkIdx, const int32_t* __restrict__ neighborIdx,
+             uint32_t* __restrict__ columnVerts, uint32_t* __restrict__ chunkVerts)
 {
     __shared__ uint32_t s_data[MMB_NUM_BLOCKS];
     __shared__ uint32_t s_total;
-    const int c = blockIdx.x, t = threadIdx.x;
+    const int o = blockIdx.x, t = threadIdx.x;
+    const int c = chunkIdx ? chunkIdx[o] : o;           // o = position in the work list (outputs), c = chunk in the block array
     if (t < MMB_NUM_BLOCKS) s_data[t] = kBlockData[t];
     if (t == 0) s_total = 0;
     __syncthreads();
     const int x = t & 15, z = t >> 4;
     const uint8_t *colN, *colE, *colS, *colW;
-    mesh_neighbours(blocks, neighborIdx, c, x, z, colN, colE, colS, colW);
+    mesh_neighbours(blocks, neighborIdx, o, c, x, z, colN, colE, colS, colW);
     const uint32_t n = 4u * mesh_column<false>(blocks + (size_t)MMGEN_BLOCKS_PER_CHUNK * c + 384 * t, colN, colE, colS, colW, s_data, t, 0, 0, nullptr, nullptr);
-    columnVerts[256 * c + t] = n;
+    columnVerts[256 * o + t] = n;
     atomicAdd(&s_total, n);
     __syncthreads();
-    if (t == 0) chunkVerts[c] = s_total;
+    if (t == 0) chunkVerts[o] = s_total;
 }
 
 // Vertex j (0-3) of quad record `r` (material m) as 10 dwords: pos xyz, nor xyz, uv, material lo / hi.  Table lookups go to the LDS
@@ -208,8 +209,8 @@ MM_DEV VertexWords vertex_words(uint32_t r, int m, int j, const float2* s_jitter
 
 #define MESH_CAP 4096      // quads staged per batch (a column has at most 384 * 6)
 __global__ void __launch_bounds__(256)
-k_mesh_fill(const uint8_t* __restrict__ blocks, const int32_t* __restrict__ neighborIdx, const int2* __restrict__ chunkWorldBlockPos,
-            const uint32_t* __restrict__ columnVerts, const uint64_t* __restrict__ vertOffset, mmgen_vertex* __restrict__ verts,
+k_mesh_fill(const uint8_t* __restrict__ blocks, const int32_t* __restrict__ chunkIdx, const int32_t* __restrict__ neighborIdx,
+            const int2* __restrict__ chunkWorldBlockPos, const uint32_t* __restrict__ columnVerts, const uint64_t* __restrict__ vertOffset, mmgen_vertex* __restrict__ verts,
             uint32_t* __restrict__ idx)
 {
     __shared__ uint32_t s_data[MMB_NUM_BLOCKS];
@@ -219,11 +220,12 @@ k_mesh_fill(const uint8_t* __restrict__ blocks, const int32_t* __restrict__ neig
     __shared__ float2 s_jitter[256];
     __shared__ int s_dv[72], s_dir[18];
     __shared__ int s_end;
-    const int c = blockIdx.x, t = threadIdx.x;
+    const int o = blockIdx.x, t = threadIdx.x;
+    const int c = chunkIdx ? chunkIdx[o] : o;
     if (t < MMB_NUM_BLOCKS) s_data[t] = kBlockData[t];
     if (t < 72) s_dv[t] = kMeshDirVert[t / 3][t % 3];
     if (t < 18) s_dir[t] = kMeshDir[t / 3][t % 3];
-    const uint32_t mine = columnVerts[256 * c + t] / 4u;
+    const uint32_t mine = columnVerts[256 * o + t] / 4u;
     s_scan[t] = mine;
     __syncthreads();
     for (int off = 1; off < 256; off <<= 1) {            // Hillis-Steele
@@ -234,17 +236,17 @@ k_mesh_fill(const uint8_t* __restrict__ blocks, const int32_t* __restrict__ neig
     }
     const uint32_t total = s_scan[255];
     if (total == 0) return;
-    const int2 wb = chunkWorldBlockPos[c];
+    const int2 wb = chunkWorldBlockPos[o];
     {   // X-shaped jitter of this column (rand2From2 of the world block xz, chunk.cu:1838-1841); cheap enough to do for every column
         const f2 r = rand2from2((float)(wb.x + (t & 15)), (float)(wb.y + (t >> 4)));
         s_jitter[t] = make_float2(0.4f * (r.x - 0.5f), 0.4f * (r.y - 0.5f));
     }
-    const uint64_t vbase = vertOffset[c];
+    const uint64_t vbase = vertOffset[o];
     uint32_t* vout = (uint32_t*)(verts + vbase);
     uint32_t* iout = idx + (vbase / 4) * 6;
     const uint8_t* col = blocks + (size_t)MMGEN_BLOCKS_PER_CHUNK * c + 384 * t;
     const uint8_t *colN, *colE, *colS, *colW;
-    mesh_neighbours(blocks, neighborIdx, c, t & 15, t >> 4, colN, colE, colS, colW);
+    mesh_neighbours(blocks, neighborIdx, o, c, t & 15, t >> 4, colN, colE, colS, colW);
 
     // batches of whole columns whose quads fit the LDS stage
     int start = 0;
@@ -286,21 +288,22 @@ k_mesh_fill(const uint8_t* __restrict__ blocks, const int32_t* __restrict__ neig
 
 extern "C" {
 
-int mmgen_mesh_count(const uint8_t* d_blocks, const int32_t* d_neighbor_idx, int n, uint32_t* d_column_verts, uint32_t* d_chunk_verts, void* stream)
+int mmgen_mesh_count(const uint8_t* d_blocks, const int32_t* d_chunk_idx, const int32_t* d_neighbor_idx, int n, uint32_t* d_column_verts,
+                     uint32_t* d_chunk_verts, void* stream)
 {
     if (n < 0 || (n > 0 && (!d_blocks || !d_column_verts || !d_chunk_verts))) return (int)hipErrorInvalidValue;
     if (n == 0) return 0;
-    hipLaunchKernelGGL(mm::k_mesh_count, dim3(n), dim3(256), 0, (hipStream_t)stream, d_blocks, d_neighbor_idx, d_column_verts, d_chunk_verts);
+    hipLaunchKernelGGL(mm::k_mesh_count, dim3(n), dim3(256), 0, (hipStream_t)stream, d_blocks, d_chunk_idx, d_neighbor_idx, d_column_verts, d_chunk_verts);
     return (int)hipGetLastError();
 }
 
-int mmgen_mesh_fill(const uint8_t* d_blocks, const int32_t* d_neighbor_idx, const int32_t* d_chunk_world_block_pos, int n,
+int mmgen_mesh_fill(const uint8_t* d_blocks, const int32_t* d_chunk_idx, const int32_t* d_neighbor_idx, const int32_t* d_chunk_world_block_pos, int n,
                     const uint32_t* d_column_verts, const uint64_t* d_vert_offset, mmgen_vertex* d_verts, uint32_t* d_idx, void* stream)
 {
     if (n < 0 || (n > 0 && (!d_blocks || !d_chunk_world_block_pos || !d_column_verts || !d_vert_offset || !d_verts || !d_idx)))
         return (int)hipErrorInvalidValue;
     if (n == 0) return 0;
-    hipLaunchKernelGGL(mm::k_mesh_fill, dim3(n), dim3(256), 0, (hipStream_t)stream, d_blocks, d_neighbor_idx, (const int2*)d_chunk_world_block_pos,
+    hipLaunchKernelGGL(mm::k_mesh_fill, dim3(n), dim3(256), 0, (hipStream_t)stream, d_blocks, d_chunk_idx, d_neighbor_idx, (const int2*)d_chunk_world_block_pos,
                        d_column_verts, d_vert_offset, d_verts, d_idx);
     return (int)hipGetLastError();
 }

@@ -388,14 +388,14 @@ void Chunk::createVBOs()
     MM_CALL(hipMemcpy(d + oN, nidx, 16, hipMemcpyHostToDevice), "H2D");
     MM_CALL(hipMemcpy(d + oPos, pos, 8, hipMemcpyHostToDevice), "H2D");
     MM_CALL(hipMemcpy(d + oOff, &zero, 8, hipMemcpyHostToDevice), "H2D");
-    MM_CALL(mmgen_mesh_count((uint8_t*)(d + oB), (int32_t*)(d + oN), 1, (uint32_t*)(d + oCol), (uint32_t*)(d + oCnt), nullptr), "Chunk::createVBOs() count failed");
+    MM_CALL(mmgen_mesh_count((uint8_t*)(d + oB), nullptr, (int32_t*)(d + oN), 1, (uint32_t*)(d + oCol), (uint32_t*)(d + oCnt), nullptr), "Chunk::createVBOs() count failed");
     uint32_t nv = 0;
     MM_CALL(hipMemcpy(&nv, d + oCnt, 4, hipMemcpyDeviceToHost), "D2H");
     if (nv == 0) return;
     static Scratch out;
     const size_t vb = (size_t)nv * sizeof(Vertex), ib = (size_t)nv / 4 * 6 * sizeof(unsigned int);
     char* o = (char*)out.get(vb + ib);
-    MM_CALL(mmgen_mesh_fill((uint8_t*)(d + oB), (int32_t*)(d + oN), (int32_t*)(d + oPos), 1, (uint32_t*)(d + oCol), (uint64_t*)(d + oOff), (Vertex*)o,
+    MM_CALL(mmgen_mesh_fill((uint8_t*)(d + oB), nullptr, (int32_t*)(d + oN), (int32_t*)(d + oPos), 1, (uint32_t*)(d + oCol), (uint64_t*)(d + oOff), (Vertex*)o,
                             (uint32_t*)(o + vb), nullptr),
             "Chunk::createVBOs() fill failed");
     verts.resize(nv);

@@ -1,0 +1,108 @@
+// Headless comparison of the two schedulers over the same C ABI:
+//   Terrain        the drop-in mirror of the reference's action-time loop (nine per-stage queues through host Chunk objects)
+//   RegionTerrain  the region-batched streaming scheduler (one device-resident region call per missing rectangle, pool meshing)
+// Both stream the world around a player position, then around a second position 13 / -5 chunks away (new strips only).  Every
+// chunk that is drawable for the player must exist in both with identical blocks, vertices and indices.
+//
+//   mmgen_region_terrain_demo [playerChunkX playerChunkZ]      exit code 0 = identical
+#include "terrain.hpp"
+#include "region_terrain.hpp"
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+using namespace mmhost;
+using Clock = std::chrono::steady_clock;
+
+static double secondsSince(Clock::time_point t0) { return std::chrono::duration<double>(Clock::now() - t0).count(); }
+
+template <class T> static int drain(T& terrain, int maxTicks)
+{
+    int ticks = 0, idle = 0;
+    while (idle < 3 && ticks < maxTicks) {
+        terrain.tick(1.f / 60.f);
+        ++ticks;
+        idle = terrain.allQueuesEmpty() ? idle + 1 : 0;
+    }
+    return ticks;
+}
+
+static int compare(Terrain& a, RegionTerrain& b, ivec2 player)
+{
+    int bad = 0, checked = 0;
+    size_t verts = 0;
+    const int r = Terrain::chunkVbosGenRadius;
+    for (int dz = -r; dz <= r; ++dz)
+        for (int dx = -r; dx <= r; ++dx) {
+            const ivec2 c = {player.x + dx, player.y + dz};
+            Chunk* ca = a.findChunk(c);
+            Chunk* cb = b.findChunk(c);
+            ++checked;
+            if (!ca || !cb || ca->getState() != ChunkState::DRAWABLE || cb->getState() != ChunkState::DRAWABLE) {
+                if (++bad <= 5) std::printf("  chunk (%d,%d): not drawable in %s\n", c.x, c.y, (!ca || ca->getState() != ChunkState::DRAWABLE) ? "Terrain" : "RegionTerrain");
+                continue;
+            }
+            const bool blocksSame = std::memcmp(ca->blocks.data(), cb->blocks.data(), devBlocksSize) == 0;
+            const bool vertsSame = ca->verts.size() == cb->verts.size() && std::memcmp(ca->verts.data(), cb->verts.data(), ca->verts.size() * sizeof(Vertex)) == 0;
+            const bool idxSame = ca->idx.size() == cb->idx.size() && std::memcmp(ca->idx.data(), cb->idx.data(), ca->idx.size() * sizeof(unsigned int)) == 0;
+            verts += ca->verts.size();
+            if (!blocksSame || !vertsSame || !idxSame) {
+                if (++bad <= 5) std::printf("  chunk (%d,%d): blocks %s, verts %s (%zu vs %zu), idx %s\n", c.x, c.y, blocksSame ? "same" : "DIFFER", vertsSame ? "same" : "DIFFER",
+                                            ca->verts.size(), cb->verts.size(), idxSame ? "same" : "DIFFER");
+            }
+        }
+    std::printf("  %d drawable chunks compared (blocks, %zu vertices, indices): %d bad\n", checked, verts, bad);
+    return bad;
+}
+
+int main(int argc, char** argv)
+{
+    ivec2 player = {argc > 2 ? std::atoi(argv[1]) : 0, argc > 2 ? std::atoi(argv[2]) : 0};
+    HipUtils::checkError("hipSetDevice", (int)hipSetDevice(0));
+    BiomeUtils::init();
+    Terrain stage;
+    stage.init();
+    RegionTerrain batched;
+    batched.init();
+    int bad = 0;
+    for (int leg = 0; leg < 2; ++leg) {
+        if (leg == 1) player = {player.x + 13, player.y - 5};
+        stage.setCurrentChunkPos(player);
+        batched.setCurrentChunkPos(player);
+        auto t0 = Clock::now();
+        const int ticksA = drain(stage, 200000);
+        const double sA = secondsSince(t0);
+        t0 = Clock::now();
+        int generated = 0, regions = 0, meshed = 0, ticksB = 0;
+        while (true) {
+            batched.tick(1.f / 60.f);
+            ++ticksB;
+            generated += batched.lastGenerated; regions += batched.lastRegions; meshed += batched.lastMeshed;
+            if (batched.allQueuesEmpty()) break;
+        }
+        const double sB = secondsSince(t0);
+        std::printf("leg %d, player chunk (%d,%d):\n  Terrain        %6d ticks (= %.1f s of frames at 60 fps) %8.3f s wall   %zu chunks exist\n  RegionTerrain  %6d ticks %8.3f s   %d chunks generated in %d regions, %d meshed"
+                    "   (%.0fx)\n",
+                    leg, player.x, player.y, ticksA, ticksA / 60.0, sA, stage.numChunks(), ticksB, sB, generated, regions, meshed, sB > 0 ? sA / sB : 0.0);
+        bad += compare(stage, batched, player);
+    }
+    {   // the same two legs with everything left on the device (renderer interop): what the GPU path itself costs
+        RegionTerrain resident;
+        resident.copyToHost = false;
+        resident.init();
+        ivec2 p = {player.x - 13, player.y + 5};
+        for (int leg = 0; leg < 2; ++leg) {
+            if (leg == 1) p = player;
+            resident.setCurrentChunkPos(p);
+            const auto t0 = Clock::now();
+            int generated = 0, meshed = 0;
+            do { resident.tick(1.f / 60.f); generated += resident.lastGenerated; meshed += resident.lastMeshed; } while (!resident.allQueuesEmpty());
+            const double s = secondsSince(t0);
+            std::printf("device-resident leg %d: %d chunks generated, %d meshed in %.1f ms (%.0f generated chunks/s incl. meshing)\n", leg, generated, meshed, 1e3 * s,
+                        generated / s);
+        }
+    }
+    std::printf("mmgen_region_terrain_demo: %s\n", bad == 0 ? "IDENTICAL" : "MISMATCH");
+    return bad == 0 ? 0 : 1;
+}

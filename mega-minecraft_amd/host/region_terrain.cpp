@@ -1,0 +1,194 @@
+// mmgen host side — region-batched streaming scheduler (see region_terrain.hpp).
+#include "region_terrain.hpp"
+#include <algorithm>
+#include <cstring>
+
+namespace mmhost {
+
+namespace {
+const ivec2 kDir4[4] = {{0, 1}, {1, 0}, {0, -1}, {-1, 0}};      // N (+z), E (+x), S (-z), W (-x): Chunk::neighbors order (util/enums.hpp:40-47)
+#define RT_CALL(expr, msg) HipUtils::checkError(msg, (int)(expr), __LINE__)
+}  // namespace
+
+RegionTerrain::RegionTerrain(size_t poolChunks) : poolChunks(poolChunks) {}
+
+RegionTerrain::~RegionTerrain()
+{
+    if (region) mmgen_region_destroy(region);
+    if (d_pool) (void)hipFree(d_pool);
+    if (d_meshOut) (void)hipFree(d_meshOut);
+    if (d_meshWork) (void)hipFree(d_meshWork);
+}
+
+void RegionTerrain::init()
+{
+    RT_CALL(mmgen_region_create(&region), "mmgen_region_create failed");
+    RT_CALL(hipMalloc((void**)&d_pool, poolChunks * (size_t)devBlocksSize), "hipMalloc (chunk pool) failed");
+}
+
+void* RegionTerrain::ensure(void*& p, size_t& cap, size_t bytes)
+{
+    if (bytes > cap) {
+        if (p) RT_CALL(hipFree(p), "hipFree failed");
+        RT_CALL(hipMalloc(&p, bytes), "hipMalloc failed");
+        cap = bytes;
+    }
+    return p;
+}
+
+Chunk* RegionTerrain::findChunk(ivec2 c)
+{
+    auto it = cells.find({c.x, c.y});
+    return it == cells.end() ? nullptr : it->second.chunk.get();
+}
+
+std::unordered_set<Chunk*> RegionTerrain::getDrawableChunks() { return drawable; }
+
+// one region call: all stages for the rectangle, blocks straight into consecutive pool slots
+void RegionTerrain::generateRect(int cx0, int cz0, int nx, int nz)
+{
+    const size_t n = (size_t)nx * nz;
+    if (poolUsed + n > poolChunks) HipUtils::checkError("RegionTerrain: chunk pool exhausted (lifetime management is SURVEY 8f rank 3)", 2, __LINE__);
+    uint8_t* dst = d_pool + poolUsed * (size_t)devBlocksSize;
+    RT_CALL(mmgen_region_generate(region, cx0, cz0, nx, nz, MMGEN_REGION_EROSION | MMGEN_REGION_FEATURES | MMGEN_REGION_DECORATORS, dst, nullptr, nullptr),
+            "mmgen_region_generate failed");
+    if (copyToHost) {
+        hostStage.resize(n * (size_t)devBlocksSize);
+        RT_CALL(hipMemcpy(hostStage.data(), dst, hostStage.size(), hipMemcpyDeviceToHost), "D2H blocks failed");
+    } else {
+        RT_CALL(hipDeviceSynchronize(), "region generation failed");
+    }
+    for (int z = 0; z < nz; ++z)
+        for (int x = 0; x < nx; ++x) {
+            const ivec2 c = {cx0 + x, cz0 + z};
+            Cell cell;
+            cell.chunk = std::make_unique<Chunk>(c);
+            cell.slot = (int)(poolUsed + (size_t)x + (size_t)nx * z);
+            cell.meshed = false;
+            if (copyToHost) std::memcpy(cell.chunk->blocks.data(), hostStage.data() + ((size_t)x + (size_t)nx * z) * devBlocksSize, devBlocksSize);
+            cell.chunk->setState(ChunkState::FILLED);
+            Chunk* cp = cell.chunk.get();
+            cells.emplace(std::make_pair(c.x, c.y), std::move(cell));
+            for (int k = 0; k < 4; ++k) {                      // neighbour links, as Terrain::updateChunk keeps them
+                auto it = cells.find({c.x + kDir4[k].x, c.y + kDir4[k].y});
+                if (it == cells.end()) continue;
+                cp->neighbors[k] = it->second.chunk.get();
+                it->second.chunk->neighbors[(k + 2) % 4] = cp;
+            }
+        }
+    poolUsed += n;
+    lastGenerated += (int)n;
+    lastRegions += 1;
+}
+
+// every unmeshed chunk of the drawable square whose four neighbours exist: one count + fill pair over the pool
+void RegionTerrain::meshReady()
+{
+    std::vector<Cell*> work;
+    std::vector<int32_t> meta;          // per chunk: slot, 4 neighbour slots, world block x, z
+    const int r = chunkVbosGenRadius;
+    for (int dz = -r; dz <= r; ++dz)
+        for (int dx = -r; dx <= r; ++dx) {
+            auto it = cells.find({plannedFor.x + dx, plannedFor.y + dz});
+            if (it == cells.end() || it->second.meshed) continue;
+            int32_t nb[4];
+            bool all = true;
+            for (int k = 0; k < 4 && all; ++k) {
+                auto n = cells.find({plannedFor.x + dx + kDir4[k].x, plannedFor.y + dz + kDir4[k].y});
+                if (n == cells.end()) all = false; else nb[k] = n->second.slot;
+            }
+            if (!all) continue;         // terrain.cpp:569-585: VBOs only once all four neighbours are filled
+            work.push_back(&it->second);
+            meta.push_back(it->second.slot);
+            for (int k = 0; k < 4; ++k) meta.push_back(nb[k]);
+            meta.push_back(it->second.chunk->worldBlockPos.x);
+            meta.push_back(it->second.chunk->worldBlockPos.z);
+        }
+    const int n = (int)work.size();
+    if (n == 0) return;
+    // device work area: chunk idx [n], neighbour idx [n][4], positions [n][2], column counts [n][256], chunk counts [n], offsets [n] (u64)
+    const size_t oIdx = 0, oNb = oIdx + (size_t)n * 4, oPos = oNb + (size_t)n * 16, oCol = oPos + (size_t)n * 8, oCnt = oCol + (size_t)n * 1024,
+                 oOff = (oCnt + (size_t)n * 4 + 7) / 8 * 8, total = oOff + (size_t)n * 8;
+    char* w = (char*)ensure(d_meshWork, meshWorkCap, total);
+    std::vector<int32_t> hIdx(n), hNb((size_t)n * 4), hPos((size_t)n * 2);
+    for (int i = 0; i < n; ++i) {
+        hIdx[i] = meta[7 * i];
+        for (int k = 0; k < 4; ++k) hNb[4 * i + k] = meta[7 * i + 1 + k];
+        hPos[2 * i] = meta[7 * i + 5]; hPos[2 * i + 1] = meta[7 * i + 6];
+    }
+    RT_CALL(hipMemcpy(w + oIdx, hIdx.data(), (size_t)n * 4, hipMemcpyHostToDevice), "H2D failed");
+    RT_CALL(hipMemcpy(w + oNb, hNb.data(), (size_t)n * 16, hipMemcpyHostToDevice), "H2D failed");
+    RT_CALL(hipMemcpy(w + oPos, hPos.data(), (size_t)n * 8, hipMemcpyHostToDevice), "H2D failed");
+    RT_CALL(mmgen_mesh_count(d_pool, (int32_t*)(w + oIdx), (int32_t*)(w + oNb), n, (uint32_t*)(w + oCol), (uint32_t*)(w + oCnt), nullptr), "mmgen_mesh_count failed");
+    std::vector<uint32_t> cnt(n);
+    RT_CALL(hipMemcpy(cnt.data(), w + oCnt, (size_t)n * 4, hipMemcpyDeviceToHost), "D2H failed");
+    std::vector<uint64_t> off(n);
+    uint64_t totalVerts = 0;
+    for (int i = 0; i < n; ++i) { off[i] = totalVerts; totalVerts += cnt[i]; }
+    RT_CALL(hipMemcpy(w + oOff, off.data(), (size_t)n * 8, hipMemcpyHostToDevice), "H2D failed");
+    const size_t vb = (size_t)totalVerts * sizeof(Vertex), ib = (size_t)totalVerts / 4 * 6 * sizeof(unsigned int);
+    char* o = (char*)ensure(d_meshOut, meshOutCap, vb + ib + 64);
+    if (totalVerts)
+        RT_CALL(mmgen_mesh_fill(d_pool, (int32_t*)(w + oIdx), (int32_t*)(w + oNb), (int32_t*)(w + oPos), n, (uint32_t*)(w + oCol), (uint64_t*)(w + oOff),
+                                (Vertex*)o, (uint32_t*)(o + vb), nullptr),
+                "mmgen_mesh_fill failed");
+    if (copyToHost && totalVerts) {
+        hostStage.resize(vb + ib);
+        RT_CALL(hipMemcpy(hostStage.data(), o, vb + ib, hipMemcpyDeviceToHost), "D2H mesh failed");
+    } else {
+        RT_CALL(hipDeviceSynchronize(), "mesh build failed");
+    }
+    for (int i = 0; i < n; ++i) {
+        Chunk* c = work[i]->chunk.get();
+        if (copyToHost) {
+            const Vertex* v = (const Vertex*)hostStage.data() + off[i];
+            const unsigned int* ix = (const unsigned int*)(hostStage.data() + vb) + off[i] / 4 * 6;
+            c->verts.assign(v, v + cnt[i]);
+            c->idx.assign(ix, ix + (size_t)cnt[i] / 4 * 6);
+        }
+        c->idxCount = (int)(cnt[i] / 4 * 6);
+        c->setState(ChunkState::DRAWABLE);
+        work[i]->meshed = true;
+        drawable.insert(c);
+    }
+    lastMeshed += n;
+}
+
+void RegionTerrain::tick(float)
+{
+    lastGenerated = lastMeshed = lastRegions = 0;
+    if (!planned || !(plannedFor == currentChunkPos)) { plannedFor = currentChunkPos; planned = true; pending = true; }
+    if (!pending) return;
+
+    // missing cells of the generation square (drawable radius + the ring the border meshes look at)
+    const int R = chunkVbosGenRadius + 1, S = 2 * R + 1;
+    std::vector<uint8_t> missing((size_t)S * S, 0);
+    int numMissing = 0;
+    for (int z = 0; z < S; ++z)
+        for (int x = 0; x < S; ++x)
+            if (!cells.count({plannedFor.x - R + x, plannedFor.y - R + z})) { missing[(size_t)x + (size_t)S * z] = 1; ++numMissing; }
+
+    // greedy rectangle cover: maximal x-run of the first missing cell, extended down while the whole run is missing
+    int budget = maxChunksPerTick;
+    for (int z = 0; z < S && numMissing > 0 && budget > 0; ++z)
+        for (int x = 0; x < S && budget > 0; ++x) {
+            if (!missing[(size_t)x + (size_t)S * z]) continue;
+            int nx = 1;
+            while (x + nx < S && missing[(size_t)(x + nx) + (size_t)S * z]) ++nx;
+            int nz = 1;
+            for (; z + nz < S; ++nz) {
+                bool full = true;
+                for (int i = 0; i < nx && full; ++i) full = missing[(size_t)(x + i) + (size_t)S * (z + nz)] != 0;
+                if (!full) break;
+            }
+            if (nx * nz > budget) { nz = std::max(1, budget / nx); if (nx * nz > budget) nx = budget; }
+            generateRect(plannedFor.x - R + x, plannedFor.y - R + z, nx, nz);
+            for (int j = 0; j < nz; ++j) for (int i = 0; i < nx; ++i) missing[(size_t)(x + i) + (size_t)S * (z + j)] = 0;
+            numMissing -= nx * nz;
+            budget -= nx * nz;
+        }
+    meshReady();
+    pending = numMissing > 0;
+}
+
+}  // namespace mmhost

@@ -1,0 +1,66 @@
+// mmgen host side — the region-batched streaming scheduler (second half).
+//
+// Same public interface as the reference's `Terrain` (src/terrain/terrain.hpp:53-120: init / tick / setCurrentChunkPos /
+// getCurrentChunkPos / getDrawableChunks / getMaxNumDrawableChunks) and the same result - the same chunks become drawable, with the
+// same blocks and the same meshes - but the work is scheduled in CHUNKS, not in "action time": instead of draining nine per-stage
+// queues through host `Chunk` objects (≈ 800 chunks/s by construction of the budget, terrain.cpp:65-82), a tick
+//   1. finds the chunks around the player that do not exist yet (drawable square of radius chunkVbosGenRadius plus the one-chunk
+//      ring whose blocks the meshes of the border chunks look at),
+//   2. covers them with a few rectangles and generates each rectangle with ONE device-resident region call (all stages, no host
+//      round trip; results are independent of the rectangle decomposition - tests config4 / config5),
+//   3. keeps the blocks in a device pool of chunk slots and meshes every chunk whose four neighbours exist in one
+//      mmgen_mesh_count / mmgen_mesh_fill pair over the pool,
+//   4. copies blocks and meshes into the host `Chunk` objects for consumers that want them there (optional).
+// Zone / chunk lifetime is the reference's: nothing is ever freed.
+#pragma once
+#include <map>
+#include <memory>
+#include <unordered_set>
+#include <vector>
+#include "chunk.hpp"
+
+namespace mmhost {
+
+class RegionTerrain {
+public:
+    static constexpr int chunkVbosGenRadius = 16;                 // terrain.cpp:65
+    explicit RegionTerrain(size_t poolChunks = 8192);
+    ~RegionTerrain();
+    void init();
+    void tick(float deltaTime);
+    std::unordered_set<Chunk*> getDrawableChunks();
+    ivec2 getCurrentChunkPos() const { return currentChunkPos; }
+    void setCurrentChunkPos(ivec2 p) { currentChunkPos = p; }
+    static int getMaxNumDrawableChunks() { return (2 * chunkVbosGenRadius + 1) * (2 * chunkVbosGenRadius + 1); }
+
+    bool allQueuesEmpty() const { return !pending; }
+    Chunk* findChunk(ivec2 worldChunkPos);
+    size_t numChunks() const { return cells.size(); }
+
+    int maxChunksPerTick = 4096;          // generation budget of one tick, in chunks
+    bool copyToHost = true;               // false: blocks and meshes stay on the device (renderer interop), Chunk::blocks / verts stay empty
+    // last tick's accounting
+    int lastGenerated = 0, lastMeshed = 0, lastRegions = 0;
+    // device-side results of the last mesh pass (valid until the next tick)
+    const Vertex* deviceVerts() const { return (const Vertex*)d_meshOut; }
+
+private:
+    struct Cell { std::unique_ptr<Chunk> chunk; int slot; bool meshed; };
+    std::map<std::pair<int, int>, Cell> cells;
+    std::unordered_set<Chunk*> drawable;
+    ivec2 currentChunkPos{0, 0}, plannedFor{0, 0};
+    bool planned = false, pending = true;
+
+    mmgen_region* region = nullptr;
+    uint8_t* d_pool = nullptr;            // [poolChunks][98304]
+    size_t poolChunks, poolUsed = 0;
+    void* d_meshOut = nullptr; size_t meshOutCap = 0;
+    void* d_meshWork = nullptr; size_t meshWorkCap = 0;
+    std::vector<uint8_t> hostStage;
+
+    void generateRect(int cx0, int cz0, int nx, int nz);
+    void meshReady();
+    void* ensure(void*& p, size_t& cap, size_t bytes);
+};
+
+}  // namespace mmhost

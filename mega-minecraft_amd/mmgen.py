@@ -177,8 +177,8 @@ class MMGen:
         t = self.torch
         n = blocks.shape[0]
         vp, i32 = ctypes.c_void_p, ctypes.c_int
-        self.lib.mmgen_mesh_count.argtypes = [vp, vp, i32, vp, vp, vp]
-        self.lib.mmgen_mesh_fill.argtypes = [vp, vp, vp, i32, vp, vp, vp, vp, vp]
+        self.lib.mmgen_mesh_count.argtypes = [vp, vp, vp, i32, vp, vp, vp]
+        self.lib.mmgen_mesh_fill.argtypes = [vp, vp, vp, vp, i32, vp, vp, vp, vp, vp]
         if neighbor_idx is None and nx is not None:
             c = t.arange(n, dtype=t.int32, device=blocks.device)
             x, z = c % nx, c // nx
@@ -187,14 +187,14 @@ class MMGen:
                                     t.where(x > 0, c - 1, neg)], dim=1).contiguous()
         colv = self._empty((n, 256), t.int32)
         chv = self._empty((n,), t.int32)
-        self._check(self.lib.mmgen_mesh_count(self._p(blocks), self._p(neighbor_idx), n, self._p(colv), self._p(chv), self._stream()), "mmgen_mesh_count")
+        self._check(self.lib.mmgen_mesh_count(self._p(blocks), None, self._p(neighbor_idx), n, self._p(colv), self._p(chv), self._stream()), "mmgen_mesh_count")
         incl = t.cumsum(chv.to(t.int64), 0)
         off = (incl - chv).contiguous()
         total = int(incl[-1].item()) if n else 0
         verts = self._empty((max(total, 1), 10), t.float32)
         idx = self._empty((max(total * 3 // 2, 1),), t.int32)
         if total:
-            self._check(self.lib.mmgen_mesh_fill(self._p(blocks), self._p(neighbor_idx), self._p(world_block_pos), n, self._p(colv), self._p(off),
+            self._check(self.lib.mmgen_mesh_fill(self._p(blocks), None, self._p(neighbor_idx), self._p(world_block_pos), n, self._p(colv), self._p(off),
                                                  self._p(verts), self._p(idx), self._stream()), "mmgen_mesh_fill")
         return dict(verts=verts[:total], idx=idx[:total * 3 // 2], chunk_verts=chv, vert_offset=off)
 
