@@ -7,6 +7,7 @@
 //   mmgen_region_terrain_demo [playerChunkX playerChunkZ]      exit code 0 = identical
 #include "terrain.hpp"
 #include "region_terrain.hpp"
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -102,6 +103,25 @@ int main(int argc, char** argv)
             std::printf("device-resident leg %d: %d chunks generated, %d meshed in %.1f ms (%.0f generated chunks/s incl. meshing)\n", leg, generated, meshed, 1e3 * s,
                         generated / s);
         }
+    }
+    {   // chunk lifetime: a pool of 2 600 slots serves a 2 x 16-step walk (each step regenerates a strip, far chunks are destroyed and
+        // their slots recycled); back at the first position everything was dropped and regenerated, and must equal the mirror's chunks
+        const ivec2 home = {player.x - 13, player.y + 5};
+        RegionTerrain walker(2600);
+        walker.dropRadius = 20;
+        walker.init();
+        int generated = 0, dropped = 0;
+        size_t peak = 0;
+        const auto t0 = Clock::now();
+        for (int step = 0; step <= 32; ++step) {
+            const int k = step <= 16 ? step : 32 - step;
+            walker.setCurrentChunkPos({home.x + 7 * k, home.y + 3 * k});
+            do { walker.tick(1.f / 60.f); generated += walker.lastGenerated; dropped += walker.lastDropped; } while (!walker.allQueuesEmpty());
+            peak = std::max(peak, walker.poolInUse());
+        }
+        std::printf("lifetime walk: 33 positions, %d chunks generated, %d destroyed, peak %zu of 2600 pool slots, %.2f s\n", generated, dropped, peak, secondsSince(t0));
+        if (dropped == 0 || peak > 2600) ++bad;
+        bad += compare(stage, walker, home);
     }
     std::printf("mmgen_region_terrain_demo: %s\n", bad == 0 ? "IDENTICAL" : "MISMATCH");
     return bad == 0 ? 0 : 1;

@@ -1,6 +1,7 @@
 // mmgen host side — region-batched streaming scheduler (see region_terrain.hpp).
 #include "region_terrain.hpp"
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 
 namespace mmhost {
@@ -16,6 +17,7 @@ RegionTerrain::~RegionTerrain()
 {
     if (region) mmgen_region_destroy(region);
     if (d_pool) (void)hipFree(d_pool);
+    if (d_stage) (void)hipFree(d_stage);
     if (d_meshOut) (void)hipFree(d_meshOut);
     if (d_meshWork) (void)hipFree(d_meshWork);
 }
@@ -24,6 +26,8 @@ void RegionTerrain::init()
 {
     RT_CALL(mmgen_region_create(&region), "mmgen_region_create failed");
     RT_CALL(hipMalloc((void**)&d_pool, poolChunks * (size_t)devBlocksSize), "hipMalloc (chunk pool) failed");
+    freeSlots.resize(poolChunks);
+    for (size_t i = 0; i < poolChunks; ++i) freeSlots[i] = (int)(poolChunks - 1 - i);
 }
 
 void* RegionTerrain::ensure(void*& p, size_t& cap, size_t bytes)
@@ -44,14 +48,35 @@ Chunk* RegionTerrain::findChunk(ivec2 c)
 
 std::unordered_set<Chunk*> RegionTerrain::getDrawableChunks() { return drawable; }
 
-// one region call: all stages for the rectangle, blocks straight into consecutive pool slots
+// one region call: all stages for the rectangle; blocks go straight into pool slots when the next free slots are one contiguous run
+// (always, until something has been dropped), else through a staging buffer and one device copy per run of consecutive slots
 void RegionTerrain::generateRect(int cx0, int cz0, int nx, int nz)
 {
     const size_t n = (size_t)nx * nz;
-    if (poolUsed + n > poolChunks) HipUtils::checkError("RegionTerrain: chunk pool exhausted (lifetime management is SURVEY 8f rank 3)", 2, __LINE__);
-    uint8_t* dst = d_pool + poolUsed * (size_t)devBlocksSize;
+    if (freeSlots.size() < n) HipUtils::checkError("RegionTerrain: chunk pool exhausted (raise poolChunks or lower dropRadius)", 2, __LINE__);
+    std::vector<int> slots(n);
+    for (size_t i = 0; i < n; ++i) { slots[i] = freeSlots.back(); freeSlots.pop_back(); }
+    bool contiguous = true;
+    for (size_t i = 1; i < n && contiguous; ++i) contiguous = slots[i] == slots[i - 1] + 1;
+    uint8_t* dst = d_pool + (size_t)slots[0] * devBlocksSize;
+    if (!contiguous) {
+        if (stageChunks < n) {
+            if (d_stage) RT_CALL(hipFree(d_stage), "hipFree failed");
+            RT_CALL(hipMalloc((void**)&d_stage, n * (size_t)devBlocksSize), "hipMalloc (stage) failed");
+            stageChunks = n;
+        }
+        dst = d_stage;
+    }
     RT_CALL(mmgen_region_generate(region, cx0, cz0, nx, nz, MMGEN_REGION_EROSION | MMGEN_REGION_FEATURES | MMGEN_REGION_DECORATORS, dst, nullptr, nullptr),
             "mmgen_region_generate failed");
+    if (!contiguous)
+        for (size_t i = 0; i < n;) {
+            size_t j = i + 1;
+            while (j < n && slots[j] == slots[j - 1] + 1) ++j;
+            RT_CALL(hipMemcpyAsync(d_pool + (size_t)slots[i] * devBlocksSize, d_stage + i * (size_t)devBlocksSize, (j - i) * (size_t)devBlocksSize, hipMemcpyDeviceToDevice, nullptr),
+                    "D2D into pool slots failed");
+            i = j;
+        }
     if (copyToHost) {
         hostStage.resize(n * (size_t)devBlocksSize);
         RT_CALL(hipMemcpy(hostStage.data(), dst, hostStage.size(), hipMemcpyDeviceToHost), "D2H blocks failed");
@@ -61,11 +86,12 @@ void RegionTerrain::generateRect(int cx0, int cz0, int nx, int nz)
     for (int z = 0; z < nz; ++z)
         for (int x = 0; x < nx; ++x) {
             const ivec2 c = {cx0 + x, cz0 + z};
+            const size_t i = (size_t)x + (size_t)nx * z;
             Cell cell;
             cell.chunk = std::make_unique<Chunk>(c);
-            cell.slot = (int)(poolUsed + (size_t)x + (size_t)nx * z);
+            cell.slot = slots[i];
             cell.meshed = false;
-            if (copyToHost) std::memcpy(cell.chunk->blocks.data(), hostStage.data() + ((size_t)x + (size_t)nx * z) * devBlocksSize, devBlocksSize);
+            if (copyToHost) std::memcpy(cell.chunk->blocks.data(), hostStage.data() + i * devBlocksSize, devBlocksSize);
             cell.chunk->setState(ChunkState::FILLED);
             Chunk* cp = cell.chunk.get();
             cells.emplace(std::make_pair(c.x, c.y), std::move(cell));
@@ -76,9 +102,25 @@ void RegionTerrain::generateRect(int cx0, int cz0, int nx, int nz)
                 it->second.chunk->neighbors[(k + 2) % 4] = cp;
             }
         }
-    poolUsed += n;
     lastGenerated += (int)n;
     lastRegions += 1;
+}
+
+// chunk lifetime: destroy what is far from the player, recycle its pool slot, unlink it from its neighbours
+void RegionTerrain::dropFarChunks()
+{
+    for (auto it = cells.begin(); it != cells.end();) {
+        const int dx = it->first.first - plannedFor.x, dz = it->first.second - plannedFor.y;
+        if (std::max(std::abs(dx), std::abs(dz)) <= dropRadius) { ++it; continue; }
+        Chunk* c = it->second.chunk.get();
+        for (int k = 0; k < 4; ++k)
+            if (c->neighbors[k]) c->neighbors[k]->neighbors[(k + 2) % 4] = nullptr;
+        drawable.erase(c);
+        freeSlots.push_back(it->second.slot);
+        it = cells.erase(it);
+        ++lastDropped;
+    }
+    if (lastDropped) std::sort(freeSlots.begin(), freeSlots.end(), [](int a, int b) { return a > b; });
 }
 
 // every unmeshed chunk of the drawable square whose four neighbours exist: one count + fill pair over the pool
@@ -156,8 +198,8 @@ void RegionTerrain::meshReady()
 
 void RegionTerrain::tick(float)
 {
-    lastGenerated = lastMeshed = lastRegions = 0;
-    if (!planned || !(plannedFor == currentChunkPos)) { plannedFor = currentChunkPos; planned = true; pending = true; }
+    lastGenerated = lastMeshed = lastRegions = lastDropped = 0;
+    if (!planned || !(plannedFor == currentChunkPos)) { plannedFor = currentChunkPos; planned = true; pending = true; dropFarChunks(); }
     if (!pending) return;
 
     // missing cells of the generation square (drawable radius + the ring the border meshes look at)

@@ -11,7 +11,9 @@
 //   3. keeps the blocks in a device pool of chunk slots and meshes every chunk whose four neighbours exist in one
 //      mmgen_mesh_count / mmgen_mesh_fill pair over the pool,
 //   4. copies blocks and meshes into the host `Chunk` objects for consumers that want them there (optional).
-// Zone / chunk lifetime is the reference's: nothing is ever freed.
+// Chunk lifetime (the reference never frees, terrain.cpp:63 DESTROY_ZONES is off): chunks farther than
+// `dropRadius` from the player are destroyed and their pool slots recycled, so a bounded pool serves an unbounded walk; a chunk that
+// is needed again is simply regenerated (generation is a pure function of position, so it comes back identical).
 #pragma once
 #include <map>
 #include <memory>
@@ -38,9 +40,11 @@ public:
     size_t numChunks() const { return cells.size(); }
 
     int maxChunksPerTick = 4096;          // generation budget of one tick, in chunks
+    int dropRadius = 40;                  // chunks farther than this (Chebyshev) from the player are destroyed; = chunkMaxGenRadius of the reference
     bool copyToHost = true;               // false: blocks and meshes stay on the device (renderer interop), Chunk::blocks / verts stay empty
     // last tick's accounting
-    int lastGenerated = 0, lastMeshed = 0, lastRegions = 0;
+    int lastGenerated = 0, lastMeshed = 0, lastRegions = 0, lastDropped = 0;
+    size_t poolInUse() const { return poolChunks - freeSlots.size(); }
     // device-side results of the last mesh pass (valid until the next tick)
     const Vertex* deviceVerts() const { return (const Vertex*)d_meshOut; }
 
@@ -53,12 +57,15 @@ private:
 
     mmgen_region* region = nullptr;
     uint8_t* d_pool = nullptr;            // [poolChunks][98304]
-    size_t poolChunks, poolUsed = 0;
+    size_t poolChunks;
+    std::vector<int> freeSlots;           // sorted descending: slots are handed out in ascending order, so fresh pools fill contiguously
+    uint8_t* d_stage = nullptr; size_t stageChunks = 0;      // region output when the free slots are not one contiguous run
     void* d_meshOut = nullptr; size_t meshOutCap = 0;
     void* d_meshWork = nullptr; size_t meshWorkCap = 0;
     std::vector<uint8_t> hostStage;
 
     void generateRect(int cx0, int cz0, int nx, int nz);
+    void dropFarChunks();
     void meshReady();
     void* ensure(void*& p, size_t& cap, size_t bytes);
 };
