@@ -143,6 +143,18 @@ int mmgen_mesh_count(const uint8_t* d_blocks, const int32_t* d_chunk_idx, const 
 int mmgen_mesh_fill(const uint8_t* d_blocks, const int32_t* d_chunk_idx, const int32_t* d_neighbor_idx, const int32_t* d_chunk_world_block_pos, int n,
                     const uint32_t* d_column_verts, const uint64_t* d_vert_offset, mmgen_vertex* d_verts, uint32_t* d_idx, void* stream);
 
+/* ---- region wire format (the reference has none) ---------------------------------------------
+ * A chunk's 98 304 block ids as per-column run-length pairs: u16 runsOfColumn[256], then for each column (x + 16 z, the blocks[]
+ * order) its runs as (u8 blockId, u8 length - 1), 1 .. 256 voxels per pair.  512 + 2 R bytes per chunk (typically 5 - 9 KB).
+ * d_chunk_idx as in the mesher (NULL = chunks 0 .. n-1 of d_blocks); d_chunk_offset = exclusive prefix of d_chunk_bytes, by the
+ * caller, who also sizes d_out.  mmgen_unpack is the device inverse (d_blocks [n][98304] dense); mmgen_unpack_chunk_host decodes one
+ * chunk on the host (plain C, no device) and returns -1 on a malformed stream. */
+int mmgen_pack_count(const uint8_t* d_blocks, const int32_t* d_chunk_idx, int n, uint16_t* d_col_runs /*[n][256]*/, uint32_t* d_chunk_bytes /*[n]*/, void* stream);
+int mmgen_pack_fill(const uint8_t* d_blocks, const int32_t* d_chunk_idx, int n, const uint16_t* d_col_runs, const uint64_t* d_chunk_offset, uint8_t* d_out,
+                    void* stream);
+int mmgen_unpack(const uint8_t* d_packed, const uint64_t* d_chunk_offset, int n, uint8_t* d_blocks, void* stream);
+int mmgen_unpack_chunk_host(const uint8_t* packed, size_t packed_bytes, uint8_t* blocks);
+
 /* Test-only: evaluates device math function `fn` (MMGEN_PROBE_*) on n packed fp32 items (ints bit-cast); used by the parity
  * tests to pin the device math against golden vectors.  Not part of the reference's interface. */
 int mmgen_debug_probe(int fn, const float* d_in, int n, float* d_out, void* stream);

@@ -76,16 +76,20 @@ int main(int argc, char** argv)
         const double sA = secondsSince(t0);
         t0 = Clock::now();
         int generated = 0, regions = 0, meshed = 0, ticksB = 0;
+        size_t blockBytes = 0;
+        batched.packedTransfer = leg == 0;            // leg 0: blocks cross PCIe in the run-length wire format; leg 1: raw
         while (true) {
             batched.tick(1.f / 60.f);
             ++ticksB;
-            generated += batched.lastGenerated; regions += batched.lastRegions; meshed += batched.lastMeshed;
+            generated += batched.lastGenerated; regions += batched.lastRegions; meshed += batched.lastMeshed; blockBytes += batched.lastBlockBytesD2H;
             if (batched.allQueuesEmpty()) break;
         }
         const double sB = secondsSince(t0);
         std::printf("leg %d, player chunk (%d,%d):\n  Terrain        %6d ticks (= %.1f s of frames at 60 fps) %8.3f s wall   %zu chunks exist\n  RegionTerrain  %6d ticks %8.3f s   %d chunks generated in %d regions, %d meshed"
                     "   (%.0fx)\n",
                     leg, player.x, player.y, ticksA, ticksA / 60.0, sA, stage.numChunks(), ticksB, sB, generated, regions, meshed, sB > 0 ? sA / sB : 0.0);
+        std::printf("  block data copied to the host: %.1f MB (%s, %.1f KB per chunk)\n", blockBytes / 1e6, batched.packedTransfer ? "wire format" : "raw",
+                    generated ? blockBytes / 1e3 / generated : 0.0);
         bad += compare(stage, batched, player);
     }
     {   // the same two legs with everything left on the device (renderer interop): what the GPU path itself costs

@@ -77,9 +77,34 @@ void RegionTerrain::generateRect(int cx0, int cz0, int nx, int nz)
                     "D2D into pool slots failed");
             i = j;
         }
-    if (copyToHost) {
+    std::vector<uint64_t> packOff;
+    std::vector<uint32_t> packBytes;
+    if (copyToHost && packedTransfer) {
+        // wire format: count, prefix on the host, fill, one copy of ~10 KB per chunk, decode into the Chunk objects below
+        const size_t oSlots = 0, oRuns = oSlots + n * 4, oBytes = oRuns + n * 512, oOff = (oBytes + n * 4 + 7) / 8 * 8, total = oOff + n * 8;
+        char* w = (char*)ensure(d_meshWork, meshWorkCap, total);
+        RT_CALL(hipMemcpy(w + oSlots, slots.data(), n * 4, hipMemcpyHostToDevice), "H2D failed");
+        RT_CALL(mmgen_pack_count(d_pool, (int32_t*)(w + oSlots), (int)n, (uint16_t*)(w + oRuns), (uint32_t*)(w + oBytes), nullptr), "mmgen_pack_count failed");
+        packBytes.resize(n); packOff.resize(n);
+        RT_CALL(hipMemcpy(packBytes.data(), w + oBytes, n * 4, hipMemcpyDeviceToHost), "D2H failed");
+        uint64_t totalBytes = 0;
+        for (size_t i = 0; i < n; ++i) { packOff[i] = totalBytes; totalBytes += packBytes[i]; }
+        RT_CALL(hipMemcpy(w + oOff, packOff.data(), n * 8, hipMemcpyHostToDevice), "H2D failed");
+        char* o = (char*)ensure(d_meshOut, meshOutCap, totalBytes + 64);
+        RT_CALL(mmgen_pack_fill(d_pool, (int32_t*)(w + oSlots), (int)n, (uint16_t*)(w + oRuns), (uint64_t*)(w + oOff), (uint8_t*)o, nullptr), "mmgen_pack_fill failed");
+        hostStage.resize(totalBytes);
+        RT_CALL(hipMemcpy(hostStage.data(), o, totalBytes, hipMemcpyDeviceToHost), "D2H packed blocks failed");
+        lastBlockBytesD2H += totalBytes;
+    } else if (copyToHost) {
         hostStage.resize(n * (size_t)devBlocksSize);
-        RT_CALL(hipMemcpy(hostStage.data(), dst, hostStage.size(), hipMemcpyDeviceToHost), "D2H blocks failed");
+        for (size_t i = 0; i < n;) {
+            size_t j = i + 1;
+            while (j < n && slots[j] == slots[j - 1] + 1) ++j;
+            RT_CALL(hipMemcpy(hostStage.data() + i * (size_t)devBlocksSize, d_pool + (size_t)slots[i] * devBlocksSize, (j - i) * (size_t)devBlocksSize, hipMemcpyDeviceToHost),
+                    "D2H blocks failed");
+            i = j;
+        }
+        lastBlockBytesD2H += hostStage.size();
     } else {
         RT_CALL(hipDeviceSynchronize(), "region generation failed");
     }
@@ -91,7 +116,12 @@ void RegionTerrain::generateRect(int cx0, int cz0, int nx, int nz)
             cell.chunk = std::make_unique<Chunk>(c);
             cell.slot = slots[i];
             cell.meshed = false;
-            if (copyToHost) std::memcpy(cell.chunk->blocks.data(), hostStage.data() + i * devBlocksSize, devBlocksSize);
+            if (copyToHost && packedTransfer) {
+                if (mmgen_unpack_chunk_host(hostStage.data() + packOff[i], packBytes[i], cell.chunk->blocks.data()) != 0)
+                    HipUtils::checkError("RegionTerrain: malformed packed chunk", 2, __LINE__);
+            } else if (copyToHost) {
+                std::memcpy(cell.chunk->blocks.data(), hostStage.data() + i * devBlocksSize, devBlocksSize);
+            }
             cell.chunk->setState(ChunkState::FILLED);
             Chunk* cp = cell.chunk.get();
             cells.emplace(std::make_pair(c.x, c.y), std::move(cell));
@@ -199,6 +229,7 @@ void RegionTerrain::meshReady()
 void RegionTerrain::tick(float)
 {
     lastGenerated = lastMeshed = lastRegions = lastDropped = 0;
+    lastBlockBytesD2H = 0;
     if (!planned || !(plannedFor == currentChunkPos)) { plannedFor = currentChunkPos; planned = true; pending = true; dropFarChunks(); }
     if (!pending) return;
 

@@ -42,6 +42,8 @@ public:
     int maxChunksPerTick = 4096;          // generation budget of one tick, in chunks
     int dropRadius = 40;                  // chunks farther than this (Chebyshev) from the player are destroyed; = chunkMaxGenRadius of the reference
     bool copyToHost = true;               // false: blocks and meshes stay on the device (renderer interop), Chunk::blocks / verts stay empty
+    bool packedTransfer = true;           // blocks cross PCIe in the run-length wire format (mmgen_pack_*, ~10 KB instead of 96 KB per chunk)
+    size_t lastBlockBytesD2H = 0;         // bytes of block data copied to the host by the last tick
     // last tick's accounting
     int lastGenerated = 0, lastMeshed = 0, lastRegions = 0, lastDropped = 0;
     size_t poolInUse() const { return poolChunks - freeSlots.size(); }

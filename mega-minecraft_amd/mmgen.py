@@ -198,6 +198,44 @@ class MMGen:
                                                  self._p(verts), self._p(idx), self._stream()), "mmgen_mesh_fill")
         return dict(verts=verts[:total], idx=idx[:total * 3 // 2], chunk_verts=chv, vert_offset=off)
 
+    # ------------------------------------------------------------------ region wire format (run-length pairs per column)
+    def pack(self, blocks):
+        """blocks uint8 [n, 98304] on the device -> dict(data uint8 [total], chunk_bytes int32 [n], chunk_offset int64 [n])."""
+        t = self.torch
+        n = blocks.shape[0]
+        vp, i32 = ctypes.c_void_p, ctypes.c_int
+        self.lib.mmgen_pack_count.argtypes = [vp, vp, i32, vp, vp, vp]
+        self.lib.mmgen_pack_fill.argtypes = [vp, vp, i32, vp, vp, vp, vp]
+        runs = self._empty((n, 256), t.int16)
+        nbytes = self._empty((n,), t.int32)
+        self._check(self.lib.mmgen_pack_count(self._p(blocks), None, n, self._p(runs), self._p(nbytes), self._stream()), "mmgen_pack_count")
+        incl = t.cumsum(nbytes.to(t.int64), 0)
+        off = (incl - nbytes).contiguous()
+        total = int(incl[-1].item()) if n else 0
+        data = self._empty((max(total, 1),), t.uint8)
+        if n:
+            self._check(self.lib.mmgen_pack_fill(self._p(blocks), None, n, self._p(runs), self._p(off), self._p(data), self._stream()), "mmgen_pack_fill")
+        return dict(data=data[:total], chunk_bytes=nbytes, chunk_offset=off)
+
+    def unpack(self, data, chunk_offset):
+        t = self.torch
+        n = chunk_offset.shape[0]
+        self.lib.mmgen_unpack.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+        blocks = self._empty((n, BLOCKS), t.uint8)
+        if n:
+            self._check(self.lib.mmgen_unpack(self._p(data), self._p(chunk_offset), n, self._p(blocks), self._stream()), "mmgen_unpack")
+        return blocks
+
+    def unpack_chunk_host(self, packed_bytes):
+        """Host decoder of one packed chunk (numpy uint8 in, numpy uint8 [98304] out); raises on a malformed stream."""
+        import numpy as np
+        self.lib.mmgen_unpack_chunk_host.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+        src = np.ascontiguousarray(packed_bytes, dtype=np.uint8)
+        out = np.zeros(BLOCKS, np.uint8)
+        if self.lib.mmgen_unpack_chunk_host(src.ctypes.data, src.size, out.ctypes.data) != 0:
+            raise ValueError("malformed packed chunk")
+        return out
+
     # ------------------------------------------------------------------ region fast path (all stages, device resident)
     EROSION, FEATURES, DECORATORS = 1, 2, 4
 
