@@ -190,11 +190,18 @@ MM_DEV uint32_t hash32(uint32_t a)
 
 struct MinStd {
     uint32_t x;
-    MM_DEV void seed(uint32_t s) { s %= 2147483647u; x = s ? s : 1u; }
+    // m = 2^31 - 1 is a Mersenne prime: 2^31 = 1 (mod m), so a residue is "low 31 bits + the rest", folded once or twice - the
+    // same value as the % of thrust's static_mod, without a division
+    MM_DEV void seed(uint32_t s)
+    {
+        s = (s >= 4294967294u) ? s - 4294967294u : (s >= 2147483647u ? s - 2147483647u : s);
+        x = s ? s : 1u;
+    }
     MM_DEV uint32_t next()
     {
-        // 48271 * x mod (2^31 - 1) without Schrage: the 64-bit product is exact and gives the same residue
-        x = (uint32_t)(((uint64_t)x * 48271ull) % 2147483647ull);
+        const uint64_t p = (uint64_t)x * 48271ull;                       // < 2^47: exact
+        uint32_t r = (uint32_t)(p & 0x7fffffffull) + (uint32_t)(p >> 31);  // < 2^31 + 2^16
+        x = (r >= 2147483647u) ? r - 2147483647u : r;
         return x;
     }
     MM_DEV float u01() { return (float)(next() - 1u) / 2147483648.f; }

@@ -60,114 +60,185 @@ MM_DEV uint32_t quad_record(int y, int kind, int column, int su, int sv, int uvS
            ((uint32_t)fu << 30) | ((uint32_t)fv << 31);
 }
 
-// One lane = one column.  EMIT = false: returns the column's quad count.  EMIT = true: appends the column's quad records to
-// recs / mats (LDS) in the reference's order (y ascending, faces in dirVecs order).
-template <bool EMIT>
-MM_DEV uint32_t mesh_column(const uint8_t* __restrict__ col, const uint8_t* __restrict__ colN /*+z*/, const uint8_t* __restrict__ colE /*+x*/,
-                            const uint8_t* __restrict__ colS /*-z*/, const uint8_t* __restrict__ colW /*-x*/, const uint32_t* s_data, int column,
-                            int wbx, int wbz, uint32_t* recs, uint8_t* mats)
+// ---------------------------------------------------------------------------------------------------------
+// Face visibility as bit arithmetic.  Every block belongs to one of five classes (AIR, OPAQUE, SEMI_TRANSPARENT, TRANSPARENT,
+// X_SHAPED) and the display rule of chunk.cu:1912-1928 only looks at classes:
+//     opaque / semi-transparent block : face shows  <=>  neighbour is not OPAQUE
+//     transparent block               : face shows  <=>  neighbour is AIR or SEMI_TRANSPARENT
+// So each column is classified ONCE into three bit planes of its class code per 16-voxel word (LDS, 3 x 16 bits per word), the
+// facing border column of a present neighbour chunk likewise, and the six face masks of a word are a handful of AND / OR / shifts
+// on 16-bit masks - instead of 98 304 x 6 table lookups and branches per chunk.  Only voxels that really emit a quad are visited.
+// ---------------------------------------------------------------------------------------------------------
+enum { C_AIR = 0, C_OPAQUE = 1, C_SEMI = 2, C_TRANS = 3, C_XSHAPED = 4 };
+#define MESH_COLS 320                                     // 256 own columns + 4 x 16 facing border columns of the neighbour chunks
+struct Planes { uint16_t p0[MESH_COLS][24], p1[MESH_COLS][24], p2[MESH_COLS][24]; };      // 46 080 bytes
+
+MM_DEV void classify_word(const uint4& v, const uint8_t* s_cls, Planes& P, int slot, int w)
 {
-    uint32_t nq = 0;
-    const int x = column & 15, z = column >> 4;
-    uint8_t prev = 0;                                            // block below the current 16-voxel word (unused at y = 0)
-    for (int w = 0; w < 24; ++w) {
-        const uint4 me4 = ((const uint4*)col)[w];
-        // cheap exit: a word of AIR emits nothing
-        if ((me4.x | me4.y | me4.z | me4.w) == 0u) { prev = 0; continue; }
-        uint4 n4[4];
-        const uint8_t* nbp[4] = {colN, colE, colS, colW};
-#pragma unroll
-        for (int k = 0; k < 4; ++k) n4[k] = nbp[k] ? ((const uint4*)nbp[k])[w] : make_uint4(0, 0, 0, 0);
-        const uint8_t next = (w < 23) ? col[16 * (w + 1)] : (uint8_t)0;
-        for (int i = 0; i < 16; ++i) {
-            const int b = byte_at(me4, i);
-            const int y = 16 * w + i;
-            if (b == MMB_AIR) continue;
-            const uint32_t bd = s_data[b];
-            const int trans = MESH_TRANS(bd);
-            if (trans == T_XSHAPED) {
-                if (EMIT) {
-                    recs[nq] = quad_record(y, 6, column, bd & 15, (bd >> 4) & 15, 0, -1);
-                    recs[nq + 1] = quad_record(y, 7, column, bd & 15, (bd >> 4) & 15, 0, -1);
-                    mats[nq] = mats[nq + 1] = (uint8_t)mesh_material(b);
-                }
-                nq += 2;
-                continue;
-            }
-#pragma unroll
-            for (int d = 0; d < 6; ++d) {
-                bool show = true;
-                const int ny = y + kMeshDir[d][1];
-                if (ny >= 0 && ny < 384) {
-                    int nb;
-                    if (d < 4) {
-                        if (!nbp[d]) continue;                      // neighbouring chunk absent: the face is skipped (chunk.cu:1906-1909)
-                        nb = byte_at(n4[d], i);
-                    } else if (d == 4) nb = (i < 15) ? byte_at(me4, i + 1) : next;
-                    else nb = (i > 0) ? byte_at(me4, i - 1) : prev;
-                    const int nt = MESH_TRANS(s_data[nb]);
-                    show = (trans == T_TRANSPARENT) ? (nb == MMB_AIR || nt == T_SEMI) : (nt != T_OPAQUE);
-                }
-                if (!show) continue;
-                if (EMIT) {
-                    const int which = d == 4 ? 1 : (d == 5 ? 2 : 0);      // 0 side, 1 top, 2 bottom
-                    const int su = (bd >> (8 * which)) & 15, sv = (bd >> (8 * which + 4)) & 15;
-                    const bool rot = (bd >> (24 + which)) & 1, flip = (bd >> (27 + which)) & 1;
-                    int uvStart = 0, uvFlip = -1;
-                    if (rot || flip) {
-                        MinStd rng = rng4(wbx + x, y, wbz + z, d);
-                        if (rot) uvStart = (int)((rng.u01() * (4.f - 0.f)) + 0.f);      // uniform_real_distribution<float>(0, 4)
-                        if (flip) uvFlip = (int)((rng.u01() * (4.f - 0.f)) + 0.f);
-                    }
-                    recs[nq] = quad_record(y, d, column, su, sv, uvStart, uvFlip);
-                    mats[nq] = (uint8_t)mesh_material(b);
-                }
-                nq += 1;
-            }
-        }
-        prev = (uint8_t)(me4.w >> 24);
+    // terrain is long vertical runs: most words hold one block id 16 times - one lookup instead of 16
+    if (v.x == v.y && v.x == v.z && v.x == v.w && v.x == ((v.x << 8) | (v.x >> 24))) {
+        const uint32_t cls = s_cls[v.x & 255u];
+        P.p0[slot][w] = (cls & 1u) ? 0xffffu : 0u; P.p1[slot][w] = (cls & 2u) ? 0xffffu : 0u; P.p2[slot][w] = (cls & 4u) ? 0xffffu : 0u;
+        return;
     }
-    return nq;
+    const uint32_t q[4] = {v.x, v.y, v.z, v.w};
+    uint32_t a = 0, b = 0, c = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t cls = s_cls[(q[k] >> (8 * j)) & 255u];
+            const int i = 4 * k + j;
+            a |= (cls & 1u) << i; b |= ((cls >> 1) & 1u) << i; c |= (cls >> 2) << i;
+        }
+    P.p0[slot][w] = (uint16_t)a; P.p1[slot][w] = (uint16_t)b; P.p2[slot][w] = (uint16_t)c;
 }
 
-// neighbour columns of column (x, z) of chunk `c`: inside the chunk, or the facing border column of the neighbouring chunk
-MM_DEV void mesh_neighbours(const uint8_t* __restrict__ blocks, const int32_t* __restrict__ neighborIdx, int o, int c, int x, int z,
-                            const uint8_t*& colN, const uint8_t*& colE, const uint8_t*& colS, const uint8_t*& colW)
+MM_DEV void classify_column(const uint8_t* __restrict__ col, const uint8_t* s_cls, Planes& P, int slot)
 {
+    // 8 independent 16-byte loads in flight per lane (a load-use-load chain would cost 24 memory latencies per column)
+    for (int w0 = 0; w0 < 24; w0 += 8) {
+        uint4 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = ((const uint4*)col)[w0 + k];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) classify_word(v[k], s_cls, P, slot, w0 + k);
+    }
+}
+
+struct WordMasks { uint32_t opq, semi, air, trn, xsh; };
+MM_DEV WordMasks word_masks(const Planes& P, int slot, int w)
+{
+    const uint32_t a = P.p0[slot][w], b = P.p1[slot][w], c = P.p2[slot][w];
+    WordMasks m;
+    m.opq = a & ~b & ~c; m.semi = ~a & b & ~c & 0xffffu; m.air = ~(a | b | c) & 0xffffu; m.trn = a & b; m.xsh = c;
+    return m;
+}
+
+// the six face masks (dirVecs order: +z, +x, -z, -x, +y, -y) and the X mask of word w of column t
+struct WordFaces { uint32_t f[6], xsh; };
+MM_DEV WordFaces word_faces(const Planes& P, int t, int w, const int nbSlot[4], const bool nbPresent[4])
+{
+    const WordMasks me = word_masks(P, t, w);
+    const uint32_t solidish = me.opq | me.semi;
+    WordFaces r;
+    r.xsh = me.xsh;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        if (!nbPresent[d]) { r.f[d] = 0; continue; }      // neighbouring chunk absent: the face is skipped (chunk.cu:1906-1909)
+        const WordMasks nb = word_masks(P, nbSlot[d], w);
+        r.f[d] = (solidish & ~nb.opq) | (me.trn & (nb.air | nb.semi));
+    }
+    // vertical neighbours: the column itself shifted by one voxel; beyond the world (y = -1, 384) the face always shows, which is
+    // what a virtual AIR neighbour gives under both rules
+    uint32_t upOpq = me.opq >> 1, upAir = me.air >> 1, upSemi = me.semi >> 1;
+    if (w < 23) { const WordMasks n = word_masks(P, t, w + 1); upOpq |= (n.opq & 1u) << 15; upAir |= (n.air & 1u) << 15; upSemi |= (n.semi & 1u) << 15; }
+    else upAir |= 1u << 15;
+    uint32_t dnOpq = (me.opq << 1) & 0xffffu, dnAir = (me.air << 1) & 0xffffu, dnSemi = (me.semi << 1) & 0xffffu;
+    if (w > 0) { const WordMasks n = word_masks(P, t, w - 1); dnOpq |= n.opq >> 15; dnAir |= n.air >> 15; dnSemi |= n.semi >> 15; }
+    else dnAir |= 1u;
+    r.f[4] = (solidish & ~upOpq) | (me.trn & (upAir | upSemi));
+    r.f[5] = (solidish & ~dnOpq) | (me.trn & (dnAir | dnSemi));
+    return r;
+}
+
+// workgroup-wide: block class table, own columns, facing border columns of the present neighbour chunks.  Ends with a barrier.
+MM_DEV void mesh_classify(const uint8_t* __restrict__ blocks, const int32_t* __restrict__ neighborIdx, int o, int c, uint8_t* s_cls, Planes& P,
+                          int nbSlot[4], bool nbPresent[4])
+{
+    const int t = threadIdx.x, x = t & 15, z = t >> 4;
+    if (t < MMB_NUM_BLOCKS) {
+        const int tr = MESH_TRANS(kBlockData[t]);
+        s_cls[t] = (uint8_t)(t == MMB_AIR ? C_AIR : (tr == T_OPAQUE ? C_OPAQUE : (tr == T_SEMI ? C_SEMI : (tr == T_TRANSPARENT ? C_TRANS : C_XSHAPED))));
+    }
+    if (t >= MMB_NUM_BLOCKS) s_cls[t] = C_OPAQUE;         // ids beyond the enum never occur; BlockData{} default is OPAQUE (block.hpp)
+    __syncthreads();
     const uint8_t* base = blocks + (size_t)MMGEN_BLOCKS_PER_CHUNK * c;
-    auto chunk_of = [&](int k) -> const uint8_t* {
-        const int n = neighborIdx ? neighborIdx[4 * o + k] : -1;
-        return n < 0 ? nullptr : blocks + (size_t)MMGEN_BLOCKS_PER_CHUNK * n;
-    };
-    const uint8_t* cN = z < 15 ? base : chunk_of(0);
-    const uint8_t* cE = x < 15 ? base : chunk_of(1);
-    const uint8_t* cS = z > 0 ? base : chunk_of(2);
-    const uint8_t* cW = x > 0 ? base : chunk_of(3);
-    colN = cN ? cN + 384 * (x + 16 * ((z + 1) & 15)) : nullptr;
-    colE = cE ? cE + 384 * (((x + 1) & 15) + 16 * z) : nullptr;
-    colS = cS ? cS + 384 * (x + 16 * ((z + 15) & 15)) : nullptr;
-    colW = cW ? cW + 384 * (((x + 15) & 15) + 16 * z) : nullptr;
+    classify_column(base + 384 * t, s_cls, P, t);
+    // neighbour of (x, z) in direction d: inside the chunk, or border slot 256 + 16 d + (position along the edge)
+    const int inside[4] = {z < 15, x < 15, z > 0, x > 0};
+    const int insideSlot[4] = {t + 16, t + 1, t - 16, t - 1};
+    const int along[4] = {x, z, x, z};
+    const int facing[4] = {x + 16 * 0, 0 + 16 * z, x + 16 * 15, 15 + 16 * z};      // the neighbour chunk's column that touches this one
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        if (inside[d]) { nbSlot[d] = insideSlot[d]; nbPresent[d] = true; continue; }
+        const int n = neighborIdx ? neighborIdx[4 * o + d] : -1;
+        nbSlot[d] = 256 + 16 * d + along[d];
+        nbPresent[d] = n >= 0;
+        if (n >= 0) classify_column(blocks + (size_t)MMGEN_BLOCKS_PER_CHUNK * n + 384 * facing[d], s_cls, P, nbSlot[d]);
+    }
+    __syncthreads();
 }
 
 __global__ void __launch_bounds__(256)
 k_mesh_count(const uint8_t* __restrict__ blocks, const int32_t* __restrict__ chunkIdx, const int32_t* __restrict__ neighborIdx,
              uint32_t* __restrict__ columnVerts, uint32_t* __restrict__ chunkVerts)
 {
-    __shared__ uint32_t s_data[MMB_NUM_BLOCKS];
+    __shared__ Planes P;
+    __shared__ uint8_t s_cls[256];
     __shared__ uint32_t s_total;
     const int o = blockIdx.x, t = threadIdx.x;
     const int c = chunkIdx ? chunkIdx[o] : o;           // o = position in the work list (outputs), c = chunk in the block array
-    if (t < MMB_NUM_BLOCKS) s_data[t] = kBlockData[t];
     if (t == 0) s_total = 0;
-    __syncthreads();
-    const int x = t & 15, z = t >> 4;
-    const uint8_t *colN, *colE, *colS, *colW;
-    mesh_neighbours(blocks, neighborIdx, o, c, x, z, colN, colE, colS, colW);
-    const uint32_t n = 4u * mesh_column<false>(blocks + (size_t)MMGEN_BLOCKS_PER_CHUNK * c + 384 * t, colN, colE, colS, colW, s_data, t, 0, 0, nullptr, nullptr);
-    columnVerts[256 * o + t] = n;
-    atomicAdd(&s_total, n);
+    int nbSlot[4]; bool nbPresent[4];
+    mesh_classify(blocks, neighborIdx, o, c, s_cls, P, nbSlot, nbPresent);
+    uint32_t quads = 0;
+    for (int w = 0; w < 24; ++w) {
+        if ((P.p0[t][w] | P.p1[t][w] | P.p2[t][w]) == 0) continue;      // a word of AIR emits nothing
+        const WordFaces f = word_faces(P, t, w, nbSlot, nbPresent);
+        quads += __popc(f.f[0]) + __popc(f.f[1]) + __popc(f.f[2]) + __popc(f.f[3]) + __popc(f.f[4]) + __popc(f.f[5]) + 2 * __popc(f.xsh);
+    }
+    columnVerts[256 * o + t] = 4u * quads;
+    atomicAdd(&s_total, 4u * quads);
     __syncthreads();
     if (t == 0) chunkVerts[o] = s_total;
+}
+
+// appends column t's quad records to recs / mats in the reference's order (y ascending, faces in dirVecs order)
+MM_DEV void emit_column(const uint8_t* __restrict__ col, const Planes& P, const uint32_t* s_data, int t, const int nbSlot[4], const bool nbPresent[4],
+                        int wbx, int wbz, uint32_t* recs, uint8_t* mats)
+{
+    const int x = t & 15, z = t >> 4;
+    uint32_t nq = 0;
+    for (int w = 0; w < 24; ++w) {
+        if ((P.p0[t][w] | P.p1[t][w] | P.p2[t][w]) == 0) continue;      // a word of AIR emits nothing
+        const WordFaces f = word_faces(P, t, w, nbSlot, nbPresent);
+        uint32_t any = f.f[0] | f.f[1] | f.f[2] | f.f[3] | f.f[4] | f.f[5] | f.xsh;
+        if (!any) continue;
+        const uint4 me4 = ((const uint4*)col)[w];
+        while (any) {
+            const int i = __builtin_ctz(any);
+            any &= any - 1;
+            const int y = 16 * w + i;
+            const int b = byte_at(me4, i);
+            const uint32_t bd = s_data[b];
+            const uint8_t mat = (uint8_t)mesh_material(b);
+            if ((f.xsh >> i) & 1u) {
+                recs[nq] = quad_record(y, 6, t, bd & 15, (bd >> 4) & 15, 0, -1);
+                recs[nq + 1] = quad_record(y, 7, t, bd & 15, (bd >> 4) & 15, 0, -1);
+                mats[nq] = mats[nq + 1] = mat;
+                nq += 2;
+                continue;
+            }
+#pragma unroll
+            for (int d = 0; d < 6; ++d) {
+                if (!((f.f[d] >> i) & 1u)) continue;
+                const int which = d == 4 ? 1 : (d == 5 ? 2 : 0);      // 0 side, 1 top, 2 bottom
+                const int su = (bd >> (8 * which)) & 15, sv = (bd >> (8 * which + 4)) & 15;
+                const bool rot = (bd >> (24 + which)) & 1, flip = (bd >> (27 + which)) & 1;
+                int uvStart = 0, uvFlip = -1;
+                if (rot || flip) {
+                    MinStd rng = rng4(wbx + x, y, wbz + z, d);
+                    if (rot) uvStart = (int)((rng.u01() * (4.f - 0.f)) + 0.f);      // uniform_real_distribution<float>(0, 4)
+                    if (flip) uvFlip = (int)((rng.u01() * (4.f - 0.f)) + 0.f);
+                }
+                recs[nq] = quad_record(y, d, t, su, sv, uvStart, uvFlip);
+                mats[nq] = mat;
+                nq += 1;
+            }
+        }
+    }
 }
 
 // Vertex j (0-3) of quad record `r` (material m) as 10 dwords: pos xyz, nor xyz, uv, material lo / hi.  Table lookups go to the LDS
@@ -213,6 +284,8 @@ k_mesh_fill(const uint8_t* __restrict__ blocks, const int32_t* __restrict__ chun
             const int2* __restrict__ chunkWorldBlockPos, const uint32_t* __restrict__ columnVerts, const uint64_t* __restrict__ vertOffset, mmgen_vertex* __restrict__ verts,
             uint32_t* __restrict__ idx)
 {
+    __shared__ Planes P;
+    __shared__ uint8_t s_cls[256];
     __shared__ uint32_t s_data[MMB_NUM_BLOCKS];
     __shared__ uint32_t s_scan[256];                     // inclusive scan of the columns' quad counts
     __shared__ uint32_t s_rec[MESH_CAP];
@@ -245,8 +318,8 @@ k_mesh_fill(const uint8_t* __restrict__ blocks, const int32_t* __restrict__ chun
     uint32_t* vout = (uint32_t*)(verts + vbase);
     uint32_t* iout = idx + (vbase / 4) * 6;
     const uint8_t* col = blocks + (size_t)MMGEN_BLOCKS_PER_CHUNK * c + 384 * t;
-    const uint8_t *colN, *colE, *colS, *colW;
-    mesh_neighbours(blocks, neighborIdx, o, c, t & 15, t >> 4, colN, colE, colS, colW);
+    int nbSlot[4]; bool nbPresent[4];
+    mesh_classify(blocks, neighborIdx, o, c, s_cls, P, nbSlot, nbPresent);
 
     // batches of whole columns whose quads fit the LDS stage
     int start = 0;
@@ -258,7 +331,7 @@ k_mesh_fill(const uint8_t* __restrict__ blocks, const int32_t* __restrict__ chun
         __syncthreads();
         const int end = s_end;
         if (t >= start && t < end && mine)
-            mesh_column<true>(col, colN, colE, colS, colW, s_data, t, wb.x, wb.y, s_rec + (s_scan[t] - mine - qbase), s_mat + (s_scan[t] - mine - qbase));
+            emit_column(col, P, s_data, t, nbSlot, nbPresent, wb.x, wb.y, s_rec + (s_scan[t] - mine - qbase), s_mat + (s_scan[t] - mine - qbase));
         __syncthreads();
         const uint32_t nq = s_scan[end - 1] - qbase;
         // vertex stream: consecutive lanes write consecutive 40-byte vertices (16 + 16 + 8 bytes): a wave covers 2 560 contiguous bytes
