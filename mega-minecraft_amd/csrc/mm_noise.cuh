@@ -277,26 +277,9 @@ MM_DEV float fbm3(float x, float y, float z)
 template <int OCT>
 MM_DEV f2 fbm2from2(float x, float y) { return mk2(fbm2<OCT>(x, y), fbm2<OCT>(x + 5923.45f, y + 4129.42f)); }
 
-#ifndef MM_FBM3X3_ILP
-#define MM_FBM3X3_ILP 0
-#endif
 template <int OCT>
 MM_DEV f3 fbm3from3(float x, float y, float z)
 {
-#if MM_FBM3X3_ILP
-    // the three components advance together: three independent simplex evaluations per octave for the scheduler to interleave
-    float ax = 0.f, ay = 0.f, az = 0.f, amp = 1.f;
-    float x1 = x + 5923.45f, y1 = y + 4129.42f, z1 = z + 5790.48f;
-    float x2 = x + 1765.68f, y2 = y + 4704.36f, z2 = z + 5692.12f;
-#pragma unroll 1
-    for (int i = 0; i < OCT; ++i) {
-        amp *= 0.5f;
-        const float n0 = simplex3_inl(x, y, z), n1 = simplex3_inl(x1, y1, z1), n2 = simplex3_inl(x2, y2, z2);
-        ax += amp * n0; ay += amp * n1; az += amp * n2;
-        x *= 2.f; y *= 2.f; z *= 2.f; x1 *= 2.f; y1 *= 2.f; z1 *= 2.f; x2 *= 2.f; y2 *= 2.f; z2 *= 2.f;
-    }
-    return mk3(ax, ay, az);
-#else
     // rolled over the three components as well: one inlined simplex body for all 3 * OCT samples
     float r[3];
 #pragma unroll 1
@@ -306,7 +289,6 @@ MM_DEV f3 fbm3from3(float x, float y, float z)
         r[k] = k == 0 ? fbm3<OCT>(x, y, z) : fbm3<OCT>(x + ox, y + oy, z + oz);
     }
     return mk3(r[0], r[1], r[2]);
-#endif
 }
 
 MM_DEV f2 simplex2from2(float x, float y) { return mk2(simplex2(x, y), simplex2(x + 5923.45f, y + 4129.42f)); }

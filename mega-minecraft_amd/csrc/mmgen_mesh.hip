@@ -339,11 +339,7 @@ k_mesh_fill(const uint8_t* __restrict__ blocks, const int32_t* __restrict__ chun
             const uint32_t q = k >> 2;
             const VertexWords w = vertex_words(s_rec[q], s_mat[q], (int)(k & 3u), s_jitter, s_dv, s_dir);
             uint32_t* o = vout + ((size_t)qbase * 4u + k) * 10u;
-#ifndef MESH_NO_VSTORE
             *(uint4*)o = w.a; *(uint4*)(o + 4) = w.b; *(uint2*)(o + 8) = w.c;
-#else
-            if (w.a.x == 0x12345678u) *(uint4*)o = w.a;
-#endif
         }
         // index stream: 6 per quad, chunk-local vertex numbers
         for (uint32_t k = t; k < nq * 6u; k += 256u) {
