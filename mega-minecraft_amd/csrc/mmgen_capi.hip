@@ -133,7 +133,7 @@ int mmgen_gather_feature_placements(const mmgen_feature_placement* d_fp, const m
 {
     if (num_targets < 0 || grid_w <= 0 || grid_h <= 0) return (int)hipErrorInvalidValue;
     if (num_targets > 0 && (!d_fp || !d_cfp || !d_counts || !d_targets || !d_gfp || !d_gcfp || !d_bounds)) return (int)hipErrorInvalidValue;
-    return mmk::launch_gather_placements(d_fp, d_cfp, d_counts, d_targets, num_targets, grid_w, grid_h, d_gfp, d_gcfp, d_bounds, (hipStream_t)stream);
+    return mmk::launch_gather_placements(d_fp, d_cfp, d_counts, d_targets, num_targets, grid_w, grid_h, d_gfp, d_gcfp, d_bounds, nullptr, (hipStream_t)stream);
 }
 
 int mmgen_place_decorators(uint8_t* d_blocks, const float* d_hf, const float* d_bw, const mmgen_cave_layer* d_cl, const int32_t* d_pos, int n,

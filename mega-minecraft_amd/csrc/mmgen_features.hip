@@ -250,14 +250,64 @@ __device__ constexpr int kGatherDX[49] = {0, 0, 1, 1, 1, 0, -1, -1, -1, 2, 2, 2,
 __device__ constexpr int kGatherDZ[49] = {0, 1, 1, 0, -1, -1, -1, 0, 1, 0, 1, 2, 2, 2, 2, 2, 1, 0, -1, -2, -2, -2, -2, -2, -1,
                                           -3, -3, -3, -3, -3, -3, -3, -2, -1, 0, 1, 2, 3, 3, 3, 3, 3, 3, 3, 2, 1, 0, -1, -2};
 
+// Chebyshev reach max(|dx|, |dz|) in blocks beyond which placeFeature / placeCaveFeature cannot return true
+__device__ constexpr int kFeatureReach[MMGEN_NUM_FEATURES] = {
+    /*NONE*/ 0, /*SPHERE*/ 5, /*CORAL*/ 8, /*KELP*/ 0, /*ICEBERG*/ 40, /*ACACIA*/ 15, /*REDWOOD*/ 20, /*CYPRESS*/ 12, /*BIRCH*/ 8,
+    /*PINE_TREE*/ 6, /*PINE_SHRUB*/ 6, /*RAFFLESIA*/ 15, /*LARGE_JUNGLE*/ 15, /*SMALL_JUNGLE*/ 8, /*TINY_JUNGLE*/ 1,
+    /*MEDIUM_PURPLE_MUSHROOM*/ 8, /*PURPLE_MUSHROOM*/ 127, /*MEDIUM_CRYSTAL*/ 25, /*CRYSTAL*/ 25, /*PALM*/ 24, /*CACTUS*/ 5};
+__device__ constexpr int kCaveFeatureReach[MMGEN_NUM_CAVE_FEATURES] = {
+    /*NONE*/ 0, /*TEST pillars*/ 0, 0, /*CAVE_VINE*/ 0, /*GLOWSTONE_CLUSTER*/ 6, /*STORMLIGHT*/ 8, /*CEILING_STORMLIGHT*/ 8,
+    /*CRYSTAL_PILLAR*/ 7, /*WARPED_FUNGUS*/ 6, /*AMBER_FUNGUS*/ 4};
+
+// stable (order-preserving) compaction of one gathered list into `out`, keeping the entries whose horizontal reach box meets the
+// target chunk's 16 x 16 footprint; entries at index >= CAP are dropped first, exactly like the reference's truncation, so the kept
+// entries are a subsequence of the reference's list and the dropped ones could not have claimed a voxel of this chunk.
+template <class Entry, int SRC_CAP, int CAP, bool CAVE>
+MM_DEV int gather_filtered(const Entry* __restrict__ src, const int* s_off, const int* s_srcChunk, int tot, int ox, int oz, Entry* __restrict__ out,
+                           int* s_w /*[4]*/, int& lo, int& hi)
+{
+    const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+    const int n = imin(tot, CAP);
+    int base = 0;
+    for (int r0 = 0; r0 < n; r0 += 256) {
+        const int i = r0 + t;
+        bool keep = false;
+        Entry p = {};
+        if (i < n) {
+            int k = 0;
+            while (s_off[k + 1] <= i) ++k;
+            p = src[(size_t)SRC_CAP * s_srcChunk[k] + (i - s_off[k])];
+            const int reach = CAVE ? kCaveFeatureReach[p.feature] : kFeatureReach[p.feature];
+            keep = p.pos[0] + reach >= ox && p.pos[0] - reach <= ox + 15 && p.pos[2] + reach >= oz && p.pos[2] - reach <= oz + 15;
+        }
+        const unsigned long long m = __ballot(keep);
+        if (lane == 0) s_w[wave] = __popcll(m);
+        __syncthreads();
+        int before = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { const int c = s_w[w]; if (w < wave) before += c; total += c; }
+        if (keep) {
+            out[base + before + __popcll(m & ((1ull << lane) - 1ull))] = p;
+            if constexpr (CAVE) {
+                lo = imin(lo, p.pos[1] + kCaveFeatureBounds[p.feature][0]); hi = imax(hi, p.pos[1] + p.layer_height + kCaveFeatureBounds[p.feature][1]);
+            } else {
+                lo = imin(lo, p.pos[1] + kFeatureBounds[p.feature][0]); hi = imax(hi, p.pos[1] + kFeatureBounds[p.feature][1]);
+            }
+        }
+        base += total;
+        __syncthreads();
+    }
+    return base;
+}
+
 __global__ void __launch_bounds__(256)
 k_gather_placements(const mmgen_feature_placement* __restrict__ fp, const mmgen_cave_feature_placement* __restrict__ cfp,
                     const int* __restrict__ counts, const int* __restrict__ targetChunk /*[nOut] index into source grid*/,
                     int gridW, int gridH, mmgen_feature_placement* __restrict__ gfp, mmgen_cave_feature_placement* __restrict__ gcfp,
-                    int* __restrict__ bounds)
+                    int* __restrict__ bounds, const int2* __restrict__ gridPos /*world block origin of every source-grid chunk; null = keep everything*/)
 {
     __shared__ int s_offS[50], s_offC[50], s_src[49];
-    __shared__ int s_b[4];
+    __shared__ int s_b[4], s_w[4];
     const int o = blockIdx.x, t = threadIdx.x;
     const int c = targetChunk[o];
     const int cx = c % gridW, cz = c / gridW;
@@ -279,6 +329,23 @@ k_gather_placements(const mmgen_feature_placement* __restrict__ fp, const mmgen_
     mmgen_feature_placement* go = gfp + (size_t)MMGEN_MAX_GATHERED_FEATURES_PER_CHUNK * o;
     mmgen_cave_feature_placement* gc = gcfp + (size_t)MMGEN_MAX_GATHERED_CAVE_FEATURES_PER_CHUNK * o;
     int lo0 = 384, hi0 = -1, lo1 = 384, hi1 = -1;
+    if (gridPos) {
+        // region path: the list only feeds k_apply_features, so entries that cannot reach this chunk are dropped here once instead of
+        // being skipped 256 times by the per-column filters (the per-stage ABI keeps the reference's full lists: gridPos == null)
+        const int2 org = gridPos[c];
+        const int nS = gather_filtered<mmgen_feature_placement, MMGEN_FP_CAP, MMGEN_MAX_GATHERED_FEATURES_PER_CHUNK, false>(fp, s_offS, s_src, totS, org.x, org.y,
+                                                                                                                            go, s_w, lo0, hi0);
+        const int nC = gather_filtered<mmgen_cave_feature_placement, MMGEN_CFP_CAP, MMGEN_MAX_GATHERED_CAVE_FEATURES_PER_CHUNK, true>(cfp, s_offC, s_src, totC, org.x,
+                                                                                                                                     org.y, gc, s_w, lo1, hi1);
+        atomicMin(&s_b[0], lo0); atomicMax(&s_b[1], hi0); atomicMin(&s_b[2], lo1); atomicMax(&s_b[3], hi1);
+        __syncthreads();
+        if (t == 0) {
+            if (nS < MMGEN_MAX_GATHERED_FEATURES_PER_CHUNK) { mmgen_feature_placement z = {}; go[nS] = z; }
+            if (nC < MMGEN_MAX_GATHERED_CAVE_FEATURES_PER_CHUNK) { mmgen_cave_feature_placement z = {}; gc[nC] = z; }
+            bounds[4 * o] = s_b[0]; bounds[4 * o + 1] = s_b[1]; bounds[4 * o + 2] = s_b[2]; bounds[4 * o + 3] = s_b[3];
+        }
+        return;
+    }
     for (int i = t; i < totS; i += 256) {
         int k = 0;
         while (s_offS[k + 1] <= i) ++k;
@@ -314,15 +381,6 @@ k_gather_placements(const mmgen_feature_placement* __restrict__ fp, const mmgen_
 // into LDS in list order (wave ballots + popcount prefix: a stable compaction, first match still wins) and the voxels then
 // scan a handful of candidates instead of hundreds of entries.  Entries skipped by the filter would have returned false.
 // ---------------------------------------------------------------------------------------------------------
-// Chebyshev reach max(|dx|, |dz|) in blocks beyond which placeFeature / placeCaveFeature cannot return true
-__device__ constexpr int kFeatureReach[MMGEN_NUM_FEATURES] = {
-    /*NONE*/ 0, /*SPHERE*/ 5, /*CORAL*/ 8, /*KELP*/ 0, /*ICEBERG*/ 40, /*ACACIA*/ 15, /*REDWOOD*/ 20, /*CYPRESS*/ 12, /*BIRCH*/ 8,
-    /*PINE_TREE*/ 6, /*PINE_SHRUB*/ 6, /*RAFFLESIA*/ 15, /*LARGE_JUNGLE*/ 15, /*SMALL_JUNGLE*/ 8, /*TINY_JUNGLE*/ 1,
-    /*MEDIUM_PURPLE_MUSHROOM*/ 8, /*PURPLE_MUSHROOM*/ 127, /*MEDIUM_CRYSTAL*/ 25, /*CRYSTAL*/ 25, /*PALM*/ 24, /*CACTUS*/ 5};
-__device__ constexpr int kCaveFeatureReach[MMGEN_NUM_CAVE_FEATURES] = {
-    /*NONE*/ 0, /*TEST pillars*/ 0, 0, /*CAVE_VINE*/ 0, /*GLOWSTONE_CLUSTER*/ 6, /*STORMLIGHT*/ 8, /*CEILING_STORMLIGHT*/ 8,
-    /*CRYSTAL_PILLAR*/ 7, /*WARPED_FUNGUS*/ 6, /*AMBER_FUNGUS*/ 4};
-
 #ifndef CAND_CAP
 #define CAND_CAP 256
 #endif
@@ -587,10 +645,10 @@ int launch_feature_placements(const float* hf, const float* bw, const float* lay
 
 int launch_gather_placements(const mmgen_feature_placement* fp, const mmgen_cave_feature_placement* cfp, const int* counts, const int* target,
                              int nOut, int gridW, int gridH, mmgen_feature_placement* gfp, mmgen_cave_feature_placement* gcfp, int* bounds,
-                             hipStream_t s)
+                             const int32_t* gridPos, hipStream_t s)
 {
     if (nOut <= 0) return 0;
-    hipLaunchKernelGGL(mm::k_gather_placements, dim3(nOut), dim3(256), 0, s, fp, cfp, counts, target, gridW, gridH, gfp, gcfp, bounds);
+    hipLaunchKernelGGL(mm::k_gather_placements, dim3(nOut), dim3(256), 0, s, fp, cfp, counts, target, gridW, gridH, gfp, gcfp, bounds, (const int2*)gridPos);
     return (int)hipGetLastError();
 }
 

@@ -241,7 +241,7 @@ int mmgen_region_finish(mmgen_region* r, uint8_t* d_blocks, float* d_heightfield
         CK(r->bounds.ensure(sizeof(int) * 4 * nr));
         CK(mmk::launch_gather_placements(r->fp.as<mmgen_feature_placement>(), r->cfp.as<mmgen_cave_feature_placement>(), r->counts.as<int>(), tgt, nr,
                                          r->pnx, r->pnz, r->gfp.as<mmgen_feature_placement>(), r->gcfp.as<mmgen_cave_feature_placement>(),
-                                         r->bounds.as<int>(), s));
+                                         r->bounds.as<int>(), posP, s));
         CK(mmk::launch_apply_features(d_blocks, posP, nr, r->gfp.as<mmgen_feature_placement>(), r->gcfp.as<mmgen_cave_feature_placement>(),
                                       r->bounds.as<int>(), tgt, s));
     }
