@@ -450,7 +450,7 @@ MM_DEV int filter_column(const Entry* __restrict__ list, int wx, int wz, int4* s
 }
 
 #ifndef MM_APPLY_WAVES
-#define MM_APPLY_WAVES 4
+#define MM_APPLY_WAVES 3        // 168 VGPRs, 32 B scratch; at 4 (128 VGPRs) the rasterisers spill 208 B per lane = 3.3 GB of HBM writes per 1024 chunks
 #endif
 __attribute__((amdgpu_waves_per_eu(MM_APPLY_WAVES, MM_APPLY_WAVES)))
 __global__ void __launch_bounds__(APPLY_THREADS)
