@@ -5,11 +5,11 @@
 //
 // LDS tables.  The path is VALU-issue bound and the LDS pipe is idle, so the integer-valued part of simplex noise is served
 // from LDS: glm's permute() only ever sees small integer-valued floats (lattice coordinates mod 289 plus earlier permute
-// results), and the gradient of a lattice corner is a function of the final permute value alone.  Every workgroup builds
+// results), and the gradient of a lattice corner is a function of the final permute value alone.  Every workgroup loads
 //   perm4[i]  = 4 * permute(i - 8)               (byte offset of the next lookup), i - 8 in [-8, 600)
 //   grad3[p]  = simplex3 corner gradient * taylorInvSqrt          grad2[p] = simplex2 (a0, h, norm factor)
-// at kernel entry with the SAME fp32 instruction sequences the direct evaluation uses (noise_tables_init), so a lookup returns
-// bit for bit what the arithmetic would have produced.  A simplex3 then costs 16 LDS reads + ~170 VALU instead of 325 VALU, a
+// at kernel entry (noise_tables_init) from a per-device image that k_noise_tables_build computed with the SAME fp32 instruction
+// sequences the direct evaluation uses, so a lookup returns bit for bit what the arithmetic would have produced.  A simplex3 then costs 16 LDS reads + ~170 VALU instead of 325 VALU, a
 // simplex2 9 reads + ~80 instead of 151.  Domain: mod289 of an integer-valued |x| < 2^24 lies in [-1, 289] and permute of
 // [-16, 700) in [0, 288] (tests/test_oracle_math.py::test_noise_table_domains); anything else (never met inside the
 // world's coordinate range) takes the direct arithmetic path.  EVERY kernel that can reach simplex2/simplex3 calls
@@ -86,21 +86,58 @@ MM_DEV int perm4(int off) { return *(__attribute__((address_space(3))) const int
 MM_DEV f4v grad3_at(int p4) { return *(__attribute__((address_space(3))) const f4v*)((lds_bytes)s_noise.grad3 + (p4 << 2)); }
 MM_DEV f4v grad2_at(int p4) { return *(__attribute__((address_space(3))) const f4v*)((lds_bytes)s_noise2.grad2 + (p4 << 2)); }
 
+// The tables are built ONCE per device and translation unit by k_noise_tables_build (below, with the arithmetic functions above)
+// into this global image; every workgroup then just copies the 12 KB image into LDS at kernel entry (16-byte words, L2 resident)
+// instead of recomputing 904 entries - 2 - 9 % of the noise kernels' time went into that.
+static __device__ NoiseTables3 g_noise;
+static __device__ NoiseTables2 g_noise2;
+
+static __global__ void __launch_bounds__(256) k_noise_tables_build()
+{
+    const int t = threadIdx.x;
+    for (int i = t; i < MM_PERM_N; i += 256) g_noise.perm4[i] = 4 * (int)permute((float)(i - MM_PERM_LO));
+    for (int i = t; i < MM_GRAD_N; i += 256) {
+        const f3 g3 = simplex3_corner((float)i);
+        const f3 g2 = simplex2_corner((float)i);
+        g_noise.grad3[i] = f4v{g3.x, g3.y, g3.z, 0.f};
+        g_noise2.grad2[i] = f4v{g2.x, g2.y, g2.z, 0.f};
+    }
+}
+
+// Host side: every launch wrapper of a translation unit that evaluates simplex noise calls this first.  The first call per device
+// builds the image on the caller's stream and waits for it, so that launches on other streams can never see a half-built image.
+static inline int noise_tables_ensure(hipStream_t s)
+{
+    static bool built[64] = {};
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return (int)e;
+    if (dev < 0 || dev >= 64) return (int)hipErrorInvalidDevice;
+    if (built[dev]) return 0;
+    hipLaunchKernelGGL(k_noise_tables_build, dim3(1), dim3(256), 0, s);
+    e = hipGetLastError();
+    if (e != hipSuccess) return (int)e;
+    e = hipStreamSynchronize(s);
+    if (e != hipSuccess) return (int)e;
+    built[dev] = true;
+    return 0;
+}
+
 // Called by every thread of the workgroup at kernel entry (ends with a workgroup barrier).  NEED2 = false: the kernel never
-// evaluates simplex2 (it must not: the table is not built).
+// evaluates simplex2 (it must not: the table is not loaded, and its LDS is not allocated).
 template <bool NEED2 = true>
 MM_DEV void noise_tables_init()
 {
     const int nt = blockDim.x * blockDim.y * blockDim.z;
     const int t = threadIdx.x + blockDim.x * (threadIdx.y + blockDim.y * threadIdx.z);
-    for (int i = t; i < MM_PERM_N; i += nt) s_noise.perm4[i] = 4 * (int)permute((float)(i - MM_PERM_LO));
-    for (int i = t; i < MM_GRAD_N; i += nt) {
-        const f3 g3 = simplex3_corner((float)i);
-        s_noise.grad3[i] = f4v{g3.x, g3.y, g3.z, 0.f};
-        if (NEED2) {
-            const f3 g2 = simplex2_corner((float)i);
-            s_noise2.grad2[i] = f4v{g2.x, g2.y, g2.z, 0.f};
-        }
+    constexpr int n3 = (int)(sizeof(NoiseTables3) / 16), n2 = (int)(sizeof(NoiseTables2) / 16);
+    const uint4* src3 = (const uint4*)&g_noise;
+    uint4* dst3 = (uint4*)&s_noise;
+    for (int i = t; i < n3; i += nt) dst3[i] = src3[i];
+    if (NEED2) {
+        const uint4* src2 = (const uint4*)&g_noise2;
+        uint4* dst2 = (uint4*)&s_noise2;
+        for (int i = t; i < n2; i += nt) dst2[i] = src2[i];
     }
     __syncthreads();
 }

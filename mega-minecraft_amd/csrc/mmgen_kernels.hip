@@ -648,6 +648,7 @@ int profile_collect(double* total_ms, long long* counts)
 
 #define LAUNCH(KID, KERNEL, GRID, BLOCK, STREAM, ...)                                        \
     do {                                                                                     \
+        { const int ne_ = mm::noise_tables_ensure(STREAM); if (ne_) return ne_; }            \
         ProfRec rec_; rec_.id = (KID);                                                       \
         if (g_prof) { rec_.a = get_event(); rec_.b = get_event(); (void)hipEventRecord(rec_.a, (STREAM)); } \
         hipLaunchKernelGGL(KERNEL, GRID, BLOCK, 0, (STREAM), __VA_ARGS__);                   \
