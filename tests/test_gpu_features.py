@@ -132,6 +132,42 @@ def test_tiled_generation_with_halo_exchange_on_one_gpu(mmgen_pkg, oracle):
     assert np.array_equal(world, ref)
 
 
+def test_gathered_list_overflow_truncates_like_the_oracle(gen, oracle):
+    """Maximum sizes: the gathered placement lists are capped at 2 048 surface / 4 096 cave entries (chunk.cu:1555-1601).  The
+    two-phase region API lets the test overwrite the per-chunk placement lists of the 7 x 7 ring with synthetic dense ones (60
+    icebergs - horizontal reach 40 blocks - and 100 glowstone clusters per chunk: 2 940 and 4 900 gathered entries), identically on
+    the HIP path and on the oracle.  Entries beyond the caps come from ring-3 chunks whose icebergs DO reach the centre chunk, so the
+    blocks only agree if both sides gather in the same order, truncate at the same entry and rasterise first-match-wins alike."""
+    import torch
+    from oracle_binding import OracleBackend
+    cx0, cz0 = 200, -300
+    ob = OracleBackend(oracle.nthreads)
+    ob.region_begin(cx0, cz0, 1, 1, 7)
+    gen.region_begin(cx0, cz0, 1, 1, 7)
+    gb = gen.region_placement_buffers()
+    obuf = ob.region_placement_buffers()
+    assert (gb["w"], gb["h"], gb["x0"], gb["z0"]) == (7, 7, cx0 - 3, cz0 - 3) == (obuf["w"], obuf["h"], obuf["x0"], obuf["z0"])
+    rng = np.random.default_rng(11)
+    fp = np.zeros((49, 256, 5), np.int32); cfp = np.zeros((49, 1024, 6), np.int32); counts = np.zeros((49, 2), np.int32)
+    for cell in range(49):
+        ox, oz = 16 * (cx0 - 3 + cell % 7), 16 * (cz0 - 3 + cell // 7)
+        counts[cell] = (60, 100)
+        fp[cell, :60, 0] = 4                                           # MMF_ICEBERG
+        fp[cell, :60, 1] = ox + rng.integers(0, 16, 60); fp[cell, :60, 2] = 120 + rng.integers(0, 30, 60); fp[cell, :60, 3] = oz + rng.integers(0, 16, 60)
+        fp[cell, :60, 4] = rng.integers(0, 2, 60)                      # canReplaceBlocks
+        cfp[cell, :100, 0] = 4                                         # MMCF_GLOWSTONE_CLUSTER
+        cfp[cell, :100, 1] = ox + rng.integers(0, 16, 100); cfp[cell, :100, 2] = 20 + rng.integers(0, 80, 100); cfp[cell, :100, 3] = oz + rng.integers(0, 16, 100)
+        cfp[cell, :100, 4] = 4 + rng.integers(0, 12, 100); cfp[cell, :100, 5] = 1
+    for k, a in (("fp", fp), ("cfp", cfp), ("counts", counts)):
+        obuf[k].copy_(torch.from_numpy(a))
+        gb[k].copy_(torch.from_numpy(a).to(gb[k].device))
+    ref = ob.region_finish(1, 1)["blocks"]
+    got = np_(gen.region_finish(1, 1)["blocks"])
+    assert np.array_equal(got, ref), f"{int((got != ref).sum())} block ids differ"
+    plain = oracle.generate_region(cx0, cz0, 1, 1, erosion=True, features=True, decorators=True)["blocks"]
+    assert int((ref != plain).sum()) > 500                            # the synthetic icebergs really claim voxels of the centre chunk
+
+
 def _tiled_world_on_one_gpu(mmgen_pkg, layout):
     """All ranks of `layout` played one after the other on this GPU: region_begin with the peer-owned ring masked out, placement
     lists exchanged by hand along the product's exchange_plan, region_finish; returns the stitched [nz_world * nx_world, 98304] blocks."""
