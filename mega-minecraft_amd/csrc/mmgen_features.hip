@@ -384,41 +384,39 @@ k_gather_placements(const mmgen_feature_placement* __restrict__ fp, const mmgen_
 #ifndef CAND_CAP
 #define CAND_CAP 256
 #endif
-#ifndef APPLY_THREADS
-#define APPLY_THREADS 128
-#endif
-#define APPLY_WAVES (APPLY_THREADS / 64)
+#define APPLY_COLS 4                      // columns per workgroup: one wave each
+#define APPLY_THREADS (64 * APPLY_COLS)
 
-// Stable block-wide compaction of the list entries that can reach column (wx, wz), as packed copies
-// (x, y, z, feature | canReplace << 8 | layerHeight << 16) so that the voxel loop never goes back to global memory.
-// Returns the number of candidates, or -1 when they do not fit CAND_CAP (caller falls back to the full scan); ylo / yhi
-// receive the union of the candidates' vertical extents (every thread gets the same values).  All threads must call it.
-template <class Entry, int LIST_CAP, bool CAVE>
-MM_DEV int filter_column(const Entry* __restrict__ list, int wx, int wz, int4* s_cand, int* s_wave /*[2 * APPLY_WAVES + 2]*/, int& ylo, int& yhi)
+// LDS hand-off inside one wave: its LDS operations execute in issue order, only the compiler must not reorder across the hand-off
+MM_DEV void wave_lds_sync()
 {
-    const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+MM_DEV int wave_min(int v) { for (int o = 32; o > 0; o >>= 1) v = imin(v, __shfl_xor(v, o)); return v; }
+MM_DEV int wave_max(int v) { for (int o = 32; o > 0; o >>= 1) v = imax(v, __shfl_xor(v, o)); return v; }
+
+// Stable WAVE-wide compaction of the list entries that can reach column (wx, wz), as packed copies
+// (x, y, z, feature | canReplace << 8 | layerHeight << 16) so that the voxel loop never goes back to global memory: 64 entries per
+// round, ballot + popcount prefix, no workgroup barrier.  Returns the number of candidates, or -1 when they do not fit CAND_CAP
+// (caller falls back to the full scan); ylo / yhi receive the union of the candidates' vertical extents (wave-uniform).
+template <class Entry, int LIST_CAP, bool CAVE>
+MM_DEV int filter_column(const Entry* __restrict__ list, int wx, int wz, int4* s_cand, int& ylo, int& yhi)
+{
+    const int lane = threadIdx.x & 63;
     int base = 0;
-    bool overflow = false;
     int lo = 384, hi = -1;
-    for (int r0 = 0; r0 < LIST_CAP; r0 += APPLY_THREADS) {
-        const int i = r0 + t;
+    for (int r0 = 0; r0 < LIST_CAP; r0 += 64) {
+        const int i = r0 + lane;
         int feat = 0, fx = 0, fz = 0;
         if (i < LIST_CAP) { feat = list[i].feature; fx = list[i].pos[0]; fz = list[i].pos[2]; }
-        const bool isNone = feat == 0;
-        const unsigned long long noneMask = __ballot(isNone);
-        if (lane == 0) s_wave[APPLY_WAVES + wave] = noneMask ? 64 * wave + (int)__builtin_ctzll(noneMask) : 1 << 20;
-        __syncthreads();
-        int firstNone = 1 << 20;
-#pragma unroll
-        for (int w = 0; w < APPLY_WAVES; ++w) firstNone = imin(firstNone, s_wave[APPLY_WAVES + w]);
+        const unsigned long long noneMask = __ballot(feat == 0);
+        const int firstNone = noneMask ? (int)__builtin_ctzll(noneMask) : 64;
         const int reach = CAVE ? kCaveFeatureReach[feat] : kFeatureReach[feat];
-        const bool cand = t < firstNone && iabs(wx - fx) <= reach && iabs(wz - fz) <= reach;
+        const bool cand = lane < firstNone && iabs(wx - fx) <= reach && iabs(wz - fz) <= reach;
         const unsigned long long cm = __ballot(cand);
-        if (lane == 0) s_wave[wave] = __popcll(cm);
-        __syncthreads();
-        int before = 0, total = 0;
-#pragma unroll
-        for (int w = 0; w < APPLY_WAVES; ++w) { const int c = s_wave[w]; if (w < wave) before += c; total += c; }
         if (cand) {
             const int fy = list[i].pos[1];
             int w = feat | ((int)list[i].can_replace_blocks << 8);
@@ -431,56 +429,54 @@ MM_DEV int filter_column(const Entry* __restrict__ list, int wx, int wz, int4* s
                 lo = imin(lo, fy + kFeatureBounds[feat][0]); top = fy + kFeatureBounds[feat][1];
             }
             hi = imax(hi, top);
-            const int slot = base + before + __popcll(cm & ((1ull << lane) - 1ull));
+            const int slot = base + __popcll(cm & ((1ull << lane) - 1ull));
             if (slot < CAND_CAP) s_cand[slot] = make_int4(fx, fy, fz, w);
         }
-        base += total;
-        if (base > CAND_CAP) overflow = true;
-        __syncthreads();                       // s_wave is reused by the next round
-        if (firstNone < APPLY_THREADS) break;
+        base += __popcll(cm);
+        if (firstNone < 64) break;
     }
-    // block-wide union of the vertical extents
-    if (t == 0) { s_wave[2 * APPLY_WAVES] = 384; s_wave[2 * APPLY_WAVES + 1] = -1; }
-    __syncthreads();
-    if (hi >= lo) { atomicMin(&s_wave[2 * APPLY_WAVES], lo); atomicMax(&s_wave[2 * APPLY_WAVES + 1], hi); }
-    __syncthreads();
-    ylo = s_wave[2 * APPLY_WAVES]; yhi = s_wave[2 * APPLY_WAVES + 1];
-    __syncthreads();
-    return overflow ? -1 : base;
+    ylo = wave_min(lo); yhi = wave_max(hi);
+    wave_lds_sync();
+    return base > CAND_CAP ? -1 : base;
 }
 
 #ifndef MM_APPLY_WAVES
 #define MM_APPLY_WAVES 3        // 168 VGPRs, 32 B scratch; at 4 (128 VGPRs) the rasterisers spill 208 B per lane = 3.3 GB of HBM writes per 1024 chunks
 #endif
+// One workgroup = 4 neighbouring columns of a chunk, one WAVE per column: the wave filters the chunk's (already chunk-prefiltered)
+// lists for its column with ballots, then its 64 lanes walk the column's own vertical extent.  No workgroup barrier after the noise
+// tables are in LDS, so a column with nothing to rasterise retires at once and a busy one does not hold the other three.
 __attribute__((amdgpu_waves_per_eu(MM_APPLY_WAVES, MM_APPLY_WAVES)))
 __global__ void __launch_bounds__(APPLY_THREADS)
 k_apply_features(uint8_t* __restrict__ blocks, const int2* __restrict__ chunkPos, const mmgen_feature_placement* __restrict__ gfp,
                  const mmgen_cave_feature_placement* __restrict__ gcfp, const int* __restrict__ bounds, const int* __restrict__ srcIdx)
 {
-    __shared__ int4 s_candS[CAND_CAP], s_candC[CAND_CAP];     // (x, y, z, feature | canReplace << 8 | layerHeight << 16)
-    __shared__ int s_wave[2 * APPLY_WAVES + 2];
-    const int col = blockIdx.x;
-    const int chunk = col >> 8, idx2d = col & 255;      // dense output / list index; positions are read at srcIdx[chunk]
+    __shared__ int4 s_cand[APPLY_COLS][2][CAND_CAP];     // per wave: surface / cave candidates (x, y, z, feature | canReplace << 8 | layerHeight << 16)
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int col = APPLY_COLS * blockIdx.x + wave;
+    const int chunk = col >> 8, idx2d = col & 255;      // dense output / list index; positions are read at srcIdx[chunk]; 256 % APPLY_COLS == 0
     const int b0 = bounds[4 * chunk], b1 = bounds[4 * chunk + 1], b2 = bounds[4 * chunk + 2], b3 = bounds[4 * chunk + 3];
-    const bool doS = gfp && b0 <= b1, doC = gcfp && b2 <= b3;      // workgroup-uniform
+    const bool doS = gfp && b0 <= b1, doC = gcfp && b2 <= b3;      // workgroup-uniform (one chunk per workgroup)
     if (!doS && !doC) return;
+    noise_tables_init();          // the only workgroup barrier
 
     const int2 cp = chunkPos[srcIdx ? srcIdx[chunk] : chunk];
     const int wx = cp.x + (idx2d & 15), wz = cp.y + (idx2d >> 4);
     const mmgen_feature_placement* listS = gfp + (size_t)MMGEN_MAX_GATHERED_FEATURES_PER_CHUNK * chunk;
     const mmgen_cave_feature_placement* listC = gcfp + (size_t)MMGEN_MAX_GATHERED_CAVE_FEATURES_PER_CHUNK * chunk;
+    const int4* candS = s_cand[wave][0];
+    const int4* candC = s_cand[wave][1];
     int nS = 0, nC = 0;
     int loS = 384, hiS = -1, loC = 384, hiC = -1;       // the column's own vertical extents: subsets of the chunk's bounds
-    if (doS) nS = filter_column<mmgen_feature_placement, MMGEN_MAX_GATHERED_FEATURES_PER_CHUNK, false>(listS, wx, wz, s_candS, s_wave, loS, hiS);
-    if (doC) nC = filter_column<mmgen_cave_feature_placement, MMGEN_MAX_GATHERED_CAVE_FEATURES_PER_CHUNK, true>(listC, wx, wz, s_candC, s_wave, loC, hiC);
+    if (doS) nS = filter_column<mmgen_feature_placement, MMGEN_MAX_GATHERED_FEATURES_PER_CHUNK, false>(listS, wx, wz, s_cand[wave][0], loS, hiS);
+    if (doC) nC = filter_column<mmgen_cave_feature_placement, MMGEN_MAX_GATHERED_CAVE_FEATURES_PER_CHUNK, true>(listC, wx, wz, s_cand[wave][1], loC, hiC);
     if (nS == 0 && nC == 0) return;
-    noise_tables_init();          // after the workgroup-uniform exits: most columns have nothing to rasterise
     loS = imax(loS, imax(b0, 0)); hiS = imin(hiS, imin(b1, 383));
     loC = imax(loC, imax(b2, 0)); hiC = imin(hiC, imin(b3, 383));
     const int ylo = imin(nS ? loS : 384, nC ? loC : 384), yhi = imax(nS ? hiS : -1, nC ? hiC : -1);
 
     uint8_t* colBlocks = blocks + (size_t)MMGEN_BLOCKS_PER_CHUNK * chunk + 384 * idx2d;
-    for (int y = ylo + (int)threadIdx.x; y <= yhi; y += APPLY_THREADS) {
+    for (int y = ylo + lane; y <= yhi; y += 64) {
         const bool inF = nS && y >= loS && y <= hiS;
         const bool inC = nC && y >= loC && y <= hiC;
         if (!inF && !inC) continue;
@@ -490,7 +486,7 @@ k_apply_features(uint8_t* __restrict__ blocks, const int2* __restrict__ chunkPos
         if (inF) {
             if (nS >= 0) {
                 for (int c = 0; c < nS; ++c) {
-                    const int4 e = s_candS[c];
+                    const int4 e = candS[c];
                     const int feature = e.w & 255;
                     if (block != MMB_AIR && !((e.w >> 8) & 1)) continue;
                     if (y < e.y + kFeatureBounds[feature][0] || y > e.y + kFeatureBounds[feature][1]) continue;
@@ -510,7 +506,7 @@ k_apply_features(uint8_t* __restrict__ blocks, const int2* __restrict__ chunkPos
         if (inC && !placed) {
             if (nC >= 0) {
                 for (int c = 0; c < nC; ++c) {
-                    const int4 e = s_candC[c];
+                    const int4 e = candC[c];
                     const int feature = e.w & 255, lh = e.w >> 16;
                     if (block != MMB_AIR && !((e.w >> 8) & 1)) continue;
                     if (y < e.y + kCaveFeatureBounds[feature][0] || y > e.y + lh + kCaveFeatureBounds[feature][1]) continue;
@@ -660,7 +656,7 @@ int launch_apply_features(uint8_t* blocks, const int32_t* pos, int n, const mmge
 {
     if (n <= 0) return 0;
     { const int ne_ = mm::noise_tables_ensure(s); if (ne_) return ne_; }
-    hipLaunchKernelGGL(mm::k_apply_features, dim3(n * 256), dim3(APPLY_THREADS), 0, s, blocks, (const int2*)pos, gfp, gcfp, bounds, srcIdx);
+    hipLaunchKernelGGL(mm::k_apply_features, dim3(n * (256 / APPLY_COLS)), dim3(APPLY_THREADS), 0, s, blocks, (const int2*)pos, gfp, gcfp, bounds, srcIdx);
     return (int)hipGetLastError();
 }
 
