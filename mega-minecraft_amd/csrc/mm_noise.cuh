@@ -11,8 +11,8 @@
 // at kernel entry (noise_tables_init) from a per-device image that k_noise_tables_build computed with the SAME fp32 instruction
 // sequences the direct evaluation uses, so a lookup returns bit for bit what the arithmetic would have produced.  A simplex3 then costs 16 LDS reads + ~170 VALU instead of 325 VALU, a
 // simplex2 9 reads + ~80 instead of 151.  Domain: mod289 of an integer-valued |x| < 2^24 lies in [-1, 289] and permute of
-// [-16, 700) in [0, 288] (tests/test_oracle_math.py::test_noise_table_domains); anything else (never met inside the
-// world's coordinate range) takes the direct arithmetic path.  EVERY kernel that can reach simplex2/simplex3 calls
+// [-16, 700) in [0, 288] (tests/test_oracle_math.py::test_noise_table_domains); lattice coordinates of 2^24 and beyond (reached
+// only at the edge of the int32 world, tests "far coordinates") take the direct arithmetic path.  EVERY kernel that can reach simplex2/simplex3 calls
 // noise_tables_init() before its first use.
 #pragma once
 #include "mm_math.cuh"
@@ -157,6 +157,8 @@ MM_DEV float simplex2_inl(float vx, float vy)
     const float ax = (x0x + C0) - i1x, ay = (x0y + C0) - i1y;     // x12.xy
     const float bx = x0x + C2, by = x0y + C2;                     // x12.zw
 
+    // table domain: lattice coordinates below 2^24 in magnitude (then glm::mod(x, 289) is an integer in [0, 288]); NaN fails the test
+    const bool inDomain = __builtin_fabsf(ix) < 16777216.f && __builtin_fabsf(iy) < 16777216.f;
     ix = gmod(ix, 289.f);
     iy = gmod(iy, 289.f);
 
@@ -167,7 +169,7 @@ MM_DEV float simplex2_inl(float vx, float vy)
     m0 = m0 * m0; m1 = m1 * m1; m2 = m2 * m2;
 
     f3 c0, c1, c2;
-    if (ix >= -1.f && ix <= 289.f && iy >= -1.f && iy <= 289.f) {
+    if (inDomain) {
         const int x4 = 4 * (int)ix, y4 = 4 * (int)iy;
         const int o1x = gt ? 4 : 0, o1y = gt ? 0 : 4;
         const f4v t0 = grad2_at(perm4(perm4(y4) + x4));
@@ -229,8 +231,10 @@ MM_DEV void simplex3_gradients_direct(float ix, float iy, float iz, int order, f
 // Same values through the LDS tables (see the header); falls back to the arithmetic outside the tables' domain.
 MM_DEV void simplex3_gradients(float ix, float iy, float iz, int order, float* __restrict__ q)
 {
+    // table domain: lattice coordinates below 2^24 in magnitude (then mod289 is an integer in [-1, 289]); NaN fails the test
+    const bool inDomain = __builtin_fabsf(ix) < 16777216.f && __builtin_fabsf(iy) < 16777216.f && __builtin_fabsf(iz) < 16777216.f;
     ix = mod289(ix); iy = mod289(iy); iz = mod289(iz);
-    if (ix >= -1.f && ix <= 289.f && iy >= -1.f && iy <= 289.f && iz >= -1.f && iz <= 289.f) {
+    if (inDomain) {
         const int gx = order & 1, gy = (order >> 1) & 1, gz = (order >> 2) & 1;
         const int i1x = gx & (gz ^ 1), i1y = gy & (gx ^ 1), i1z = gz & (gy ^ 1);
         const int i2x = gx | (gz ^ 1), i2y = gy | (gx ^ 1), i2z = gz | (gy ^ 1);
@@ -251,10 +255,11 @@ MM_DEV void simplex3_gradients(float ix, float iy, float iz, int order, float* _
 MM_DEV float simplex3_part3(const Sx3Cell& c, const float* __restrict__ q)
 {
     const float Cx = (float)(1.0 / 6.0), Cy = (float)(1.0 / 3.0);
-    const float gx = (c.order & 1) ? 1.f : 0.f, gy = (c.order & 2) ? 1.f : 0.f, gz = (c.order & 4) ? 1.f : 0.f;
-    const float lx = 1.f - gx, ly = 1.f - gy, lz = 1.f - gz;
-    const float i1x = gmin(gx, lz), i1y = gmin(gy, lx), i1z = gmin(gz, ly);
-    const float i2x = gmax(gx, lz), i2y = gmax(gy, lx), i2z = gmax(gz, ly);
+    // g = step(x0.yzx, x0), l = 1 - g, i1 = min(g, l.zxy), i2 = max(g, l.zxy): all in {0, 1}, so min / max are AND / OR of the order
+    // bits (the same integers simplex3_gradients indexes the tables with) and the floats are exact conversions of them
+    const int gxi = c.order & 1, gyi = (c.order >> 1) & 1, gzi = (c.order >> 2) & 1;
+    const float i1x = (float)(gxi & (gzi ^ 1)), i1y = (float)(gyi & (gxi ^ 1)), i1z = (float)(gzi & (gyi ^ 1));
+    const float i2x = (float)(gxi | (gzi ^ 1)), i2y = (float)(gyi | (gxi ^ 1)), i2z = (float)(gzi | (gyi ^ 1));
     const float cx[4] = {c.x0x, (c.x0x - i1x) + Cx, (c.x0x - i2x) + Cy, c.x0x - 0.5f};
     const float cy[4] = {c.x0y, (c.x0y - i1y) + Cx, (c.x0y - i2y) + Cy, c.x0y - 0.5f};
     const float cz[4] = {c.x0z, (c.x0z - i1z) + Cx, (c.x0z - i2z) + Cy, c.x0z - 0.5f};
