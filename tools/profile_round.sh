@@ -14,9 +14,28 @@ B="python3 $root/bench.py --steps 3 --warmup 1 --cpu-sample 0 --full-extra 0 --n
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY GRBM_GUI_ACTIVE --output-format csv -d $out/${tag}_pmc_sq -- $B > $out/${tag}_pmc_sq.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/${tag}_pmc_fetch -- $B > $out/${tag}_pmc_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/${tag}_pmc_write -- $B > $out/${tag}_pmc_write.log 2>&1
+BF="python3 $root/bench.py --workload full --steps 2 --warmup 1 --no-kernel-events"
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/${tag}_full_pmc_fetch -- $BF > $out/${tag}_full_pmc_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/${tag}_full_pmc_write -- $BF > $out/${tag}_full_pmc_write.log 2>&1
 python3 - <<PY
 import csv, glob, json, collections
 out, tag = "$out", "$tag"
+# full pipeline: HBM bytes per kernel launch (32x32-chunk tile)
+facc = collections.defaultdict(lambda: collections.defaultdict(float)); fcnt = collections.Counter()
+for d in ("fetch", "write"):
+    for f in glob.glob(f"{out}/{tag}_full_pmc_{d}/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            k = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("mm::", "").split("<")[0]
+            facc[k][r["Counter_Name"]] += float(r["Counter_Value"]); fcnt[(k, r["Counter_Name"])] += 1
+fres = {}
+for k, cs in facc.items():
+    if not k.startswith("k_"): continue
+    e = {c: round(v / fcnt[(k, c)]) for c, v in cs.items()}
+    e["hbm_bytes"] = (2 * e.get("FETCH_SIZE", 0) + e.get("WRITE_SIZE", 0)) * 1024
+    fres[k] = e
+json.dump({"command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE --output-format csv -- python3 bench.py --workload full --steps 2 --warmup 1 --no-kernel-events (two separate passes)",
+           "workload": "full pipeline, 32x32-chunk tile (38x38 ring-extended grid for caves / placements)",
+           "units": "per launch averages, KiB as reported; hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024", "kernels": fres}, open(f"{out}/{tag}_full_pmc.json", "w"), indent=1)
 acc = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.Counter()
 for d in ("sq", "fetch", "write"):
     for f in glob.glob(f"{out}/{tag}_pmc_{d}/**/*counter_collection.csv", recursive=True):
