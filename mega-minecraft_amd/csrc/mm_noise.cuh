@@ -383,6 +383,11 @@ MM_DEV Worley2 worley2(float px, float py)
 // Direct (no table) provider of 3D cell points.
 struct CellDirect {
     MM_DEV f3 operator()(int cx, int cy, int cz) const { return rand3from3((float)cx, (float)cy, (float)cz); }
+    MM_DEV void row3(int cx, int cy, int cz, f3 (&out)[3]) const
+    {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) out[k] = (*this)(cx, cy, cz - 1 + k);
+    }
 };
 
 struct Worley3 { float d1, d2, d3; f3 closest; };
@@ -426,9 +431,11 @@ MM_DEV float special_cave_noise(float px, float py, float pz, const Cells& cells
     for (int xy = 0; xy < 9; ++xy) {
         const int x = xy / 3 - 1, y = xy % 3 - 1;
         {
+            f3 row[3];
+            cells.row3(ux + x, uy + y, uz, row);
 #pragma unroll
             for (int z = -1; z <= 1; ++z) {
-                const f3 pt = cells(ux + x, uy + y, uz + z);
+                const f3 pt = row[z + 1];
                 const float dx = ((float)x + pt.x) - fx, dy = ((float)y + pt.y) - fy, dz = ((float)z + pt.z) - fz;
                 const float d2 = (dx * dx + dy * dy) + dz * dz;
                 // keep the three smallest: s1 <= s2 <= s3

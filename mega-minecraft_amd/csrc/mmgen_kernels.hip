@@ -216,6 +216,19 @@ struct CellTile {
         }
         return rand3from3((float)cx, (float)cy, (float)cz);   // outside the staged box: same value, computed directly
     }
+    // the three z-consecutive cells (cx, cy, cz - 1 .. cz + 1): one bounds test and 9 consecutive LDS words when the row is staged
+    MM_DEV void row3(int cx, int cy, int cz, f3 (&out)[3]) const
+    {
+        const int ix = cx - ox, iy = cy - oy, iz = cz - oz - 1;
+        if ((unsigned)ix < CELL_NX && (unsigned)iy < CELL_NY && iz >= 0 && iz + 2 < CELL_NZ) {
+            const float* p = pts + 3 * ((ix * CELL_NY + iy) * CELL_NZ + iz);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) out[k] = mk3(p[3 * k], p[3 * k + 1], p[3 * k + 2]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) out[k] = (*this)(cx, cy, cz - 1 + k);
+        }
+    }
 };
 
 // One workgroup = 4 neighbouring columns = 4 x 144 evaluated voxels (e -> column e / 144, y = e % 144), walked by CAVE_THREADS
