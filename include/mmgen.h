@@ -147,8 +147,10 @@ int mmgen_mesh_fill(const uint8_t* d_blocks, const int32_t* d_chunk_idx, const i
  * A chunk's 98 304 block ids as per-column run-length pairs: u16 runsOfColumn[256], then for each column (x + 16 z, the blocks[]
  * order) its runs as (u8 blockId, u8 length - 1), 1 .. 256 voxels per pair.  512 + 2 R bytes per chunk (typically 5 - 9 KB).
  * d_chunk_idx as in the mesher (NULL = chunks 0 .. n-1 of d_blocks); d_chunk_offset = exclusive prefix of d_chunk_bytes, by the
- * caller, who also sizes d_out.  mmgen_unpack is the device inverse (d_blocks [n][98304] dense); mmgen_unpack_chunk_host decodes one
- * chunk on the host (plain C, no device) and returns -1 on a malformed stream. */
+ * caller, who also sizes d_out.  mmgen_unpack is the device inverse (d_blocks [n][98304] dense) for streams this library produced
+ * (it never writes outside a chunk, but it trusts the run counts of the header when reading); mmgen_unpack_chunk_host decodes one
+ * chunk on the host (plain C, no device), validates every count and length against packed_bytes and returns -1 on a malformed stream:
+ * use it for data of unknown origin. */
 int mmgen_pack_count(const uint8_t* d_blocks, const int32_t* d_chunk_idx, int n, uint16_t* d_col_runs /*[n][256]*/, uint32_t* d_chunk_bytes /*[n]*/, void* stream);
 int mmgen_pack_fill(const uint8_t* d_blocks, const int32_t* d_chunk_idx, int n, const uint16_t* d_col_runs, const uint64_t* d_chunk_offset, uint8_t* d_out,
                     void* stream);
