@@ -250,7 +250,7 @@ MM_DEV float column_height(int wxi, int wzi, float* w24 /* nullable */)
 //   AMBER = (1-shallow)(1-warped).  The noises are evaluated lazily in the order the cumulative test consumes them —
 //   the values used are identical to evaluating all four up front, the unused ones are simply never computed.
 // ---------------------------------------------------------------------------------------------------------
-MM_DEV int cave_biome(int wx, int wy, int wz, float maxHeight, int seed)
+MM_DEV int cave_biome(int wx, int wy, int wz, float maxHeight, int seed, bool wantDeep = true)
 {
     const float fx = (float)wx, fy = (float)wy, fz = (float)wz;
     const f3 o = fbm3from3<3>(fx * 0.0470f, fy * 0.0470f, fz * 0.0470f);
@@ -284,7 +284,9 @@ MM_DEV int cave_biome(int wx, int wy, int wz, float maxHeight, int seed)
         if (rand <= 0.f) return MMCB_LUSH_CAVES;
     }
     const float deepW = 1.f - shallow;
-    if (deepW != 0.f) {
+    // wantDeep = false: the caller has no use for WARPED_FOREST / AMBER_FOREST (k_fill: those two only re-skin the top DEEPSLATE /
+    // BLACKSTONE block of a cave floor, biomeFuncs.hpp), so their simplex3 is not evaluated and NONE stands in for both
+    if (deepW != 0.f && wantDeep) {
         const float warped = smoothstep(-0.05f, 0.05f, simplex3(px * 0.0030f + 5821.32f, py * 0.0030f + 4920.12f, pz * 0.0030f + 7931.59f));
         rand -= deepW * warped;                     // WARPED_FOREST
         if (rand <= 0.f) return MMCB_WARPED_FOREST;

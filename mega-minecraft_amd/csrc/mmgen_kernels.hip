@@ -563,7 +563,9 @@ k_fill(const float* __restrict__ hf, const float* __restrict__ bw, const float* 
         const int c = v / 384, y = v - 384 * c;
         const int idx2d = idxBase + c;
         const int wx = cp.x + (idx2d & 15), wz = cp.y + (idx2d >> 4);
-        const int cb = cave_biome(wx, y, wz, s_lh[c][MMGEN_NUM_MATERIALS], 190249401);
+        // WARPED / AMBER only act on the top DEEPSLATE / BLACKSTONE block of a cave floor (caveBottomDepth == 0)
+        const bool wantDeep = bottomDepth == 0 && (block == MMB_DEEPSLATE || block == MMB_BLACKSTONE);
+        const int cb = cave_biome(wx, y, wz, s_lh[c][MMGEN_NUM_MATERIALS], 190249401, wantDeep);
         cave_biome_block_post(block, cb, wx, y, wz, bottomDepth, topDepth);
         outBase[v] = block;
     }
