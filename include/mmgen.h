@@ -118,6 +118,13 @@ int mmgen_region_placement_buffers(mmgen_region* region, mmgen_feature_placement
 int mmgen_region_finish(mmgen_region* region, uint8_t* d_blocks, float* d_heightfields /*nullable*/, float* d_layers /*[n][20][256], nullable*/,
                         mmgen_cave_layer* d_cave_layers /*[n][256][32], nullable*/, void* stream);
 int mmgen_region_last_erosion_passes(const mmgen_region* region);
+/* Copies the placement lists of n whole cells between two placement grids with the per-cell layout of mmgen_region_placement_buffers
+ * (fp [cells][MMGEN_FP_CAP], cfp [cells][MMGEN_CFP_CAP], counts [cells][2]): cell d_dst_idx[i] of dst <- cell d_src_idx[i] of src.  A streaming
+ * caller keeps the lists of chunks it has generated in its own grid and feeds them back as ring cells of later regions (mask 0 in
+ * mmgen_region_begin) instead of having their caves and placements recomputed. */
+int mmgen_copy_placements(const mmgen_feature_placement* d_src_fp, const mmgen_cave_feature_placement* d_src_cfp, const int32_t* d_src_counts,
+                          const int32_t* d_src_idx, mmgen_feature_placement* d_dst_fp, mmgen_cave_feature_placement* d_dst_cfp, int32_t* d_dst_counts,
+                          const int32_t* d_dst_idx, int n, void* stream);
 
 /* Measurement hooks (not part of the reference's interface): when enabled every kernel launch is bracketed by HIP events on its
  * launch stream; mmgen_profile_collect() waits for them and returns total milliseconds and launch counts per kernel id

@@ -42,6 +42,24 @@ struct DevBuf {
 
 inline int floordiv(int a, int b) { int q = a / b; return (a % b != 0 && ((a < 0) != (b < 0))) ? q - 1 : q; }
 
+// placement lists of whole cells from one placement grid (region buffers or a caller-owned cache) to another
+__global__ void __launch_bounds__(256)
+k_copy_placements(const mmgen_feature_placement* __restrict__ sfp, const mmgen_cave_feature_placement* __restrict__ scfp, const int32_t* __restrict__ scnt,
+                  const int32_t* __restrict__ srcIdx, mmgen_feature_placement* __restrict__ dfp, mmgen_cave_feature_placement* __restrict__ dcfp,
+                  int32_t* __restrict__ dcnt, const int32_t* __restrict__ dstIdx)
+{
+    const int s = srcIdx[blockIdx.x], d = dstIdx[blockIdx.x], t = threadIdx.x;
+    static_assert(sizeof(mmgen_feature_placement) * MMGEN_FP_CAP % 16 == 0 && sizeof(mmgen_cave_feature_placement) * MMGEN_CFP_CAP % 16 == 0, "16-byte words");
+    constexpr int nF = (int)(sizeof(mmgen_feature_placement) * MMGEN_FP_CAP / 16), nC = (int)(sizeof(mmgen_cave_feature_placement) * MMGEN_CFP_CAP / 16);
+    const uint4* a = (const uint4*)(sfp + (size_t)MMGEN_FP_CAP * s);
+    uint4* b = (uint4*)(dfp + (size_t)MMGEN_FP_CAP * d);
+    for (int i = t; i < nF; i += 256) b[i] = a[i];
+    const uint4* c = (const uint4*)(scfp + (size_t)MMGEN_CFP_CAP * s);
+    uint4* e = (uint4*)(dcfp + (size_t)MMGEN_CFP_CAP * d);
+    for (int i = t; i < nC; i += 256) e[i] = c[i];
+    if (t < 2) dcnt[2 * d + t] = scnt[2 * s + t];
+}
+
 __global__ void __launch_bounds__(256) k_select(const float* __restrict__ src, const int* __restrict__ idx, float* __restrict__ dst, int floatsPerChunk)
 {
     const int i = blockIdx.x;
@@ -263,5 +281,17 @@ int mmgen_region_generate(mmgen_region* r, int cx0, int cz0, int nx, int nz, uns
 }
 
 int mmgen_region_last_erosion_passes(const mmgen_region* r) { return r ? r->lastMaxPasses : -1; }
+
+int mmgen_copy_placements(const mmgen_feature_placement* d_src_fp, const mmgen_cave_feature_placement* d_src_cfp, const int32_t* d_src_counts,
+                          const int32_t* d_src_idx, mmgen_feature_placement* d_dst_fp, mmgen_cave_feature_placement* d_dst_cfp, int32_t* d_dst_counts,
+                          const int32_t* d_dst_idx, int n, void* stream)
+{
+    if (n < 0 || (n > 0 && (!d_src_fp || !d_src_cfp || !d_src_counts || !d_src_idx || !d_dst_fp || !d_dst_cfp || !d_dst_counts || !d_dst_idx)))
+        return (int)hipErrorInvalidValue;
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(k_copy_placements, dim3(n), dim3(256), 0, (hipStream_t)stream, d_src_fp, d_src_cfp, d_src_counts, d_src_idx, d_dst_fp, d_dst_cfp,
+                       d_dst_counts, d_dst_idx);
+    return (int)hipGetLastError();
+}
 
 }  // extern "C"

@@ -101,11 +101,14 @@ int main(int argc, char** argv)
             if (leg == 1) p = player;
             resident.setCurrentChunkPos(p);
             const auto t0 = Clock::now();
-            int generated = 0, meshed = 0;
-            do { resident.tick(1.f / 60.f); generated += resident.lastGenerated; meshed += resident.lastMeshed; } while (!resident.allQueuesEmpty());
+            int generated = 0, meshed = 0, reused = 0, computed = 0;
+            do {
+                resident.tick(1.f / 60.f);
+                generated += resident.lastGenerated; meshed += resident.lastMeshed; reused += resident.lastRingReused; computed += resident.lastRingComputed;
+            } while (!resident.allQueuesEmpty());
             const double s = secondsSince(t0);
-            std::printf("device-resident leg %d: %d chunks generated, %d meshed in %.1f ms (%.0f generated chunks/s incl. meshing)\n", leg, generated, meshed, 1e3 * s,
-                        generated / s);
+            std::printf("device-resident leg %d: %d chunks generated, %d meshed in %.1f ms (%.0f generated chunks/s incl. meshing); ring cells: %d computed, %d from the placement cache\n",
+                        leg, generated, meshed, 1e3 * s, generated / s, computed, reused);
         }
     }
     {   // chunk lifetime: a pool of 2 600 slots serves a 2 x 16-step walk (each step regenerates a strip, far chunks are destroyed and

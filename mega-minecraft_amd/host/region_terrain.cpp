@@ -18,6 +18,10 @@ RegionTerrain::~RegionTerrain()
     if (region) mmgen_region_destroy(region);
     if (d_pool) (void)hipFree(d_pool);
     if (d_stage) (void)hipFree(d_stage);
+    if (d_cacheFp) (void)hipFree(d_cacheFp);
+    if (d_cacheCfp) (void)hipFree(d_cacheCfp);
+    if (d_cacheCnt) (void)hipFree(d_cacheCnt);
+    if (d_idxWork) (void)hipFree(d_idxWork);
     if (d_meshOut) (void)hipFree(d_meshOut);
     if (d_meshWork) (void)hipFree(d_meshWork);
 }
@@ -28,6 +32,13 @@ void RegionTerrain::init()
     RT_CALL(hipMalloc((void**)&d_pool, poolChunks * (size_t)devBlocksSize), "hipMalloc (chunk pool) failed");
     freeSlots.resize(poolChunks);
     for (size_t i = 0; i < poolChunks; ++i) freeSlots[i] = (int)(poolChunks - 1 - i);
+    // the cache also holds ring chunks that were computed for a region but never generated themselves: 2 x the pool is ample
+    cacheCells = 2 * poolChunks;
+    RT_CALL(hipMalloc((void**)&d_cacheFp, cacheCells * MMGEN_FP_CAP * sizeof(FeaturePlacement)), "hipMalloc (placement cache) failed");
+    RT_CALL(hipMalloc((void**)&d_cacheCfp, cacheCells * MMGEN_CFP_CAP * sizeof(CaveFeaturePlacement)), "hipMalloc (placement cache) failed");
+    RT_CALL(hipMalloc((void**)&d_cacheCnt, cacheCells * 2 * sizeof(int32_t)), "hipMalloc (placement cache) failed");
+    freePlacementSlots.resize(cacheCells);
+    for (size_t i = 0; i < cacheCells; ++i) freePlacementSlots[i] = (int)(cacheCells - 1 - i);
 }
 
 void* RegionTerrain::ensure(void*& p, size_t& cap, size_t bytes)
@@ -67,8 +78,46 @@ void RegionTerrain::generateRect(int cx0, int cz0, int nx, int nz)
         }
         dst = d_stage;
     }
-    RT_CALL(mmgen_region_generate(region, cx0, cz0, nx, nz, MMGEN_REGION_EROSION | MMGEN_REGION_FEATURES | MMGEN_REGION_DECORATORS, dst, nullptr, nullptr),
-            "mmgen_region_generate failed");
+    const unsigned flags = MMGEN_REGION_EROSION | MMGEN_REGION_FEATURES | MMGEN_REGION_DECORATORS;
+    if (!cachePlacements) {
+        RT_CALL(mmgen_region_generate(region, cx0, cz0, nx, nz, flags, dst, nullptr, nullptr), "mmgen_region_generate failed");
+    } else {
+        // two-phase region: ring cells whose placement lists are cached are masked out of the compute list (no caves, no placements
+        // for them) and their lists are copied in; everything this region computed goes into the cache for the regions to come
+        const int gw = nx + 6, gh = nz + 6;
+        std::vector<uint8_t> mask((size_t)gw * gh, 1);
+        std::vector<int32_t> impSrc, impDst, expSrc, expDst;
+        for (int z = 0; z < gh; ++z)
+            for (int x = 0; x < gw; ++x) {
+                const int cell = x + gw * z;
+                const bool inR = x >= 3 && x < nx + 3 && z >= 3 && z < nz + 3;
+                auto it = placementSlot.find({cx0 - 3 + x, cz0 - 3 + z});
+                if (it != placementSlot.end() && !inR) { mask[cell] = 0; impSrc.push_back(it->second); impDst.push_back(cell); ++lastRingReused; }
+                else if (it == placementSlot.end()) {
+                    if (freePlacementSlots.empty()) continue;              // cache full: this cell is simply recomputed next time
+                    const int slot = freePlacementSlots.back(); freePlacementSlots.pop_back();
+                    placementSlot[{cx0 - 3 + x, cz0 - 3 + z}] = slot;
+                    expSrc.push_back(cell); expDst.push_back(slot);
+                    if (!inR) ++lastRingComputed;
+                }
+            }
+        RT_CALL(mmgen_region_begin(region, cx0, cz0, nx, nz, flags, mask.data(), nullptr), "mmgen_region_begin failed");
+        FeaturePlacement* gfp; CaveFeaturePlacement* gcfp; int32_t* gcnt; int gx0, gz0, w, h;
+        RT_CALL(mmgen_region_placement_buffers(region, &gfp, &gcfp, &gcnt, &gx0, &gz0, &w, &h), "mmgen_region_placement_buffers failed");
+        const size_t ni = impSrc.size(), ne = expSrc.size();
+        int32_t* wk = (int32_t*)ensure(d_idxWork, idxWorkCap, (2 * ni + 2 * ne + 4) * sizeof(int32_t));
+        if (ni) {
+            RT_CALL(hipMemcpy(wk, impSrc.data(), ni * 4, hipMemcpyHostToDevice), "H2D failed");
+            RT_CALL(hipMemcpy(wk + ni, impDst.data(), ni * 4, hipMemcpyHostToDevice), "H2D failed");
+            RT_CALL(mmgen_copy_placements(d_cacheFp, d_cacheCfp, d_cacheCnt, wk, gfp, gcfp, gcnt, wk + ni, (int)ni, nullptr), "mmgen_copy_placements failed");
+        }
+        if (ne) {
+            RT_CALL(hipMemcpy(wk + 2 * ni, expSrc.data(), ne * 4, hipMemcpyHostToDevice), "H2D failed");
+            RT_CALL(hipMemcpy(wk + 2 * ni + ne, expDst.data(), ne * 4, hipMemcpyHostToDevice), "H2D failed");
+            RT_CALL(mmgen_copy_placements(gfp, gcfp, gcnt, wk + 2 * ni, d_cacheFp, d_cacheCfp, d_cacheCnt, wk + 2 * ni + ne, (int)ne, nullptr), "mmgen_copy_placements failed");
+        }
+        RT_CALL(mmgen_region_finish(region, dst, nullptr, nullptr, nullptr, nullptr), "mmgen_region_finish failed");
+    }
     if (!contiguous)
         for (size_t i = 0; i < n;) {
             size_t j = i + 1;
@@ -151,6 +200,12 @@ void RegionTerrain::dropFarChunks()
         ++lastDropped;
     }
     if (lastDropped) std::sort(freeSlots.begin(), freeSlots.end(), [](int a, int b) { return a > b; });
+    for (auto it = placementSlot.begin(); it != placementSlot.end();) {
+        const int dx = it->first.first - plannedFor.x, dz = it->first.second - plannedFor.y;
+        if (std::max(std::abs(dx), std::abs(dz)) <= dropRadius + 3) { ++it; continue; }
+        freePlacementSlots.push_back(it->second);
+        it = placementSlot.erase(it);
+    }
 }
 
 // every unmeshed chunk of the drawable square whose four neighbours exist: one count + fill pair over the pool
@@ -228,7 +283,7 @@ void RegionTerrain::meshReady()
 
 void RegionTerrain::tick(float)
 {
-    lastGenerated = lastMeshed = lastRegions = lastDropped = 0;
+    lastGenerated = lastMeshed = lastRegions = lastDropped = lastRingReused = lastRingComputed = 0;
     lastBlockBytesD2H = 0;
     if (!planned || !(plannedFor == currentChunkPos)) { plannedFor = currentChunkPos; planned = true; pending = true; dropFarChunks(); }
     if (!pending) return;

@@ -42,10 +42,11 @@ public:
     int maxChunksPerTick = 4096;          // generation budget of one tick, in chunks
     int dropRadius = 40;                  // chunks farther than this (Chebyshev) from the player are destroyed; = chunkMaxGenRadius of the reference
     bool copyToHost = true;               // false: blocks and meshes stay on the device (renderer interop), Chunk::blocks / verts stay empty
+    bool cachePlacements = true;          // keep the placement lists of generated chunks and feed them back as ring cells of later regions
     bool packedTransfer = true;           // blocks cross PCIe in the run-length wire format (mmgen_pack_*, ~10 KB instead of 96 KB per chunk)
     size_t lastBlockBytesD2H = 0;         // bytes of block data copied to the host by the last tick
     // last tick's accounting
-    int lastGenerated = 0, lastMeshed = 0, lastRegions = 0, lastDropped = 0;
+    int lastGenerated = 0, lastMeshed = 0, lastRegions = 0, lastDropped = 0, lastRingReused = 0, lastRingComputed = 0;
     size_t poolInUse() const { return poolChunks - freeSlots.size(); }
     // device-side results of the last mesh pass (valid until the next tick)
     const Vertex* deviceVerts() const { return (const Vertex*)d_meshOut; }
@@ -66,6 +67,14 @@ private:
     void* d_meshWork = nullptr; size_t meshWorkCap = 0;
     std::vector<uint8_t> hostStage;
 
+    // placement-list cache (device): one slot per chunk whose lists are known, same per-cell layout as the region's placement grid
+    std::map<std::pair<int, int>, int> placementSlot;
+    std::vector<int> freePlacementSlots;
+    FeaturePlacement* d_cacheFp = nullptr;
+    CaveFeaturePlacement* d_cacheCfp = nullptr;
+    int32_t* d_cacheCnt = nullptr;
+    size_t cacheCells = 0;
+    void* d_idxWork = nullptr; size_t idxWorkCap = 0;
     void generateRect(int cx0, int cz0, int nx, int nz);
     void dropFarChunks();
     void meshReady();
