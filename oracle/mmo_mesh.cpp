@@ -56,6 +56,19 @@ const int kUvOff[4][2] = {{0, 0}, {1, 0}, {1, 1}, {0, 1}};
 
 }  // namespace
 
+// the oracle's render-data table and face directions, in the layout of oracle/ref_block_probe.cpp (tests pin them to the reference)
+extern "C" void mmo_block_data(int* out)
+{
+    for (int b = 0; b < numBlocks; ++b) {
+        const BlockRender& d = kBlockRender[b];
+        int* o = out + 13 * b;
+        o[0] = d.side.u; o[1] = d.side.v; o[2] = d.top.u; o[3] = d.top.v; o[4] = d.bottom.u; o[5] = d.bottom.v;
+        for (int k = 0; k < 3; ++k) { o[6 + k] = d.rot[k]; o[9 + k] = d.flip[k]; }
+        o[12] = d.trans;
+    }
+}
+extern "C" void mmo_dir_vecs(int* out18) { for (int d = 0; d < 6; ++d) for (int k = 0; k < 3; ++k) out18[3 * d + k] = kDir[d][k]; }
+
 // Returns the number of vertices (and *nIdxOut indices) the chunk produces; writes at most capVerts / capIdx of them (either
 // output may be null to count only).  neighbors: N(+z), E(+x), S(-z), W(-x) block arrays, null = chunk absent (faces skipped).
 extern "C" long mmo_create_vbos(const uint8_t* blocks, const uint8_t* const neighbors[4], int worldBlockX, int worldBlockZ,

@@ -143,8 +143,18 @@ def make_stages(o):
     print("stages.npz", len(coords), "chunks", ub)
 
 
+def make_block_data():
+    """Per-block render data and face directions straight from the reference's own block.cpp / enums.hpp (oracle/_ref/libblockprobe.so)."""
+    ref = ctypes.CDLL(os.path.join(ROOT, "oracle", "_ref", "libblockprobe.so"))
+    n = ref.ref_num_blocks()
+    data = np.zeros((n, 13), np.int32); dirs = np.zeros((6, 3), np.int32)
+    ref.ref_block_data(data.ctypes.data_as(ctypes.c_void_p)); ref.ref_dir_vecs(dirs.ctypes.data_as(ctypes.c_void_p))
+    np.savez_compressed(os.path.join(HERE, "block_data.npz"), block_data=data, dir_vecs=dirs)
+
+
 if __name__ == "__main__":
     oracle = Oracle()
+    make_block_data()
     make_glm_probe()
     make_oracle_kat(oracle)
     make_stages(oracle)

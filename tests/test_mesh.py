@@ -20,6 +20,43 @@ def _verts(v):
     return f[:, 0:3], f[:, 3:6], f[:, 6:8], v[:, 32:40].copy().view(np.uint64).reshape(-1)
 
 
+def _golden_block_data():
+    import os
+    return np.load(os.path.join(os.path.dirname(__file__), "golden", "block_data.npz"))
+
+
+def test_block_render_data_pinned_to_reference(oracle):
+    """tests/golden/block_data.npz holds the output of the reference's OWN BlockUtils::init / getBlockData and DirectionEnums::dirVecs
+    (compiled from /root/reference/src/terrain/block.cpp + its vendored glm by oracle/Makefile into oracle/_ref/libblockprobe.so; the
+    generating script is tests/golden/make_golden.py).  The oracle's table, the product's packed table (csrc/mm_blockdata.cuh) and,
+    where oracle/_ref exists, the live probe all agree with it."""
+    import ctypes, os, re
+    g = _golden_block_data()
+    ref, dirs = g["block_data"], g["dir_vecs"]
+    n = ref.shape[0]
+    assert n == len(_ids()) == 140
+    got = np.zeros((n, 13), np.int32); d = np.zeros((6, 3), np.int32)
+    oracle.lib.mmo_block_data(got.ctypes.data_as(ctypes.c_void_p)); oracle.lib.mmo_dir_vecs(d.ctypes.data_as(ctypes.c_void_p))
+    assert np.array_equal(got, ref) and np.array_equal(d, dirs)
+    # the product's packed words: bits 0-23 six 4-bit uv components, 24-26 randRot, 27-29 randFlip, 30-31 transparency
+    txt = open(os.path.join(os.path.dirname(__file__), "..", "mega-minecraft_amd", "csrc", "mm_blockdata.cuh")).read()
+    words = [int(w, 16) for w in re.findall(r"0x([0-9a-f]{8})u,", txt)]
+    assert len(words) == n
+    for b, w in enumerate(words):
+        dec = [(w >> (4 * k)) & 15 for k in range(6)] + [(w >> (24 + k)) & 1 for k in range(3)] + [(w >> (27 + k)) & 1 for k in range(3)] + [w >> 30]
+        assert dec == ref[b].tolist(), f"block {b}"
+    # the mesher's face directions in the product source
+    src = open(os.path.join(os.path.dirname(__file__), "..", "mega-minecraft_amd", "csrc", "mmgen_mesh.hip")).read()
+    m = re.search(r"kMeshDir\[6\]\[3\] = \{(.*?)\};", src)
+    assert [int(v) for v in re.findall(r"-?\d+", m.group(1))] == dirs.reshape(-1).tolist()
+    live = os.path.join(os.path.dirname(__file__), "..", "oracle", "_ref", "libblockprobe.so")
+    if os.path.exists(live):
+        r = ctypes.CDLL(live)
+        a = np.zeros((n, 13), np.int32)
+        r.ref_block_data(a.ctypes.data_as(ctypes.c_void_p))
+        assert r.ref_num_blocks() == n and np.array_equal(a, ref)
+
+
 def test_oracle_mesh_hand_cases(oracle):
     ids = _ids()
     assert ids["STONE"] == 57 and ids["GRASS"] == 7 and ids["GRASS_BLOCK"] == 59
