@@ -13,6 +13,7 @@
 #include "mmo_math.h"
 #include "mmo_noise.h"
 #include "mmo_biome.h"
+#include "../include/mmgen_types.h"      // the product's ABI types: reported by mmo_abi_layout for the pinning test only
 
 using namespace mmo;
 
@@ -68,6 +69,31 @@ extern "C" void mmo_block_data(int* out)
     }
 }
 extern "C" void mmo_dir_vecs(int* out18) { for (int d = 0; d < 6; ++d) for (int k = 0; k < 3; ++k) out18[3 * d + k] = kDir[d][k]; }
+
+// ABI layout and constants of include/mmgen_types.h, in the order of ref_abi_layout (oracle/ref_block_probe.cpp)
+extern "C" int mmo_abi_layout(int* out)
+{
+    int n = 0;
+    out[n++] = (int)sizeof(mmgen_cave_layer); out[n++] = (int)offsetof(mmgen_cave_layer, start); out[n++] = (int)offsetof(mmgen_cave_layer, end);
+    out[n++] = (int)offsetof(mmgen_cave_layer, bottom_biome); out[n++] = (int)offsetof(mmgen_cave_layer, top_biome);
+    out[n++] = (int)sizeof(mmgen_feature_placement); out[n++] = (int)offsetof(mmgen_feature_placement, feature); out[n++] = (int)offsetof(mmgen_feature_placement, pos);
+    out[n++] = (int)offsetof(mmgen_feature_placement, can_replace_blocks);
+    out[n++] = (int)sizeof(mmgen_cave_feature_placement); out[n++] = (int)offsetof(mmgen_cave_feature_placement, feature);
+    out[n++] = (int)offsetof(mmgen_cave_feature_placement, pos); out[n++] = (int)offsetof(mmgen_cave_feature_placement, layer_height);
+    out[n++] = (int)offsetof(mmgen_cave_feature_placement, can_replace_blocks);
+    out[n++] = MMGEN_MAX_CAVE_LAYERS_PER_COLUMN; out[n++] = MMGEN_MAX_GATHERED_FEATURES_PER_CHUNK; out[n++] = MMGEN_MAX_GATHERED_CAVE_FEATURES_PER_CHUNK;
+    out[n++] = MMGEN_SEA_LEVEL; out[n++] = MMGEN_LAVA_LEVEL;
+    out[n++] = MMGEN_NUM_BIOMES; out[n++] = MMGEN_NUM_OCEAN_BIOMES; out[n++] = MMGEN_NUM_OCEAN_AND_BEACH_BIOMES; out[n++] = MMGEN_NUM_CAVE_BIOMES;
+    out[n++] = MMGEN_NUM_MATERIALS; out[n++] = MMGEN_NUM_STRATIFIED_MATERIALS; out[n++] = MMGEN_NUM_FORWARD_MATERIALS; out[n++] = MMGEN_NUM_ERODED_MATERIALS;
+    out[n++] = MMGEN_NUM_FEATURES; out[n++] = MMGEN_NUM_CAVE_FEATURES; out[n++] = MMB_NUM_BLOCKS; out[n++] = MMB_NUM_NON_SOLID_BLOCKS;
+    out[n++] = MMB_BEDROCK; out[n++] = MMB_STONE; out[n++] = MMB_DEEPSLATE; out[n++] = MMB_BLACKSTONE; out[n++] = MMB_QUARTZ;
+    out[n++] = MMBIO_BEACH; out[n++] = MMBIO_MESA; out[n++] = MMBIO_CRYSTALS; out[n++] = MMBIO_ARCHIPELAGO;
+    out[n++] = MMCB_CRYSTAL_CAVES; out[n++] = MMCB_LUSH_CAVES; out[n++] = MMCB_WARPED_FOREST;
+    out[n++] = MMM_DIRT; out[n++] = MMM_SANDSTONE; out[n++] = MMM_GRAVEL;
+    out[n++] = MMF_ICEBERG; out[n++] = MMF_PURPLE_MUSHROOM; out[n++] = MMF_PALM_TREE;
+    out[n++] = MMCF_GLOWSTONE_CLUSTER; out[n++] = MMCF_CRYSTAL_PILLAR;
+    return n;
+}
 
 // Returns the number of vertices (and *nIdxOut indices) the chunk produces; writes at most capVerts / capIdx of them (either
 // output may be null to count only).  neighbors: N(+z), E(+x), S(-z), W(-x) block arrays, null = chunk absent (faces skipped).

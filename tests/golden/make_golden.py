@@ -149,7 +149,9 @@ def make_block_data():
     n = ref.ref_num_blocks()
     data = np.zeros((n, 13), np.int32); dirs = np.zeros((6, 3), np.int32)
     ref.ref_block_data(data.ctypes.data_as(ctypes.c_void_p)); ref.ref_dir_vecs(dirs.ctypes.data_as(ctypes.c_void_p))
-    np.savez_compressed(os.path.join(HERE, "block_data.npz"), block_data=data, dir_vecs=dirs)
+    abi = np.zeros(256, np.int32)
+    na = ref.ref_abi_layout(abi.ctypes.data_as(ctypes.c_void_p))
+    np.savez_compressed(os.path.join(HERE, "block_data.npz"), block_data=data, dir_vecs=dirs, abi_layout=abi[:na])
 
 
 if __name__ == "__main__":

@@ -57,6 +57,23 @@ def test_block_render_data_pinned_to_reference(oracle):
         assert r.ref_num_blocks() == n and np.array_equal(a, ref)
 
 
+def test_abi_types_pinned_to_reference_headers(oracle):
+    """Struct sizes / field offsets of CaveLayer, FeaturePlacement, CaveFeaturePlacement, the path's constants, the enum counts and
+    a sample of enumerators, as the reference's own biome.hpp / block.hpp define them (golden from oracle/_ref/libblockprobe.so),
+    equal what include/mmgen_types.h declares (reported by the oracle library, which includes that header for this purpose)."""
+    import ctypes, os
+    ref = _golden_block_data()["abi_layout"]
+    got = np.zeros(256, np.int32)
+    n = oracle.lib.mmo_abi_layout(got.ctypes.data_as(ctypes.c_void_p))
+    assert n == len(ref) and np.array_equal(got[:n], ref), (got[:n].tolist(), ref.tolist())
+    assert ref[0] == 12 and ref[5] == 20 and ref[9] == 24              # sizeof(CaveLayer), sizeof(FeaturePlacement), sizeof(CaveFeaturePlacement)
+    live = os.path.join(os.path.dirname(__file__), "..", "oracle", "_ref", "libblockprobe.so")
+    if os.path.exists(live):
+        a = np.zeros(256, np.int32)
+        m = ctypes.CDLL(live).ref_abi_layout(a.ctypes.data_as(ctypes.c_void_p))
+        assert m == n and np.array_equal(a[:m], ref)
+
+
 def test_oracle_mesh_hand_cases(oracle):
     ids = _ids()
     assert ids["STONE"] == 57 and ids["GRASS"] == 7 and ids["GRASS_BLOCK"] == 59
