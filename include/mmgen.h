@@ -21,7 +21,11 @@ extern "C" {
 #endif
 
 /* BiomeUtils::init() (src/terrain/biome.hpp:299-305, biomeFuncs.hpp:725-1256) + cudaSetDevice (src/main.cpp:31).
- * Rule tables are compile-time constants of the code object, so this only selects the device and checks it is gfx950. */
+ * Rule tables are compile-time constants of the code object; this selects the device, checks it is gfx950 and builds the per-device
+ * simplex-noise lookup image (one tiny launch + wait), so that no later call synchronises or allocates behind the caller's back.
+ * Threading contract: calls may come from several host threads and streams; the stage calls that use library-owned scratch
+ * (mmgen_generate_caves, mmgen_erode_zone(s)) are serialised per process by the caller (the reference is single-threaded,
+ * terrain.cpp:587-960) - use one mmgen_region per stream for concurrent pipelines, it owns its scratch. */
 int mmgen_init(int device);
 const char* mmgen_error_string(int code);
 /* pre-size the library-internal scratch (per-column cave info) so that later calls allocate nothing (graph capture) */
@@ -115,6 +119,9 @@ int mmgen_region_begin(mmgen_region* region, int cx0, int cz0, int nx, int nz, u
 int mmgen_region_placement_buffers(mmgen_region* region, mmgen_feature_placement** d_fp /*[grid][MMGEN_FP_CAP]*/,
                                    mmgen_cave_feature_placement** d_cfp /*[grid][MMGEN_CFP_CAP]*/, int32_t** d_counts /*[grid][2]*/,
                                    int* grid_cx0, int* grid_cz0, int* grid_w, int* grid_h);
+/* optional middle step: the base blocks of the rectangle (kernFill without feature lists, chunk.cu:1202-1510).  It needs nothing from the
+ * placement ring, so a tiling caller issues it while the ring exchange is in flight; finish (same d_blocks) then skips it. */
+int mmgen_region_fill(mmgen_region* region, uint8_t* d_blocks, void* stream);
 int mmgen_region_finish(mmgen_region* region, uint8_t* d_blocks, float* d_heightfields /*nullable*/, float* d_layers /*[n][20][256], nullable*/,
                         mmgen_cave_layer* d_cave_layers /*[n][256][32], nullable*/, void* stream);
 int mmgen_region_last_erosion_passes(const mmgen_region* region);
@@ -125,6 +132,21 @@ int mmgen_region_last_erosion_passes(const mmgen_region* region);
 int mmgen_copy_placements(const mmgen_feature_placement* d_src_fp, const mmgen_cave_feature_placement* d_src_cfp, const int32_t* d_src_counts,
                           const int32_t* d_src_idx, mmgen_feature_placement* d_dst_fp, mmgen_cave_feature_placement* d_dst_cfp, int32_t* d_dst_counts,
                           const int32_t* d_dst_idx, int n, void* stream);
+
+/* Compact wire form of placement-grid cells for the ring exchange between spatial tiles (SURVEY 8e "counts, then payload"; the reference
+ * has no multi-GPU path, the lists are those of chunk.cu:1158-1196).  For a list of n grid cells d_cells:
+ *   mmgen_ring_header : d_header [n][2] = the cells' two list lengths (as counted, a cave count may exceed MMGEN_CFP_CAP);
+ *   mmgen_ring_offsets: d_offsets [n+1] = exclusive scan of the cells' payload words 5 min(c0, FP_CAP) + 6 min(c1, CFP_CAP)
+ *                       (both sides run it: the receiver sizes its payload buffer from the received header);
+ *   mmgen_ring_pack   : payload words of cell i at d_payload + d_offsets[i]: its surface entries (5 words each), then its cave entries (6);
+ *   mmgen_ring_unpack : the inverse, into the placement grid of the receiver, lengths included.
+ * Cells of several peers are handled in one call: concatenate the peers' cell lists, the peers' messages are contiguous slices. */
+int mmgen_ring_header(const int32_t* d_counts, const int32_t* d_cells, int n, int32_t* d_header, void* stream);
+int mmgen_ring_offsets(const int32_t* d_header, int n, int32_t* d_offsets, void* stream);
+int mmgen_ring_pack(const mmgen_feature_placement* d_fp, const mmgen_cave_feature_placement* d_cfp, const int32_t* d_cells, const int32_t* d_header,
+                    const int32_t* d_offsets, int n, int32_t* d_payload, void* stream);
+int mmgen_ring_unpack(const int32_t* d_payload, const int32_t* d_header, const int32_t* d_offsets, const int32_t* d_cells, int n,
+                      mmgen_feature_placement* d_fp, mmgen_cave_feature_placement* d_cfp, int32_t* d_counts, void* stream);
 
 /* Measurement hooks (not part of the reference's interface): when enabled every kernel launch is bracketed by HIP events on its
  * launch stream; mmgen_profile_collect() waits for them and returns total milliseconds and launch counts per kernel id

@@ -15,6 +15,8 @@
 // only at the edge of the int32 world, tests "far coordinates") take the direct arithmetic path.  EVERY kernel that can reach simplex2/simplex3 calls
 // noise_tables_init() before its first use.
 #pragma once
+#include <atomic>
+#include <mutex>
 #include "mm_math.cuh"
 
 namespace mm {
@@ -104,22 +106,26 @@ static __global__ void __launch_bounds__(256) k_noise_tables_build()
     }
 }
 
-// Host side: every launch wrapper of a translation unit that evaluates simplex noise calls this first.  The first call per device
-// builds the image on the caller's stream and waits for it, so that launches on other streams can never see a half-built image.
+// Host side: mmgen_init() builds the image of every translation unit on the selected device (mmk::prepare_*), so launches after
+// init only test a flag here (safe under stream capture).  A launch on a device that was never initialised builds the image on
+// the caller's stream and waits for it, so that launches on other streams can never see a half-built image.
 static inline int noise_tables_ensure(hipStream_t s)
 {
-    static bool built[64] = {};
+    static std::atomic<bool> built[64];
+    static std::mutex mu;
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return (int)e;
     if (dev < 0 || dev >= 64) return (int)hipErrorInvalidDevice;
-    if (built[dev]) return 0;
+    if (built[dev].load(std::memory_order_acquire)) return 0;
+    std::lock_guard<std::mutex> lk(mu);
+    if (built[dev].load(std::memory_order_relaxed)) return 0;
     hipLaunchKernelGGL(k_noise_tables_build, dim3(1), dim3(256), 0, s);
     e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
     e = hipStreamSynchronize(s);
     if (e != hipSuccess) return (int)e;
-    built[dev] = true;
+    built[dev].store(true, std::memory_order_release);
     return 0;
 }
 

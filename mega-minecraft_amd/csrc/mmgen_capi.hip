@@ -3,6 +3,7 @@
 #include "mmgen_kernels.h"
 #include "mmgen_erosion.h"
 #include "mmgen_features.h"
+#include "mmgen_prof.h"
 #include <mutex>
 #include <cstring>
 #include <cstdio>
@@ -57,7 +58,11 @@ int mmgen_init(int device)
         return (int)hipErrorNoBinaryForGpu;
     }
     g_device = device;
-    return 0;
+    // per-device noise-table images of the translation units that evaluate simplex noise: built here once, so that stage calls
+    // after init only launch (no synchronisation on their first use, safe under stream capture)
+    int ne = mmk::prepare_kernels();
+    if (ne) return ne;
+    return mmk::prepare_features();
 }
 
 const char* mmgen_error_string(int code) { return hipGetErrorString((hipError_t)code); }
@@ -95,7 +100,7 @@ int mmgen_erode_zones(float* d_gathered, int num_zones, float* d_acc, int* max_p
     int e = ensure_erosion(num_zones);
     if (e) return e;
     return mmk::erode_zones(d_gathered, (size_t)MMGEN_GATHERED_LAYERS_SIZE, num_zones, g_erodeWork, g_erodeState, d_acc,
-                            (size_t)MMGEN_EROSION_GRID_NUM_COLS, (hipStream_t)stream, max_passes, nullptr);
+                            (size_t)MMGEN_EROSION_GRID_NUM_COLS, (hipStream_t)stream, max_passes);
 }
 
 int mmgen_erode_zone(float* d_gathered, float* d_acc, void* stream) { return mmgen_erode_zones(d_gathered, 1, d_acc, nullptr, stream); }

@@ -26,7 +26,7 @@ namespace mmk {
 size_t erosion_work_bytes(int zones);
 size_t erosion_state_bytes(int zones);
 int erode_zones(float* gathered, size_t strideFloats, int zones, float* work, mm::ErosionState* states, float* accOut, size_t accStride,
-                hipStream_t s, int* maxPasses, void (*prof)(int, hipStream_t, bool));
+                hipStream_t s, int* maxPasses);
 int erosion_gather(const float* layers, const float* hf, const int* zoneChunkIdx, int zones, float* gathered, size_t strideFloats, hipStream_t s);
 int erosion_scatter(const float* gathered, size_t strideFloats, const int* zoneChunkIdxOut, int zones, float* layersOut, hipStream_t s);
 }  // namespace mmk

@@ -15,6 +15,7 @@
 #include <vector>
 #include "mm_biome.cuh"
 #include "mmgen_erosion.h"
+#include "mmgen_prof.h"
 
 namespace mm {
 
@@ -220,21 +221,22 @@ size_t erosion_state_bytes(int zones) { return (size_t)zones * sizeof(mm::Erosio
 // Runs the relaxation to convergence for `zones` packed zone buffers (stride in floats).  Synchronises the stream (the
 // reference's erodeZone is synchronous too).  Returns 0 or a hipError_t; *maxPasses receives the largest pass count.
 int erode_zones(float* gathered, size_t strideFloats, int zones, float* work, mm::ErosionState* states, float* accOut, size_t accStride,
-                hipStream_t s, int* maxPasses, void (*prof)(int, hipStream_t, bool))
+                hipStream_t s, int* maxPasses)
 {
     if (zones <= 0) return 0;
-    hipLaunchKernelGGL(mm::k_erode_init, dim3((2 * ZN + 255) / 256, zones), dim3(256), 0, s, states, work, zones);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return (int)e;
+    MMK_LAUNCH(KID_ERODE_INIT, mm::k_erode_init, dim3((2 * ZN + 255) / 256, zones), dim3(256), s, states, work, zones);
+    hipError_t e = hipSuccess;
 
     std::vector<mm::ErosionState> h(zones);
     const dim3 grid(12, 12, zones), block(32, EROSION_ROWS);
     int launched = 0;
     for (;;) {
         const int batch = launched == 0 ? 48 : 16;
-        if (prof) prof(0, s, true);
+        // one event pair around the whole batch of passes (an event per 19 us launch would perturb what it measures)
+        const bool prof_ = profile_enabled();
+        if (prof_) profile_begin(KID_ERODE_PASS, s);
         for (int i = 0; i < batch; ++i) hipLaunchKernelGGL(mm::k_erode_pass, grid, block, 0, s, gathered, strideFloats, work, states, launched + i);
-        if (prof) prof(batch, s, false);
+        if (prof_) profile_end(s);
         launched += batch;
         e = hipMemcpyAsync(h.data(), states, sizeof(mm::ErosionState) * zones, hipMemcpyDeviceToHost, s);
         if (e != hipSuccess) return (int)e;
@@ -247,24 +249,23 @@ int erode_zones(float* gathered, size_t strideFloats, int zones, float* work, mm
         if (launched > 100000) return (int)hipErrorLaunchFailure;
     }
     if (maxPasses) { int m = 0; for (auto& z : h) { const int ps = z.slot[(launched - 1) & 1].passes; m = ps > m ? ps : m; } *maxPasses = m; }
-    hipLaunchKernelGGL(mm::k_erode_writeback, dim3(ZN / 256, 1, zones), dim3(256), 0, s, gathered, strideFloats, work, states, accOut, accStride,
-                       launched - 1);
-    e = hipGetLastError();
-    return (int)e;
+    MMK_LAUNCH(KID_ERODE_WRITEBACK, mm::k_erode_writeback, dim3(ZN / 256, 1, zones), dim3(256), s, gathered, strideFloats, work, states, accOut,
+               accStride, launched - 1);
+    return 0;
 }
 
 int erosion_gather(const float* layers, const float* hf, const int* zoneChunkIdx, int zones, float* gathered, size_t strideFloats, hipStream_t s)
 {
     if (zones <= 0) return 0;
-    hipLaunchKernelGGL(mm::k_erosion_gather, dim3(576, 9, zones), dim3(256), 0, s, layers, hf, zoneChunkIdx, gathered, strideFloats);
-    return (int)hipGetLastError();
+    MMK_LAUNCH(KID_EROSION_GATHER, mm::k_erosion_gather, dim3(576, 9, zones), dim3(256), s, layers, hf, zoneChunkIdx, gathered, strideFloats);
+    return 0;
 }
 
 int erosion_scatter(const float* gathered, size_t strideFloats, const int* zoneChunkIdxOut, int zones, float* layersOut, hipStream_t s)
 {
     if (zones <= 0) return 0;
-    hipLaunchKernelGGL(mm::k_erosion_scatter, dim3(144, 8, zones), dim3(256), 0, s, gathered, strideFloats, zoneChunkIdxOut, layersOut);
-    return (int)hipGetLastError();
+    MMK_LAUNCH(KID_EROSION_SCATTER, mm::k_erosion_scatter, dim3(144, 8, zones), dim3(256), s, gathered, strideFloats, zoneChunkIdxOut, layersOut);
+    return 0;
 }
 
 }  // namespace mmk

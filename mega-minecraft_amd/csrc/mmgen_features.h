@@ -5,6 +5,7 @@
 #include "../../include/mmgen_types.h"
 
 namespace mmk {
+int prepare_features();    // builds this translation unit's noise-table image on the current device (called from mmgen_init)
 int launch_feature_placements(const float* hf, const float* bw, const float* layers, const mmgen_cave_layer* cl, const int32_t* pos, int n,
                               mmgen_feature_placement* fp, mmgen_cave_feature_placement* cfp, int* counts, const int* chunkList, hipStream_t s);
 int launch_gather_placements(const mmgen_feature_placement* fp, const mmgen_cave_feature_placement* cfp, const int* counts, const int* target,

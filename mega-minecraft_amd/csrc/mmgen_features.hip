@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 #include "mm_features.cuh"
 #include "mmgen_features.h"
+#include "mmgen_prof.h"
 
 namespace mm {
 
@@ -622,23 +623,29 @@ k_feature_box(int isCave, int feature, int fx, int fy, int fz, int layerHeight, 
 
 namespace mmk {
 
+#define LAUNCH(KID, KERNEL, GRID, BLOCK, STREAM, ...)                                        \
+    do {                                                                                     \
+        { const int ne_ = mm::noise_tables_ensure(STREAM); if (ne_) return ne_; }            \
+        MMK_LAUNCH(KID, KERNEL, GRID, BLOCK, STREAM, __VA_ARGS__);                           \
+    } while (0)
+
+int prepare_features() { return mm::noise_tables_ensure(nullptr); }
+
 int launch_feature_box(int isCave, int feature, const int* fpos, int layerHeight, const int* boxMin, const int* boxSize, uint8_t* out, hipStream_t s)
 {
     const int n = boxSize[0] * boxSize[1] * boxSize[2];
     if (n <= 0) return 0;
-    { const int ne_ = mm::noise_tables_ensure(s); if (ne_) return ne_; }
-    hipLaunchKernelGGL(mm::k_feature_box, dim3((n + 255) / 256), dim3(256), 0, s, isCave, feature, fpos[0], fpos[1], fpos[2], layerHeight,
-                       boxMin[0], boxMin[1], boxMin[2], boxSize[0], boxSize[1], boxSize[2], out);
-    return (int)hipGetLastError();
+    LAUNCH(KID_FEATURE_BOX, mm::k_feature_box, dim3((n + 255) / 256), dim3(256), s, isCave, feature, fpos[0], fpos[1], fpos[2], layerHeight,
+           boxMin[0], boxMin[1], boxMin[2], boxSize[0], boxSize[1], boxSize[2], out);
+    return 0;
 }
 
 int launch_feature_placements(const float* hf, const float* bw, const float* layers, const mmgen_cave_layer* cl, const int32_t* pos, int n,
                               mmgen_feature_placement* fp, mmgen_cave_feature_placement* cfp, int* counts, const int* chunkList, hipStream_t s)
 {
     if (n <= 0) return 0;
-    { const int ne_ = mm::noise_tables_ensure(s); if (ne_) return ne_; }
-    hipLaunchKernelGGL(mm::k_feature_placements, dim3(n), dim3(256), 0, s, hf, bw, layers, cl, (const int2*)pos, fp, cfp, counts, chunkList);
-    return (int)hipGetLastError();
+    LAUNCH(KID_FEATURE_PLACEMENTS, mm::k_feature_placements, dim3(n), dim3(256), s, hf, bw, layers, cl, (const int2*)pos, fp, cfp, counts, chunkList);
+    return 0;
 }
 
 int launch_gather_placements(const mmgen_feature_placement* fp, const mmgen_cave_feature_placement* cfp, const int* counts, const int* target,
@@ -646,26 +653,25 @@ int launch_gather_placements(const mmgen_feature_placement* fp, const mmgen_cave
                              const int32_t* gridPos, hipStream_t s)
 {
     if (nOut <= 0) return 0;
-    { const int ne_ = mm::noise_tables_ensure(s); if (ne_) return ne_; }
-    hipLaunchKernelGGL(mm::k_gather_placements, dim3(nOut), dim3(256), 0, s, fp, cfp, counts, target, gridW, gridH, gfp, gcfp, bounds, (const int2*)gridPos);
-    return (int)hipGetLastError();
+    LAUNCH(KID_GATHER_PLACEMENTS, mm::k_gather_placements, dim3(nOut), dim3(256), s, fp, cfp, counts, target, gridW, gridH, gfp, gcfp, bounds,
+           (const int2*)gridPos);
+    return 0;
 }
 
 int launch_apply_features(uint8_t* blocks, const int32_t* pos, int n, const mmgen_feature_placement* gfp, const mmgen_cave_feature_placement* gcfp,
                           const int* bounds, const int* srcIdx, hipStream_t s)
 {
     if (n <= 0) return 0;
-    { const int ne_ = mm::noise_tables_ensure(s); if (ne_) return ne_; }
-    hipLaunchKernelGGL(mm::k_apply_features, dim3(n * (256 / APPLY_COLS)), dim3(APPLY_THREADS), 0, s, blocks, (const int2*)pos, gfp, gcfp, bounds, srcIdx);
-    return (int)hipGetLastError();
+    LAUNCH(KID_APPLY_FEATURES, mm::k_apply_features, dim3(n * (256 / APPLY_COLS)), dim3(APPLY_THREADS), s, blocks, (const int2*)pos, gfp, gcfp, bounds,
+           srcIdx);
+    return 0;
 }
 
 int launch_decorators(uint8_t* blocks, const float* hf, const float* bw, const mmgen_cave_layer* cl, const int32_t* pos, int n, const int* srcIdx, hipStream_t s)
 {
     if (n <= 0) return 0;
-    { const int ne_ = mm::noise_tables_ensure(s); if (ne_) return ne_; }
-    hipLaunchKernelGGL(mm::k_decorators, dim3(n), dim3(256), 0, s, blocks, hf, bw, cl, (const int2*)pos, srcIdx);
-    return (int)hipGetLastError();
+    LAUNCH(KID_DECORATORS, mm::k_decorators, dim3(n), dim3(256), s, blocks, hf, bw, cl, (const int2*)pos, srcIdx);
+    return 0;
 }
 
 }  // namespace mmk

@@ -13,8 +13,5 @@ int launch_caves(const float* hf, const float* bw, const int32_t* pos, int n, mm
 int launch_fill(const float* hf, const float* bw, const float* layers, const mmgen_cave_layer* caveLayers, const int32_t* pos, int n,
                 uint8_t* blocks, const int* srcIdx /*nullable: input chunk of each output chunk*/, hipStream_t s);
 int launch_probe(int fn, const float* in, int n, float* out, hipStream_t s);
-void profile_enable(bool on);
-int profile_num_kernels();
-const char* profile_kernel_name(int id);
-int profile_collect(double* total_ms, long long* counts);
+int prepare_kernels();      // builds this translation unit's noise-table image on the current device (called from mmgen_init)
 }  // namespace mmk

@@ -8,7 +8,7 @@
 // shouldGenerateCaveAtBlock :755-810, kernGenerateCaves :812-937, chunkFillPlaceBlock :1202-1380, kernFill :1382-1510.
 #include "mm_biome.cuh"
 #include "mmgen_kernels.h"
-#include <vector>
+#include "mmgen_prof.h"
 
 namespace mm {
 
@@ -625,52 +625,18 @@ __global__ void __launch_bounds__(256) k_probe(int fn, const float* __restrict__
 // =========================================================================================================
 namespace mmk {
 
-// ---------------------------------------------------------------------------------------------------------
-// Optional per-kernel timing with HIP events on the launch stream (used by bench.py for the roofline line; off by default).
-// ---------------------------------------------------------------------------------------------------------
-struct ProfRec { int id; hipEvent_t a, b; };
-static bool g_prof = false;
-static std::vector<ProfRec> g_recs;
-static std::vector<hipEvent_t> g_pool;
-static const char* const kKernelNames[] = {"k_heightfield", "k_layers", "k_fix_backward", "k_cave_columns", "k_cave_voxels", "k_cave_biomes", "k_fill", "k_probe"};
-enum { KID_HEIGHTFIELD, KID_LAYERS, KID_FIX_BACKWARD, KID_CAVE_COLUMNS, KID_CAVE_VOXELS, KID_CAVE_BIOMES, KID_FILL, KID_PROBE, KID_COUNT };
+using mmk::KID_HEIGHTFIELD; using mmk::KID_LAYERS; using mmk::KID_FIX_BACKWARD; using mmk::KID_CAVE_COLUMNS; using mmk::KID_CAVE_VOXELS;
+using mmk::KID_CAVE_BIOMES; using mmk::KID_FILL; using mmk::KID_PROBE;
 
-static hipEvent_t get_event()
-{
-    if (!g_pool.empty()) { hipEvent_t e = g_pool.back(); g_pool.pop_back(); return e; }
-    hipEvent_t e; (void)hipEventCreate(&e); return e;
-}
-
-void profile_enable(bool on) { g_prof = on; }
-int profile_num_kernels() { return KID_COUNT; }
-const char* profile_kernel_name(int id) { return (id >= 0 && id < KID_COUNT) ? kKernelNames[id] : ""; }
-// Synchronises the recorded events, accumulates total milliseconds and launch counts per kernel id, and clears the records.
-int profile_collect(double* total_ms, long long* counts)
-{
-    for (int i = 0; i < KID_COUNT; ++i) { total_ms[i] = 0; counts[i] = 0; }
-    for (auto& r : g_recs) {
-        hipError_t e = hipEventSynchronize(r.b);
-        if (e != hipSuccess) return (int)e;
-        float ms = 0.f;
-        e = hipEventElapsedTime(&ms, r.a, r.b);
-        if (e != hipSuccess) return (int)e;
-        total_ms[r.id] += ms; counts[r.id] += 1;
-        g_pool.push_back(r.a); g_pool.push_back(r.b);
-    }
-    g_recs.clear();
-    return 0;
-}
-
+// every kernel of this translation unit can reach simplex noise: make sure the per-device table image exists, then launch (timed when
+// profiling is on, mmgen_prof.h)
 #define LAUNCH(KID, KERNEL, GRID, BLOCK, STREAM, ...)                                        \
     do {                                                                                     \
         { const int ne_ = mm::noise_tables_ensure(STREAM); if (ne_) return ne_; }            \
-        ProfRec rec_; rec_.id = (KID);                                                       \
-        if (g_prof) { rec_.a = get_event(); rec_.b = get_event(); (void)hipEventRecord(rec_.a, (STREAM)); } \
-        hipLaunchKernelGGL(KERNEL, GRID, BLOCK, 0, (STREAM), __VA_ARGS__);                   \
-        if (g_prof) { (void)hipEventRecord(rec_.b, (STREAM)); g_recs.push_back(rec_); }      \
-        hipError_t e_ = hipGetLastError();                                                   \
-        if (e_ != hipSuccess) return (int)e_;                                                \
+        MMK_LAUNCH(KID, KERNEL, GRID, BLOCK, STREAM, __VA_ARGS__);                           \
     } while (0)
+
+int prepare_kernels() { return mm::noise_tables_ensure(nullptr); }
 
 int launch_heightfield(const int32_t* pos, int n, float* hf, float* bw, float* gathered, hipStream_t s)
 {

@@ -20,6 +20,7 @@
 #include "mm_noise.cuh"
 #include "mm_blockdata.cuh"
 #include "../../include/mmgen.h"
+#include "mmgen_prof.h"
 
 namespace mm {
 
@@ -362,7 +363,7 @@ int mmgen_mesh_count(const uint8_t* d_blocks, const int32_t* d_chunk_idx, const 
 {
     if (n < 0 || (n > 0 && (!d_blocks || !d_column_verts || !d_chunk_verts))) return (int)hipErrorInvalidValue;
     if (n == 0) return 0;
-    hipLaunchKernelGGL(mm::k_mesh_count, dim3(n), dim3(256), 0, (hipStream_t)stream, d_blocks, d_chunk_idx, d_neighbor_idx, d_column_verts, d_chunk_verts);
+    MMK_LAUNCH_NORET(mmk::KID_MESH_COUNT, mm::k_mesh_count, dim3(n), dim3(256), (hipStream_t)stream, d_blocks, d_chunk_idx, d_neighbor_idx, d_column_verts, d_chunk_verts);
     return (int)hipGetLastError();
 }
 
@@ -372,7 +373,7 @@ int mmgen_mesh_fill(const uint8_t* d_blocks, const int32_t* d_chunk_idx, const i
     if (n < 0 || (n > 0 && (!d_blocks || !d_chunk_world_block_pos || !d_column_verts || !d_vert_offset || !d_verts || !d_idx)))
         return (int)hipErrorInvalidValue;
     if (n == 0) return 0;
-    hipLaunchKernelGGL(mm::k_mesh_fill, dim3(n), dim3(256), 0, (hipStream_t)stream, d_blocks, d_chunk_idx, d_neighbor_idx, (const int2*)d_chunk_world_block_pos,
+    MMK_LAUNCH_NORET(mmk::KID_MESH_FILL, mm::k_mesh_fill, dim3(n), dim3(256), (hipStream_t)stream, d_blocks, d_chunk_idx, d_neighbor_idx, (const int2*)d_chunk_world_block_pos,
                        d_column_verts, d_vert_offset, d_verts, d_idx);
     return (int)hipGetLastError();
 }

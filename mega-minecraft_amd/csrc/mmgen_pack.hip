@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "../../include/mmgen.h"
+#include "mmgen_prof.h"
 
 namespace mm {
 
@@ -113,7 +114,7 @@ int mmgen_pack_count(const uint8_t* d_blocks, const int32_t* d_chunk_idx, int n,
 {
     if (n < 0 || (n > 0 && (!d_blocks || !d_col_runs || !d_chunk_bytes))) return (int)hipErrorInvalidValue;
     if (n == 0) return 0;
-    hipLaunchKernelGGL(mm::k_pack_count, dim3(n), dim3(256), 0, (hipStream_t)stream, d_blocks, d_chunk_idx, d_col_runs, d_chunk_bytes);
+    MMK_LAUNCH_NORET(mmk::KID_PACK_COUNT, mm::k_pack_count, dim3(n), dim3(256), (hipStream_t)stream, d_blocks, d_chunk_idx, d_col_runs, d_chunk_bytes);
     return (int)hipGetLastError();
 }
 
@@ -122,7 +123,7 @@ int mmgen_pack_fill(const uint8_t* d_blocks, const int32_t* d_chunk_idx, int n, 
 {
     if (n < 0 || (n > 0 && (!d_blocks || !d_col_runs || !d_chunk_offset || !d_out))) return (int)hipErrorInvalidValue;
     if (n == 0) return 0;
-    hipLaunchKernelGGL(mm::k_pack_fill, dim3(n), dim3(256), 0, (hipStream_t)stream, d_blocks, d_chunk_idx, d_col_runs, d_chunk_offset, d_out);
+    MMK_LAUNCH_NORET(mmk::KID_PACK_FILL, mm::k_pack_fill, dim3(n), dim3(256), (hipStream_t)stream, d_blocks, d_chunk_idx, d_col_runs, d_chunk_offset, d_out);
     return (int)hipGetLastError();
 }
 
@@ -130,7 +131,7 @@ int mmgen_unpack(const uint8_t* d_packed, const uint64_t* d_chunk_offset, int n,
 {
     if (n < 0 || (n > 0 && (!d_packed || !d_chunk_offset || !d_blocks))) return (int)hipErrorInvalidValue;
     if (n == 0) return 0;
-    hipLaunchKernelGGL(mm::k_unpack, dim3(n), dim3(256), 0, (hipStream_t)stream, d_packed, d_chunk_offset, d_blocks);
+    MMK_LAUNCH_NORET(mmk::KID_UNPACK, mm::k_unpack, dim3(n), dim3(256), (hipStream_t)stream, d_packed, d_chunk_offset, d_blocks);
     return (int)hipGetLastError();
 }
 

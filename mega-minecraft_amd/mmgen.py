@@ -248,6 +248,11 @@ class MMGen:
             vp, i32 = ctypes.c_void_p, ctypes.c_int
             self.lib.mmgen_region_begin.argtypes = [vp, i32, i32, i32, i32, ctypes.c_uint, vp, vp]
             self.lib.mmgen_region_finish.argtypes = [vp, vp, vp, vp, vp, vp]
+            self.lib.mmgen_region_fill.argtypes = [vp, vp, vp]
+            self.lib.mmgen_ring_header.argtypes = [vp, vp, i32, vp, vp]
+            self.lib.mmgen_ring_offsets.argtypes = [vp, i32, vp, vp]
+            self.lib.mmgen_ring_pack.argtypes = [vp, vp, vp, vp, vp, i32, vp, vp]
+            self.lib.mmgen_ring_unpack.argtypes = [vp, vp, vp, vp, i32, vp, vp, vp, vp]
             self.lib.mmgen_region_placement_buffers.argtypes = [vp] + [ctypes.POINTER(vp)] * 3 + [ctypes.POINTER(i32)] * 4
             self.lib.mmgen_region_last_erosion_passes.argtypes = [vp]
         return self._region_handle
@@ -255,8 +260,37 @@ class MMGen:
     def region_begin(self, cx0, cz0, nx, nz, flags, local_mask=None):
         mask = None
         if local_mask is not None:
-            mask = (ctypes.c_uint8 * len(local_mask))(*[1 if m else 0 for m in local_mask])
+            mask = local_mask if isinstance(local_mask, ctypes.Array) else (ctypes.c_uint8 * len(local_mask))(*[1 if m else 0 for m in local_mask])
         self._check(self.lib.mmgen_region_begin(self._region(), cx0, cz0, nx, nz, flags, mask, self._stream()), "mmgen_region_begin")
+        self._region_blocks = None
+
+    def region_fill(self, nx, nz):
+        """Base blocks of the rectangle (no feature lists needed): issued while the placement-ring exchange is in flight."""
+        self._region_blocks = self._empty((nx * nz, BLOCKS), self.torch.uint8)
+        self._check(self.lib.mmgen_region_fill(self._region(), self._p(self._region_blocks), self._stream()), "mmgen_region_fill")
+
+    # compact ring exchange (include/mmgen.h mmgen_ring_*): all tensors int32 on the device
+    def ring_header(self, bufs, cells):
+        n = cells.shape[0]
+        header = self._empty((n, 2), self.torch.int32)
+        self._check(self.lib.mmgen_ring_header(self._p(bufs["counts"]), self._p(cells), n, self._p(header), self._stream()), "mmgen_ring_header")
+        return header
+
+    def ring_offsets(self, header):
+        n = header.shape[0]
+        off = self._empty((n + 1,), self.torch.int32)
+        self._check(self.lib.mmgen_ring_offsets(self._p(header), n, self._p(off), self._stream()), "mmgen_ring_offsets")
+        return off
+
+    def ring_pack(self, bufs, cells, header, offsets, total_words):
+        payload = self._empty((max(total_words, 1),), self.torch.int32)
+        self._check(self.lib.mmgen_ring_pack(self._p(bufs["fp"]), self._p(bufs["cfp"]), self._p(cells), self._p(header), self._p(offsets),
+                                             cells.shape[0], self._p(payload), self._stream()), "mmgen_ring_pack")
+        return payload
+
+    def ring_unpack(self, bufs, cells, header, offsets, payload):
+        self._check(self.lib.mmgen_ring_unpack(self._p(payload), self._p(header), self._p(offsets), self._p(cells), cells.shape[0],
+                                               self._p(bufs["fp"]), self._p(bufs["cfp"]), self._p(bufs["counts"]), self._stream()), "mmgen_ring_unpack")
 
     def region_placement_buffers(self):
         """Torch views (no copy) of the region's ring-extended placement grid: fp [cells,256,5], cfp [cells,1024,6], counts [cells,2]."""
@@ -281,7 +315,8 @@ class MMGen:
     def region_finish(self, nx, nz, want=()):
         n = nx * nz
         t = self.torch
-        blocks = self._empty((n, BLOCKS), t.uint8)
+        blocks = self._region_blocks if getattr(self, "_region_blocks", None) is not None else self._empty((n, BLOCKS), t.uint8)
+        self._region_blocks = None
         hf = self._empty((n, HF), t.float32)
         layers = self._empty((n, 20, 256), t.float32) if "layers" in want else None
         cave = self._empty((n, 256, 32, 3), t.int32) if "cave" in want else None

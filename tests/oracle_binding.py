@@ -133,13 +133,53 @@ class OracleBackend:
         self.fp = t.zeros((self.cells, self.FP_CAP, 5), dtype=t.int32)
         self.cfp = t.zeros((self.cells, self.CFP_CAP, 6), dtype=t.int32)
         self.counts = t.zeros((self.cells, 2), dtype=t.int32)
-        mask = (ctypes.c_uint8 * len(local_mask))(*local_mask) if local_mask is not None else None
+        mask = None
+        if local_mask is not None:
+            mask = local_mask if isinstance(local_mask, ctypes.Array) else (ctypes.c_uint8 * len(local_mask))(*local_mask)
         vp = ctypes.c_void_p
         self.o.lib.mmo_region_begin(self.ctx, cx0, cz0, nx, nz, flags, mask, vp(self.fp.data_ptr()), vp(self.cfp.data_ptr()),
                                     vp(self.counts.data_ptr()), self.FP_CAP, self.CFP_CAP, self.o.nthreads)
 
     def region_placement_buffers(self):
         return dict(fp=self.fp, cfp=self.cfp, counts=self.counts, x0=self.dims[0], z0=self.dims[1], w=self.dims[2], h=self.dims[3])
+
+    device = "cpu"
+
+    def region_fill(self, nx, nz):
+        pass                                  # the oracle's finish does the whole fill
+
+    # CPU statement of the compact ring wire format (include/mmgen.h mmgen_ring_*): header = raw counts, payload = min(count, cap)
+    # entries per cell, surface entries (5 words) then cave entries (6 words)
+    def ring_header(self, bufs, cells):
+        return bufs["counts"][cells.long()].clone()
+
+    def _words(self, header):
+        t = self.torch
+        return 5 * t.clamp(header[:, 0], max=self.FP_CAP) + 6 * t.clamp(header[:, 1], max=self.CFP_CAP)
+
+    def ring_offsets(self, header):
+        t = self.torch
+        off = t.zeros(header.shape[0] + 1, dtype=t.int32)
+        off[1:] = t.cumsum(self._words(header), 0)
+        return off
+
+    def ring_pack(self, bufs, cells, header, offsets, total_words):
+        t = self.torch
+        out = t.zeros(max(total_words, 1), dtype=t.int32)
+        for i, c in enumerate(cells.tolist()):
+            n0, n1 = min(int(header[i, 0]), self.FP_CAP), min(int(header[i, 1]), self.CFP_CAP)
+            o = int(offsets[i])
+            out[o:o + 5 * n0] = bufs["fp"][c, :n0].reshape(-1)
+            out[o + 5 * n0:o + 5 * n0 + 6 * n1] = bufs["cfp"][c, :n1].reshape(-1)
+        return out
+
+    def ring_unpack(self, bufs, cells, header, offsets, payload):
+        for i, c in enumerate(cells.tolist()):
+            n0, n1 = min(int(header[i, 0]), self.FP_CAP), min(int(header[i, 1]), self.CFP_CAP)
+            o = int(offsets[i])
+            bufs["fp"][c, :n0] = payload[o:o + 5 * n0].reshape(n0, 5)
+            bufs["cfp"][c, :n1] = payload[o + 5 * n0:o + 5 * n0 + 6 * n1].reshape(n1, 6)
+            bufs["counts"][c] = header[i]
 
     def region_finish(self, nx, nz, want=()):
         n = nx * nz

@@ -82,3 +82,43 @@ def test_four_rank_tiling_without_features_needs_no_exchange(oracle, tmp_path):
     ref = oracle.generate_region(-1, -1, 2, 2, erosion=True, features=False, decorators=False)
     assert np.array_equal(_stitch(tiles, layout_args), ref["blocks"])
     assert halo == [0, 0, 0, 0]
+
+
+def test_four_rank_2x2_tiling_with_features_compact_exchange(oracle, tmp_path):
+    """world_size 4 (2x2 tiles of 2x2 chunks), ALL stages: every rank exchanges ring placements with its three neighbours (edge and
+    corner peers) through the compact header + payload protocol; the stitched world equals the single-process region and the bytes
+    that travelled are far below the dense 29.7 KB per ring cell."""
+    layout_args = (1486, -1112, 2, 2, 2, 2)
+    tiles, halo = _run(layout_args, 7, tmp_path)
+    ref = oracle.generate_region(1486, -1112, 4, 4, erosion=True, features=True, decorators=True)
+    assert np.array_equal(_stitch(tiles, layout_args), ref["blocks"])
+    # each rank receives 2*2 + 2*2 + 2*2 = 12 remote ring cells... (tile 2x2: the 3 peers' whole tiles lie inside its ring)
+    assert all(0 < h < 12 * 29704 // 4 for h in halo), halo
+
+
+def test_compact_wire_format_round_trip():
+    """ring_header / ring_offsets / ring_pack / ring_unpack of the CPU backend against a hand-built case (the device kernels are held to
+    the same statement in tests/test_gpu_features.py)."""
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle_binding import OracleBackend
+    b = OracleBackend.__new__(OracleBackend)
+    b.torch = torch
+    g = torch.Generator().manual_seed(5)
+    cells = 7
+    bufs = dict(fp=torch.randint(0, 1000, (cells, 256, 5), dtype=torch.int32, generator=g),
+                cfp=torch.randint(0, 1000, (cells, 1024, 6), dtype=torch.int32, generator=g),
+                counts=torch.tensor([[0, 0], [3, 0], [0, 5], [256, 1024], [2, 1500], [1, 1], [7, 9]], dtype=torch.int32))
+    sel = torch.tensor([6, 1, 4, 2, 3], dtype=torch.int32)
+    hdr = b.ring_header(bufs, sel)
+    off = b.ring_offsets(hdr)
+    assert hdr.tolist() == [[7, 9], [3, 0], [2, 1500], [0, 5], [256, 1024]]
+    assert off.tolist() == [0, 89, 104, 104 + 10 + 6144, 6258 + 30, 6288 + 1280 + 6144]
+    payload = b.ring_pack(bufs, sel, hdr, off, int(off[-1]))
+    dst = dict(fp=torch.zeros_like(bufs["fp"]), cfp=torch.zeros_like(bufs["cfp"]), counts=torch.zeros_like(bufs["counts"]))
+    b.ring_unpack(dst, sel, hdr, off, payload)
+    for c in sel.tolist():
+        n0, n1 = min(int(bufs["counts"][c, 0]), 256), min(int(bufs["counts"][c, 1]), 1024)
+        assert torch.equal(dst["fp"][c, :n0], bufs["fp"][c, :n0]) and torch.equal(dst["cfp"][c, :n1], bufs["cfp"][c, :n1])
+        assert torch.equal(dst["counts"][c], bufs["counts"][c])          # raw count travels, also beyond the cap
+    assert int(dst["counts"][0].sum()) == 0 and int(dst["fp"][5].abs().sum()) == 0
