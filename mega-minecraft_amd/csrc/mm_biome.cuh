@@ -381,31 +381,57 @@ MM_DEV void biome_block_post(uint8_t& block, int biome, int wx, int wy, int wz, 
 // these blocks, biomeFuncs.hpp:606,647,673-683,693-703); otherwise the cave biome need not be evaluated at all.
 MM_DEV bool cave_post_can_apply(uint8_t block) { return block == MMB_STONE || block == MMB_DEEPSLATE || block == MMB_BLACKSTONE; }
 
+// caveBiomeBlockPostProcess (biomeFuncs.hpp:596-707) in three stages, so that a kernel can run each stage DENSELY over the voxels that
+// reach it (k_fill): the rules of CRYSTAL_CAVES and LUSH_CAVES both start with one simplex3, and only the few lush voxels within a
+// noise-dependent distance of a cave floor / ceiling go on to the expensive clay-or-moss evaluation.  `block` is one of
+// STONE / DEEPSLATE / BLACKSTONE (cave_post_can_apply), the only blocks any rule touches.
+MM_DEV void cave_post_noise_pos(int caveBiome, int wx, int wy, int wz, float& ax, float& ay, float& az)
+{
+    if (caveBiome == MMCB_CRYSTAL_CAVES) {
+        ax = (float)(wx + wy) * 0.05f; ay = (float)(wz + 5819323) * 0.05f; az = ((float)(wx + wz) * 2.0f) * 0.05f;
+    } else {                                                 // LUSH_CAVES
+        ax = (float)wx * 0.025f; ay = (float)wy * 0.025f; az = (float)wz * 0.025f;
+    }
+}
+
+// n = simplex3(cave_post_noise_pos).  Returns true when the voxel needs lush_clay_or_moss(); otherwise `block` is final.
+MM_DEV bool cave_post_apply(uint8_t& block, int caveBiome, float n, int wx, int wy, int wz, int caveBottomDepth, int caveTopDepth)
+{
+    if (caveBiome == MMCB_CRYSTAL_CAVES) {
+        if (n < -0.25f) { block = MMB_QUARTZ; return false; }
+        if (block == MMB_BLACKSTONE) return false;
+        const float chance = (block == MMB_STONE) ? 0.5f : 0.4f;
+        const uint8_t cobble = (block == MMB_STONE) ? MMB_COBBLESTONE : MMB_COBBLED_DEEPSLATE;
+        if (rand1from3((float)wx, (float)wy, (float)wz) < chance) block = cobble;
+        return false;
+    }
+    const float threshold = 1.5f + 4.5f * n;                 // LUSH_CAVES
+    const float bd = (float)caveBottomDepth, td = (float)caveTopDepth;
+    return (bd >= 0.f && bd <= threshold) || (td >= 0.f && td <= threshold);
+}
+
+template <class Cells>
+MM_DEV uint8_t lush_clay_or_moss(int wx, int wy, int wz, const Cells& cells)
+{
+    const float nx = (float)wx * 0.025f, nz = (float)wz * 0.025f;
+    const float ny = (float)wy * 0.025f + 192031.9821f;
+    const f3 o = fbm3from3<3>(nx * 0.4f, ny * 0.4f, nz * 0.4f);
+    const float clay = worley3(nx + o.x * 2.f, ny + o.y * 2.f, nz + o.z * 2.f, cells).d1;
+    return clay < 0.25f ? MMB_CLAY : MMB_MOSS;
+}
+
 MM_DEV void cave_biome_block_post(uint8_t& block, int caveBiome, int wx, int wy, int wz, int caveBottomDepth, int caveTopDepth)
 {
     if (caveBiome == MMCB_NONE) return;
     const bool isTop = caveBottomDepth == 0;
     switch (caveBiome) {
-    case MMCB_CRYSTAL_CAVES: {
-        if (!cave_post_can_apply(block)) return;
-        const float nx = (float)(wx + wy) * 0.05f, ny = (float)(wz + 5819323) * 0.05f, nz = ((float)(wx + wz) * 2.0f) * 0.05f;
-        if (simplex3(nx, ny, nz) < -0.25f) { block = MMB_QUARTZ; return; }
-        if (block == MMB_BLACKSTONE) return;
-        const float chance = (block == MMB_STONE) ? 0.5f : 0.4f;
-        const uint8_t cobble = (block == MMB_STONE) ? MMB_COBBLESTONE : MMB_COBBLED_DEEPSLATE;
-        if (rand1from3((float)wx, (float)wy, (float)wz) < chance) block = cobble;
-        return;
-    }
+    case MMCB_CRYSTAL_CAVES:
     case MMCB_LUSH_CAVES: {
         if (!cave_post_can_apply(block)) return;
-        float nx = (float)wx * 0.025f, ny = (float)wy * 0.025f, nz = (float)wz * 0.025f;
-        const float threshold = 1.5f + 4.5f * simplex3(nx, ny, nz);
-        const float bd = (float)caveBottomDepth, td = (float)caveTopDepth;
-        if (!(bd >= 0.f && bd <= threshold) && !(td >= 0.f && td <= threshold)) return;
-        ny += 192031.9821f;
-        const f3 o = fbm3from3<3>(nx * 0.4f, ny * 0.4f, nz * 0.4f);
-        const float clay = worley3(nx + o.x * 2.f, ny + o.y * 2.f, nz + o.z * 2.f, CellDirect()).d1;
-        block = clay < 0.25f ? MMB_CLAY : MMB_MOSS;
+        float ax, ay, az;
+        cave_post_noise_pos(caveBiome, wx, wy, wz, ax, ay, az);
+        if (cave_post_apply(block, caveBiome, simplex3(ax, ay, az), wx, wy, wz, caveBottomDepth, caveTopDepth))
+            block = lush_clay_or_moss(wx, wy, wz, CellDirect());
         return;
     }
     case MMCB_WARPED_FOREST:

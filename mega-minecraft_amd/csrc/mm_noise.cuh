@@ -76,6 +76,10 @@ MM_DEV f3 simplex3_corner(float p)
 #define MM_PERM_LO 8
 #define MM_PERM_N 608
 #define MM_GRAD_N 296
+// Fused last level: the gradient of a corner is looked up directly with the index that used to go into the last permute:
+//   gradf[j] = corner(permute(j - 1)),  j - 1 = (b + x + o) in [-1, 578];  permute has period 289 exactly in fp32 on this range
+//   (tests/test_oracle_math.py::test_noise_table_domains), so indices of 289 and beyond wrap: j' = min_u32(j, j - 289) in [0, 290].
+// One dependent LDS read less per corner (4 per simplex3, 3 per simplex2) for two integer VALU.
 // two objects (known LDS bases, immediate offsets in the non-inlined callees): a kernel that never reaches simplex2 does not
 // reference s_noise2 and does not pay its 4.6 KB
 struct alignas(16) NoiseTables3 { f4v grad3[MM_GRAD_N]; int perm4[MM_PERM_N]; };
@@ -85,8 +89,10 @@ static __shared__ NoiseTables2 s_noise2;
 
 typedef __attribute__((address_space(3))) const char* lds_bytes;
 MM_DEV int perm4(int off) { return *(__attribute__((address_space(3))) const int*)((lds_bytes)s_noise.perm4 + 4 * MM_PERM_LO + off); }
-MM_DEV f4v grad3_at(int p4) { return *(__attribute__((address_space(3))) const f4v*)((lds_bytes)s_noise.grad3 + (p4 << 2)); }
-MM_DEV f4v grad2_at(int p4) { return *(__attribute__((address_space(3))) const f4v*)((lds_bytes)s_noise2.grad2 + (p4 << 2)); }
+// s4 = 4 * (b + x + o): byte offset of the index that the last permute would have taken
+MM_DEV int grad_wrap(int s4) { const unsigned j4 = (unsigned)(s4 + 4); const unsigned w = j4 - 4u * 289u; return (int)((w < j4 ? w : j4) << 2); }
+MM_DEV f4v grad3_at(int s4) { return *(__attribute__((address_space(3))) const f4v*)((lds_bytes)s_noise.grad3 + grad_wrap(s4)); }
+MM_DEV f4v grad2_at(int s4) { return *(__attribute__((address_space(3))) const f4v*)((lds_bytes)s_noise2.grad2 + grad_wrap(s4)); }
 
 // The tables are built ONCE per device and translation unit by k_noise_tables_build (below, with the arithmetic functions above)
 // into this global image; every workgroup then just copies the 12 KB image into LDS at kernel entry (16-byte words, L2 resident)
@@ -99,8 +105,9 @@ static __global__ void __launch_bounds__(256) k_noise_tables_build()
     const int t = threadIdx.x;
     for (int i = t; i < MM_PERM_N; i += 256) g_noise.perm4[i] = 4 * (int)permute((float)(i - MM_PERM_LO));
     for (int i = t; i < MM_GRAD_N; i += 256) {
-        const f3 g3 = simplex3_corner((float)i);
-        const f3 g2 = simplex2_corner((float)i);
+        const float p = permute((float)(i - 1));
+        const f3 g3 = simplex3_corner(p);
+        const f3 g2 = simplex2_corner(p);
         g_noise.grad3[i] = f4v{g3.x, g3.y, g3.z, 0.f};
         g_noise2.grad2[i] = f4v{g2.x, g2.y, g2.z, 0.f};
     }
@@ -177,10 +184,10 @@ MM_DEV float simplex2_inl(float vx, float vy)
     f3 c0, c1, c2;
     if (inDomain) {
         const int x4 = 4 * (int)ix, y4 = 4 * (int)iy;
-        const int o1x = gt ? 4 : 0, o1y = gt ? 0 : 4;
-        const f4v t0 = grad2_at(perm4(perm4(y4) + x4));
-        const f4v t1 = grad2_at(perm4((perm4(y4 + o1y) + x4) + o1x));
-        const f4v t2 = grad2_at(perm4((perm4(y4 + 4) + x4) + 4));
+        const int py0 = perm4(y4), py1 = perm4(y4 + 4);              // i1.y is 0 or 1: the middle corner re-uses one of the two
+        const f4v t0 = grad2_at(py0 + x4);
+        const f4v t1 = grad2_at(gt ? (py0 + x4) + 4 : (py1 + x4));
+        const f4v t2 = grad2_at((py1 + x4) + 4);
         c0 = mk3(t0.x, t0.y, t0.z); c1 = mk3(t1.x, t1.y, t1.z); c2 = mk3(t2.x, t2.y, t2.z);
     } else {
         c0 = simplex2_corner(permute((permute(iy + 0.f) + ix) + 0.f));
@@ -202,7 +209,7 @@ MM_DEV float simplex2_inl(float vx, float vy)
 // LDS tables.  simplex3 = part3(part1(v), gradients(part1(v))): glm's operations in glm's order, merely regrouped (checked by
 // the probe tests against real glm).
 // ---------------------------------------------------------------------------------------------------------
-struct Sx3Cell { float ix, iy, iz; float x0x, x0y, x0z; int order; };      // order bits: gx | gy << 1 | gz << 2
+struct Sx3Cell { float ix, iy, iz; float x0x, x0y, x0z; bool gx, gy, gz; };      // g = step(x0.yzx, x0) as three predicates
 
 MM_DEV Sx3Cell simplex3_part1(float vx, float vy, float vz)
 {
@@ -213,15 +220,15 @@ MM_DEV Sx3Cell simplex3_part1(float vx, float vy, float vz)
     const float e = (c.ix * Cx + c.iy * Cx) + c.iz * Cx;
     c.x0x = (vx - c.ix) + e; c.x0y = (vy - c.iy) + e; c.x0z = (vz - c.iz) + e;
     // g = step(x0.yzx, x0)
-    c.order = ((c.x0x < c.x0y) ? 0 : 1) | ((c.x0y < c.x0z) ? 0 : 2) | ((c.x0z < c.x0x) ? 0 : 4);
+    c.gx = !(c.x0x < c.x0y); c.gy = !(c.x0y < c.x0z); c.gz = !(c.x0z < c.x0x);
     return c;
 }
 
 // 12 floats: (qx, qy, qz) of the 4 corners, already scaled by taylorInvSqrt.  Arithmetic form; ix, iy, iz already mod289'd.
-MM_DEV void simplex3_gradients_direct(float ix, float iy, float iz, int order, float* __restrict__ q)
+MM_DEV void simplex3_gradients_direct(float ix, float iy, float iz, bool gxb, bool gyb, bool gzb, float* __restrict__ q)
 {
     // l = 1 - g; i1 = min(g, l.zxy); i2 = max(g, l.zxy)
-    const int gx = order & 1, gy = (order >> 1) & 1, gz = (order >> 2) & 1;
+    const int gx = gxb, gy = gyb, gz = gzb;
     const int i1x = gx & (gz ^ 1), i1y = gy & (gx ^ 1), i1z = gz & (gy ^ 1);
     const int i2x = gx | (gz ^ 1), i2y = gy | (gx ^ 1), i2z = gz | (gy ^ 1);
     const float oz[4] = {0.f, (float)i1z, (float)i2z, 1.f}, oy[4] = {0.f, (float)i1y, (float)i2y, 1.f}, ox[4] = {0.f, (float)i1x, (float)i2x, 1.f};
@@ -235,26 +242,27 @@ MM_DEV void simplex3_gradients_direct(float ix, float iy, float iz, int order, f
 }
 
 // Same values through the LDS tables (see the header); falls back to the arithmetic outside the tables' domain.
-MM_DEV void simplex3_gradients(float ix, float iy, float iz, int order, float* __restrict__ q)
+MM_DEV void simplex3_gradients(float ix, float iy, float iz, bool gx, bool gy, bool gz, float* __restrict__ q)
 {
     // table domain: lattice coordinates below 2^24 in magnitude (then mod289 is an integer in [-1, 289]); NaN fails the test
     const bool inDomain = __builtin_fabsf(ix) < 16777216.f && __builtin_fabsf(iy) < 16777216.f && __builtin_fabsf(iz) < 16777216.f;
     ix = mod289(ix); iy = mod289(iy); iz = mod289(iz);
     if (inDomain) {
-        const int gx = order & 1, gy = (order >> 1) & 1, gz = (order >> 2) & 1;
-        const int i1x = gx & (gz ^ 1), i1y = gy & (gx ^ 1), i1z = gz & (gy ^ 1);
-        const int i2x = gx | (gz ^ 1), i2y = gy | (gx ^ 1), i2z = gz | (gy ^ 1);
+        const bool i1x = gx && !gz, i1y = gy && !gx, i1z = gz && !gy;
+        const bool i2x = gx || !gz, i2y = gy || !gx, i2z = gz || !gy;
         const int x4 = 4 * (int)ix, y4 = 4 * (int)iy, z4 = 4 * (int)iz;
-        const int oz[4] = {0, 4 * i1z, 4 * i2z, 4}, oy[4] = {0, 4 * i1y, 4 * i2y, 4}, ox[4] = {0, 4 * i1x, 4 * i2x, 4};
+        // level z: the four corners only ever need permute(z) and permute(z + 1)
+        const int pz0 = perm4(z4), pz1 = perm4(z4 + 4);
+        const int a[4] = {pz0, i1z ? pz1 : pz0, i2z ? pz1 : pz0, pz1};
+        const int oy[4] = {0, i1y ? 4 : 0, i2y ? 4 : 0, 4}, ox[4] = {0, i1x ? 4 : 0, i2x ? 4 : 0, 4};
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const int a = perm4(z4 + oz[k]);
-            const int b = perm4((a + y4) + oy[k]);
-            const f4v g = grad3_at(perm4((b + x4) + ox[k]));
+            const int b = perm4((a[k] + y4) + oy[k]);
+            const f4v g = grad3_at((b + x4) + ox[k]);       // fused: gradient of permute(b + x + o)
             q[3 * k] = g.x; q[3 * k + 1] = g.y; q[3 * k + 2] = g.z;
         }
     } else {
-        simplex3_gradients_direct(ix, iy, iz, order, q);
+        simplex3_gradients_direct(ix, iy, iz, gx, gy, gz, q);
     }
 }
 
@@ -263,9 +271,8 @@ MM_DEV float simplex3_part3(const Sx3Cell& c, const float* __restrict__ q)
     const float Cx = (float)(1.0 / 6.0), Cy = (float)(1.0 / 3.0);
     // g = step(x0.yzx, x0), l = 1 - g, i1 = min(g, l.zxy), i2 = max(g, l.zxy): all in {0, 1}, so min / max are AND / OR of the order
     // bits (the same integers simplex3_gradients indexes the tables with) and the floats are exact conversions of them
-    const int gxi = c.order & 1, gyi = (c.order >> 1) & 1, gzi = (c.order >> 2) & 1;
-    const float i1x = (float)(gxi & (gzi ^ 1)), i1y = (float)(gyi & (gxi ^ 1)), i1z = (float)(gzi & (gyi ^ 1));
-    const float i2x = (float)(gxi | (gzi ^ 1)), i2y = (float)(gyi | (gxi ^ 1)), i2z = (float)(gzi | (gyi ^ 1));
+    const float i1x = (c.gx && !c.gz) ? 1.f : 0.f, i1y = (c.gy && !c.gx) ? 1.f : 0.f, i1z = (c.gz && !c.gy) ? 1.f : 0.f;
+    const float i2x = (c.gx || !c.gz) ? 1.f : 0.f, i2y = (c.gy || !c.gx) ? 1.f : 0.f, i2z = (c.gz || !c.gy) ? 1.f : 0.f;
     const float cx[4] = {c.x0x, (c.x0x - i1x) + Cx, (c.x0x - i2x) + Cy, c.x0x - 0.5f};
     const float cy[4] = {c.x0y, (c.x0y - i1y) + Cx, (c.x0y - i2y) + Cy, c.x0y - 0.5f};
     const float cz[4] = {c.x0z, (c.x0z - i1z) + Cx, (c.x0z - i2z) + Cy, c.x0z - 0.5f};
@@ -284,7 +291,7 @@ MM_DEV float simplex3_inl(float vx, float vy, float vz)
 {
     const Sx3Cell c = simplex3_part1(vx, vy, vz);
     float q[12];
-    simplex3_gradients(c.ix, c.iy, c.iz, c.order, q);
+    simplex3_gradients(c.ix, c.iy, c.iz, c.gx, c.gy, c.gz, q);
     return simplex3_part3(c, q);
 }
 

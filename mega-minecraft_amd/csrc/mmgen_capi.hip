@@ -32,6 +32,21 @@ int ensure_erosion(int zones)
     return 0;
 }
 
+unsigned* g_fillQueue = nullptr;  // deferred clay / moss voxels of mmgen_fill
+size_t g_fillQueueBytes = 0;
+
+int ensure_fill_queue(int n)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    const size_t want = mmk::fill_queue_bytes(n);
+    if (want <= g_fillQueueBytes) return 0;
+    if (g_fillQueue) { hipError_t e = hipFree(g_fillQueue); if (e != hipSuccess) return (int)e; g_fillQueue = nullptr; g_fillQueueBytes = 0; }
+    hipError_t e = hipMalloc((void**)&g_fillQueue, want);
+    if (e != hipSuccess) return (int)e;
+    g_fillQueueBytes = want;
+    return 0;
+}
+
 int ensure_scratch(int n)
 {
     std::lock_guard<std::mutex> lk(g_mu);
@@ -67,7 +82,11 @@ int mmgen_init(int device)
 
 const char* mmgen_error_string(int code) { return hipGetErrorString((hipError_t)code); }
 
-int mmgen_reserve(int max_chunks_per_call) { return ensure_scratch(max_chunks_per_call); }
+int mmgen_reserve(int max_chunks_per_call)
+{
+    const int e = ensure_scratch(max_chunks_per_call);
+    return e ? e : ensure_fill_queue(max_chunks_per_call);
+}
 
 int mmgen_generate_heightfields(const int32_t* d_pos, int n, float* d_hf, float* d_bw, void* stream)
 {
@@ -120,7 +139,9 @@ int mmgen_fill(const float* d_hf, const float* d_bw, const float* d_layers, cons
 {
     if (n < 0 || (n > 0 && (!d_hf || !d_bw || !d_layers || !d_cl || !d_pos || !d_blocks))) return (int)hipErrorInvalidValue;
     if ((d_fp || d_cfp) && !d_bounds) return (int)hipErrorInvalidValue;
-    int e = mmk::launch_fill(d_hf, d_bw, d_layers, d_cl, d_pos, n, d_blocks, nullptr, (hipStream_t)stream);
+    int e = ensure_fill_queue(n);
+    if (e) return e;
+    e = mmk::launch_fill(d_hf, d_bw, d_layers, d_cl, d_pos, n, d_blocks, nullptr, g_fillQueue, mmk::fill_queue_bytes(n), (hipStream_t)stream);
     if (e || !(d_fp || d_cfp)) return e;
     return mmk::launch_apply_features(d_blocks, d_pos, n, d_fp, d_cfp, d_bounds, nullptr, (hipStream_t)stream);
 }

@@ -493,6 +493,9 @@ MM_DEV BaseBlock place_block_base(const float* s_bw, const float* s_lh, const mm
     return r;
 }
 
+#ifndef MM_FILL_EXP
+#define MM_FILL_EXP 0      // timing experiments only (tools/build_variant.sh): 1 = no cave-biome phase, 2 = no cave-biome block rules
+#endif
 #define FILL_COLS 4
 #ifndef FILL_THREADS
 #define FILL_THREADS 256      // phase 2 walks ~450 compacted voxels: 2 passes at 88 % lane use (768 lanes: 1 pass at 59 %)
@@ -505,15 +508,16 @@ __attribute__((amdgpu_waves_per_eu(MM_FILL_WAVES, MM_FILL_WAVES)))
 __global__ void __launch_bounds__(FILL_THREADS)
 k_fill(const float* __restrict__ hf, const float* __restrict__ bw, const float* __restrict__ layers,
        const mmgen_cave_layer* __restrict__ caveLayers, const int2* __restrict__ chunkPos, uint8_t* __restrict__ blocks,
-       const int* __restrict__ srcIdx)
+       const int* __restrict__ srcIdx, unsigned* __restrict__ lushQueue /*[0] = count, entries from [1]; nullable*/, unsigned lushCap)
 {
     noise_tables_init();
     __shared__ float s_bw[FILL_COLS][MMGEN_NUM_BIOMES];
     __shared__ float s_lh[FILL_COLS][MMGEN_NUM_MATERIALS + 1];
     __shared__ mmgen_cave_layer s_cl[FILL_COLS][MMGEN_MAX_CAVE_LAYERS_PER_COLUMN];
-    __shared__ unsigned int s_list[FILL_COLS * 384];          // voxel (11 bits) | block (8) | 13 spare
-    __shared__ int s_depth[FILL_COLS * 384];                  // bottomDepth (low 16, signed) | topDepth (high 16, signed)
-    __shared__ int s_count;
+    __shared__ unsigned int s_list[FILL_COLS * 384];          // voxel (11 bits) | block (8) << 11 | bottomDepth code (6) << 19 | topDepth code (6) << 25
+    __shared__ unsigned short s_list2[FILL_COLS * 384];       // index into s_list (11 bits) | isLush << 11: voxels whose cave biome has a noise rule
+    __shared__ unsigned short s_list3[FILL_COLS * 384];       // index into s_list: lush voxels close enough to a cave surface for clay / moss
+    __shared__ int s_count[3];
 
     const int t = threadIdx.x;
     const int bid = xcd_block(blockIdx.x, gridDim.x);
@@ -530,44 +534,117 @@ k_fill(const float* __restrict__ hf, const float* __restrict__ bw, const float* 
         else if (k == MMGEN_NUM_BIOMES + MMGEN_NUM_MATERIALS) s_lh[c][MMGEN_NUM_MATERIALS] = hf[chunk * 256 + idx2d];
         else ((int*)s_cl[c])[k - 45] = ((const int*)(caveLayers + (size_t)MMGEN_MAX_CAVE_LAYERS_PER_COLUMN * (chunk * 256 + idx2d)))[k - 45];
     }
-    if (t == 0) s_count = 0;
+    if (t < 3) s_count[t] = 0;
     __syncthreads();
 
     const int2 cp = chunkPos[chunk];
     uint8_t* outBase = blocks + (size_t)MMGEN_BLOCKS_PER_CHUNK * outChunk + 384 * idxBase;     // the 4 columns are contiguous: 1536 bytes
 
-    // phase 1: base blocks
+    // phase 1: base blocks.  The two cave-surface distances only matter as "== 0" and "0 .. threshold" with threshold = 1.5 + 4.5 * simplex3
+    // (|simplex3| < 3.5 by the crudest bound: 42 * 4 corners * max((0.6 - r^2)^4 r) = 3.5), so they travel as 6-bit codes:
+    // negative -> 63, 62 and beyond -> 62.
     for (int v = t; v < FILL_COLS * 384; v += FILL_THREADS) {
         const int c = v / 384, y = v - 384 * c;
         const int idx2d = idxBase + c;
         const int wx = cp.x + (idx2d & 15), wz = cp.y + (idx2d >> 4);
         const BaseBlock r = place_block_base(s_bw[c], s_lh[c], s_cl[c], y, s_lh[c][MMGEN_NUM_MATERIALS], wx, wz);
         if (r.needCave) {
-            const int slot = atomicAdd(&s_count, 1);
-            s_list[slot] = (unsigned)v | ((unsigned)r.block << 11);
-            s_depth[slot] = (r.bottomDepth & 0xffff) | (r.topDepth << 16);
+            const int slot = atomicAdd(&s_count[0], 1);
+            const unsigned bdc = r.bottomDepth < 0 ? 63u : (unsigned)imin(r.bottomDepth, 62);
+            const unsigned tdc = r.topDepth < 0 ? 63u : (unsigned)imin(r.topDepth, 62);
+            s_list[slot] = (unsigned)v | ((unsigned)r.block << 11) | (bdc << 19) | (tdc << 25);
         } else {
             outBase[v] = r.block;
         }
     }
     __syncthreads();
 
-    // phase 2: cave-biome rules on the compacted stone voxels
-    const int count = s_count;
+    // phase 2: cave biome of the compacted stone voxels (9 simplex3 + 6 .. 12 simplex2 + 0 .. 2 simplex3 each).  NONE / WARPED / AMBER are
+    // final here; CRYSTAL and LUSH voxels go to list 2
+    const int count = s_count[0];
     for (int i = t; i < count; i += FILL_THREADS) {
         const unsigned e = s_list[i];
         const int v = e & 2047;
-        uint8_t block = (uint8_t)(e >> 11);
-        const int d = s_depth[i];
-        const int bottomDepth = (int)(short)(d & 0xffff), topDepth = d >> 16;
+        uint8_t block = (uint8_t)((e >> 11) & 255);
+        const int bdc = (e >> 19) & 63;
         const int c = v / 384, y = v - 384 * c;
         const int idx2d = idxBase + c;
         const int wx = cp.x + (idx2d & 15), wz = cp.y + (idx2d >> 4);
+#if MM_FILL_EXP != 1
         // WARPED / AMBER only act on the top DEEPSLATE / BLACKSTONE block of a cave floor (caveBottomDepth == 0)
-        const bool wantDeep = bottomDepth == 0 && (block == MMB_DEEPSLATE || block == MMB_BLACKSTONE);
+        const bool wantDeep = bdc == 0 && (block == MMB_DEEPSLATE || block == MMB_BLACKSTONE);
         const int cb = cave_biome(wx, y, wz, s_lh[c][MMGEN_NUM_MATERIALS], 190249401, wantDeep);
-        cave_biome_block_post(block, cb, wx, y, wz, bottomDepth, topDepth);
+        if (MM_FILL_EXP != 2 && (cb == MMCB_CRYSTAL_CAVES || cb == MMCB_LUSH_CAVES)) {
+            s_list2[atomicAdd(&s_count[1], 1)] = (unsigned short)(i | (cb == MMCB_LUSH_CAVES ? 2048 : 0));
+            continue;
+        }
+        if (wantDeep && cb != MMCB_NONE) cave_biome_block_post(block, cb, wx, y, wz, 0, -1);      // WARPED / AMBER re-skin, no noise
+#endif
         outBase[v] = block;
+    }
+    __syncthreads();
+
+    // phase 3: the one simplex3 both noise rules start with, densely; lush voxels within reach of a cave surface go to list 3
+    const int count2 = s_count[1];
+    for (int k = t; k < count2; k += FILL_THREADS) {
+        const int item = s_list2[k];
+        const int i = item & 2047, cb = (item & 2048) ? MMCB_LUSH_CAVES : MMCB_CRYSTAL_CAVES;
+        const unsigned e = s_list[i];
+        const int v = e & 2047;
+        uint8_t block = (uint8_t)((e >> 11) & 255);
+        const int bdc = (e >> 19) & 63, tdc = (e >> 25) & 63;
+        const int c = v / 384, y = v - 384 * c;
+        const int idx2d = idxBase + c;
+        const int wx = cp.x + (idx2d & 15), wz = cp.y + (idx2d >> 4);
+        float ax, ay, az;
+        cave_post_noise_pos(cb, wx, y, wz, ax, ay, az);
+        const float n = simplex3_inl(ax, ay, az);
+        if (cave_post_apply(block, cb, n, wx, y, wz, bdc == 63 ? -1 : bdc, tdc == 63 ? -1 : tdc)) {
+            s_list3[atomicAdd(&s_count[2], 1)] = (unsigned short)i;
+            continue;
+        }
+        outBase[v] = block;
+    }
+    __syncthreads();
+
+    // phase 4: clay or moss (fbm3from3<3> + a 27-cell Worley search with 81 sin hashes = ~5 600 instructions) for the few lush voxels that
+    // got here: typically 0 - 30 per workgroup, which would leave most lanes of the workgroup idle through the longest code path of the
+    // kernel.  They are appended to a device-wide queue instead and k_fill_lush evaluates them 64 to a wave; only when the queue is
+    // full (or absent) are they evaluated here.
+    const int count3 = s_count[2];
+    if (count3 == 0) return;
+    __shared__ unsigned s_qbase;
+    if (t == 0) s_qbase = lushQueue ? atomicAdd(lushQueue, (unsigned)count3) : 0xffffffffu;
+    __syncthreads();
+    const unsigned qbase = s_qbase;
+    const bool queued = lushQueue && qbase <= lushCap && (unsigned)count3 <= lushCap - qbase;
+    for (int k = t; k < count3; k += FILL_THREADS) {
+        const unsigned e = s_list[s_list3[k]];
+        const int v = e & 2047;
+        const int c = v / 384, y = v - 384 * c;
+        const int idx2d = idxBase + c;
+        if (queued) { lushQueue[1 + qbase + k] = ((unsigned)outChunk << 17) | ((unsigned)idx2d << 9) | (unsigned)y; continue; }
+        // a reservation that straddles the capacity marks its in-range slots as holes (they hold the previous launch's entries)
+        if (lushQueue && qbase < lushCap && (unsigned)k < lushCap - qbase) lushQueue[1 + qbase + k] = 0xffffffffu;
+        outBase[v] = MM_FILL_EXP == 3 ? (uint8_t)MMB_MOSS : lush_clay_or_moss(cp.x + (idx2d & 15), y, cp.y + (idx2d >> 4), CellDirect());
+    }
+}
+
+// The queued lush voxels of a whole k_fill launch, 64 to a wave (entry = outChunk << 17 | column << 9 | y).
+__global__ void __launch_bounds__(256)
+k_fill_lush(const unsigned* __restrict__ lushQueue, unsigned lushCap, const int2* __restrict__ chunkPos, const int* __restrict__ srcIdx,
+            uint8_t* __restrict__ blocks)
+{
+    noise_tables_init<false>();
+    const unsigned reserved = lushQueue[0];
+    // reservations beyond the capacity were evaluated by k_fill itself; every reservation that fits lies below lushCap
+    const unsigned n = reserved < lushCap ? reserved : lushCap;
+    for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const unsigned e = lushQueue[1 + i];
+        if (e == 0xffffffffu) continue;                       // hole left by a reservation that straddled the capacity
+        const int outChunk = e >> 17, idx2d = (e >> 9) & 255, y = e & 511;
+        const int2 cp = chunkPos[srcIdx ? srcIdx[outChunk] : outChunk];
+        blocks[(size_t)MMGEN_BLOCKS_PER_CHUNK * outChunk + 384 * idx2d + y] = lush_clay_or_moss(cp.x + (idx2d & 15), y, cp.y + (idx2d >> 4), CellDirect());
     }
 }
 
@@ -611,7 +688,7 @@ __global__ void __launch_bounds__(256) k_probe(int fn, const float* __restrict__
     case MMGEN_PROBE_SIMPLEX3_SPLIT: {
         const Sx3Cell c = simplex3_part1(in[3 * i], in[3 * i + 1], in[3 * i + 2]);
         float q[12];
-        simplex3_gradients(c.ix, c.iy, c.iz, c.order, q);
+        simplex3_gradients(c.ix, c.iy, c.iz, c.gx, c.gy, c.gz, q);
         out[i] = simplex3_part3(c, q);
         break; }
     default: break;
@@ -626,7 +703,7 @@ __global__ void __launch_bounds__(256) k_probe(int fn, const float* __restrict__
 namespace mmk {
 
 using mmk::KID_HEIGHTFIELD; using mmk::KID_LAYERS; using mmk::KID_FIX_BACKWARD; using mmk::KID_CAVE_COLUMNS; using mmk::KID_CAVE_VOXELS;
-using mmk::KID_CAVE_BIOMES; using mmk::KID_FILL; using mmk::KID_PROBE;
+using mmk::KID_CAVE_BIOMES; using mmk::KID_FILL; using mmk::KID_PROBE; using mmk::KID_FILL_LUSH;
 
 // every kernel of this translation unit can reach simplex noise: make sure the per-device table image exists, then launch (timed when
 // profiling is on, mmgen_prof.h)
@@ -671,10 +748,30 @@ int launch_caves(const float* hf, const float* bw, const int32_t* pos, int n, mm
 }
 
 int launch_fill(const float* hf, const float* bw, const float* layers, const mmgen_cave_layer* caveLayers, const int32_t* pos, int n,
-                uint8_t* blocks, const int* srcIdx, hipStream_t s)
+                uint8_t* blocks, const int* srcIdx, unsigned* lushQueue, size_t lushQueueBytes, hipStream_t s)
 {
     if (n <= 0) return 0;
-    LAUNCH(KID_FILL, mm::k_fill, dim3(n * 64), dim3(FILL_THREADS), s, hf, bw, layers, caveLayers, (const int2*)pos, blocks, srcIdx);
+    const unsigned cap = lushQueue && lushQueueBytes >= 8 ? (unsigned)(lushQueueBytes / 4 - 1) : 0u;
+    if (!cap) lushQueue = nullptr;
+    constexpr int kBatch = 1 << 14;                // queue entries carry the (batch-relative) chunk index in 15 bits
+    for (int b0 = 0; b0 < n; b0 += kBatch) {
+        const int nb = n - b0 < kBatch ? n - b0 : kBatch;
+        // without an index list inputs and outputs are both dense: shift every per-chunk pointer; with one only the list and the output move
+        const size_t in0 = srcIdx ? 0 : (size_t)b0;
+        const int* idx = srcIdx ? srcIdx + b0 : nullptr;
+        uint8_t* out = blocks + (size_t)MMGEN_BLOCKS_PER_CHUNK * b0;
+        const int2* p = (const int2*)pos + in0;
+        if (lushQueue) {
+            hipError_t e = hipMemsetAsync(lushQueue, 0, 4, s);                   // the counter; entries are (re)written by every launch
+            if (e != hipSuccess) return (int)e;
+        }
+        LAUNCH(KID_FILL, mm::k_fill, dim3(nb * 64), dim3(FILL_THREADS), s, hf + 256 * in0, bw + (size_t)MMGEN_BIOME_WEIGHTS_SIZE * in0,
+               layers + (size_t)MMGEN_LAYERS_SIZE * in0, caveLayers + (size_t)MMGEN_CAVE_LAYERS_SIZE * in0, p, out, idx, lushQueue, cap);
+        if (lushQueue) {
+            const unsigned grid = (unsigned)nb * 4 < 2048u ? (unsigned)nb * 4 : 2048u;
+            LAUNCH(KID_FILL_LUSH, mm::k_fill_lush, dim3(grid), dim3(256), s, (const unsigned*)lushQueue, cap, p, idx, out);
+        }
+    }
     return 0;
 }
 

@@ -142,7 +142,7 @@ struct mmgen_region {
     bool began = false;
     DevBuf posA, hfA, bwA, gathA, layersA;
     DevBuf posP, hfP, bwP, layersP, caveP, colInfo, fp, cfp, counts;
-    DevBuf selAP, zoneIdx, zoneIdxOut, gathered, erodeWork, erodeState, computeList, targets, gfp, gcfp, bounds;
+    DevBuf selAP, zoneIdx, zoneIdxOut, gathered, erodeWork, erodeState, computeList, targets, gfp, gcfp, bounds, fillQueue;
     int lastMaxPasses = 0;
     // layout cache: the host-built index tables (positions, A->P selection, compute list, zone gather / scatter lists, fill targets)
     // depend only on (rectangle, flags, mask); a caller that regenerates the same layout (bench loop, fixed tiles) re-uses the
@@ -157,7 +157,7 @@ struct mmgen_region {
     ~mmgen_region()
     {
         DevBuf* all[] = {&posA, &hfA, &bwA, &gathA, &layersA, &posP, &hfP, &bwP, &layersP, &caveP, &colInfo, &fp, &cfp, &counts, &selAP, &zoneIdx,
-                         &zoneIdxOut, &gathered, &erodeWork, &erodeState, &computeList, &targets, &gfp, &gcfp, &bounds};
+                         &zoneIdxOut, &gathered, &erodeWork, &erodeState, &computeList, &targets, &gfp, &gcfp, &bounds, &fillQueue};
         for (DevBuf* b : all) b->release();
     }
 };
@@ -357,7 +357,9 @@ int mmgen_region_fill(mmgen_region* r, uint8_t* d_blocks, void* stream)
     float* layersP = erosion ? r->layersP.as<float>() : r->layersA.as<float>();
     int32_t* posP = erosion ? r->posP.as<int32_t>() : r->posA.as<int32_t>();
     mmk::StageRange sr("mmgen:fill");
-    CK(mmk::launch_fill(hfP, bwP, layersP, r->caveP.as<mmgen_cave_layer>(), posP, r->nx * r->nz, d_blocks, r->targets.as<int>(), s));
+    CK(r->fillQueue.ensure(mmk::fill_queue_bytes(r->nx * r->nz)));
+    CK(mmk::launch_fill(hfP, bwP, layersP, r->caveP.as<mmgen_cave_layer>(), posP, r->nx * r->nz, d_blocks, r->targets.as<int>(),
+                        r->fillQueue.as<unsigned>(), mmk::fill_queue_bytes(r->nx * r->nz), s));
     r->filled = true; r->filledInto = d_blocks;
     return 0;
 }
