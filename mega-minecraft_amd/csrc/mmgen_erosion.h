@@ -3,22 +3,27 @@
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 
+#ifndef EROSION_K
+#define EROSION_K 4         // relaxation passes per launch (temporal blocking; 40 x 40-cell LDS tiles).  Measured on 84 zones: K = 2 / 3 / 4 / 6 / 8 / 12
+                            // -> 3.1 / 3.1 / 2.3 / 2.6 / 3.3 / 3.4 ms (one pass per launch: 3.8 ms): larger K = fewer launches but more ring cells and LDS
+#endif
+
 namespace mm {
-struct ErosionPhase {       // state of the relaxation loop of one zone as seen by one pass (host loop of chunk.cu:682-705)
+struct ErosionPhase {       // state of the relaxation loop of one zone as seen by one launch (host loop of chunk.cu:682-705)
     int layer;              // eroded layer being relaxed, 7 -> 0
-    int isFirst;            // first pass of this layer (adds the accumulated lift of the layers above)
+    int isFirst;            // this launch starts the layer (its first pass adds the accumulated lift of the layers above)
     int done;               // all 8 layers converged
-    int passes;             // relaxation passes executed before this one
-    int accParity;          // which accumulator buffer is current
-    int fresh;              // written by k_erode_init: the first pass takes it as is
-    int parity[8];          // which ping-pong plane holds the current start plane of each layer
+    int passes;             // relaxation passes the reference's loop would have executed before this launch
+    int accSel;             // which accumulator buffer is current
+    int fresh;              // written by k_erode_init: the first launch takes it as is
+    int sel[8];             // which of a layer's three planes holds its current start plane (2 = state after its first pass)
 };
-// Per-zone device-side state machine WITHOUT same-address atomics: pass t reads the phase pass t-1 ran with (slot[(t-1) & 1]) and
-// pass t-1's "some column changed" word (changed[(t-1) & 3]), derives its own phase (every workgroup redundantly, a few scalar
-// ops), and workgroup (0,0) stores it to slot[t & 1] for pass t+1.  Kernel boundaries on the stream order everything.
+// Per-zone device-side state machine: launch t reads the phase launch t-1 ran with (slot[(t-1) & 1]) and launch t-1's "changed" mask
+// (changed[(t-1) & 3], bit j = pass j altered a column), derives its own phase (every workgroup redundantly, a few scalar ops), and
+// workgroup (0,0) stores it to slot[t & 1] for launch t+1.  Kernel boundaries on the stream order everything.
 struct ErosionState {
     ErosionPhase slot[2];
-    int changed[4];         // changed[t & 3] = 1 if pass t altered any column; pass t clears changed[(t + 1) & 3]
+    unsigned changed[4];    // launch t ORs into changed[t & 3] and clears changed[(t + 1) & 3]
 };
 }  // namespace mm
 

@@ -2,15 +2,22 @@
 // Behavioural spec: kernDoErosion chunk.cu:477-601 + the host loop of Chunk::erodeZone chunk.cu:682-705, copyLayers :603-656.
 //
 // Design (MI355X-first):
-//  * every relaxation pass is a synchronous Jacobi step: it reads (start, accumulated) from one buffer of a ping-pong pair
-//    and writes the other, so no workgroup ever reads a halo cell another workgroup is rewriting (the reference updates in
-//    place across thread blocks; its result depends on block scheduling — DESIGN.md "Canonical semantics");
-//  * the convergence loop lives on the device: every pass derives its phase {layer, isFirst, done, parities} from the previous
-//    pass's phase and its "changed" word (mmgen_erosion.h) with plain loads/stores — no ticket, no same-address atomics (144
-//    agent-scope atomics on one word per zone and pass cost more than the relaxation itself); the host just enqueues passes back
-//    to back on one stream and only reads the state every few dozen passes.  Passes launched after a zone is done exit immediately;
-//  * many zones run in one launch (blockIdx.z = zone), 12x12 tiles of 32x32 columns per zone with 34x34 LDS halo tiles;
-//  * the zone working set (2 planes + 2 accumulators in flight) is 2.4 MB: L2 / Infinity-Cache resident, HBM sees it once.
+//  * every relaxation pass is a synchronous Jacobi step on a snapshot, so no workgroup ever reads a halo cell another workgroup is
+//    rewriting (the reference updates in place across thread blocks; its result depends on block scheduling — DESIGN.md "Canonical
+//    semantics");
+//  * TEMPORAL BLOCKING: a pass is 19 us of launch latency for 3 us of L2-resident work, and a zone needs 27 - 39 of them.  One
+//    launch therefore runs EROSION_K passes of the current layer on (32 + 2 K)^2 LDS tiles: after pass j the cells at distance > j
+//    from the tile border are still exact, the 32 x 32 centre is exact after all K (the ring is recomputed by the neighbouring
+//    tiles: 1.5 x the arithmetic, 1/K of the launches and of the global traffic).  Grid edges clamp like the reference (chunk.cu:545),
+//    so towards an edge of the grid nothing is lost;
+//  * convergence is a property of the whole zone, known only after the launch.  Passes after the first unchanged one are the
+//    identity EXCEPT after an unchanged FIRST pass of a layer (it lifts by the accumulated height, later passes do not): the launch
+//    that starts a layer also stores the state after its first pass, and the next launch picks that plane if bit 0 of the zone's
+//    "changed" mask is clear.  The number of passes the reference's host loop would have run is recovered from the mask;
+//  * the loop lives on the device: every launch derives its phase {layer, isFirst, done, planes} from the previous launch's phase and
+//    "changed" mask with plain loads (every workgroup redundantly, a few scalar ops); one no-return atomicOr per workgroup and launch
+//    publishes the mask.  The host enqueues launches back to back and reads the states every few launches;
+//  * many zones per launch (blockIdx.z = zone); the zone working set stays L2 / Infinity-Cache resident.
 #include <hip/hip_runtime.h>
 #include <vector>
 #include "mm_biome.cuh"
@@ -22,130 +29,186 @@ namespace mm {
 #define ZS MMGEN_EROSION_GRID_SIDE
 #define ZN MMGEN_EROSION_GRID_NUM_COLS
 
-// Per-zone workspace layout (floats): work[8 layers][2][ZN] ping-pong start planes, acc[2][ZN].
-#define ZONE_WORK_FLOATS ((size_t)(8 * 2 + 2) * ZN)
+// Per-zone workspace layout (floats): work[8 layers][3][ZN] start planes (0 / 1: ping-pong across launches, 2: state after the
+// layer's first pass), acc[2][ZN].
+#define ZONE_WORK_FLOATS ((size_t)(8 * 3 + 2) * ZN)
 
-MM_DEV ErosionPhase next_phase(const ErosionPhase& prev, int changedPrev)
+#define EROSION_EXT (32 + 2 * EROSION_K)
+#define EROSION_CELLS_EXT (EROSION_EXT * EROSION_EXT)
+#ifndef EROSION_STRIPS
+#define EROSION_STRIPS 4                                   // row groups: one lane = one column of the extended tile x EROSION_ROWS rows
+#endif
+#define EROSION_ROWS (EROSION_EXT / EROSION_STRIPS)
+#define EROSION_THREADS (EROSION_EXT * EROSION_STRIPS)
+static_assert(EROSION_EXT % EROSION_STRIPS == 0, "strips must tile the extended tile");
+
+// phase of launch t from the phase and the changed mask of launch t - 1 (bit j = pass j of that launch altered some column)
+MM_DEV ErosionPhase next_phase(const ErosionPhase& prev, unsigned maskPrev)
 {
     ErosionPhase cur = prev;
     if (prev.fresh) { cur.fresh = 0; return cur; }
     if (prev.done) return cur;
-    cur.passes = prev.passes + 1;
-    cur.parity[prev.layer] = 1 - prev.parity[prev.layer];
-    cur.accParity = 1 - prev.accParity;
-    if (changedPrev) cur.isFirst = 0;
-    else if (prev.layer == 0) cur.done = 1;
-    else { cur.layer = prev.layer - 1; cur.isFirst = 1; }
+    const int L = prev.layer;
+    const int outSel = prev.isFirst ? 0 : 1 - prev.sel[L];           // plane the previous launch wrote its final state to
+    const unsigned full = (1u << EROSION_K) - 1u;
+    if ((maskPrev & full) == full) {                                 // every pass changed something: not converged yet
+        cur.passes = prev.passes + EROSION_K;
+        cur.sel[L] = outSel; cur.accSel = 1 - prev.accSel; cur.isFirst = 0;
+        return cur;
+    }
+    const int firstUnchanged = __builtin_ctz(~maskPrev);             // the pass at which the reference's loop stops
+    cur.passes = prev.passes + firstUnchanged + 1;
+    if (prev.isFirst && firstUnchanged == 0) cur.sel[L] = 2;         // unchanged first pass: its own output is final, acc untouched
+    else { cur.sel[L] = outSel; cur.accSel = 1 - prev.accSel; }
+    if (L == 0) cur.done = 1;
+    else { cur.layer = L - 1; cur.isFirst = 1; }
     return cur;
 }
 
-// One workgroup = one 32x32-column tile; EROSION_ROWS rows of 32 lanes, each lane relaxes 32 / EROSION_ROWS columns (independent
-// loads in flight per lane; a 1024-lane workgroup spends its life in two barriers and one dependent load)
-#ifndef EROSION_ROWS
-#define EROSION_ROWS 4
-#endif
-#define EROSION_CELLS (32 / EROSION_ROWS)
-__global__ void __launch_bounds__(32 * EROSION_ROWS)
+// One Jacobi pass of one lane: column ex of the extended tile, rows [r0, r1].  sIn / tIn = start plane and thickness (end - start)
+// of the previous state, read through a sliding 3 x 3 register window (6 LDS reads per cell); sOut / tOut receive the new state.
+// LIFT = first pass of a layer: sIn / tIn hold the values RAISED by the accumulated height of the layers above (built by the caller),
+// the cell's own un-raised start is in sOut (it stays if the reference would not write, chunk.cu:578) and its end is raised too.
+// Returns: bit 0 = some cell changed, bit 1 = some cell of the tile's own 32 x 32 centre changed.
+template <bool LIFT>
+MM_DEV int relax_strip(const float* __restrict__ sIn, const float* __restrict__ tIn, float* __restrict__ sOut, float* __restrict__ tOut,
+                       const float* __restrict__ s_end, float* __restrict__ s_acc, float k1, float k2, int ex, int exL, int exR, int r0, int r1, int ezMin,
+                       int ezMax, bool ownCol, float* __restrict__ startFirst /*grid pointer of this column, row 0 of the tile*/)
+{
+    int flags = 0;
+    if (r0 > r1) return 0;
+    // window rows: a = row above, b = this row, c = row below (clamped at the grid edges: chunk.cu:545)
+    int rowA = EROSION_EXT * imax(r0 - 1, ezMin), rowB = EROSION_EXT * r0;
+    float aS0 = sIn[rowA + exL], aS1 = sIn[rowA + ex], aS2 = sIn[rowA + exR];
+    float aT0 = tIn[rowA + exL], aT1 = tIn[rowA + ex], aT2 = tIn[rowA + exR];
+    float bS0 = sIn[rowB + exL], bS1 = sIn[rowB + ex], bS2 = sIn[rowB + exR];
+    float bT0 = tIn[rowB + exL], bT1 = tIn[rowB + ex], bT2 = tIn[rowB + exR];
+#pragma unroll 2
+    for (int ez = r0; ez <= r1; ++ez) {
+        const int rowC = EROSION_EXT * imin(ez + 1, ezMax);
+        const float cS0 = sIn[rowC + exL], cS1 = sIn[rowC + ex], cS2 = sIn[rowC + exR];
+        const float cT0 = tIn[rowC + exL], cT1 = tIn[rowC + ex], cT2 = tIn[rowC + exR];
+        const int c = EROSION_EXT * ez + ex;
+        const float thisStart = bS1;
+        float raw = thisStart, thisEnd = s_end[c];
+        if (LIFT) { raw = sOut[c]; thisEnd = thisEnd + s_acc[c]; }
+        // neighbour order of dev_dirVecs2d (N, NE, E, SE, S, SW, W, NW; +z = "north" = row below in this layout): max is order-free
+        float newStart = thisStart;
+        newStart = gmax(newStart, cS1 - k1); newStart = gmax(newStart, cS2 - k2); newStart = gmax(newStart, bS2 - k1); newStart = gmax(newStart, aS2 - k2);
+        newStart = gmax(newStart, aS1 - k1); newStart = gmax(newStart, aS0 - k2); newStart = gmax(newStart, bS0 - k1); newStart = gmax(newStart, cS0 - k2);
+        float maxThickness = thisEnd - thisStart;
+        maxThickness = gmax(maxThickness, cT1); maxThickness = gmax(maxThickness, cT2); maxThickness = gmax(maxThickness, bT2); maxThickness = gmax(maxThickness, aT2);
+        maxThickness = gmax(maxThickness, aT1); maxThickness = gmax(maxThickness, aT0); maxThickness = gmax(maxThickness, bT0); maxThickness = gmax(maxThickness, cT0);
+        newStart = gmin(newStart, thisEnd);
+        float outStart = raw;
+        if (maxThickness > 0.f) {
+            outStart = newStart;
+            if (newStart != thisStart) {
+                s_acc[c] = s_acc[c] + (newStart - thisStart);
+                flags |= (ownCol && ez >= EROSION_K && ez < EROSION_K + 32) ? 3 : 1;
+            }
+        }
+        sOut[c] = outStart;
+        tOut[c] = s_end[c] - outStart;
+        if (LIFT && ownCol && ez >= EROSION_K && ez < EROSION_K + 32) startFirst[(size_t)ZS * ez] = outStart;
+        aS0 = bS0; aS1 = bS1; aS2 = bS2; aT0 = bT0; aT1 = bT1; aT2 = bT2;
+        bS0 = cS0; bS1 = cS1; bS2 = cS2; bT0 = cT0; bT1 = cT1; bT2 = cT2;
+    }
+    return flags;
+}
+
+__global__ void __launch_bounds__(EROSION_THREADS)
 k_erode_pass(const float* __restrict__ gatheredBase, size_t gatheredStride, float* __restrict__ workBase, ErosionState* __restrict__ states, int t)
 {
-    __shared__ float s_start[34 * 34];
-    __shared__ float s_end[34 * 34];
-    __shared__ int s_changed;
+    __shared__ float s_s[2][EROSION_CELLS_EXT];            // start planes, ping-pong over the passes
+    __shared__ float s_t[2][EROSION_CELLS_EXT];            // thickness = end - start of the same states (what the neighbours compare)
+    __shared__ float s_end[EROSION_CELLS_EXT];
+    __shared__ float s_acc[EROSION_CELLS_EXT];             // accumulated heights; after the load every cell is touched by its own lane only
+    __shared__ unsigned s_mask;
 
     const int zone = blockIdx.z;
     ErosionState* st = states + zone;
-    const int lx = threadIdx.x, lz0 = threadIdx.y;
-    const int lid = lx + 32 * lz0;
+    const int tid = threadIdx.x;
     const ErosionPhase ph = next_phase(st->slot[(t + 1) & 1], st->changed[(t + 3) & 3]);
-    if (lid == 0 && blockIdx.x == 0 && blockIdx.y == 0) {
+    if (tid == 0 && blockIdx.x == 0 && blockIdx.y == 0) {
         st->slot[t & 1] = ph;
         st->changed[(t + 1) & 3] = 0;
     }
     if (ph.done) return;
     const int layer = ph.layer;
     const bool isFirst = ph.isFirst != 0;
-    const int p = ph.parity[layer];           // buffer holding the current start plane of this layer (ignored on the first pass)
-    const int ap = ph.accParity;
 
     const float* gathered = gatheredBase + gatheredStride * zone;
     float* work = workBase + ZONE_WORK_FLOATS * zone;
-    const float* accIn = work + (size_t)16 * ZN + (size_t)ap * ZN;
-    float* accOut = work + (size_t)16 * ZN + (size_t)(1 - ap) * ZN;
-    const float* startIn = isFirst ? (gathered + (size_t)layer * ZN) : (work + ((size_t)layer * 2 + p) * ZN);
-    float* startOut = work + ((size_t)layer * 2 + (1 - p)) * ZN;
+    const float* accIn = work + (size_t)24 * ZN + (size_t)ph.accSel * ZN;
+    float* accOut = work + (size_t)24 * ZN + (size_t)(1 - ph.accSel) * ZN;
+    const float* startIn = isFirst ? (gathered + (size_t)layer * ZN) : (work + ((size_t)layer * 3 + ph.sel[layer]) * ZN);
+    float* startOut = work + ((size_t)layer * 3 + (isFirst ? 0 : 1 - ph.sel[layer])) * ZN;
+    float* startFirst = work + ((size_t)layer * 3 + 2) * ZN;
     // end plane = final start plane of the layer above (already eroded), or the heightfield plane for the top layer
     const float* endIn = (layer == MMGEN_NUM_ERODED_MATERIALS - 1) ? (gathered + (size_t)8 * ZN)
-                                                                   : (work + ((size_t)(layer + 1) * 2 + ph.parity[layer + 1]) * ZN);
+                                                                   : (work + ((size_t)(layer + 1) * 3 + ph.sel[layer + 1]) * ZN);
 
-    const int bx = blockIdx.x * 32, bz = blockIdx.y * 32;
-    if (lid == 0) s_changed = 0;
+    // extended tile: ex, ez in [0, EXT) <-> grid (gx0 + ex, gz0 + ez); cells beyond the grid do not exist (neighbours clamp to the edge)
+    const int gx0 = blockIdx.x * 32 - EROSION_K, gz0 = blockIdx.y * 32 - EROSION_K;
+    const int exMin = imax(0, -gx0), exMax = imin(EROSION_EXT - 1, ZS - 1 - gx0);
+    const int ezMin = imax(0, -gz0), ezMax = imin(EROSION_EXT - 1, ZS - 1 - gz0);
+    const int ex = tid % EROSION_EXT, strip = tid / EROSION_EXT;
+    const int rowLo = strip * EROSION_ROWS, rowHi = rowLo + EROSION_ROWS - 1;
+    const bool colExists = ex >= exMin && ex <= exMax;
+    const int exL = imax(ex - 1, exMin), exR = imin(ex + 1, exMax);
+    const bool ownCol = ex >= EROSION_K && ex < EROSION_K + 32;
+    if (tid == 0) s_mask = 0u;
 
-    float rawStart[EROSION_CELLS], accPrev[EROSION_CELLS], thisStart[EROSION_CELLS], thisEnd[EROSION_CELLS];
-#pragma unroll
-    for (int k = 0; k < EROSION_CELLS; ++k) {
-        const int lz = lz0 + EROSION_ROWS * k;
-        const int c = (bx + lx) + ZS * (bz + lz);
-        rawStart[k] = startIn[c];
-        accPrev[k] = accIn[c];
-        const float thisAcc = isFirst ? accPrev[k] : 0.f;
-        thisStart[k] = rawStart[k] + thisAcc;
-        thisEnd[k] = endIn[c] + thisAcc;
-        const int sc = (lx + 1) + 34 * (lz + 1);
-        s_start[sc] = thisStart[k];
-        s_end[sc] = thisEnd[k];
-    }
-
-    // halo: 132 border cells, clamped to the grid (values outside extend the border, chunk.cu:545)
-    for (int h = lid; h < 132; h += 32 * EROSION_ROWS) {
-        int hx, hz;
-        if (h < 32) { hx = h + 1; hz = 0; }
-        else if (h < 64) { hx = h - 32 + 1; hz = 33; }
-        else if (h < 96) { hx = 0; hz = h - 64 + 1; }
-        else if (h < 128) { hx = 33; hz = h - 96 + 1; }
-        else { hx = (h & 1) ? 33 : 0; hz = (h & 2) ? 33 : 0; }
-        const int px = imin(imax(bx - 1 + hx, 0), ZS - 1), pz = imin(imax(bz - 1 + hz, 0), ZS - 1);
-        const int n = px + ZS * pz;
-        const float a = isFirst ? accIn[n] : 0.f;
-        s_start[hx + 34 * hz] = startIn[n] + a;
-        s_end[hx + 34 * hz] = endIn[n] + a;
+    // load: a first launch stages the un-raised start in plane 0 and the RAISED start / thickness in plane 1 (the input of pass 0)
+    if (colExists) {
+        for (int ez = imax(rowLo, ezMin); ez <= imin(rowHi, ezMax); ++ez) {
+            const int c = EROSION_EXT * ez + ex, g = (gx0 + ex) + ZS * (gz0 + ez);
+            const float sv = startIn[g], ev = endIn[g], av = accIn[g];
+            s_s[0][c] = sv; s_end[c] = ev; s_acc[c] = av;
+            if (isFirst) { const float ls = sv + av; s_s[1][c] = ls; s_t[1][c] = (ev + av) - ls; }
+            else s_t[0][c] = ev - sv;
+        }
     }
     __syncthreads();
 
-    const float tanAoR = kMaterialAmpOrTan[MMGEN_NUM_STRATIFIED_MATERIALS + layer];
-    bool changed = false;
-#pragma unroll
-    for (int k = 0; k < EROSION_CELLS; ++k) {
-        const int lz = lz0 + EROSION_ROWS * k;
-        const int c = (bx + lx) + ZS * (bz + lz);
-        const int sc = (lx + 1) + 34 * (lz + 1);
-        float newStart = thisStart[k];
-        float maxThickness = thisEnd[k] - thisStart[k];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int n = sc + kDirX[i] + 34 * kDirZ[i];
-            const float ns = s_start[n];
-            newStart = gmax(newStart, ns - tanAoR * ((i & 1) ? MM_SQRT_2 : 1.f));
-            maxThickness = gmax(maxThickness, s_end[n] - ns);
+    const float k1 = kMaterialAmpOrTan[MMGEN_NUM_STRATIFIED_MATERIALS + layer];
+    const float k2 = k1 * MM_SQRT_2;
+    float* colFirst = startFirst + (gx0 + ex) + (size_t)ZS * gz0;
+    int cur = 0;                                             // plane holding the current state (after a first pass: 0 again)
+    unsigned myMask = 0u;
+#pragma unroll 1
+    for (int j = 0; j < EROSION_K; ++j) {
+        // cells still exact after this pass: at distance > j from every tile border that is not an edge of the grid
+        const int xl = gx0 < 0 ? exMin : j + 1, xh = gx0 + EROSION_EXT > ZS ? exMax : EROSION_EXT - 2 - j;
+        const int zl = gz0 < 0 ? ezMin : j + 1, zh = gz0 + EROSION_EXT > ZS ? ezMax : EROSION_EXT - 2 - j;
+        const bool colLive = ex >= xl && ex <= xh;
+        const int r0 = colLive ? imax(rowLo, zl) : 1, r1 = colLive ? imin(rowHi, zh) : 0;
+        int flags;
+        if (isFirst && j == 0) {
+            flags = relax_strip<true>(s_s[1], s_t[1], s_s[0], s_t[0], s_end, s_acc, k1, k2, ex, exL, exR, r0, r1, ezMin, ezMax, ownCol, colFirst);
+            // the result is in plane 0 again
+        } else {
+            flags = relax_strip<false>(s_s[cur], s_t[cur], s_s[1 - cur], s_t[1 - cur], s_end, s_acc, k1, k2, ex, exL, exR, r0, r1, ezMin, ezMax, ownCol,
+                                       colFirst);
+            cur = 1 - cur;
         }
-        newStart = gmin(newStart, thisEnd[k]);
-
-        // the reference writes only when maxThickness > 0; otherwise the stored plane keeps its previous value (without the lift)
-        float outStart = rawStart[k];
-        float outAcc = accPrev[k];
-        if (maxThickness > 0.f) {
-            outStart = newStart;
-            if (newStart != thisStart[k]) {
-                changed = true;
-                outAcc = accPrev[k] + (newStart - thisStart[k]);
-            }
-        }
-        startOut[c] = outStart;
-        accOut[c] = outAcc;
+        if (flags & 2) myMask |= 1u << j;
+        // a pass (other than a first pass) that changes no live cell of the tile is the identity from here on: stop
+        const int any = __syncthreads_or(flags & 1);
+        if (!any && !(isFirst && j == 0)) break;
     }
-    if (changed) s_changed = 1;
+    if (myMask) atomicOr(&s_mask, myMask);
+    // results of the centre
+    if (ownCol) {
+        for (int ez = imax(rowLo, EROSION_K); ez <= imin(rowHi, EROSION_K + 31); ++ez) {
+            const int c = EROSION_EXT * ez + ex, g = (gx0 + ex) + ZS * (gz0 + ez);
+            startOut[g] = s_s[cur][c];
+            accOut[g] = s_acc[c];
+        }
+    }
     __syncthreads();
-
-    if (lid == 0 && s_changed) st->changed[t & 3] = 1;      // plain store of the same value by every workgroup that changed something
+    if (tid == 0 && s_mask) atomicOr(&st->changed[t & 3], s_mask);
 }
 
 // final planes back into the caller's gathered-layers buffer (in-place contract of Chunk::erodeZone) and the accumulated heights
@@ -154,13 +217,13 @@ k_erode_writeback(float* __restrict__ gatheredBase, size_t gatheredStride, const
                   float* __restrict__ accOutBase, size_t accStride, int lastT)
 {
     const int zone = blockIdx.z;
-    const ErosionPhase* st = &states[zone].slot[lastT & 1];      // the phase the last launched pass ran with: done, all parities final
+    const ErosionPhase* st = &states[zone].slot[lastT & 1];      // the phase the last launch ran with: done, all planes final
     const int c = blockIdx.x * 256 + threadIdx.x;
     const float* work = workBase + ZONE_WORK_FLOATS * zone;
     float* gathered = gatheredBase + gatheredStride * zone;
 #pragma unroll
-    for (int l = 0; l < 8; ++l) gathered[(size_t)l * ZN + c] = work[((size_t)l * 2 + st->parity[l]) * ZN + c];
-    if (accOutBase) accOutBase[accStride * zone + c] = work[(size_t)16 * ZN + (size_t)st->accParity * ZN + c];
+    for (int l = 0; l < 8; ++l) gathered[(size_t)l * ZN + c] = work[((size_t)l * 3 + st->sel[l]) * ZN + c];
+    if (accOutBase) accOutBase[accStride * zone + c] = work[(size_t)24 * ZN + (size_t)st->accSel * ZN + c];
 }
 
 __global__ void k_erode_init(ErosionState* states, float* workBase, int zones)
@@ -169,15 +232,15 @@ __global__ void k_erode_init(ErosionState* states, float* workBase, int zones)
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (zone >= zones) return;
     // zero both accumulator buffers (thrust::fill_n of chunk.cu:679-680)
-    float* acc = workBase + ZONE_WORK_FLOATS * zone + (size_t)16 * ZN;
+    float* acc = workBase + ZONE_WORK_FLOATS * zone + (size_t)24 * ZN;
     if (i < 2 * ZN) acc[i] = 0.f;
     if (i == 0) {
         ErosionPhase s;
-        s.layer = MMGEN_NUM_ERODED_MATERIALS - 1; s.isFirst = 1; s.done = 0; s.passes = 0; s.accParity = 0; s.fresh = 1;
-        for (int l = 0; l < 8; ++l) s.parity[l] = 0;
-        states[zone].slot[1] = s;            // pass 0 reads slot[(0 - 1) & 1]
+        s.layer = MMGEN_NUM_ERODED_MATERIALS - 1; s.isFirst = 1; s.done = 0; s.passes = 0; s.accSel = 0; s.fresh = 1;
+        for (int l = 0; l < 8; ++l) s.sel[l] = 0;
+        states[zone].slot[1] = s;            // launch 0 reads slot[(0 - 1) & 1]
         states[zone].slot[0] = s;
-        for (int k = 0; k < 4; ++k) states[zone].changed[k] = 0;
+        for (int k = 0; k < 4; ++k) states[zone].changed[k] = 0u;
     }
 }
 
@@ -228,11 +291,13 @@ int erode_zones(float* gathered, size_t strideFloats, int zones, float* work, mm
     hipError_t e = hipSuccess;
 
     std::vector<mm::ErosionState> h(zones);
-    const dim3 grid(12, 12, zones), block(32, EROSION_ROWS);
+    const dim3 grid(12, 12, zones), block(EROSION_THREADS);
     int launched = 0;
     for (;;) {
-        const int batch = launched == 0 ? 48 : 16;
-        // one event pair around the whole batch of passes (an event per 19 us launch would perturb what it measures)
+        // a zone needs one launch per layer plus one for every further EROSION_K passes of a layer (27 - 39 passes in total); a launch
+        // whose zones are all done costs ~10 us, a host round trip to find out ~50 us
+        const int batch = launched == 0 ? 8 + 32 / EROSION_K : 4;
+        // one event pair around the whole batch of launches (an event per launch would perturb what it measures)
         const bool prof_ = profile_enabled();
         if (prof_) profile_begin(KID_ERODE_PASS, s);
         for (int i = 0; i < batch; ++i) hipLaunchKernelGGL(mm::k_erode_pass, grid, block, 0, s, gathered, strideFloats, work, states, launched + i);
@@ -242,7 +307,7 @@ int erode_zones(float* gathered, size_t strideFloats, int zones, float* work, mm
         if (e != hipSuccess) return (int)e;
         e = hipStreamSynchronize(s);
         if (e != hipSuccess) return (int)e;
-        // slot[(launched - 1) & 1] = the phase the last launched pass ran with; `done` shows up there one pass after convergence
+        // slot[(launched - 1) & 1] = the phase the last launch ran with; `done` shows up there one launch after convergence
         bool all = true;
         for (auto& z : h) all = all && z.slot[(launched - 1) & 1].done;
         if (all) break;
