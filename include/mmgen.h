@@ -189,6 +189,9 @@ int mmgen_unpack_chunk_host(const uint8_t* packed, size_t packed_bytes, uint8_t*
 /* Test-only: evaluates device math function `fn` (MMGEN_PROBE_*) on n packed fp32 items (ints bit-cast); used by the parity
  * tests to pin the device math against golden vectors.  Not part of the reference's interface. */
 int mmgen_debug_probe(int fn, const float* d_in, int n, float* d_out, void* stream);
+/* Test-only: the library's constant rule tables (BiomeUtils::init, biomeFuncs.hpp:725-1256) as floats in the layout of
+ * tools/extract_ref_tables.py, so that a test can hold them to the reference's literals.  d_out == NULL: returns the number of floats. */
+int mmgen_debug_tables(float* d_out, int capacity_floats, void* stream);
 /* Test-only: rasterises ONE (cave) feature placement into a box of voxels (placeFeature / placeCaveFeature per voxel,
  * featurePlacement.hpp:147,1110); d_out[box_size x*y*z] in z, x, y order (y fastest), 255 = voxel not claimed. */
 int mmgen_debug_feature_box(int is_cave, int feature, const int32_t* h_feature_pos, int layer_height, const int32_t* h_box_min,

@@ -176,6 +176,13 @@ int mmgen_debug_feature_box(int is_cave, int feature, const int32_t* h_feature_p
     return mmk::launch_feature_box(is_cave, feature, h_feature_pos, layer_height, h_box_min, h_box_size, d_out, (hipStream_t)stream);
 }
 
+int mmgen_debug_tables(float* d_out, int capacity_floats, void* stream)
+{
+    if (!d_out) return mmk::table_dump_floats();                 // query: number of floats
+    if (capacity_floats < mmk::table_dump_floats()) return (int)hipErrorInvalidValue;
+    return mmk::launch_dump_tables(d_out, (hipStream_t)stream);
+}
+
 int mmgen_debug_probe(int fn, const float* d_in, int n, float* d_out, void* stream)
 {
     if (n < 0 || (n > 0 && (!d_in || !d_out))) return (int)hipErrorInvalidValue;

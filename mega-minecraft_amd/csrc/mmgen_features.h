@@ -14,5 +14,7 @@ int launch_gather_placements(const mmgen_feature_placement* fp, const mmgen_cave
 int launch_apply_features(uint8_t* blocks, const int32_t* pos, int n, const mmgen_feature_placement* gfp, const mmgen_cave_feature_placement* gcfp,
                           const int* bounds, const int* srcIdx, hipStream_t s);
 int launch_decorators(uint8_t* blocks, const float* hf, const float* bw, const mmgen_cave_layer* cl, const int32_t* pos, int n, const int* srcIdx, hipStream_t s);
+int table_dump_floats();
+int launch_dump_tables(float* out, hipStream_t s);
 int launch_feature_box(int isCave, int feature, const int* fpos, int layerHeight, const int* boxMin, const int* boxSize, uint8_t* out, hipStream_t s);
 }  // namespace mmk

@@ -641,6 +641,52 @@ k_feature_box(int isCave, int feature, int fx, int fy, int fz, int layerHeight, 
     out[i] = placed ? b : 255;
 }
 
+// Test probe: the constant rule tables of this library in the numeric layout of tools/extract_ref_tables.py (tests hold them to the
+// literals of the reference's BiomeUtils::init).  Sections, all as floats: biome rules [24][6], grass [24], material infos [20][4],
+// biome material weights [24][20], feature bounds [21][2], cave feature bounds [10][2], surface gens [24][4][11], cave gens [5][3][9],
+// decorator gens [24][7][10], cave decorator gens [5][6][10]; then this library's own horizontal reach tables [21] + [10] (not a reference
+// table: the bound the column filters rely on, validated by tests) and the gather order [49][2].
+#define MMGEN_TABLE_DUMP_FLOATS (144 + 24 + 80 + 480 + 42 + 20 + 1056 + 135 + 1680 + 300 + 21 + 10 + 98)
+__device__ void dump_deco(const DecoGen& g, float* o)
+{
+    int u[3] = {g.nUnder > 0 ? g.under[0] : 0, g.nUnder > 1 ? g.under[1] : 0, g.nUnder > 2 ? g.under[2] : 0};
+    // ascending over the first nUnder entries (the reference keeps them in an unordered_set)
+    for (int a = 0; a < g.nUnder; ++a) for (int b = a + 1; b < g.nUnder; ++b) if (u[b] < u[a]) { const int t = u[a]; u[a] = u[b]; u[b] = t; }
+    o[0] = 1.f; o[1] = (float)g.block; o[2] = g.chance; o[3] = (float)g.nUnder; o[4] = (float)u[0]; o[5] = (float)u[1]; o[6] = (float)u[2];
+    o[7] = (float)g.replace; o[8] = (float)g.second; o[9] = (float)g.fromCeiling;
+}
+__global__ void k_dump_tables(float* __restrict__ out)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    for (int i = 0; i < MMGEN_TABLE_DUMP_FLOATS; ++i) out[i] = 0.f;
+    float* o = out;
+    for (int b = 0; b < MMGEN_NUM_BIOMES; ++b) for (int k = 0; k < 6; ++k) *o++ = (float)kBiomeRules[b][k];
+    for (int b = 0; b < MMGEN_NUM_BIOMES; ++b) *o++ = (float)kGrassBlock[b];
+    for (int m = 0; m < MMGEN_NUM_MATERIALS; ++m) { *o++ = (float)kMaterialBlock[m]; *o++ = kMaterialThickness[m]; *o++ = kMaterialAmpOrTan[m]; *o++ = kMaterialScaleOrMaxSlope[m]; }
+    for (int b = 0; b < MMGEN_NUM_BIOMES; ++b) for (int m = 0; m < MMGEN_NUM_MATERIALS; ++m) *o++ = kMatWeights.w[b][m];
+    for (int f = 0; f < MMGEN_NUM_FEATURES; ++f) { *o++ = (float)kFeatureBounds[f][0]; *o++ = (float)kFeatureBounds[f][1]; }
+    for (int f = 0; f < MMGEN_NUM_CAVE_FEATURES; ++f) { *o++ = (float)kCaveFeatureBounds[f][0]; *o++ = (float)kCaveFeatureBounds[f][1]; }
+    for (int b = 0; b < MMGEN_NUM_BIOMES; ++b)
+        for (int k = 0; k < 4; ++k, o += 11) {
+            if (k >= kSurfGenCount[b]) continue;
+            const SurfGen& g = kSurfGens[b][k];
+            o[0] = 1.f; o[1] = (float)g.feature; o[2] = (float)g.cell; o[3] = (float)g.pad; o[4] = g.chance; o[5] = (float)g.canReplace; o[6] = (float)g.nTop;
+            for (int j = 0; j < g.nTop; ++j) { o[7 + 2 * j] = (float)g.topMat[j]; o[8 + 2 * j] = g.topMin[j]; }
+        }
+    for (int b = 0; b < MMGEN_NUM_CAVE_BIOMES; ++b)
+        for (int k = 0; k < 3; ++k, o += 9) {
+            if (k >= kCaveGenCount[b]) continue;
+            const CaveGen& g = kCaveGens[b][k];
+            o[0] = 1.f; o[1] = (float)g.feature; o[2] = (float)g.cell; o[3] = (float)g.pad; o[4] = g.chance; o[5] = (float)g.minLayerHeight;
+            o[6] = (float)g.canReplace; o[7] = (float)g.fromCeiling; o[8] = (float)g.canLava;
+        }
+    for (int b = 0; b < MMGEN_NUM_BIOMES; ++b) for (int k = 0; k < 7; ++k, o += 10) if (k < kDecoCount[b]) dump_deco(kDecoGens[b][k], o);
+    for (int b = 0; b < MMGEN_NUM_CAVE_BIOMES; ++b) for (int k = 0; k < 6; ++k, o += 10) if (k < kCaveDecoCount[b]) dump_deco(kCaveDecoGens[b][k], o);
+    for (int f = 0; f < MMGEN_NUM_FEATURES; ++f) *o++ = (float)kFeatureReach[f];
+    for (int f = 0; f < MMGEN_NUM_CAVE_FEATURES; ++f) *o++ = (float)kCaveFeatureReach[f];
+    for (int k = 0; k < 49; ++k) { *o++ = (float)kGatherDX[k]; *o++ = (float)kGatherDZ[k]; }
+}
+
 }  // namespace mm
 
 namespace mmk {
@@ -652,6 +698,13 @@ namespace mmk {
     } while (0)
 
 int prepare_features() { return mm::noise_tables_ensure(nullptr); }
+
+int table_dump_floats() { return MMGEN_TABLE_DUMP_FLOATS; }
+int launch_dump_tables(float* out, hipStream_t s)
+{
+    MMK_LAUNCH(KID_PROBE, mm::k_dump_tables, dim3(1), dim3(64), s, out);
+    return 0;
+}
 
 int launch_feature_box(int isCave, int feature, const int* fpos, int layerHeight, const int* boxMin, const int* boxSize, uint8_t* out, hipStream_t s)
 {

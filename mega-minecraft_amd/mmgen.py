@@ -358,6 +358,26 @@ class MMGen:
         self._check(self.lib.mmgen_debug_probe(self.PROBES[name], self._p(t), n, self._p(out), self._stream()), "mmgen_debug_probe")
         return out.cpu().numpy()
 
+    def debug_tables(self):
+        """The library's constant rule tables as numpy arrays in the layout of tools/extract_ref_tables.py (+ its own reach tables)."""
+        import numpy as np
+        self.lib.mmgen_debug_tables.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+        n = self.lib.mmgen_debug_tables(None, 0, None)
+        out = self._empty((n,), self.torch.float32)
+        self._check(self.lib.mmgen_debug_tables(self._p(out), n, self._stream()), "mmgen_debug_tables")
+        a = out.cpu().numpy()
+        t, o = {}, 0
+        for name, shape, dt in (("biome_rules", (24, 6), np.uint8), ("grass", (24,), np.uint8), ("material_infos", (20, 4), np.float32),
+                                ("biome_material_weights", (24, 20), np.float32), ("feature_bounds", (21, 2), np.int32),
+                                ("cave_feature_bounds", (10, 2), np.int32), ("surf_gens", (24, 4, 11), np.float32), ("cave_gens", (5, 3, 9), np.float32),
+                                ("deco_gens", (24, 7, 10), np.float32), ("cave_deco_gens", (5, 6, 10), np.float32), ("feature_reach", (21,), np.int32),
+                                ("cave_feature_reach", (10,), np.int32), ("gather_offsets", (49, 2), np.int32)):
+            k = int(np.prod(shape))
+            t[name] = a[o:o + k].reshape(shape).astype(dt)
+            o += k
+        assert o == n
+        return t
+
     def debug_feature_box(self, is_cave, feature, fpos, layer_height, box_min, box_size):
         i3 = ctypes.c_int32 * 3
         n = box_size[0] * box_size[1] * box_size[2]

@@ -2,6 +2,7 @@
 // extern "C" surface of the CPU oracle, loaded with ctypes by tests/, __graft_entry__.smoke() and bench.py's
 // cpu_baseline leg.  Never linked into or called from the product (mega-minecraft_amd/).
 #include "mmo_stages.h"
+#include <algorithm>
 #include <thread>
 #include <atomic>
 #include <map>
@@ -52,6 +53,14 @@ void mmo_rng_u01(int n, const int* xyzw, int use_w, int k, float* out)
         const int* s = xyzw + 4 * i;
         Rng r = use_w ? makeSeededRandomEngine(s[0], s[1], s[2], s[3]) : makeSeededRandomEngine(s[0], s[1], s[2]);
         for (int j = 0; j < k; ++j) out[i * k + j] = r.u01();
+    }
+}
+// the bare engine: raw outputs and u01 draws for arbitrary 32-bit seeds (pinned against the real thrust engine, tests/golden/thrust_probe.npz)
+void mmo_minstd(int n, const uint32_t* seeds, int k, uint32_t* raw, float* u01)
+{
+    for (int i = 0; i < n; ++i) {
+        Rng a(seeds[i]), b(seeds[i]);
+        for (int j = 0; j < k; ++j) { raw[i * k + j] = a.next(); u01[i * k + j] = b.u01(); }
     }
 }
 void mmo_simplex2(int n, const float* xy, float* out) { for (int i = 0; i < n; ++i) out[i] = simplex(vec2(xy[2 * i], xy[2 * i + 1])); }
@@ -120,6 +129,49 @@ void mmo_tables_material_infos(float* out80)
     }
 }
 void mmo_tables_biome_material_weights(float* out480) { std::memcpy(out480, T().biomeMaterialWeights, sizeof(float) * numBiomes * numMaterials); }
+// The gen tables in the numeric layout of tools/extract_ref_tables.py (tests/golden/ref_tables.npz), so that a test can hold them to
+// the literals of the reference's BiomeUtils::init.  Material infos: column 2 of the eroded materials is the TANGENT here (the reference
+// converts at the end of init); the test compares it with tan(radians(degrees)) of the extracted literal.
+void mmo_tables_gens(int* featureBounds /*[21][2]*/, int* caveFeatureBounds /*[10][2]*/, float* surfGens /*[24][4][11]*/, float* caveGens /*[5][3][9]*/,
+                     float* decoGens /*[24][7][10]*/, float* caveDecoGens /*[5][6][10]*/)
+{
+    const Tables& t = T();
+    for (int f = 0; f < numFeatures; ++f) { featureBounds[2 * f] = t.featureHeightBounds[f].x; featureBounds[2 * f + 1] = t.featureHeightBounds[f].y; }
+    for (int f = 0; f < numCaveFeatures; ++f) { caveFeatureBounds[2 * f] = t.caveFeatureHeightBounds[f].x; caveFeatureBounds[2 * f + 1] = t.caveFeatureHeightBounds[f].y; }
+    std::memset(surfGens, 0, sizeof(float) * numBiomes * 4 * 11);
+    for (int b = 0; b < numBiomes; ++b)
+        for (size_t k = 0; k < t.biomeFeatureGens[b].size(); ++k) {
+            const FeatureGen& g = t.biomeFeatureGens[b][k];
+            float* o = surfGens + (b * 4 + k) * 11;
+            o[0] = 1; o[1] = (float)(int)g.feature; o[2] = (float)g.gridCellSize; o[3] = (float)g.gridCellPadding; o[4] = g.chancePerGridCell;
+            o[5] = g.canReplaceBlocks ? 1.f : 0.f; o[6] = (float)g.possibleTopLayers.size();
+            for (size_t j = 0; j < g.possibleTopLayers.size() && j < 2; ++j) { o[7 + 2 * j] = (float)(int)g.possibleTopLayers[j].material; o[8 + 2 * j] = g.possibleTopLayers[j].minThickness; }
+        }
+    std::memset(caveGens, 0, sizeof(float) * numCaveBiomes * 3 * 9);
+    for (int b = 0; b < numCaveBiomes; ++b)
+        for (size_t k = 0; k < t.caveBiomeFeatureGens[b].size(); ++k) {
+            const CaveFeatureGen& g = t.caveBiomeFeatureGens[b][k];
+            float* o = caveGens + (b * 3 + k) * 9;
+            o[0] = 1; o[1] = (float)(int)g.caveFeature; o[2] = (float)g.gridCellSize; o[3] = (float)g.gridCellPadding; o[4] = g.chancePerGridCell;
+            o[5] = (float)g.minLayerHeight; o[6] = g.canReplaceBlocks ? 1.f : 0.f; o[7] = g.generatesFromCeiling ? 1.f : 0.f; o[8] = g.canGenerateInLava ? 1.f : 0.f;
+        }
+    auto deco = [](const std::vector<DecoratorGen>& gens, float* base) {
+        for (size_t k = 0; k < gens.size(); ++k) {
+            const DecoratorGen& g = gens[k];
+            float* o = base + k * 10;
+            std::vector<int> under;
+            for (Block u : g.possibleUnderBlocks) under.push_back((int)u);
+            std::sort(under.begin(), under.end());
+            o[0] = 1; o[1] = (float)(int)g.decoratorBlock; o[2] = g.chance; o[3] = (float)under.size();
+            for (size_t j = 0; j < under.size() && j < 3; ++j) o[4 + j] = (float)under[j];
+            o[7] = (float)(int)g.possibleReplaceBlocks[0]; o[8] = (float)(int)g.secondDecoratorBlock; o[9] = g.generatesFromCeiling ? 1.f : 0.f;
+        }
+    };
+    std::memset(decoGens, 0, sizeof(float) * numBiomes * 7 * 10);
+    for (int b = 0; b < numBiomes; ++b) deco(t.biomeDecoratorGens[b], decoGens + b * 70);
+    std::memset(caveDecoGens, 0, sizeof(float) * numCaveBiomes * 6 * 10);
+    for (int b = 0; b < numCaveBiomes; ++b) deco(t.caveBiomeDecoratorGens[b], caveDecoGens + b * 60);
+}
 void mmo_tables_rules(uint8_t* biome144, uint8_t* cave20, uint8_t* grass24)
 {
     for (int b = 0; b < numBiomes; ++b) {

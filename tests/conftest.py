@@ -23,7 +23,7 @@ def oracle():
 
 @pytest.fixture(scope="session")
 def golden():
-    return {name: np.load(os.path.join(GOLDEN, name + ".npz")) for name in ("glm_probe", "oracle_kat", "stages")}
+    return {name: np.load(os.path.join(GOLDEN, name + ".npz")) for name in ("glm_probe", "oracle_kat", "stages", "ref_tables", "thrust_probe")}
 
 
 @pytest.fixture(scope="session")

@@ -269,3 +269,155 @@ def test_region_batched_scheduler_equals_action_time_scheduler(mmgen_pkg):
     print(r.stdout[-3000:])
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert "IDENTICAL" in r.stdout and "1089 drawable chunks compared" in r.stdout
+
+
+# ------------------------------------------------------------------------------------------------ F1 / F2 observed directly
+def _fields(fp, cfp):
+    """placement records as plain fields (padding bytes of the 20 / 24-byte structs masked out)"""
+    f = np.stack([fp[..., 0] & 255, fp[..., 1], fp[..., 2], fp[..., 3], fp[..., 4] & 255], -1)
+    c = np.stack([cfp[..., 0] & 255, cfp[..., 1], cfp[..., 2], cfp[..., 3], cfp[..., 4], cfp[..., 5] & 255], -1)
+    return f, c
+
+
+F1_REGIONS = [(1488, -1110, 2, 2), (2669, -2199, 2, 2), (3654, -2794, 2, 1), (-1268, -1773, 1, 2), (3946, -3906, 2, 2), (0, 0, 2, 2),
+              (3518, 2777, 1, 1), (1767, -1044, 2, 1), (-2105, -2470, 1, 1), (-88, -3971, 1, 1)]
+
+
+def test_placement_lists_match_oracle_cell_for_cell(gen, oracle):
+    """F1 (chunk.cu:1041-1156): the per-chunk placement lists the device emits — counts, entries and EMISSION ORDER (columns z-major,
+    emission order inside a column) — equal the oracle's on every cell of the ring-extended grid of ten regions (jungle, crystals, birch,
+    coral reef, mushrooms, origin, redwood, swamp, ...), with erosion on (the surface test reads eroded layer thickness)."""
+    from oracle_binding import OracleBackend
+    ob = OracleBackend(nthreads=oracle.nthreads)
+    seen_surface, seen_cave, total = set(), set(), [0, 0]
+    for cx0, cz0, nx, nz in F1_REGIONS:
+        ob.region_begin(cx0, cz0, nx, nz, 7)
+        want = ob.region_placement_buffers()
+        gen.region_begin(cx0, cz0, nx, nz, 7)
+        got = gen.region_placement_buffers()
+        assert (got["x0"], got["z0"], got["w"], got["h"]) == (want["x0"], want["z0"], want["w"], want["h"])
+        gc, wc = np_(got["counts"]), want["counts"].numpy()
+        assert np.array_equal(gc, wc), f"placement counts differ in region {(cx0, cz0)}: cells {np.argwhere(gc != wc)[:5].tolist()}"
+        gf, gcf = _fields(np_(got["fp"]), np_(got["cfp"]))
+        wf, wcf = _fields(want["fp"].numpy(), want["cfp"].numpy())
+        for cell in range(gc.shape[0]):
+            n0, n1 = int(wc[cell, 0]), min(int(wc[cell, 1]), 1024)
+            assert np.array_equal(gf[cell, :n0], wf[cell, :n0]), f"surface placements of cell {cell} in region {(cx0, cz0)}"
+            assert np.array_equal(gcf[cell, :n1], wcf[cell, :n1]), f"cave placements of cell {cell} in region {(cx0, cz0)}"
+            seen_surface.update(wf[cell, :n0, 0].tolist()); seen_cave.update(wcf[cell, :n1, 0].tolist())
+        total[0] += int(wc[:, 0].sum()); total[1] += int(wc[:, 1].sum())
+        gen.region_finish(nx, nz)
+    assert total[0] > 500 and total[1] > 500, total
+    # the sample really exercises the gens: jungle trees, crystals, cave vines, glowstone, a crystal-caves feature
+    assert {12, 13, 14} <= seen_surface and {17, 18} & seen_surface and {3, 4} <= seen_cave and {5, 6, 7} & seen_cave, (seen_surface, seen_cave)
+
+
+def test_gathered_lists_match_reference_order(gen, golden):
+    """F2 (chunk.cu:1158-1196 + :1555-1601) through the per-stage ABI: for every chunk of a jungle region the gathered lists are the
+    concatenation of the 49 neighbour lists in the reference's offset order (tests/golden/ref_tables.npz: gather_offsets, extracted from
+    chunk.cu), NONE-terminated, and the bounds are the union of pos.y + featureHeightBounds over the un-truncated lists."""
+    import torch
+    ref = golden["ref_tables"]
+    nx, nz = 3, 2
+    gen.region_begin(1487, -1111, nx, nz, 7)
+    b = gen.region_placement_buffers()
+    w, h = b["w"], b["h"]
+    targets = torch.tensor([(x + 3) + w * (z + 3) for z in range(nz) for x in range(nx)], dtype=torch.int32, device=gen.device)
+    gfp, gcfp, bounds = gen.gather_feature_placements(b["fp"], b["cfp"], b["counts"], targets, w, h)
+    fp, cfp, cnt = np_(b["fp"]), np_(b["cfp"]), np_(b["counts"])
+    gfp, gcfp, bounds = np_(gfp), np_(gcfp), np_(bounds)
+    gen.region_finish(nx, nz)
+    for k, cell in enumerate(targets.tolist()):
+        cx, cz = cell % w, cell // w
+        ls, lc = [], []
+        for dx, dz in ref["gather_offsets"].tolist():
+            n = (cx + dx) + w * (cz + dz)
+            ls.append(fp[n, :cnt[n, 0]]); lc.append(cfp[n, :min(cnt[n, 1], 1024)])
+        ls, lc = np.concatenate(ls), np.concatenate(lc)
+        assert len(ls) < 2048 and len(lc) < 4096 and len(ls) > 20 and len(lc) > 20
+        wf, wcf = _fields(ls, lc)
+        gf, gcf = _fields(gfp[k], gcfp[k])
+        assert np.array_equal(gf[:len(ls)], wf) and gf[len(ls), 0] == 0, f"gathered surface list of chunk {k}"
+        assert np.array_equal(gcf[:len(lc)], wcf) and gcf[len(lc), 0] == 0, f"gathered cave list of chunk {k}"
+        fb, cfb = ref["feature_bounds"], ref["cave_feature_bounds"]
+        want = [int((wf[:, 2] + fb[wf[:, 0], 0]).min()), int((wf[:, 2] + fb[wf[:, 0], 1]).max()),
+                int((wcf[:, 2] + cfb[wcf[:, 0], 0]).min()), int((wcf[:, 2] + wcf[:, 4] + cfb[wcf[:, 0], 1]).max())]
+        assert bounds[k].tolist() == want, (bounds[k].tolist(), want)
+
+
+def test_config4_world_placement_counts_stay_below_the_caps(gen):
+    """MMGEN_FP_CAP (256) and MMGEN_CFP_CAP (1024) are product-only limits (the reference pushes to unbounded vectors, chunk.cu:1028-1038):
+    over the whole config-4 world (4 096 chunks + ring) no chunk comes near them, so no placement is ever dropped."""
+    gen.region_begin(-32, -32, 64, 64, 7)
+    c = np_(gen.region_placement_buffers()["counts"])
+    gen.region_finish(64, 64)
+    assert c.shape[0] == 70 * 70
+    assert c[:, 0].max() <= 256 and c[:, 1].max() <= 1024, (c[:, 0].max(), c[:, 1].max())
+    assert c[:, 0].max() < 128 and c[:, 1].max() < 512, "within a factor 2 of a cap: raise MMGEN_FP_CAP / MMGEN_CFP_CAP"
+    assert c[:, 0].sum() > 10000 and c[:, 1].sum() > 10000
+
+
+def test_ring_wire_format_on_the_device(gen):
+    """mmgen_ring_header / offsets / pack / unpack == the CPU statement of the wire format (tests/oracle_binding.py), incl. a cell whose
+    cave count exceeds the cap, and a pack -> unpack round trip into a second placement grid."""
+    import torch
+    from oracle_binding import OracleBackend
+    cpu = OracleBackend.__new__(OracleBackend); cpu.torch = torch
+    gen.region_begin(1487, -1111, 2, 2, 7)
+    b = gen.region_placement_buffers()
+    bufs_cpu = dict(fp=b["fp"].cpu().clone(), cfp=b["cfp"].cpu().clone(), counts=b["counts"].cpu().clone())
+    cells = torch.tensor([27, 3, 40, 41, 12, 63, 0], dtype=torch.int32)
+    bufs_cpu["counts"][12, 1] = 1500                         # over the cap: the raw count travels, 1 024 entries do
+    b["counts"][12, 1] = 1500
+    dcells = cells.to(gen.device)
+    hdr = gen.ring_header(b, dcells); off = gen.ring_offsets(hdr)
+    chdr = cpu.ring_header(bufs_cpu, cells); coff = cpu.ring_offsets(chdr)
+    assert torch.equal(hdr.cpu(), chdr) and torch.equal(off.cpu(), coff)
+    total = int(off[-1])
+    payload = gen.ring_pack(b, dcells, hdr, off, total)
+    assert torch.equal(payload.cpu()[:total], cpu.ring_pack(bufs_cpu, cells, chdr, coff, total)[:total])
+    dst = dict(fp=torch.zeros_like(b["fp"]), cfp=torch.zeros_like(b["cfp"]), counts=torch.zeros_like(b["counts"]))
+    gen.ring_unpack(dst, dcells, hdr, off, payload)
+    for c in cells.tolist():
+        n0, n1 = min(int(bufs_cpu["counts"][c, 0]), 256), min(int(bufs_cpu["counts"][c, 1]), 1024)
+        assert torch.equal(dst["fp"][c, :n0].cpu(), bufs_cpu["fp"][c, :n0]) and torch.equal(dst["cfp"][c, :n1].cpu(), bufs_cpu["cfp"][c, :n1])
+        assert torch.equal(dst["counts"][c].cpu(), bufs_cpu["counts"][c])
+    assert int(dst["counts"].cpu().sum()) == int(bufs_cpu["counts"][cells.long()].sum())
+    gen.region_finish(2, 2)
+
+
+@pytest.mark.parametrize("is_cave", [False, True])
+def test_rasterisers_stay_inside_reach(gen, golden, is_cave):
+    """The column filters drop a placement whose Chebyshev distance exceeds the library's reach table (a product-only bound; the height
+    bounds are the reference's own and are applied by the caller, chunk.cu:1446-1452): hundreds of placements per feature (per-feature
+    RNG streams: iceberg radius, branch angles, crystal directions, mushroom splines) rasterised on the device into boxes that extend
+    16 blocks beyond the reach and 6 beyond the height bounds never claim a voxel farther away than the reach."""
+    t = gen.debug_tables()
+    rs = np.random.RandomState(7 + is_cave)
+    reach = t["cave_feature_reach" if is_cave else "feature_reach"]
+    bounds = golden["ref_tables"]["cave_feature_bounds" if is_cave else "feature_bounds"]
+    for feature in (CAVE_FEATURES if is_cave else SURFACE_FEATURES):
+        r = int(reach[feature])
+        side = 2 * (r + 16) + 1
+        n_place = 12 if r > 60 else (60 if r > 20 else 200)
+        lo, hi = int(bounds[feature, 0]), int(bounds[feature, 1])
+        claimed = 0
+        for _ in range(n_place):
+            fpos = (int(rs.randint(-5000, 5000)), int(rs.randint(20, 200) if not is_cave else rs.randint(12, 100)), int(rs.randint(-5000, 5000)))
+            if not is_cave and feature in (2, 3, 4):                      # coral / kelp / iceberg only generate under water
+                fpos = (fpos[0], int(rs.randint(60, 96)), fpos[2])
+            lh = int(rs.randint(4, 40)) if is_cave else 0
+            y0 = max(fpos[1] + lo - 6, 0)
+            y1 = min(fpos[1] + lh + hi + 6, 383)
+            if not is_cave and feature == 4:
+                y1 = 383                                                  # icebergs are placed relative to sea level
+            box_min = (fpos[0] - r - 16, y0, fpos[2] - r - 16)
+            size = (side, y1 - y0 + 1, side)
+            got = gen.debug_feature_box(is_cave, feature, fpos, lh, box_min, size).reshape(side, side, size[1])   # z, x, y
+            zz, xx, yy = np.nonzero(got != 255)
+            claimed += len(zz)
+            if len(zz) == 0:
+                continue
+            dx, dz = xx + box_min[0] - fpos[0], zz + box_min[2] - fpos[2]
+            assert max(np.abs(dx).max(), np.abs(dz).max()) <= r, f"feature {feature} at {fpos}: claims at distance {max(np.abs(dx).max(), np.abs(dz).max())} > reach {r}"
+        assert claimed > 0 or feature in (1, 2), f"feature {feature} never claimed a voxel"

@@ -214,3 +214,23 @@ def test_erosion_batched_zones_equal_single(gen):
     batched, _ = gen.erode_zones(both)
     for i in range(2):
         assert torch.equal(batched[i], singles[i][0])
+
+
+# ------------------------------------------------------------------------------------------------ pins to reference-derived data
+def test_device_tables_match_reference_literals(gen, golden):
+    """The constant rule tables compiled into libmmgen == the literals of the reference's BiomeUtils::init (tests/golden/ref_tables.npz,
+    extracted from biomeFuncs.hpp:725-1256 by tools/extract_ref_tables.py), and the gather order == chunk.cu:1158-1167."""
+    from test_oracle_math import check_tables_against_reference
+    t = gen.debug_tables()
+    check_tables_against_reference(t, golden["ref_tables"], "device")
+    assert np.array_equal(t["gather_offsets"], golden["ref_tables"]["gather_offsets"])
+    assert (t["feature_reach"][1:] >= 0).all() and t["feature_reach"].max() <= 127      # reach travels in 8 bits (k_apply_features)
+
+
+def test_device_rng_matches_real_thrust(gen, golden):
+    """rng3 / rng4 + u01 on the device == the real rocThrust engine composed like rng.hpp:86-96 (tests/golden/thrust_probe.npz)."""
+    t = golden["thrust_probe"]
+    xyzw = t["xyzw"].copy()
+    assert_bit_equal(gen.debug_probe("rng4_u01", xyzw, len(xyzw), 4), t["u01_4"], "u01 (4-arg seed) vs thrust")
+    x3 = xyzw.copy(); x3[:, 3] = np.int32(-2 ** 31)
+    assert_bit_equal(gen.debug_probe("rng4_u01", x3, len(x3), 4), t["u01_3"], "u01 (3-arg seed) vs thrust")

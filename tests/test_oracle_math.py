@@ -142,3 +142,66 @@ def test_noise_table_domains():
     p = (t - np.floor(t * (f(1.0) / f(289.0))) * f(289.0)).astype(f)
     assert p.min() >= 0 and p.max() <= 288 and np.array_equal(p, np.floor(p))
     assert -1 + -1 + 0 >= -8 and 288 + 289 + 1 < 600 - 8 + 8       # chained index range vs table range [-8, 600)
+
+
+def _oracle_tables(oracle):
+    """The oracle's rule tables in the numeric layout of tools/extract_ref_tables.py."""
+    t = {}
+    br = np.zeros((24, 6), np.uint8); cr = np.zeros((5, 4), np.uint8); gr = np.zeros(24, np.uint8)
+    oracle.lib.mmo_tables_rules(_p(br), _p(cr), _p(gr))
+    mi = np.zeros((20, 4), np.float32); oracle.lib.mmo_tables_material_infos(_p(mi))
+    bm = np.zeros((24, 20), np.float32); oracle.lib.mmo_tables_biome_material_weights(_p(bm))
+    fb = np.zeros((21, 2), np.int32); cfb = np.zeros((10, 2), np.int32)
+    sg = np.zeros((24, 4, 11), np.float32); cg = np.zeros((5, 3, 9), np.float32)
+    dg = np.zeros((24, 7, 10), np.float32); cdg = np.zeros((5, 6, 10), np.float32)
+    oracle.lib.mmo_tables_gens(_p(fb), _p(cfb), _p(sg), _p(cg), _p(dg), _p(cdg))
+    t.update(biome_rules=br, cave_rules=cr, grass=gr, material_infos=mi, biome_material_weights=bm, feature_bounds=fb,
+             cave_feature_bounds=cfb, surf_gens=sg, cave_gens=cg, deco_gens=dg, cave_deco_gens=cdg)
+    return t
+
+
+def check_tables_against_reference(tables, ref, what):
+    """Shared by the CPU (oracle) and GPU (device constant tables) tests: every rule table == the literals extracted from the
+    reference's BiomeUtils::init (tests/golden/ref_tables.npz, made by tools/extract_ref_tables.py)."""
+    for name in ("biome_rules", "grass", "biome_material_weights", "feature_bounds", "cave_feature_bounds", "surf_gens", "cave_gens",
+                 "deco_gens", "cave_deco_gens"):
+        got, want = np.asarray(tables[name]), ref[name]
+        assert got.shape == want.shape, (what, name, got.shape, want.shape)
+        assert np.array_equal(got.astype(want.dtype), want), f"{what}: {name} differs from the reference's literals at {np.argwhere(got.astype(want.dtype) != want)[:5]}"
+    if "cave_rules" in tables:
+        assert np.array_equal(tables["cave_rules"], ref["cave_rules"]), f"{what}: cave rules"
+    mi, rmi = np.asarray(tables["material_infos"], np.float32), ref["material_infos"]
+    assert np.array_equal(mi[:, [0, 1, 3]], rmi[:, [0, 1, 3]]), f"{what}: material block / thickness / scale"
+    assert np.array_equal(mi[:12, 2], rmi[:12, 2]), f"{what}: stratified noise amplitudes"
+    # eroded materials: the reference stores tanf(glm::radians(degrees)) (biomeFuncs.hpp:840-845); ours is the correctly rounded tangent
+    rad = rmi[12:, 2].astype(np.float32) * np.float32(0.01745329251994329576923690768489)
+    assert np.array_equal(mi[12:, 2], np.tan(rad.astype(np.float64)).astype(np.float32)), f"{what}: tan(angle of repose)"
+
+
+def test_tables_match_reference_literals(oracle, golden):
+    check_tables_against_reference(_oracle_tables(oracle), golden["ref_tables"], "oracle")
+    assert golden["ref_tables"]["enum_counts"].tolist()[:5] == [24, 5, 20, 21, 10]
+
+
+def test_minstd_matches_real_thrust(oracle, golden):
+    """oracle Rng == the real rocThrust minstd_rand + uniform_real_distribution<float> (tests/golden/thrust_probe.npz, generated by
+    executing /opt/rocm/include/thrust host-side): bare engine incl. the seed-0 -> 1 rule and seeds >= m, and the reference's two
+    seeding compositions (rng.hpp:86-96) incl. negative / far coordinates."""
+    t = golden["thrust_probe"]
+    seeds = np.ascontiguousarray(t["seeds"])
+    raw = np.zeros((len(seeds), 4), np.uint32); u01 = np.zeros((len(seeds), 4), np.float32)
+    oracle.lib.mmo_minstd(len(seeds), _p(seeds), 4, _p(raw), _p(u01))
+    assert np.array_equal(raw, t["raw"]) and t["raw"][0, 0] == 48271
+    assert_bit_equal(u01, t["u01"][:, :4], "u01 of the bare engine")
+    xyzw = np.ascontiguousarray(t["xyzw"])
+    for use_w, key in ((0, "u01_3"), (1, "u01_4")):
+        out = np.zeros((len(xyzw), 4), np.float32)
+        oracle.lib.mmo_rng_u01(len(xyzw), _p(xyzw), use_w, 4, _p(out))
+        assert_bit_equal(out, t[key], f"makeSeededRandomEngine {3 + use_w}-arg")
+    # third derivation, in Python integers: x <- 48271 x mod (2^31 - 1), u = float32(x - 1) / float32(2^31 - 2 + 1)
+    m = 2 ** 31 - 1
+    for s, r in zip(seeds[:16].tolist(), t["raw"][:16].tolist()):
+        x = s % m or 1
+        for want in r:
+            x = 48271 * x % m
+            assert x == want
