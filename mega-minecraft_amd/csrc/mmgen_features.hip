@@ -399,12 +399,31 @@ MM_DEV void wave_lds_sync()
 MM_DEV int wave_min(int v) { for (int o = 32; o > 0; o >>= 1) v = imin(v, __shfl_xor(v, o)); return v; }
 MM_DEV int wave_max(int v) { for (int o = 32; o > 0; o >>= 1) v = imax(v, __shfl_xor(v, o)); return v; }
 
+// Horizontal reach and vertical extent (relative to pos.y) of ONE surface placement.  The tables are per-feature worst cases; for
+// PURPLE_MUSHROOM the worst case (reach 127, 121 voxels tall: the smallest universal scale AND the 20 % half-scale draw) makes a single
+// placement visit 7.9 M voxels, 10 x all other features of the bench world together, while the typical one claims nothing beyond
+// 16 - 35 blocks.  Its first three draws (featurePlacement.hpp:705-709: universal scale, half-scale, height) bound what it can
+// claim exactly: |pos.xz| <= 35 and -1 <= pos.y <= height + 12 in the scaled frame, or the rasteriser returns false.
+MM_DEV void surface_extent(int feat, int fx, int fy, int fz, int& reach, int& dlo, int& dhi)
+{
+    reach = kFeatureReach[feat]; dlo = kFeatureBounds[feat][0]; dhi = kFeatureBounds[feat][1];
+    if (feat == MMF_PURPLE_MUSHROOM) {
+        MinStd frng = rng4(fx, fy, fz, 1293012);
+        float sc = 1.f + frng.u01() * 1.2f;
+        if (frng.u01() < 0.2f) sc *= 0.5f;
+        const float height = 25.f + frng.u01() * 30.f;
+        reach = imin(reach, (int)(35.f / sc) + 2);                        // + 2: rounding of the scaled coordinates and of this division
+        dhi = imin(dhi, (int)((height + 12.f) / sc) + 2);
+    }
+}
+
 // Stable WAVE-wide compaction of the list entries that can reach column (wx, wz), as packed copies
-//   .x = (fx - wx + 128) | (fz - wz + 128) << 8 | fy << 16 | feature << 25 | canReplace << 30,   .y = layerHeight (cave entries)
+//   .x = (fx - wx + 128) | (fz - wz + 128) << 8 | fy << 16 | feature << 25 | canReplace << 30,
+//   .y = layerHeight (cave entries) or the placement's own vertical extent (dlo + 128) | dhi << 8 relative to fy (surface entries)
 // so that the voxel loop never goes back to global memory: 64 entries per round, ballot + popcount prefix, no workgroup barrier.
 // Returns the number of candidates, or -1 when they do not fit CAND_CAP (caller falls back to the full scan).
 template <class Entry, int LIST_CAP, bool CAVE>
-MM_DEV int filter_column(const Entry* __restrict__ list, int wx, int wz, int2* s_cand)
+MM_DEV int filter_column(const Entry* __restrict__ list, int wx, int wz, int2* s_cand, unsigned& featureMask)
 {
     const int lane = threadIdx.x & 63;
     int base = 0;
@@ -414,14 +433,23 @@ MM_DEV int filter_column(const Entry* __restrict__ list, int wx, int wz, int2* s
         if (i < LIST_CAP) { feat = list[i].feature; fx = list[i].pos[0]; fz = list[i].pos[2]; }
         const unsigned long long noneMask = __ballot(feat == 0);
         const int firstNone = noneMask ? (int)__builtin_ctzll(noneMask) : 64;
-        const int reach = CAVE ? kCaveFeatureReach[feat] : kFeatureReach[feat];
-        const bool cand = lane < firstNone && iabs(wx - fx) <= reach && iabs(wz - fz) <= reach;
+        int reach = CAVE ? kCaveFeatureReach[feat] : kFeatureReach[feat];
+        bool cand = lane < firstNone && iabs(wx - fx) <= reach && iabs(wz - fz) <= reach;
+        int fy = 0, lh = 0;
+        if (cand) {
+            fy = list[i].pos[1];
+            if constexpr (CAVE) lh = list[i].layer_height;
+            else {
+                int dlo, dhi;
+                surface_extent(feat, fx, fy, fz, reach, dlo, dhi);
+                cand = iabs(wx - fx) <= reach && iabs(wz - fz) <= reach;
+                lh = (dlo + 128) | (dhi << 8);
+            }
+        }
         const unsigned long long cm = __ballot(cand);
         if (cand) {
-            const int fy = list[i].pos[1];
+            featureMask |= 1u << feat;
             const int w = (fx - wx + 128) | ((fz - wz + 128) << 8) | ((fy & 511) << 16) | (feat << 25) | ((int)(list[i].can_replace_blocks != 0) << 30);
-            int lh = 0;
-            if constexpr (CAVE) lh = list[i].layer_height;
             const int slot = base + __popcll(cm & ((1ull << lane) - 1ull));
             if (slot < CAND_CAP) s_cand[slot] = make_int2(w, lh);
         }
@@ -431,6 +459,9 @@ MM_DEV int filter_column(const Entry* __restrict__ list, int wx, int wz, int2* s
     return base > CAND_CAP ? -1 : base;
 }
 
+#ifndef MM_APPLY_EXP
+#define MM_APPLY_EXP 0       // timing experiments only (tools/build_variant.sh)
+#endif
 #ifndef MM_APPLY_WAVES
 #define MM_APPLY_WAVES 3        // 168 VGPRs: the union of the 31 rasterisers
 #endif
@@ -458,7 +489,6 @@ k_apply_features(uint8_t* __restrict__ blocks, const int2* __restrict__ chunkPos
     const int b0 = bounds[4 * chunk], b1 = bounds[4 * chunk + 1], b2 = bounds[4 * chunk + 2], b3 = bounds[4 * chunk + 3];
     const bool doS = gfp && b0 <= b1, doC = gcfp && b2 <= b3;      // workgroup-uniform (one chunk per workgroup)
     if (!doS && !doC) return;
-    noise_tables_init();          // the only workgroup barrier
 
     const int2 cp = chunkPos[srcIdx ? srcIdx[chunk] : chunk];
     const int wx = cp.x + (idx2d & 15), wz = cp.y + (idx2d >> 4);
@@ -466,8 +496,16 @@ k_apply_features(uint8_t* __restrict__ blocks, const int2* __restrict__ chunkPos
     const mmgen_cave_feature_placement* listC = gcfp + (size_t)MMGEN_MAX_GATHERED_CAVE_FEATURES_PER_CHUNK * chunk;
     int2* cand = s_cand[wave];
     int nS = 0, nC = 0;
-    if (doS) nS = filter_column<mmgen_feature_placement, MMGEN_MAX_GATHERED_FEATURES_PER_CHUNK, false>(listS, wx, wz, cand);
-    if (doC) nC = filter_column<mmgen_cave_feature_placement, MMGEN_MAX_GATHERED_CAVE_FEATURES_PER_CHUNK, true>(listC, wx, wz, cand + imax(nS, 0));
+    unsigned maskS = 0u, maskC = 0u;
+    if (doS) nS = filter_column<mmgen_feature_placement, MMGEN_MAX_GATHERED_FEATURES_PER_CHUNK, false>(listS, wx, wz, cand, maskS);
+    if (doC) nC = filter_column<mmgen_cave_feature_placement, MMGEN_MAX_GATHERED_CAVE_FEATURES_PER_CHUNK, true>(listC, wx, wz, cand + imax(nS, 0), maskC);
+    // two workgroup-uniform decisions (the only workgroup barriers): nothing reaches these four columns -> done; the simplex tables
+    // (12 KB from L2 per workgroup) are only staged when a candidate's rasteriser evaluates simplex noise (coral, iceberg, redwood,
+    // cypress; glowstone, the two fungi) or the gathered lists must be scanned directly
+    constexpr unsigned kNoiseS = (1u << MMF_CORAL) | (1u << MMF_ICEBERG) | (1u << MMF_REDWOOD_TREE) | (1u << MMF_CYPRESS_TREE);
+    constexpr unsigned kNoiseC = (1u << MMCF_GLOWSTONE_CLUSTER) | (1u << MMCF_WARPED_FUNGUS) | (1u << MMCF_AMBER_FUNGUS);
+    if (!__syncthreads_or(nS != 0 || nC != 0)) return;
+    if (__syncthreads_or((__ballot((maskS & kNoiseS) || (maskC & kNoiseC)) != 0ull) || nS < 0 || nC < 0)) noise_tables_init();
     if (nS == 0 && nC == 0) return;
     uint8_t* colBlocks = blocks + (size_t)MMGEN_BLOCKS_PER_CHUNK * chunk + 384 * idx2d;
     const int sLo = imax(b0, 0), sHi = imin(b1, 383), cLo = imax(b2, 0), cHi = imin(b3, 383);   // the chunk's height bounds (chunk.cu:1555-1570)
@@ -507,6 +545,7 @@ k_apply_features(uint8_t* __restrict__ blocks, const int2* __restrict__ chunkPos
     const int nTot = nS + nC;
     int* pref = s_pref[wave];
     int total = 0;
+    int yLo = 384, yHi = -1;                               // union of the candidates' extents: the only voxels staged and written back
     for (int k0 = 0; k0 < nTot; k0 += 64) {
         const int k = k0 + lane;
         int n = 0;
@@ -514,9 +553,10 @@ k_apply_features(uint8_t* __restrict__ blocks, const int2* __restrict__ chunkPos
             const int2 e = cand[k];
             const int fy = (e.x >> 16) & 511, feature = (e.x >> 25) & 31;
             int lo, hi;
-            if (k < nS) { lo = imax(fy + kFeatureBounds[feature][0], sLo); hi = imin(fy + kFeatureBounds[feature][1], sHi); }
+            if (k < nS) { lo = imax(fy + (e.y & 255) - 128, sLo); hi = imin(fy + (e.y >> 8), sHi); }
             else { lo = imax(fy + kCaveFeatureBounds[feature][0], cLo); hi = imin(fy + e.y + kCaveFeatureBounds[feature][1], cHi); }
             n = imax(hi - lo + 1, 0);
+            if (n > 0) { yLo = imin(yLo, lo); yHi = imax(yHi, hi); }
         }
         int incl = n;
 #pragma unroll
@@ -525,9 +565,14 @@ k_apply_features(uint8_t* __restrict__ blocks, const int2* __restrict__ chunkPos
         total += __shfl(incl, 63);
     }
     if (lane == 0) pref[nTot] = total;
-    for (int y = lane; y < 384; y += 64) { s_blk[wave][y] = colBlocks[y]; s_claim[wave][y] = 0xffffffffu; }
+    if (total == 0) return;
+    yLo = wave_min(yLo); yHi = wave_max(yHi);
+    for (int y = yLo + lane; y <= yHi; y += 64) { s_blk[wave][y] = colBlocks[y]; s_claim[wave][y] = 0xffffffffu; }
     wave_lds_sync();
 
+#if MM_APPLY_EXP == 1
+    total = 0;                                                          // timing experiment: fixed per-column work only
+#endif
     for (int j0 = 0; j0 < total; j0 += 64) {
         const int j = j0 + lane;
         if (j >= total) break;
@@ -536,15 +581,19 @@ k_apply_features(uint8_t* __restrict__ blocks, const int2* __restrict__ chunkPos
         const int2 e = cand[k];
         const int fx = wx + (e.x & 255) - 128, fz = wz + ((e.x >> 8) & 255) - 128, fy = (e.x >> 16) & 511, feature = (e.x >> 25) & 31;
         const bool cave = k >= nS;
-        const int lo = cave ? imax(fy + kCaveFeatureBounds[feature][0], cLo) : imax(fy + kFeatureBounds[feature][0], sLo);
+        const int lo = cave ? imax(fy + kCaveFeatureBounds[feature][0], cLo) : imax(fy + (e.y & 255) - 128, sLo);
         const int y = lo + (j - pref[k]);
         if (s_blk[wave][y] != MMB_AIR && !((e.x >> 30) & 1)) continue;
         uint8_t fb = 0;
+#if MM_APPLY_EXP == 2
+        const bool placed = (fx + fy + fz + y) == 0x7fffffff;          // timing experiment: no rasteriser
+#else
         const bool placed = cave ? place_cave_feature(feature, fx, fy, fz, e.y, wx, y, wz, fb) : place_feature(feature, fx, fy, fz, wx, y, wz, fb);
+#endif
         if (placed) atomicMin(&s_claim[wave][y], ((unsigned)k << 8) | fb);
     }
     wave_lds_sync();
-    for (int y = lane; y < 384; y += 64) {
+    for (int y = yLo + lane; y <= yHi; y += 64) {
         const unsigned c = s_claim[wave][y];
         if (c != 0xffffffffu) colBlocks[y] = (uint8_t)(c & 255u);
     }

@@ -135,25 +135,4 @@ int mmgen_unpack(const uint8_t* d_packed, const uint64_t* d_chunk_offset, int n,
     return (int)hipGetLastError();
 }
 
-/* Host-side decoder of one packed chunk (for consumers that receive the wire format): returns 0, or -1 on a malformed stream. */
-int mmgen_unpack_chunk_host(const uint8_t* packed, size_t packed_bytes, uint8_t* blocks)
-{
-    if (!packed || !blocks || packed_bytes < 512) return -1;
-    const uint16_t* counts = (const uint16_t*)packed;
-    size_t pos = 512;
-    for (int col = 0; col < 256; ++col) {
-        int y = 0;
-        for (unsigned r = 0; r < counts[col]; ++r) {
-            if (pos + 2 > packed_bytes) return -1;
-            const uint8_t id = packed[pos];
-            const int len = (int)packed[pos + 1] + 1;
-            pos += 2;
-            if (y + len > 384) return -1;
-            for (int k = 0; k < len; ++k) blocks[384 * col + y++] = id;
-        }
-        if (y != 384) return -1;
-    }
-    return pos == packed_bytes ? 0 : -1;
-}
-
 }  // extern "C"

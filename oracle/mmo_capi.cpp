@@ -215,8 +215,8 @@ void mmo_feature_placements(int n, const int* posXZ, const float* hf, const floa
         generateFeaturePlacements(ivec2{posXZ[2 * i], posXZ[2 * i + 1]}, hf + 256 * i, bw + 6144 * i, layers + 5120 * i,
                                   (const CaveLayer*)caveLayers + 8192 * i, a, b);
         counts[2 * i] = (int)a.size(); counts[2 * i + 1] = (int)b.size();
-        std::memcpy((FeaturePlacement*)fp + (size_t)maxPer * i, a.data(), sizeof(FeaturePlacement) * std::min((int)a.size(), maxPer));
-        std::memcpy((CaveFeaturePlacement*)cfp + (size_t)maxPer * i, b.data(), sizeof(CaveFeaturePlacement) * std::min((int)b.size(), maxPer));
+        if (!a.empty()) std::memcpy((FeaturePlacement*)fp + (size_t)maxPer * i, a.data(), sizeof(FeaturePlacement) * std::min((int)a.size(), maxPer));
+        if (!b.empty()) std::memcpy((CaveFeaturePlacement*)cfp + (size_t)maxPer * i, b.data(), sizeof(CaveFeaturePlacement) * std::min((int)b.size(), maxPer));
     });
 }
 // fill one batch; features for chunk i are fp[fpOff[i] .. fpOff[i+1]) (gathered lists, un-truncated)
@@ -378,8 +378,9 @@ void mmo_region_begin(void* ctx, int cx0, int cz0, int nx, int nz, int flags, co
             generateFeaturePlacements(ivec2{ppos[2 * i], ppos[2 * i + 1]}, hf.data() + (size_t)256 * i, bw.data() + (size_t)6144 * i,
                                       layers.data() + (size_t)5120 * i, r.cave.data() + (size_t)8192 * i, a, b);
             counts_out[2 * i] = (int)a.size(); counts_out[2 * i + 1] = (int)b.size();
-            std::memcpy((FeaturePlacement*)fp_out + (size_t)fpCap * i, a.data(), sizeof(FeaturePlacement) * std::min((int)a.size(), fpCap));
-            std::memcpy((CaveFeaturePlacement*)cfp_out + (size_t)cfpCap * i, b.data(), sizeof(CaveFeaturePlacement) * std::min((int)b.size(), cfpCap));
+            // (an empty vector's data() may be null: memcpy's arguments must not be, even for 0 bytes - found by the UBSan job)
+            if (!a.empty()) std::memcpy((FeaturePlacement*)fp_out + (size_t)fpCap * i, a.data(), sizeof(FeaturePlacement) * std::min((int)a.size(), fpCap));
+            if (!b.empty()) std::memcpy((CaveFeaturePlacement*)cfp_out + (size_t)cfpCap * i, b.data(), sizeof(CaveFeaturePlacement) * std::min((int)b.size(), cfpCap));
         });
     }
 }

@@ -122,3 +122,29 @@ def test_compact_wire_format_round_trip():
         assert torch.equal(dst["fp"][c, :n0], bufs["fp"][c, :n0]) and torch.equal(dst["cfp"][c, :n1], bufs["cfp"][c, :n1])
         assert torch.equal(dst["counts"][c], bufs["counts"][c])          # raw count travels, also beyond the cap
     assert int(dst["counts"][0].sum()) == 0 and int(dst["fp"][5].abs().sum()) == 0
+
+
+@pytest.mark.parametrize("layout_args", [(-5, 7, 2, 2, 4, 5), (-128, -128, 4, 2, 64, 128), (0, 0, 3, 1, 3, 3), (10, -20, 2, 1, 2, 2)])
+def test_cpp_exchange_plan_equals_python_plan(layout_args, tmp_path):
+    """The C++ host (mega-minecraft_amd/host/tile_layout.hpp, used by TiledWorld over RCCL) and distributed.py must enumerate the same
+    cells in the same order on both ends of every link: the plan printed by host/tile_plan_dump (pure host C++) == TileContext's."""
+    import subprocess
+    import torch
+    sys.path.insert(0, ROOT)
+    exe = os.path.join(ROOT, "mega-minecraft_amd", "tile_plan_dump")
+    if not os.path.exists(exe):
+        subprocess.run(["g++", "-O2", "-std=c++17", "-o", exe, os.path.join(ROOT, "mega-minecraft_amd", "host", "tile_plan_dump.cpp")], check=True)
+    out = subprocess.run([exe] + [str(a) for a in layout_args], capture_output=True, text=True, check=True).stdout.splitlines()
+    d = importlib.import_module("mega-minecraft_amd.distributed")
+    lay = d.TileLayout(*layout_args)
+    it = iter(out)
+    for rank in range(lay.world_size):
+        ctx = d.TileContext(lay, rank, torch, "cpu")
+        head = next(it).split()
+        assert head[:2] == ["rank", str(rank)] and int(head[3]) == sum(ctx.mask_list) and int(head[5]) == len(ctx.peers)
+        for k, peer in enumerate(ctx.peers):
+            tok = next(it).split()
+            assert tok[0] == "peer" and int(tok[1]) == peer
+            i_send = tok.index("send")
+            assert [int(t) for t in tok[3:i_send]] == ctx.recv_cells[ctx.recv_seg[k]:ctx.recv_seg[k + 1]].tolist()
+            assert [int(t) for t in tok[i_send + 1:]] == ctx.send_cells[ctx.send_seg[k]:ctx.send_seg[k + 1]].tolist()

@@ -271,6 +271,20 @@ def test_region_batched_scheduler_equals_action_time_scheduler(mmgen_pkg):
     assert "IDENTICAL" in r.stdout and "1089 drawable chunks compared" in r.stdout
 
 
+def test_cpp_tiled_world_host_single_tile(mmgen_pkg):
+    """The C++ multi-GPU host (host/tiled_world.hpp: TileLayout + ExchangePlan + RCCL grouped send / recv, linked against librccl) on one
+    GPU: the tiled path with a single tile gives the same blocks as mmgen_region_generate (the demo compares checksums in-process).
+    The N > 1 exchange needs N GPUs; its plan is held to distributed.py's by tests/test_distributed_cpu.py and its device kernels by
+    test_ring_wire_format_on_the_device."""
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(mmgen_pkg.LIB_PATH), "mmgen_tiled_demo")
+    assert os.path.exists(exe), "build it with make -C mega-minecraft_amd/csrc"
+    r = subprocess.run([exe, "--gpus", "1", "--tile", "12", "12", "--steps", "2"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "single tile == mmgen_region_generate: ok" in r.stdout
+
+
 # ------------------------------------------------------------------------------------------------ F1 / F2 observed directly
 def _fields(fp, cfp):
     """placement records as plain fields (padding bytes of the 20 / 24-byte structs masked out)"""
