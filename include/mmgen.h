@@ -112,9 +112,14 @@ void mmgen_region_destroy(mmgen_region* region);
 int mmgen_region_generate(mmgen_region* region, int cx0, int cz0, int nx, int nz, unsigned flags, uint8_t* d_blocks /*[nx*nz][98304]*/,
                           float* d_heightfields /*[nx*nz][256], nullable*/, void* stream);
 /* two-phase form for spatial multi-GPU tiling: begin runs heightfield .. feature placements on the tile plus its 3-chunk ring;
- * h_local_mask (host, [(nx+6)*(nz+6)] bytes over the ring-extended grid, nullable = all) marks the ring cells whose placements this
- * GPU must compute itself (world border); the other ring cells are expected to be written into the placement buffers by the caller
- * (RCCL halo exchange with the neighbouring tiles) before finish. */
+ * h_local_mask (host, [(nx+6)*(nz+6)] bytes over the ring-extended grid, nullable = all 1) says for every RING cell who provides its
+ * placement lists (cells of the rectangle itself are always computed in full):
+ *   0  the caller writes them into the placement buffers before finish (RCCL halo exchange with the neighbouring tiles, a cache);
+ *   1  computed here, complete (the lists may be kept and re-used as ring cells of later regions);
+ *   2  computed here LAZILY: only the placements that can reach the rectangle are generated, and only the columns that can produce one
+ *      get cave noise (a cave feature reaches <= 8 blocks; a surface feature only stands on its gen's jittered grid point, chunk.cu:999-1008,
+ *      which is known before the caves are) - about 1/5 of the ring's cave work.  The blocks of the rectangle are identical; the
+ *      ring's lists are a subset of the complete ones and must not be re-used elsewhere.  mmgen_region_generate uses 2 throughout. */
 int mmgen_region_begin(mmgen_region* region, int cx0, int cz0, int nx, int nz, unsigned flags, const uint8_t* h_local_mask, void* stream);
 int mmgen_region_placement_buffers(mmgen_region* region, mmgen_feature_placement** d_fp /*[grid][MMGEN_FP_CAP]*/,
                                    mmgen_cave_feature_placement** d_cfp /*[grid][MMGEN_CFP_CAP]*/, int32_t** d_counts /*[grid][2]*/,

@@ -130,7 +130,7 @@ int mmgen_generate_caves(const float* d_hf, const float* d_bw, const int32_t* d_
     if (n == 0) return 0;
     int e = ensure_scratch(n);
     if (e) return e;
-    return mmk::launch_caves(d_hf, d_bw, d_pos, n, d_cl, g_colInfo, nullptr, (hipStream_t)stream);
+    return mmk::launch_caves(d_hf, d_bw, d_pos, n, d_cl, g_colInfo, nullptr, nullptr, (hipStream_t)stream);
 }
 
 int mmgen_fill(const float* d_hf, const float* d_bw, const float* d_layers, const mmgen_cave_layer* d_cl, const int32_t* d_pos, int n,
@@ -150,7 +150,7 @@ int mmgen_generate_feature_placements(const float* d_hf, const float* d_bw, cons
                                       int n, mmgen_feature_placement* d_fp, mmgen_cave_feature_placement* d_cfp, int32_t* d_counts, void* stream)
 {
     if (n < 0 || (n > 0 && (!d_hf || !d_bw || !d_layers || !d_cl || !d_pos || !d_fp || !d_cfp || !d_counts))) return (int)hipErrorInvalidValue;
-    return mmk::launch_feature_placements(d_hf, d_bw, d_layers, d_cl, d_pos, n, d_fp, d_cfp, d_counts, nullptr, (hipStream_t)stream);
+    return mmk::launch_feature_placements(d_hf, d_bw, d_layers, d_cl, d_pos, n, d_fp, d_cfp, d_counts, nullptr, nullptr, (hipStream_t)stream);
 }
 
 int mmgen_gather_feature_placements(const mmgen_feature_placement* d_fp, const mmgen_cave_feature_placement* d_cfp, const int32_t* d_counts,

@@ -7,7 +7,10 @@
 namespace mmk {
 int prepare_features();    // builds this translation unit's noise-table image on the current device (called from mmgen_init)
 int launch_feature_placements(const float* hf, const float* bw, const float* layers, const mmgen_cave_layer* cl, const int32_t* pos, int n,
-                              mmgen_feature_placement* fp, mmgen_cave_feature_placement* cfp, int* counts, const int* chunkList, hipStream_t s);
+                              mmgen_feature_placement* fp, mmgen_cave_feature_placement* cfp, int* counts, const int* chunkList,
+                              const uint8_t* colNeed /*nullable*/, hipStream_t s);
+int launch_ring_need(const float* bw, const int32_t* pos, const int* chunkList, int n, const uint8_t* cellLazy, int rx0, int rz0, int rx1, int rz1,
+                     uint8_t* colNeed, hipStream_t s);
 int launch_gather_placements(const mmgen_feature_placement* fp, const mmgen_cave_feature_placement* cfp, const int* counts, const int* target,
                              int nOut, int gridW, int gridH, mmgen_feature_placement* gfp, mmgen_cave_feature_placement* gcfp, int* bounds,
                              const int32_t* gridPos, hipStream_t s);

@@ -127,6 +127,15 @@ __device__ constexpr DecoGen kCaveDecoGens[MMGEN_NUM_CAVE_BIOMES][6] = {
     {DG(MMB_INFECTED_MUSHROOM, 0.020f, 2, MMB_AMBER_DEEPSLATE, MMB_AMBER_BLACKSTONE, 0, MMB_AIR, MMB_AIR, 0),
      DG(MMB_AMBER_ROOTS, 0.060f, 2, MMB_AMBER_DEEPSLATE, MMB_AMBER_BLACKSTONE, 0, MMB_AIR, MMB_AIR, 0)}};
 
+// Chebyshev reach max(|dx|, |dz|) in blocks beyond which placeFeature / placeCaveFeature cannot return true
+__device__ constexpr int kFeatureReach[MMGEN_NUM_FEATURES] = {
+    /*NONE*/ 0, /*SPHERE*/ 5, /*CORAL*/ 8, /*KELP*/ 0, /*ICEBERG*/ 40, /*ACACIA*/ 15, /*REDWOOD*/ 20, /*CYPRESS*/ 12, /*BIRCH*/ 8,
+    /*PINE_TREE*/ 6, /*PINE_SHRUB*/ 6, /*RAFFLESIA*/ 15, /*LARGE_JUNGLE*/ 15, /*SMALL_JUNGLE*/ 8, /*TINY_JUNGLE*/ 1,
+    /*MEDIUM_PURPLE_MUSHROOM*/ 8, /*PURPLE_MUSHROOM*/ 127, /*MEDIUM_CRYSTAL*/ 25, /*CRYSTAL*/ 25, /*PALM*/ 24, /*CACTUS*/ 5};
+__device__ constexpr int kCaveFeatureReach[MMGEN_NUM_CAVE_FEATURES] = {
+    /*NONE*/ 0, /*TEST pillars*/ 0, 0, /*CAVE_VINE*/ 0, /*GLOWSTONE_CLUSTER*/ 6, /*STORMLIGHT*/ 8, /*CEILING_STORMLIGHT*/ 8,
+    /*CRYSTAL_PILLAR*/ 7, /*WARPED_FUNGUS*/ 6, /*AMBER_FUNGUS*/ 4};
+
 // ---------------------------------------------------------------------------------------------------------
 // F1 — placement generation (chunk.cu:999-1156)
 // ---------------------------------------------------------------------------------------------------------
@@ -212,11 +221,42 @@ MM_DEV void column_placements(int wx, int wz, float height, const float* cbw /*s
     }
 }
 
+// Lazy ring (region path): a ring chunk outside the rectangle only matters through the placements that can reach the rectangle, and
+// whether a column can produce one is decidable BEFORE its caves exist: a cave feature reaches at most kCaveFeatureReach blocks, and a
+// surface feature only ever stands on the jittered grid point of its gen (is_feature_pos depends on position and gen alone, chunk.cu:999-1008;
+// the rng stream only decides which of the possible gens fires).  Columns that can produce nothing that reaches the rectangle need no
+// cave noise at all: that is ~80 % of a 3-chunk ring.  need[cell][column] = 1 for every column of a fully computed cell.
+__global__ void __launch_bounds__(256)
+k_ring_need(const float* __restrict__ bw, const int2* __restrict__ chunkPos, const int* __restrict__ chunkList, const uint8_t* __restrict__ cellLazy,
+            int rx0, int rz0, int rx1, int rz1 /*the rectangle in block coordinates, inclusive*/, uint8_t* __restrict__ colNeed)
+{
+    const int chunk = chunkList[blockIdx.x], t = threadIdx.x;
+    uint8_t need = 1;
+    if (cellLazy[chunk]) {
+        const int2 cp = chunkPos[chunk];
+        const int wx = cp.x + (t & 15), wz = cp.y + (t >> 4);
+        const int dist = imax(imax(rx0 - wx, wx - rx1), imax(imax(rz0 - wz, wz - rz1), 0));      // Chebyshev distance to the rectangle
+        int maxCave = 0;
+        for (int f = 0; f < MMGEN_NUM_CAVE_FEATURES; ++f) maxCave = imax(maxCave, kCaveFeatureReach[f]);
+        need = dist <= maxCave;
+        const float* cbw = bw + (size_t)MMGEN_BIOME_WEIGHTS_SIZE * chunk + t;
+        for (int b = 0; b < MMGEN_NUM_BIOMES && !need; ++b) {
+            // random_biome can return a biome only if its weight is positive - or biome 0 when the draw is exactly 0
+            if (b != 0 && !(cbw[256 * b] > 0.f)) continue;
+            for (int g = 0; g < kSurfGenCount[b] && !need; ++g) {
+                const SurfGen& gen = kSurfGens[b][g];
+                if (dist <= kFeatureReach[gen.feature] && is_feature_pos(wx, wz, gen.cell, gen.pad, (int)gen.feature * 518721)) need = 1;
+            }
+        }
+    }
+    colNeed[(size_t)256 * chunk + t] = need;
+}
+
 __global__ void __launch_bounds__(256)
 k_feature_placements(const float* __restrict__ hf, const float* __restrict__ bw, const float* __restrict__ layers,
                      const mmgen_cave_layer* __restrict__ caveLayers, const int2* __restrict__ chunkPos,
                      mmgen_feature_placement* __restrict__ fpOut, mmgen_cave_feature_placement* __restrict__ cfpOut, int* __restrict__ counts,
-                     const int* __restrict__ chunkList)
+                     const int* __restrict__ chunkList, const uint8_t* __restrict__ colNeed /*nullable: [chunk][256], 0 = column skipped (lazy ring)*/)
 {
     noise_tables_init();
     __shared__ int s_ns[256], s_nc[256];
@@ -228,8 +268,9 @@ k_feature_placements(const float* __restrict__ hf, const float* __restrict__ bw,
     const float* cl = layers + (size_t)MMGEN_LAYERS_SIZE * chunk + t;
     const mmgen_cave_layer* ccl = caveLayers + ((size_t)256 * chunk + t) * MMGEN_MAX_CAVE_LAYERS_PER_COLUMN;
 
-    int ns, nc;
-    column_placements<false>(wx, wz, height, cbw, cl, ccl, ns, nc, nullptr, nullptr, 0);
+    int ns = 0, nc = 0;
+    const bool need = !colNeed || colNeed[(size_t)256 * chunk + t];
+    if (need) column_placements<false>(wx, wz, height, cbw, cl, ccl, ns, nc, nullptr, nullptr, 0);
     s_ns[t] = ns; s_nc[t] = nc;
     __syncthreads();
     int offS = 0, offC = 0;
@@ -250,15 +291,6 @@ __device__ constexpr int kGatherDX[49] = {0, 0, 1, 1, 1, 0, -1, -1, -1, 2, 2, 2,
                                           -3, -2, -1, 0, 1, 2, 3, 3, 3, 3, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -3, -3, -3};
 __device__ constexpr int kGatherDZ[49] = {0, 1, 1, 0, -1, -1, -1, 0, 1, 0, 1, 2, 2, 2, 2, 2, 1, 0, -1, -2, -2, -2, -2, -2, -1,
                                           -3, -3, -3, -3, -3, -3, -3, -2, -1, 0, 1, 2, 3, 3, 3, 3, 3, 3, 3, 2, 1, 0, -1, -2};
-
-// Chebyshev reach max(|dx|, |dz|) in blocks beyond which placeFeature / placeCaveFeature cannot return true
-__device__ constexpr int kFeatureReach[MMGEN_NUM_FEATURES] = {
-    /*NONE*/ 0, /*SPHERE*/ 5, /*CORAL*/ 8, /*KELP*/ 0, /*ICEBERG*/ 40, /*ACACIA*/ 15, /*REDWOOD*/ 20, /*CYPRESS*/ 12, /*BIRCH*/ 8,
-    /*PINE_TREE*/ 6, /*PINE_SHRUB*/ 6, /*RAFFLESIA*/ 15, /*LARGE_JUNGLE*/ 15, /*SMALL_JUNGLE*/ 8, /*TINY_JUNGLE*/ 1,
-    /*MEDIUM_PURPLE_MUSHROOM*/ 8, /*PURPLE_MUSHROOM*/ 127, /*MEDIUM_CRYSTAL*/ 25, /*CRYSTAL*/ 25, /*PALM*/ 24, /*CACTUS*/ 5};
-__device__ constexpr int kCaveFeatureReach[MMGEN_NUM_CAVE_FEATURES] = {
-    /*NONE*/ 0, /*TEST pillars*/ 0, 0, /*CAVE_VINE*/ 0, /*GLOWSTONE_CLUSTER*/ 6, /*STORMLIGHT*/ 8, /*CEILING_STORMLIGHT*/ 8,
-    /*CRYSTAL_PILLAR*/ 7, /*WARPED_FUNGUS*/ 6, /*AMBER_FUNGUS*/ 4};
 
 // stable (order-preserving) compaction of one gathered list into `out`, keeping the entries whose horizontal reach box meets the
 // target chunk's 16 x 16 footprint; entries at index >= CAP are dropped first, exactly like the reference's truncation, so the kept
@@ -765,10 +797,19 @@ int launch_feature_box(int isCave, int feature, const int* fpos, int layerHeight
 }
 
 int launch_feature_placements(const float* hf, const float* bw, const float* layers, const mmgen_cave_layer* cl, const int32_t* pos, int n,
-                              mmgen_feature_placement* fp, mmgen_cave_feature_placement* cfp, int* counts, const int* chunkList, hipStream_t s)
+                              mmgen_feature_placement* fp, mmgen_cave_feature_placement* cfp, int* counts, const int* chunkList, const uint8_t* colNeed,
+                              hipStream_t s)
 {
     if (n <= 0) return 0;
-    LAUNCH(KID_FEATURE_PLACEMENTS, mm::k_feature_placements, dim3(n), dim3(256), s, hf, bw, layers, cl, (const int2*)pos, fp, cfp, counts, chunkList);
+    LAUNCH(KID_FEATURE_PLACEMENTS, mm::k_feature_placements, dim3(n), dim3(256), s, hf, bw, layers, cl, (const int2*)pos, fp, cfp, counts, chunkList, colNeed);
+    return 0;
+}
+
+int launch_ring_need(const float* bw, const int32_t* pos, const int* chunkList, int n, const uint8_t* cellLazy, int rx0, int rz0, int rx1, int rz1,
+                     uint8_t* colNeed, hipStream_t s)
+{
+    if (n <= 0) return 0;
+    LAUNCH(KID_RING_NEED, mm::k_ring_need, dim3(n), dim3(256), s, bw, (const int2*)pos, chunkList, cellLazy, rx0, rz0, rx1, rz1, colNeed);
     return 0;
 }
 

@@ -9,7 +9,7 @@ int launch_heightfield(const int32_t* pos, int n, float* hf, float* bw, float* g
 int launch_layers(const float* gathered, const float* bw, const int32_t* pos, int n, float* layers, hipStream_t s);
 int launch_fix_backward(float* layers, int n, hipStream_t s);
 int launch_caves(const float* hf, const float* bw, const int32_t* pos, int n, mmgen_cave_layer* caveLayers, float* colInfoScratch,
-                 const int* chunkList /*nullable: chunks to process*/, hipStream_t s);
+                 const int* chunkList /*nullable: chunks to process*/, const uint8_t* colNeed /*nullable: [chunk][256], lazy ring*/, hipStream_t s);
 int launch_fill(const float* hf, const float* bw, const float* layers, const mmgen_cave_layer* caveLayers, const int32_t* pos, int n,
                 uint8_t* blocks, const int* srcIdx /*nullable: input chunk of each output chunk*/,
                 unsigned* lushQueue /*nullable device scratch: deferred clay / moss voxels*/, size_t lushQueueBytes, hipStream_t s);

@@ -242,7 +242,7 @@ struct CellTile {
 __attribute__((amdgpu_waves_per_eu(MM_CAVE_WAVES, MM_CAVE_WAVES)))
 __global__ void __launch_bounds__(CAVE_THREADS)
 k_cave_voxels(const float* __restrict__ hf, const float2* __restrict__ colInfo, const int2* __restrict__ chunkPos,
-              mmgen_cave_layer* __restrict__ caveLayers, const int* __restrict__ chunkList)
+              mmgen_cave_layer* __restrict__ caveLayers, const int* __restrict__ chunkList, const uint8_t* __restrict__ colNeed /*nullable, lazy ring*/)
 {
     __shared__ float s_cells[3 * CELL_N];
     __shared__ unsigned long long s_solid[CAVE_COLS][6];      // solid bit of voxel y at word y / 64, bit y % 64
@@ -256,6 +256,13 @@ k_cave_voxels(const float* __restrict__ hf, const float2* __restrict__ colInfo, 
     const int chunk = chunkList ? chunkList[bid >> 6] : (bid >> 6);
     const int group = bid & 63;                                // 64 groups of 4 columns per chunk: x = 4 (group % 4) + c, z = group / 4
     const int2 cp = chunkPos[chunk];
+    // lazy ring: columns that cannot produce a placement reaching the rectangle get no cave noise: no solid bit is ever set for them,
+    // so no flip is found and their 32 layers stay at the default {384, 384, NONE, NONE}
+    unsigned needMask = 0xfu;
+    if (colNeed) {
+        const uchar4 nd = *(const uchar4*)(colNeed + (size_t)256 * chunk + 4 * group);
+        needMask = (nd.x ? 1u : 0u) | (nd.y ? 2u : 0u) | (nd.z ? 4u : 0u) | (nd.w ? 8u : 0u);
+    }
 
     // cell tile: sample position = noisePos * (1, 1.6, 1) + offset with |offset| < 1.8; origin from the group's first column
     CellTile tile;
@@ -263,7 +270,7 @@ k_cave_voxels(const float* __restrict__ hf, const float2* __restrict__ colInfo, 
     tile.ox = (int)__builtin_floorf(((float)(cp.x + ((4 * group) & 15)) * 0.0050f) * 1.f) - 3;
     tile.oy = -3;
     tile.oz = (int)__builtin_floorf(((float)(cp.y + ((4 * group) >> 4)) * 0.0050f) * 1.f) - 3;
-    for (int i = t; i < CELL_N; i += CAVE_THREADS) {
+    for (int i = t; i < (needMask ? CELL_N : 0); i += CAVE_THREADS) {
         const int iz = i % CELL_NZ, iy = (i / CELL_NZ) % CELL_NY, ix = i / (CELL_NZ * CELL_NY);
         const f3 p = rand3from3((float)(tile.ox + ix), (float)(tile.oy + iy), (float)(tile.oz + iz));
         s_cells[3 * i] = p.x; s_cells[3 * i + 1] = p.y; s_cells[3 * i + 2] = p.z;
@@ -282,6 +289,7 @@ k_cave_voxels(const float* __restrict__ hf, const float2* __restrict__ colInfo, 
     //   C  list 2: position warp (fbm3from3<5>) + Worley; "cave" clears the solid bit again
     for (int e = t; e < CAVE_VOXELS; e += CAVE_THREADS) {
         const int c = e / CAVE_YEVAL, y = e - c * CAVE_YEVAL;
+        if (!((needMask >> c) & 1u)) continue;
         const int col = chunk * 256 + 4 * group + c;
         const float maxHeight = hf[col];
         const float2 ci = colInfo[col];
@@ -339,7 +347,7 @@ k_cave_voxels(const float* __restrict__ hf, const float2* __restrict__ colInfo, 
     if (t < CAVE_COLS * 4) {   // 4 lanes per column fill words 2..5 (word 2 holds y 128..191: bits >= 16 only)
         const int c = t >> 2, w = 2 + (t & 3);
         const int col = chunk * 256 + 4 * group + c;
-        const int topSolid = imax((int)hf[col], MMGEN_SEA_LEVEL);
+        const int topSolid = ((needMask >> c) & 1u) ? imax((int)hf[col], MMGEN_SEA_LEVEL) : -1;
         const float ravineY = colInfo[col].y;
         unsigned long long m = 0ull;
         for (int b = 0; b < 64; ++b) {
@@ -738,11 +746,11 @@ int launch_fix_backward(float* layers, int n, hipStream_t s)
 }
 
 int launch_caves(const float* hf, const float* bw, const int32_t* pos, int n, mmgen_cave_layer* caveLayers, float* colInfoScratch,
-                 const int* chunkList, hipStream_t s)
+                 const int* chunkList, const uint8_t* colNeed, hipStream_t s)
 {
     if (n <= 0) return 0;
     LAUNCH(KID_CAVE_COLUMNS, mm::k_cave_columns, dim3(n), dim3(256), s, bw, (const int2*)pos, (float2*)colInfoScratch, chunkList);
-    LAUNCH(KID_CAVE_VOXELS, mm::k_cave_voxels, dim3(n * 64), dim3(CAVE_THREADS), s, hf, (const float2*)colInfoScratch, (const int2*)pos, caveLayers, chunkList);
+    LAUNCH(KID_CAVE_VOXELS, mm::k_cave_voxels, dim3(n * 64), dim3(CAVE_THREADS), s, hf, (const float2*)colInfoScratch, (const int2*)pos, caveLayers, chunkList, colNeed);
     LAUNCH(KID_CAVE_BIOMES, mm::k_cave_biomes, dim3(n * (256 / CB_COLS)), dim3(CB_THREADS), s, hf, (const int2*)pos, caveLayers, chunkList);
     return 0;
 }

@@ -138,11 +138,11 @@ struct mmgen_region {
     unsigned flags = 0;
     int ring = 0, px0 = 0, pz0 = 0, pnx = 0, pnz = 0, np = 0;
     int ax0 = 0, az0 = 0, anx = 0, anz = 0, na = 0;
-    int nCompute = 0, nZones = 0;
+    int nCompute = 0, nZones = 0, nLazy = 0;
     bool began = false;
     DevBuf posA, hfA, bwA, gathA, layersA;
     DevBuf posP, hfP, bwP, layersP, caveP, colInfo, fp, cfp, counts;
-    DevBuf selAP, zoneIdx, zoneIdxOut, gathered, erodeWork, erodeState, computeList, targets, gfp, gcfp, bounds, fillQueue;
+    DevBuf selAP, zoneIdx, zoneIdxOut, gathered, erodeWork, erodeState, computeList, targets, gfp, gcfp, bounds, fillQueue, cellLazy, colNeed;
     int lastMaxPasses = 0;
     // layout cache: the host-built index tables (positions, A->P selection, compute list, zone gather / scatter lists, fill targets)
     // depend only on (rectangle, flags, mask); a caller that regenerates the same layout (bench loop, fixed tiles) re-uses the
@@ -157,7 +157,7 @@ struct mmgen_region {
     ~mmgen_region()
     {
         DevBuf* all[] = {&posA, &hfA, &bwA, &gathA, &layersA, &posP, &hfP, &bwP, &layersP, &caveP, &colInfo, &fp, &cfp, &counts, &selAP, &zoneIdx,
-                         &zoneIdxOut, &gathered, &erodeWork, &erodeState, &computeList, &targets, &gfp, &gcfp, &bounds, &fillQueue};
+                         &zoneIdxOut, &gathered, &erodeWork, &erodeState, &computeList, &targets, &gfp, &gcfp, &bounds, &fillQueue, &cellLazy, &colNeed};
         for (DevBuf* b : all) b->release();
     }
 };
@@ -206,14 +206,18 @@ static int region_layout(mmgen_region* r, int cx0, int cz0, int nx, int nz, unsi
     const int na = r->na, nr = nx * nz, Z = r->nZones;
 
     std::vector<int32_t> posA(2 * (size_t)na), selAP(np), computeList, targets(nr);
+    std::vector<uint8_t> lazy(np, 0);
     for (int z = 0; z < r->anz; ++z) for (int x = 0; x < r->anx; ++x) { posA[2 * (x + r->anx * z)] = (r->ax0 + x) * 16; posA[2 * (x + r->anx * z) + 1] = (r->az0 + z) * 16; }
     for (int z = 0; z < r->pnz; ++z) for (int x = 0; x < r->pnx; ++x) selAP[x + r->pnx * z] = (r->px0 + x - r->ax0) + r->anx * (r->pz0 + z - r->az0);
     for (int i = 0; i < np; ++i) {
         const int x = i % r->pnx - ring, z = i / r->pnx - ring;
         const bool inR = x >= 0 && x < nx && z >= 0 && z < nz;
         if (inR || !h_local_mask || h_local_mask[i]) computeList.push_back(i);
+        if (!inR && h_local_mask && h_local_mask[i] == 2) lazy[i] = 1;
     }
     r->nCompute = (int)computeList.size();
+    r->nLazy = 0;
+    for (uint8_t l : lazy) r->nLazy += l;
     for (int z = 0; z < nz; ++z) for (int x = 0; x < nx; ++x) targets[x + nx * z] = (x + ring) + r->pnx * (z + ring);
     std::vector<int> zi((size_t)Z * 576), zo((size_t)Z * 144);
     for (int z = 0; z < Z; ++z) {
@@ -233,6 +237,11 @@ static int region_layout(mmgen_region* r, int cx0, int cz0, int nx, int nz, unsi
     CK(hipMemcpyAsync(r->selAP.p, selAP.data(), sizeof(int) * np, hipMemcpyHostToDevice, s));
     CK(hipMemcpyAsync(r->computeList.p, computeList.data(), sizeof(int) * r->nCompute, hipMemcpyHostToDevice, s));
     CK(hipMemcpyAsync(r->targets.p, targets.data(), sizeof(int) * nr, hipMemcpyHostToDevice, s));
+    if (r->nLazy) {
+        CK(r->cellLazy.ensure(np));
+        CK(r->colNeed.ensure((size_t)256 * np));
+        CK(hipMemcpyAsync(r->cellLazy.p, lazy.data(), np, hipMemcpyHostToDevice, s));
+    }
     if (Z) {
         CK(r->zoneIdx.ensure(sizeof(int) * zi.size()));
         CK(r->zoneIdxOut.ensure(sizeof(int) * zo.size()));
@@ -314,9 +323,16 @@ int mmgen_region_begin(mmgen_region* r, int cx0, int cz0, int nx, int nz, unsign
     // ---- E3 fix-up, K4 caves, F1 placements
     CK(mmk::launch_fix_backward(layersP, np, s));
     const int* list = r->computeList.as<int>();
+    const uint8_t* colNeed = nullptr;
+    if (r->nLazy && features) {
+        // lazy ring cells: only the columns that can produce a placement reaching the rectangle get caves and placements
+        CK(mmk::launch_ring_need(bwP, posP, list, r->nCompute, r->cellLazy.as<uint8_t>(), 16 * cx0, 16 * cz0, 16 * (cx0 + nx) - 1, 16 * (cz0 + nz) - 1,
+                                 r->colNeed.as<uint8_t>(), s));
+        colNeed = r->colNeed.as<uint8_t>();
+    }
     {
         mmk::StageRange sr("mmgen:caves");
-        CK(mmk::launch_caves(hfP, bwP, posP, r->nCompute, r->caveP.as<mmgen_cave_layer>(), r->colInfo.as<float>(), list, s));
+        CK(mmk::launch_caves(hfP, bwP, posP, r->nCompute, r->caveP.as<mmgen_cave_layer>(), r->colInfo.as<float>(), list, colNeed, s));
     }
     if (features) {
         mmk::StageRange sr("mmgen:feature_placements");
@@ -325,7 +341,7 @@ int mmgen_region_begin(mmgen_region* r, int cx0, int cz0, int nx, int nz, unsign
         CK(r->counts.ensure(sizeof(int) * 2 * np));
         CK(hipMemsetAsync(r->counts.p, 0, sizeof(int) * 2 * np, s));
         CK(mmk::launch_feature_placements(hfP, bwP, layersP, r->caveP.as<mmgen_cave_layer>(), posP, r->nCompute, r->fp.as<mmgen_feature_placement>(),
-                                          r->cfp.as<mmgen_cave_feature_placement>(), r->counts.as<int>(), list, s));
+                                          r->cfp.as<mmgen_cave_feature_placement>(), r->counts.as<int>(), list, colNeed, s));
     }
     r->began = true;
     return 0;
@@ -404,7 +420,11 @@ int mmgen_region_finish(mmgen_region* r, uint8_t* d_blocks, float* d_heightfield
 
 int mmgen_region_generate(mmgen_region* r, int cx0, int cz0, int nx, int nz, unsigned flags, uint8_t* d_blocks, float* d_heightfields, void* stream)
 {
-    CK(mmgen_region_begin(r, cx0, cz0, nx, nz, flags, nullptr, stream));
+    // the ring's placement lists never leave this call: compute them lazily (mask value 2)
+    const uint8_t* mask = nullptr;
+    std::vector<uint8_t> lazyMask;
+    if (r && (flags & MMGEN_REGION_FEATURES) && nx > 0 && nz > 0) { lazyMask.assign((size_t)(nx + 6) * (nz + 6), 2); mask = lazyMask.data(); }
+    CK(mmgen_region_begin(r, cx0, cz0, nx, nz, flags, mask, stream));
     return mmgen_region_finish(r, d_blocks, d_heightfields, nullptr, nullptr, stream);
 }
 

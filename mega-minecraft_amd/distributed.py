@@ -92,14 +92,15 @@ class TileLayout:
                 cx, cz = cx0 - RING + x, cz0 - RING + z
                 yield (x + w * z, cx, cz, self.owner(cx, cz))
 
-    def local_mask(self, rank):
-        """1 for ring cells this rank must compute itself (no owner), 0 for cells that arrive from a peer; tile cells are always local."""
+    def local_mask(self, rank, lazy=True):
+        """Per cell of the ring-extended grid (include/mmgen.h, mmgen_region_begin): 0 = arrives from the peer that owns it; 2 (1 with
+        lazy=False) = no owner (beyond the world's border), computed here - lazily, since those lists go nowhere else; cells of the tile
+        itself are always computed in full."""
         cx0, cz0, nx, nz = self.region(rank)
         w, h = nx + 2 * RING, nz + 2 * RING
         mask = [1] * (w * h)
         for cell, _, _, own in self._ring_only(rank):
-            if own >= 0 and own != rank:
-                mask[cell] = 0
+            mask[cell] = 0 if (own >= 0 and own != rank) else (2 if lazy else 1)
         return mask
 
 
@@ -177,7 +178,7 @@ def generate_tile(backend, layout, rank, flags, dist=None, torch=None, want=(), 
     cx0, cz0, nx, nz = ctx.region
     features = bool(flags & 2)
     exchange = features and ctx.multi
-    backend.region_begin(cx0, cz0, nx, nz, flags, ctx.mask if exchange else None)
+    backend.region_begin(cx0, cz0, nx, nz, flags, ctx.mask if features else None)
     halo_bytes = 0
     if exchange:
         bufs = backend.region_placement_buffers()

@@ -48,11 +48,12 @@ struct TileLayout {
                 f(x + w * z, cx, cz, owner(cx, cz));
             }
     }
-    // 1 for ring cells this rank computes itself (no owner), 0 for cells that arrive from a peer; tile cells are always local
+    // mmgen_region_begin's mask: 0 for ring cells that arrive from the peer that owns them, 2 (computed here, lazily: the lists go nowhere
+    // else) for ring cells beyond the world's border, 1 for the tile's own cells
     std::vector<uint8_t> localMask(int rank) const
     {
         std::vector<uint8_t> m((size_t)gridW() * gridH(), 1);
-        forRing(rank, [&](int cell, int, int, int own) { if (own >= 0 && own != rank) m[cell] = 0; });
+        forRing(rank, [&](int cell, int, int, int own) { m[cell] = (own >= 0 && own != rank) ? 0 : 2; });
         return m;
     }
 };

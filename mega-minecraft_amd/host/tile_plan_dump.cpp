@@ -12,7 +12,7 @@ int main(int argc, char** argv)
         mmhost::ExchangePlan p(lay, rank);
         const auto mask = lay.localMask(rank);
         int local = 0;
-        for (uint8_t m : mask) local += m;
+        for (uint8_t m : mask) local += m != 0;
         std::printf("rank %d local %d peers %zu\n", rank, local, p.peers.size());
         for (size_t k = 0; k < p.peers.size(); ++k) {
             std::printf("peer %d recv", p.peers[k]);

@@ -86,7 +86,7 @@ int TiledWorld::generate(unsigned flags, uint8_t* d_blocks, float* d_heightfield
     const auto r = layout.region(rank);
     const bool exch = (flags & MMGEN_REGION_FEATURES) && layout.worldSize() > 1 && !plan.peers.empty();
     haloBytes = 0;
-    TW_MM(mmgen_region_begin(region, r[0], r[1], r[2], r[3], flags, exch ? mask.data() : nullptr, sMain));
+    TW_MM(mmgen_region_begin(region, r[0], r[1], r[2], r[3], flags, (flags & MMGEN_REGION_FEATURES) ? mask.data() : nullptr, sMain));
     if (exch) {
         if (!comm) return (int)hipErrorInvalidValue;
         TW_MM(exchange(d_blocks));

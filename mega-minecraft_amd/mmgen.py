@@ -260,7 +260,7 @@ class MMGen:
     def region_begin(self, cx0, cz0, nx, nz, flags, local_mask=None):
         mask = None
         if local_mask is not None:
-            mask = local_mask if isinstance(local_mask, ctypes.Array) else (ctypes.c_uint8 * len(local_mask))(*[1 if m else 0 for m in local_mask])
+            mask = local_mask if isinstance(local_mask, ctypes.Array) else (ctypes.c_uint8 * len(local_mask))(*[int(m) for m in local_mask])
         self._check(self.lib.mmgen_region_begin(self._region(), cx0, cz0, nx, nz, flags, mask, self._stream()), "mmgen_region_begin")
         self._region_blocks = None
 
@@ -329,9 +329,11 @@ class MMGen:
             out["cave"] = cave
         return out
 
-    def generate_region(self, cx0, cz0, nx, nz, erosion=True, features=True, decorators=True, want=()):
+    def generate_region(self, cx0, cz0, nx, nz, erosion=True, features=True, decorators=True, want=(), lazy_ring=True):
         flags = (self.EROSION if erosion else 0) | (self.FEATURES if features else 0) | (self.DECORATORS if decorators else 0)
-        self.region_begin(cx0, cz0, nx, nz, flags)
+        # the ring's placement lists never leave this call: mask value 2 = computed lazily (include/mmgen.h)
+        mask = (ctypes.c_uint8 * ((nx + 6) * (nz + 6)))(*([2] * ((nx + 6) * (nz + 6)))) if (features and lazy_ring) else None
+        self.region_begin(cx0, cz0, nx, nz, flags, mask)
         out = self.region_finish(nx, nz, want)
         out["erosion_passes"] = self.lib.mmgen_region_last_erosion_passes(self._region())
         return out
