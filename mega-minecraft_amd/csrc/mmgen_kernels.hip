@@ -253,33 +253,46 @@ k_cave_voxels(const float* __restrict__ hf, const float2* __restrict__ colInfo, 
 
     const int t = threadIdx.x;
     const int bid = xcd_block(blockIdx.x, gridDim.x);
-    const int chunk = chunkList ? chunkList[bid >> 6] : (bid >> 6);
-    const int group = bid & 63;                                // 64 groups of 4 columns per chunk: x = 4 (group % 4) + c, z = group / 4
+    const int chunk = chunkList ? chunkList[bid >> 4] : (bid >> 4);
+    const int row = bid & 15;                                  // one workgroup = one 16-column row of a chunk (z = row), in 4 batches of 4 columns
     const int2 cp = chunkPos[chunk];
     // lazy ring: columns that cannot produce a placement reaching the rectangle get no cave noise: no solid bit is ever set for them,
     // so no flip is found and their 32 layers stay at the default {384, 384, NONE, NONE}
-    unsigned needMask = 0xfu;
+    unsigned rowNeed = 0xffffu;
     if (colNeed) {
-        const uchar4 nd = *(const uchar4*)(colNeed + (size_t)256 * chunk + 4 * group);
-        needMask = (nd.x ? 1u : 0u) | (nd.y ? 2u : 0u) | (nd.z ? 4u : 0u) | (nd.w ? 8u : 0u);
+        const uint4 nd = *(const uint4*)(colNeed + (size_t)256 * chunk + 16 * row);
+        rowNeed = 0u;
+        const unsigned w[4] = {nd.x, nd.y, nd.z, nd.w};
+        for (int k = 0; k < 16; ++k) rowNeed |= ((w[k >> 2] >> (8 * (k & 3))) & 255u) ? (1u << k) : 0u;
+    }
+    if (!rowNeed) {                                            // nothing to evaluate: all 16 columns keep the default layers
+        for (int i = t; i < 16 * 3 * MMGEN_MAX_CAVE_LAYERS_PER_COLUMN; i += CAVE_THREADS)
+            ((int*)(caveLayers + (size_t)MMGEN_MAX_CAVE_LAYERS_PER_COLUMN * (chunk * 256 + 16 * row)))[i] = ((i % 3) == 2) ? 0 : 384;
+        return;
     }
 
-    // cell tile: sample position = noisePos * (1, 1.6, 1) + offset with |offset| < 1.8; origin from the group's first column
+    // cell tile, shared by the row's 4 batches: sample position = noisePos * (1, 1.6, 1) + offset with |offset| < 1.8; origin from the
+    // row's first column (16 columns are 0.08 cells wide: at most one cell boundary inside the row, like inside 4 columns)
     CellTile tile;
     tile.pts = s_cells;
-    tile.ox = (int)__builtin_floorf(((float)(cp.x + ((4 * group) & 15)) * 0.0050f) * 1.f) - 3;
+    tile.ox = (int)__builtin_floorf(((float)cp.x * 0.0050f) * 1.f) - 3;
     tile.oy = -3;
-    tile.oz = (int)__builtin_floorf(((float)(cp.y + ((4 * group) >> 4)) * 0.0050f) * 1.f) - 3;
-    for (int i = t; i < (needMask ? CELL_N : 0); i += CAVE_THREADS) {
+    tile.oz = (int)__builtin_floorf(((float)(cp.y + row) * 0.0050f) * 1.f) - 3;
+    for (int i = t; i < CELL_N; i += CAVE_THREADS) {
         const int iz = i % CELL_NZ, iy = (i / CELL_NZ) % CELL_NY, ix = i / (CELL_NZ * CELL_NY);
         const f3 p = rand3from3((float)(tile.ox + ix), (float)(tile.oy + iy), (float)(tile.oz + iz));
         s_cells[3 * i] = p.x; s_cells[3 * i + 1] = p.y; s_cells[3 * i + 2] = p.z;
     }
+    noise_tables_init<false>();                                // no simplex2 in this kernel; ends with the workgroup barrier
+
+  for (int sub = 0; sub < 4; ++sub) {
+    const int group = 4 * row + sub;                           // 64 groups of 4 columns per chunk: x = 4 (group % 4) + c, z = group / 4
+    const unsigned needMask = (rowNeed >> (4 * sub)) & 0xfu;
     if (t < CAVE_COLS * 6) s_solid[t / 6][t % 6] = 0ull;
     if (t < 2) s_count[t] = 0;
     for (int i = t; i < CAVE_COLS * 3 * MMGEN_MAX_CAVE_LAYERS_PER_COLUMN; i += CAVE_THREADS)
         (&s_layers[0][0])[i] = ((i % 3) == 2) ? 0 : 384;       // {384, 384, biomes = 0}
-    noise_tables_init<false>();                                // no simplex2 in this kernel; ends with the workgroup barrier
+    __syncthreads();
 
     // Three dense phases over LDS-compacted voxel lists (order inside a list is irrelevant: voxels are independent).  Ocean columns
     // need the noise only below y ~ 92 and most voxels that pass the first test pass the second, so without compaction 4 - 40 %
@@ -383,6 +396,8 @@ k_cave_voxels(const float* __restrict__ hf, const float2* __restrict__ colInfo, 
         const int cc = i / (3 * MMGEN_MAX_CAVE_LAYERS_PER_COLUMN), k = i % (3 * MMGEN_MAX_CAVE_LAYERS_PER_COLUMN);
         ((int*)(caveLayers + (size_t)MMGEN_MAX_CAVE_LAYERS_PER_COLUMN * (chunk * 256 + 4 * group + cc)))[k] = s_layers[cc][k];
     }
+    __syncthreads();                                           // the bit words, lists and layer slots are re-used by the next batch
+  }
 }
 
 // Cave biomes of the layers' end blocks: at most 2 getCaveBiome evaluations per occupied layer slot, and only a few of a column's
@@ -504,7 +519,9 @@ MM_DEV BaseBlock place_block_base(const float* s_bw, const float* s_lh, const mm
 #ifndef MM_FILL_EXP
 #define MM_FILL_EXP 0      // timing experiments only (tools/build_variant.sh): 1 = no cave-biome phase, 2 = no cave-biome block rules
 #endif
-#define FILL_COLS 4
+#define FILL_COLS 4          // columns per batch
+#define FILL_ROW 16          // columns per workgroup: one row of the chunk, staged with whole-line loads
+#define FILL_L3_CAP 256      // deferred lush voxels per batch (typically 0 - 30)
 #ifndef FILL_THREADS
 #define FILL_THREADS 256      // phase 2 walks ~450 compacted voxels: 2 passes at 88 % lane use (768 lanes: 1 pass at 59 %)
 #endif
@@ -519,33 +536,40 @@ k_fill(const float* __restrict__ hf, const float* __restrict__ bw, const float* 
        const int* __restrict__ srcIdx, unsigned* __restrict__ lushQueue /*[0] = count, entries from [1]; nullable*/, unsigned lushCap)
 {
     noise_tables_init();
-    __shared__ float s_bw[FILL_COLS][MMGEN_NUM_BIOMES];
-    __shared__ float s_lh[FILL_COLS][MMGEN_NUM_MATERIALS + 1];
+    __shared__ float s_bw[FILL_ROW][MMGEN_NUM_BIOMES];
+    __shared__ float s_lh[FILL_ROW][MMGEN_NUM_MATERIALS + 1];
     __shared__ mmgen_cave_layer s_cl[FILL_COLS][MMGEN_MAX_CAVE_LAYERS_PER_COLUMN];
     __shared__ unsigned int s_list[FILL_COLS * 384];          // voxel (11 bits) | block (8) << 11 | bottomDepth code (6) << 19 | topDepth code (6) << 25
     __shared__ unsigned short s_list2[FILL_COLS * 384];       // index into s_list (11 bits) | isLush << 11: voxels whose cave biome has a noise rule
-    __shared__ unsigned short s_list3[FILL_COLS * 384];       // index into s_list: lush voxels close enough to a cave surface for clay / moss
+    __shared__ unsigned short s_list3[FILL_L3_CAP];           // index into s_list: lush voxels close enough to a cave surface for clay / moss
     __shared__ int s_count[3];
+    __shared__ unsigned s_qbase;
 
     const int t = threadIdx.x;
     const int bid = xcd_block(blockIdx.x, gridDim.x);
-    const int outChunk = bid >> 6, group = bid & 63;
+    const int outChunk = bid >> 4, row = bid & 15;                 // one workgroup = one 16-column row of a chunk (z = row), in 4 batches of 4 columns
     const int chunk = srcIdx ? srcIdx[outChunk] : outChunk;        // inputs are read at `chunk`, blocks are written densely at outChunk
-    const int idxBase = 4 * group;
+    const int2 cp = chunkPos[chunk];
 
-    // stage the 4 columns: 24 weights + 20 layer starts + height + 96 cave-layer words each = 141 words per column
-    for (int i = t; i < FILL_COLS * 141; i += FILL_THREADS) {
-        const int c = i / 141, k = i % 141;
-        const int idx2d = idxBase + c;
+    // the row's plane attributes, once: 24 weights + 20 layer starts + height per column.  A row of a plane is one 64-byte line, read whole
+    // (4-column workgroups fetched every line four times, from four workgroups that rarely share an L2: 2.3 x the algorithmic bytes)
+    for (int i = t; i < FILL_ROW * 45; i += FILL_THREADS) {
+        const int k = i / FILL_ROW, c = i % FILL_ROW;               // consecutive lanes = consecutive columns of one plane
+        const int idx2d = FILL_ROW * row + c;
         if (k < MMGEN_NUM_BIOMES) s_bw[c][k] = bw[(size_t)MMGEN_BIOME_WEIGHTS_SIZE * chunk + 256 * k + idx2d];
         else if (k < MMGEN_NUM_BIOMES + MMGEN_NUM_MATERIALS) s_lh[c][k - MMGEN_NUM_BIOMES] = layers[(size_t)MMGEN_LAYERS_SIZE * chunk + 256 * (k - MMGEN_NUM_BIOMES) + idx2d];
-        else if (k == MMGEN_NUM_BIOMES + MMGEN_NUM_MATERIALS) s_lh[c][MMGEN_NUM_MATERIALS] = hf[chunk * 256 + idx2d];
-        else ((int*)s_cl[c])[k - 45] = ((const int*)(caveLayers + (size_t)MMGEN_MAX_CAVE_LAYERS_PER_COLUMN * (chunk * 256 + idx2d)))[k - 45];
+        else s_lh[c][MMGEN_NUM_MATERIALS] = hf[chunk * 256 + idx2d];
     }
+
+  for (int sub = 0; sub < FILL_ROW / FILL_COLS; ++sub) {
+    const int idxBase = FILL_ROW * row + FILL_COLS * sub;
+    const int cRow = FILL_COLS * sub;                              // first column of the batch inside the staged row
+    // the batch's cave layers: 4 columns x 32 layers x 12 bytes, contiguous
+    for (int i = t; i < FILL_COLS * 96; i += FILL_THREADS)
+        ((int*)s_cl)[i] = ((const int*)(caveLayers + (size_t)MMGEN_MAX_CAVE_LAYERS_PER_COLUMN * (chunk * 256 + idxBase)))[i];
     if (t < 3) s_count[t] = 0;
     __syncthreads();
 
-    const int2 cp = chunkPos[chunk];
     uint8_t* outBase = blocks + (size_t)MMGEN_BLOCKS_PER_CHUNK * outChunk + 384 * idxBase;     // the 4 columns are contiguous: 1536 bytes
 
     // phase 1: base blocks.  The two cave-surface distances only matter as "== 0" and "0 .. threshold" with threshold = 1.5 + 4.5 * simplex3
@@ -555,7 +579,7 @@ k_fill(const float* __restrict__ hf, const float* __restrict__ bw, const float* 
         const int c = v / 384, y = v - 384 * c;
         const int idx2d = idxBase + c;
         const int wx = cp.x + (idx2d & 15), wz = cp.y + (idx2d >> 4);
-        const BaseBlock r = place_block_base(s_bw[c], s_lh[c], s_cl[c], y, s_lh[c][MMGEN_NUM_MATERIALS], wx, wz);
+        const BaseBlock r = place_block_base(s_bw[cRow + c], s_lh[cRow + c], s_cl[c], y, s_lh[cRow + c][MMGEN_NUM_MATERIALS], wx, wz);
         if (r.needCave) {
             const int slot = atomicAdd(&s_count[0], 1);
             const unsigned bdc = r.bottomDepth < 0 ? 63u : (unsigned)imin(r.bottomDepth, 62);
@@ -581,7 +605,7 @@ k_fill(const float* __restrict__ hf, const float* __restrict__ bw, const float* 
 #if MM_FILL_EXP != 1
         // WARPED / AMBER only act on the top DEEPSLATE / BLACKSTONE block of a cave floor (caveBottomDepth == 0)
         const bool wantDeep = bdc == 0 && (block == MMB_DEEPSLATE || block == MMB_BLACKSTONE);
-        const int cb = cave_biome(wx, y, wz, s_lh[c][MMGEN_NUM_MATERIALS], 190249401, wantDeep);
+        const int cb = cave_biome(wx, y, wz, s_lh[cRow + c][MMGEN_NUM_MATERIALS], 190249401, wantDeep);
         if (MM_FILL_EXP != 2 && (cb == MMCB_CRYSTAL_CAVES || cb == MMCB_LUSH_CAVES)) {
             s_list2[atomicAdd(&s_count[1], 1)] = (unsigned short)(i | (cb == MMCB_LUSH_CAVES ? 2048 : 0));
             continue;
@@ -608,8 +632,9 @@ k_fill(const float* __restrict__ hf, const float* __restrict__ bw, const float* 
         cave_post_noise_pos(cb, wx, y, wz, ax, ay, az);
         const float n = simplex3_inl(ax, ay, az);
         if (cave_post_apply(block, cb, n, wx, y, wz, bdc == 63 ? -1 : bdc, tdc == 63 ? -1 : tdc)) {
-            s_list3[atomicAdd(&s_count[2], 1)] = (unsigned short)i;
-            continue;
+            const int slot = atomicAdd(&s_count[2], 1);
+            if (slot < FILL_L3_CAP) { s_list3[slot] = (unsigned short)i; continue; }
+            block = lush_clay_or_moss(wx, y, wz, CellDirect());       // more than FILL_L3_CAP in one batch: in place
         }
         outBase[v] = block;
     }
@@ -619,12 +644,10 @@ k_fill(const float* __restrict__ hf, const float* __restrict__ bw, const float* 
     // got here: typically 0 - 30 per workgroup, which would leave most lanes of the workgroup idle through the longest code path of the
     // kernel.  They are appended to a device-wide queue instead and k_fill_lush evaluates them 64 to a wave; only when the queue is
     // full (or absent) are they evaluated here.
-    const int count3 = s_count[2];
-    if (count3 == 0) return;
-    __shared__ unsigned s_qbase;
-    if (t == 0) s_qbase = lushQueue ? atomicAdd(lushQueue, (unsigned)count3) : 0xffffffffu;
+    const int count3 = imin(s_count[2], FILL_L3_CAP);
+    if (t == 0 && count3) s_qbase = lushQueue ? atomicAdd(lushQueue, (unsigned)count3) : 0xffffffffu;
     __syncthreads();
-    const unsigned qbase = s_qbase;
+    const unsigned qbase = count3 ? s_qbase : 0u;
     const bool queued = lushQueue && qbase <= lushCap && (unsigned)count3 <= lushCap - qbase;
     for (int k = t; k < count3; k += FILL_THREADS) {
         const unsigned e = s_list[s_list3[k]];
@@ -636,6 +659,8 @@ k_fill(const float* __restrict__ hf, const float* __restrict__ bw, const float* 
         if (lushQueue && qbase < lushCap && (unsigned)k < lushCap - qbase) lushQueue[1 + qbase + k] = 0xffffffffu;
         outBase[v] = MM_FILL_EXP == 3 ? (uint8_t)MMB_MOSS : lush_clay_or_moss(cp.x + (idx2d & 15), y, cp.y + (idx2d >> 4), CellDirect());
     }
+    __syncthreads();                                               // the lists and s_cl are re-used by the next batch
+  }
 }
 
 // The queued lush voxels of a whole k_fill launch, 64 to a wave (entry = outChunk << 17 | column << 9 | y).
@@ -750,7 +775,7 @@ int launch_caves(const float* hf, const float* bw, const int32_t* pos, int n, mm
 {
     if (n <= 0) return 0;
     LAUNCH(KID_CAVE_COLUMNS, mm::k_cave_columns, dim3(n), dim3(256), s, bw, (const int2*)pos, (float2*)colInfoScratch, chunkList);
-    LAUNCH(KID_CAVE_VOXELS, mm::k_cave_voxels, dim3(n * 64), dim3(CAVE_THREADS), s, hf, (const float2*)colInfoScratch, (const int2*)pos, caveLayers, chunkList, colNeed);
+    LAUNCH(KID_CAVE_VOXELS, mm::k_cave_voxels, dim3(n * 16), dim3(CAVE_THREADS), s, hf, (const float2*)colInfoScratch, (const int2*)pos, caveLayers, chunkList, colNeed);
     LAUNCH(KID_CAVE_BIOMES, mm::k_cave_biomes, dim3(n * (256 / CB_COLS)), dim3(CB_THREADS), s, hf, (const int2*)pos, caveLayers, chunkList);
     return 0;
 }
@@ -773,7 +798,7 @@ int launch_fill(const float* hf, const float* bw, const float* layers, const mmg
             hipError_t e = hipMemsetAsync(lushQueue, 0, 4, s);                   // the counter; entries are (re)written by every launch
             if (e != hipSuccess) return (int)e;
         }
-        LAUNCH(KID_FILL, mm::k_fill, dim3(nb * 64), dim3(FILL_THREADS), s, hf + 256 * in0, bw + (size_t)MMGEN_BIOME_WEIGHTS_SIZE * in0,
+        LAUNCH(KID_FILL, mm::k_fill, dim3(nb * (256 / FILL_ROW)), dim3(FILL_THREADS), s, hf + 256 * in0, bw + (size_t)MMGEN_BIOME_WEIGHTS_SIZE * in0,
                layers + (size_t)MMGEN_LAYERS_SIZE * in0, caveLayers + (size_t)MMGEN_CAVE_LAYERS_SIZE * in0, p, out, idx, lushQueue, cap);
         if (lushQueue) {
             const unsigned grid = (unsigned)nb * 4 < 2048u ? (unsigned)nb * 4 : 2048u;
