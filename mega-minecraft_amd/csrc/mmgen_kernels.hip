@@ -455,19 +455,32 @@ k_cave_biomes(const float* __restrict__ hf, const int2* __restrict__ chunkPos, m
 // =========================================================================================================
 struct BaseBlock { uint8_t block; bool needCave; int bottomDepth, topDepth; };
 
-MM_DEV BaseBlock place_block_base(const float* s_bw, const float* s_lh, const mmgen_cave_layer* s_cl, int y, float height, int wx, int wz)
+// The column's biome weights in the compact form getRandomBiome (biomeFuncs.hpp:39-53) can be walked in: biome 0 (returned by a draw of
+// exactly 0 whatever its weight) plus the biomes of positive weight, ascending.  Subtracting a zero weight changes nothing and cannot
+// trigger the "<= 0" exit of a positive remainder, so the walk returns exactly what the 24-entry walk returns - in 2 - 4 steps, not 10 - 23.
+#define FILL_NZ_CAP 8
+struct ColumnBiomes { int n; bool isOcean; const uint8_t* idx; const float* w; const float* all; };
+MM_DEV int random_biome(const ColumnBiomes& cb, float rand)
+{
+    if (cb.n > FILL_NZ_CAP) return random_biome(cb.all, 1, rand);          // more than 8 biomes meet in this column: the plain walk
+    for (int k = 0; k < cb.n; ++k) {
+        rand -= cb.w[k];
+        if (rand <= 0.f) return cb.idx[k];
+    }
+    return MMBIO_PLAINS;
+}
+
+MM_DEV BaseBlock place_block_base(const ColumnBiomes& cbi, const float* s_lh, const mmgen_cave_layer* s_cl, int y, float height, int wx, int wz)
 {
     BaseBlock r; r.needCave = false; r.bottomDepth = -384; r.topDepth = -384;
     if (y == 0) { r.block = MMB_BEDROCK; return r; }
     const float fy = (float)y;
     if (fy > height && y > MMGEN_SEA_LEVEL) { r.block = MMB_AIR; return r; }
 
-    bool isOcean = false;
-#pragma unroll
-    for (int b = 0; b < MMGEN_NUM_OCEAN_BIOMES; ++b) isOcean = isOcean || (s_bw[b] > 0.f);
+    const bool isOcean = cbi.isOcean;
 
     MinStd rng = rng3(wx, y, wz);
-    const int randBiome = random_biome(s_bw, 1, rng.u01());
+    const int randBiome = random_biome(cbi, rng.u01());
     const bool isTop = fy >= height - 1.f;
 
     uint8_t block = MMB_AIR;
@@ -544,6 +557,8 @@ k_fill(const float* __restrict__ hf, const float* __restrict__ bw, const float* 
     __shared__ unsigned short s_list3[FILL_L3_CAP];           // index into s_list: lush voxels close enough to a cave surface for clay / moss
     __shared__ int s_count[3];
     __shared__ unsigned s_qbase;
+    __shared__ float s_nzW[FILL_ROW][FILL_NZ_CAP];
+    __shared__ uint8_t s_nzIdx[FILL_ROW][FILL_NZ_CAP], s_nzN[FILL_ROW], s_ocean[FILL_ROW];
 
     const int t = threadIdx.x;
     const int bid = xcd_block(blockIdx.x, gridDim.x);
@@ -559,6 +574,18 @@ k_fill(const float* __restrict__ hf, const float* __restrict__ bw, const float* 
         if (k < MMGEN_NUM_BIOMES) s_bw[c][k] = bw[(size_t)MMGEN_BIOME_WEIGHTS_SIZE * chunk + 256 * k + idx2d];
         else if (k < MMGEN_NUM_BIOMES + MMGEN_NUM_MATERIALS) s_lh[c][k - MMGEN_NUM_BIOMES] = layers[(size_t)MMGEN_LAYERS_SIZE * chunk + 256 * (k - MMGEN_NUM_BIOMES) + idx2d];
         else s_lh[c][MMGEN_NUM_MATERIALS] = hf[chunk * 256 + idx2d];
+    }
+
+    __syncthreads();
+    if (t < FILL_ROW) {
+        int n = 0;
+        bool ocean = false;
+        for (int b = 0; b < MMGEN_NUM_BIOMES; ++b) {
+            const float w = s_bw[t][b];
+            if (b < MMGEN_NUM_OCEAN_BIOMES) ocean = ocean || (w > 0.f);
+            if (b == 0 || w > 0.f) { if (n < FILL_NZ_CAP) { s_nzIdx[t][n] = (uint8_t)b; s_nzW[t][n] = w; } ++n; }
+        }
+        s_nzN[t] = (uint8_t)n; s_ocean[t] = ocean ? 1 : 0;
     }
 
   for (int sub = 0; sub < FILL_ROW / FILL_COLS; ++sub) {
@@ -579,7 +606,8 @@ k_fill(const float* __restrict__ hf, const float* __restrict__ bw, const float* 
         const int c = v / 384, y = v - 384 * c;
         const int idx2d = idxBase + c;
         const int wx = cp.x + (idx2d & 15), wz = cp.y + (idx2d >> 4);
-        const BaseBlock r = place_block_base(s_bw[cRow + c], s_lh[cRow + c], s_cl[c], y, s_lh[cRow + c][MMGEN_NUM_MATERIALS], wx, wz);
+        const ColumnBiomes cbi = {s_nzN[cRow + c], s_ocean[cRow + c] != 0, s_nzIdx[cRow + c], s_nzW[cRow + c], s_bw[cRow + c]};
+        const BaseBlock r = place_block_base(cbi, s_lh[cRow + c], s_cl[c], y, s_lh[cRow + c][MMGEN_NUM_MATERIALS], wx, wz);
         if (r.needCave) {
             const int slot = atomicAdd(&s_count[0], 1);
             const unsigned bdc = r.bottomDepth < 0 ? 63u : (unsigned)imin(r.bottomDepth, 62);
