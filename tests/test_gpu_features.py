@@ -271,6 +271,55 @@ def test_region_batched_scheduler_equals_action_time_scheduler(mmgen_pkg):
     assert "IDENTICAL" in r.stdout and "1089 drawable chunks compared" in r.stdout
 
 
+def _two_process_worker(rank, world, port, layout_args, outdir):
+    import importlib
+    import os
+    import sys
+    import torch
+    import torch.distributed as dist
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pkg = importlib.import_module("mega-minecraft_amd")
+    d = importlib.import_module("mega-minecraft_amd.distributed")
+    from host_staged_dist import HostStagedDist
+    gen = pkg.MMGen(0)                                   # both ranks share GPU 0
+    layout = d.TileLayout(*layout_args)
+    ctx = d.TileContext(layout, rank, torch, gen.device)
+    shim = HostStagedDist(dist, torch)
+    for _ in range(2):                                   # twice: the cached layout / plan path of the second step too
+        out = d.generate_tile(gen, layout, rank, 7, dist=shim, torch=torch, ctx=ctx)
+    torch.cuda.synchronize()
+    np.save(os.path.join(outdir, f"blocks_{rank}.npy"), out["blocks"].cpu().numpy())
+    np.save(os.path.join(outdir, f"halo_{rank}.npy"), np.array([out["halo_bytes_received"]]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_process_tiling_on_one_gpu_runs_the_real_exchange(gen, tmp_path):
+    """The product's N > 1 path end to end on the device with a real process group: two PROCESSES (gloo group, device tensors staged
+    through the host by tests/host_staged_dist.py because RCCL refuses two ranks on one GPU) generate the two 6x4-chunk tiles of a
+    12x4 world with distributed.generate_tile - TileContext, mmgen_ring_header / offsets / pack / unpack on the device, the two-phase
+    exchange, region_fill overlapped with it, lazy world-border ring cells - and the stitched tiles equal the single region."""
+    import socket
+    import torch.multiprocessing as mp
+    layout_args = (1484, -1112, 2, 1, 6, 4)
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_two_process_worker, args=(2, port, layout_args, str(tmp_path)), nprocs=2, join=True)
+    tiles = [np.load(tmp_path / f"blocks_{r}.npy") for r in range(2)]
+    halo = [int(np.load(tmp_path / f"halo_{r}.npy")[0]) for r in range(2)]
+    single = np_(gen.generate_region(1484, -1112, 12, 4)["blocks"])
+    world = np.zeros_like(single)
+    for r, t in enumerate(tiles):
+        for z in range(4):
+            for x in range(6):
+                world[(6 * r + x) + 12 * z] = t[x + 6 * z]
+    assert np.array_equal(world, single), f"{int((world != single).sum())} block ids differ between the two-process tiling and the single region"
+    # 3 x 4 ring cells arrive per rank: headers (8 B per cell) + only the entries that exist, far below the dense 29.7 KB per cell
+    assert all(12 * 8 < h < 12 * 29704 // 4 for h in halo), halo
+
+
 def test_cpp_tiled_world_host_single_tile(mmgen_pkg):
     """The C++ multi-GPU host (host/tiled_world.hpp: TileLayout + ExchangePlan + RCCL grouped send / recv, linked against librccl) on one
     GPU: the tiled path with a single tile gives the same blocks as mmgen_region_generate (the demo compares checksums in-process).
