@@ -23,13 +23,15 @@ extern "C" {
 /* BiomeUtils::init() (src/terrain/biome.hpp:299-305, biomeFuncs.hpp:725-1256) + cudaSetDevice (src/main.cpp:31).
  * Rule tables are compile-time constants of the code object; this selects the device, checks it is gfx950 and builds the per-device
  * simplex-noise lookup image (one tiny launch + wait), so that no later call synchronises or allocates behind the caller's back.
- * Threading contract: calls may come from several host threads and streams; the stage calls that use library-owned scratch
- * (mmgen_generate_caves, mmgen_erode_zone(s)) are serialised per process by the caller (the reference is single-threaded,
- * terrain.cpp:587-960) - use one mmgen_region per stream for concurrent pipelines, it owns its scratch. */
+ * Threading contract: calls may come from several host threads, streams and devices; the library-owned scratch of the per-stage
+ * calls (mmgen_generate_caves, mmgen_erode_zone(s), mmgen_fill) is keyed by (device, stream), so calls on different streams never
+ * share a buffer; calls that use the SAME stream from several threads must be serialised by the caller (the reference is
+ * single-threaded, terrain.cpp:587-960).  A mmgen_region owns its scratch. */
 int mmgen_init(int device);
 const char* mmgen_error_string(int code);
-/* pre-size the library-internal scratch (per-column cave info) so that later calls allocate nothing (graph capture) */
-int mmgen_reserve(int max_chunks_per_call);
+/* pre-size the library-internal scratch of the per-stage calls on `stream` (per-column cave info, deferred-voxel queue) so that later
+ * calls on that stream allocate nothing (graph capture).  Scratch is keyed by (device, stream). */
+int mmgen_reserve(int max_chunks_per_call, void* stream);
 
 /* Chunk::generateHeightfields, device part (chunk.cu:150-185,207-213): kernGenerateHeightfield.
  * in : d_chunk_world_block_pos [n][2] int32 (x, z) world block position of each chunk's (0,0) column

@@ -4,57 +4,74 @@
 #include "mmgen_erosion.h"
 #include "mmgen_features.h"
 #include "mmgen_prof.h"
+#include <map>
 #include <mutex>
+#include <utility>
 #include <cstring>
 #include <cstdio>
 
 namespace {
+// Library-owned scratch of the per-stage calls, keyed by (device, stream): two calls on different streams or devices never share a
+// buffer (calls on ONE stream are ordered by the stream, so they may).  Grow-only; a buffer is only replaced after its stream is idle.
+struct Scratch {
+    float* colInfo = nullptr; size_t colInfoChunks = 0;            // [chunks][256] float2 per-column cave info
+    float* erodeWork = nullptr; mm::ErosionState* erodeState = nullptr; int erodeZones = 0;
+    unsigned* fillQueue = nullptr; size_t fillQueueBytes = 0;        // deferred clay / moss voxels, then apply_features hand-over flags
+};
 std::mutex g_mu;
-float* g_colInfo = nullptr;      // [chunks][256] float2 per-column cave info
-size_t g_colInfoChunks = 0;
+std::map<std::pair<int, void*>, Scratch> g_scratch;
 int g_device = -1;
-float* g_erodeWork = nullptr;     // erosion ping-pong planes + accumulators for g_erodeZones zones
-mm::ErosionState* g_erodeState = nullptr;
-int g_erodeZones = 0;
 
-int ensure_erosion(int zones)
+Scratch* scratch_for(void* stream)
 {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
     std::lock_guard<std::mutex> lk(g_mu);
-    if (zones <= g_erodeZones) return 0;
-    if (g_erodeWork) (void)hipFree(g_erodeWork);
-    if (g_erodeState) (void)hipFree(g_erodeState);
-    g_erodeWork = nullptr; g_erodeState = nullptr; g_erodeZones = 0;
-    hipError_t e = hipMalloc((void**)&g_erodeWork, mmk::erosion_work_bytes(zones));
-    if (e != hipSuccess) return (int)e;
-    e = hipMalloc((void**)&g_erodeState, mmk::erosion_state_bytes(zones));
-    if (e != hipSuccess) return (int)e;
-    g_erodeZones = zones;
+    return &g_scratch[{dev, stream}];                                // std::map nodes are stable: the pointer stays valid
+}
+
+template <class T> int regrow(T*& p, size_t bytes, void* stream)
+{
+    if (p) {
+        hipError_t e = hipStreamSynchronize((hipStream_t)stream);   // the old buffer may still be in use by queued work of this stream
+        if (e != hipSuccess) return (int)e;
+        e = hipFree(p);
+        if (e != hipSuccess) return (int)e;
+        p = nullptr;
+    }
+    return (int)hipMalloc((void**)&p, bytes);
+}
+
+int ensure_erosion(Scratch& sc, int zones, void* stream)
+{
+    if (zones <= sc.erodeZones) return 0;
+    sc.erodeZones = 0;
+    int e = regrow(sc.erodeWork, mmk::erosion_work_bytes(zones), stream);
+    if (e) return e;
+    e = regrow(sc.erodeState, mmk::erosion_state_bytes(zones), stream);
+    if (e) return e;
+    sc.erodeZones = zones;
     return 0;
 }
 
-unsigned* g_fillQueue = nullptr;  // deferred clay / moss voxels of mmgen_fill
-size_t g_fillQueueBytes = 0;
-
-int ensure_fill_queue(int n)
+int ensure_fill_queue(Scratch& sc, int n, void* stream)
 {
-    std::lock_guard<std::mutex> lk(g_mu);
     const size_t want = mmk::fill_queue_bytes(n);
-    if (want <= g_fillQueueBytes) return 0;
-    if (g_fillQueue) { hipError_t e = hipFree(g_fillQueue); if (e != hipSuccess) return (int)e; g_fillQueue = nullptr; g_fillQueueBytes = 0; }
-    hipError_t e = hipMalloc((void**)&g_fillQueue, want);
-    if (e != hipSuccess) return (int)e;
-    g_fillQueueBytes = want;
+    if (want <= sc.fillQueueBytes) return 0;
+    sc.fillQueueBytes = 0;
+    const int e = regrow(sc.fillQueue, want, stream);
+    if (e) return e;
+    sc.fillQueueBytes = want;
     return 0;
 }
 
-int ensure_scratch(int n)
+int ensure_col_info(Scratch& sc, int n, void* stream)
 {
-    std::lock_guard<std::mutex> lk(g_mu);
-    if ((size_t)n <= g_colInfoChunks) return 0;
-    if (g_colInfo) { hipError_t e = hipFree(g_colInfo); if (e != hipSuccess) return (int)e; g_colInfo = nullptr; g_colInfoChunks = 0; }
-    hipError_t e = hipMalloc((void**)&g_colInfo, (size_t)n * 256 * sizeof(float2));
-    if (e != hipSuccess) return (int)e;
-    g_colInfoChunks = (size_t)n;
+    if ((size_t)n <= sc.colInfoChunks) return 0;
+    sc.colInfoChunks = 0;
+    const int e = regrow(sc.colInfo, (size_t)n * 256 * sizeof(float2), stream);
+    if (e) return e;
+    sc.colInfoChunks = (size_t)n;
     return 0;
 }
 }  // namespace
@@ -82,10 +99,12 @@ int mmgen_init(int device)
 
 const char* mmgen_error_string(int code) { return hipGetErrorString((hipError_t)code); }
 
-int mmgen_reserve(int max_chunks_per_call)
+int mmgen_reserve(int max_chunks_per_call, void* stream)
 {
-    const int e = ensure_scratch(max_chunks_per_call);
-    return e ? e : ensure_fill_queue(max_chunks_per_call);
+    Scratch* sc = scratch_for(stream);
+    if (!sc) return (int)hipErrorInvalidDevice;
+    const int e = ensure_col_info(*sc, max_chunks_per_call, stream);
+    return e ? e : ensure_fill_queue(*sc, max_chunks_per_call, stream);
 }
 
 int mmgen_generate_heightfields(const int32_t* d_pos, int n, float* d_hf, float* d_bw, void* stream)
@@ -116,9 +135,11 @@ int mmgen_erode_zones(float* d_gathered, int num_zones, float* d_acc, int* max_p
 {
     if (num_zones < 0 || (num_zones > 0 && !d_gathered)) return (int)hipErrorInvalidValue;
     if (num_zones == 0) return 0;
-    int e = ensure_erosion(num_zones);
+    Scratch* sc = scratch_for(stream);
+    if (!sc) return (int)hipErrorInvalidDevice;
+    int e = ensure_erosion(*sc, num_zones, stream);
     if (e) return e;
-    return mmk::erode_zones(d_gathered, (size_t)MMGEN_GATHERED_LAYERS_SIZE, num_zones, g_erodeWork, g_erodeState, d_acc,
+    return mmk::erode_zones(d_gathered, (size_t)MMGEN_GATHERED_LAYERS_SIZE, num_zones, sc->erodeWork, sc->erodeState, d_acc,
                             (size_t)MMGEN_EROSION_GRID_NUM_COLS, (hipStream_t)stream, max_passes);
 }
 
@@ -128,9 +149,11 @@ int mmgen_generate_caves(const float* d_hf, const float* d_bw, const int32_t* d_
 {
     if (n < 0 || (n > 0 && (!d_hf || !d_bw || !d_pos || !d_cl))) return (int)hipErrorInvalidValue;
     if (n == 0) return 0;
-    int e = ensure_scratch(n);
+    Scratch* sc = scratch_for(stream);
+    if (!sc) return (int)hipErrorInvalidDevice;
+    int e = ensure_col_info(*sc, n, stream);
     if (e) return e;
-    return mmk::launch_caves(d_hf, d_bw, d_pos, n, d_cl, g_colInfo, nullptr, nullptr, (hipStream_t)stream);
+    return mmk::launch_caves(d_hf, d_bw, d_pos, n, d_cl, sc->colInfo, nullptr, nullptr, (hipStream_t)stream);
 }
 
 int mmgen_fill(const float* d_hf, const float* d_bw, const float* d_layers, const mmgen_cave_layer* d_cl, const int32_t* d_pos, int n,
@@ -139,9 +162,11 @@ int mmgen_fill(const float* d_hf, const float* d_bw, const float* d_layers, cons
 {
     if (n < 0 || (n > 0 && (!d_hf || !d_bw || !d_layers || !d_cl || !d_pos || !d_blocks))) return (int)hipErrorInvalidValue;
     if ((d_fp || d_cfp) && !d_bounds) return (int)hipErrorInvalidValue;
-    int e = ensure_fill_queue(n);
+    Scratch* sc = scratch_for(stream);
+    if (!sc) return (int)hipErrorInvalidDevice;
+    int e = ensure_fill_queue(*sc, n, stream);
     if (e) return e;
-    e = mmk::launch_fill(d_hf, d_bw, d_layers, d_cl, d_pos, n, d_blocks, nullptr, g_fillQueue, mmk::fill_queue_bytes(n), (hipStream_t)stream);
+    e = mmk::launch_fill(d_hf, d_bw, d_layers, d_cl, d_pos, n, d_blocks, nullptr, sc->fillQueue, mmk::fill_queue_bytes(n), (hipStream_t)stream);
     if (e || !(d_fp || d_cfp)) return e;
     return mmk::launch_apply_features(d_blocks, d_pos, n, d_fp, d_cfp, d_bounds, nullptr, (hipStream_t)stream);
 }

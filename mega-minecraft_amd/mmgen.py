@@ -32,7 +32,7 @@ def load_library():
     lib.mmgen_init.argtypes = [i32]
     lib.mmgen_error_string.restype = ctypes.c_char_p
     lib.mmgen_error_string.argtypes = [i32]
-    lib.mmgen_reserve.argtypes = [i32]
+    lib.mmgen_reserve.argtypes = [i32, vp]
     lib.mmgen_generate_heightfields.argtypes = [vp, i32, vp, vp, vp]
     lib.mmgen_generate_heightfields_gathered.argtypes = [vp, i32, vp, vp, vp, vp]
     lib.mmgen_generate_layers.argtypes = [vp, vp, vp, i32, vp, vp]

@@ -234,3 +234,25 @@ def test_device_rng_matches_real_thrust(gen, golden):
     assert_bit_equal(gen.debug_probe("rng4_u01", xyzw, len(xyzw), 4), t["u01_4"], "u01 (4-arg seed) vs thrust")
     x3 = xyzw.copy(); x3[:, 3] = np.int32(-2 ** 31)
     assert_bit_equal(gen.debug_probe("rng4_u01", x3, len(x3), 4), t["u01_3"], "u01 (3-arg seed) vs thrust")
+
+
+def test_stage_calls_on_two_streams_do_not_share_scratch(gen):
+    """mmgen_generate_caves keeps per-column scratch inside the library: it is keyed by (device, stream), so the same batch generated
+    concurrently on two streams (different positions) gives the results of the single-stream runs."""
+    import torch
+    pos_a = gen.positions([(x, 7) for x in range(24)])
+    pos_b = gen.positions([(-900 + x, -33) for x in range(24)])
+    ref = []
+    for pos in (pos_a, pos_b):
+        hf, bw = gen.generate_heightfields(pos)
+        ref.append((hf, bw, gen.generate_caves(hf, bw, pos).clone()))
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    outs = [None, None]
+    for _ in range(3):
+        for i, (st, pos) in enumerate(((s1, pos_a), (s2, pos_b))):
+            with torch.cuda.stream(st):
+                outs[i] = gen.generate_caves(ref[i][0], ref[i][1], pos)
+    torch.cuda.synchronize()
+    for i in range(2):
+        assert torch.equal(outs[i], ref[i][2])
