@@ -33,6 +33,13 @@ MM_DEV int iabs(int v) { return v < 0 ? -v : v; }
 #define MM_TWO_PI 6.28318530717958647692528676655f
 #define MM_PI_OVER_TWO 1.57079632679489661923132169163f
 
+// A minstd stream that is seeded (two integer hashes) on its first draw: most voxels a rasteriser looks at never draw from the per-voxel
+// stream.  Every use site draws at most once before returning, so the first draw is the only one.
+struct LazyRng {
+    int x, y, z, w;
+    MM_DEV float u01() { MinStd r = rng4(x, y, z, w); return r.u01(); }
+};
+
 MM_DEV float u11(MinStd& r) { return (r.u01() * (1.f - -1.f)) + -1.f; }
 MM_DEV bool in_range_f(float v, float lo, float hi) { return v >= lo && v <= hi; }
 MM_DEV bool in_range_i(int v, int lo, int hi) { return v >= lo && v <= hi; }
@@ -141,7 +148,7 @@ MM_DEV bool place_feature(int feature, int fx, int fy, int fz, int wx, int wy, i
     v3 pos = V3((float)fp.x, (float)fp.y, (float)fp.z);
     const v3 wbp = V3((float)wx, (float)wy, (float)wz);
     MinStd frng = rng4(fx, fy, fz, 1293012);
-    MinStd brng = rng4(wx, wy, wz, 57847812);
+    LazyRng brng = {wx, wy, wz, 57847812};       // the per-voxel stream (featurePlacement.hpp:154): seeded only where a rule draws from it
 
     switch (feature) {
     case MMF_SPHERE: {
@@ -591,7 +598,7 @@ MM_DEV bool place_cave_feature(int feature, int fx, int fy, int fz, int layerHei
     const v3 pos = V3((float)fp.x, (float)fp.y, (float)fp.z);
     v3 topPos = V3((float)ftp.x, (float)ftp.y, (float)ftp.z);
     MinStd frng = rng4(fx, fy, fz, 398132);
-    MinStd brng = rng4(wx, wy, wz, 9322743);
+    LazyRng brng = {wx, wy, wz, 9322743};        // the per-voxel stream (featurePlacement.hpp:1120): seeded only where a rule draws from it
 
     switch (feature) {
     case MMCF_TEST_GLOWSTONE_PILLAR:
