@@ -250,14 +250,41 @@ MM_DEV float column_height(int wxi, int wzi, float* w24 /* nullable */)
 //   AMBER = (1-shallow)(1-warped).  The noises are evaluated lazily in the order the cumulative test consumes them —
 //   the values used are identical to evaluating all four up front, the unused ones are simply never computed.
 // ---------------------------------------------------------------------------------------------------------
+// Exact pruning (the values that ARE computed are the reference's; what is skipped provably cannot change the result): the depth bands
+// are smoothsteps of the warped height py between band edges that are fbm2<3> offsets around fixed levels, and |fbm2<3>| <= 0.875 B2 with
+// B2 = 1.06 >= sup |simplex2| (130 * max table gradient 0.7897 * sup sum (0.5 - r^2)^4 r over the simplex 0.010080 = 1.0348: adversarially
+// aligned gradients, tests/test_oracle_math.py::test_simplex_bounds).  So once py (3 of the 9 warp evaluations) is known:
+//   py >= top - 19 + 23 * 0.9275 + slack  =>  none == 1 exactly  =>  the draw minus 1 is <= 0  =>  NONE   (skips 6 simplex3 + 6 simplex2)
+//   py <= top - 82 - 25 * 0.9275 - slack  =>  none == 0 and shallow == 0 exactly  =>  only the two deep biomes remain; a caller that has no
+//                                            use for them (wantDeep = false) gets NONE                         (skips 6 simplex3 + 12 simplex2)
+#ifndef MM_CAVE_BIOME_PRUNE
+#define MM_CAVE_BIOME_PRUNE 1
+#endif
 MM_DEV int cave_biome(int wx, int wy, int wz, float maxHeight, int seed, bool wantDeep = true)
 {
     const float fx = (float)wx, fy = (float)wy, fz = (float)wz;
-    const f3 o = fbm3from3<3>(fx * 0.0470f, fy * 0.0470f, fz * 0.0470f);
-    const float px = (fx + o.x * 30.f) * 1.f, py = (fy + o.y * 24.f) * 1.f, pz = (fz + o.z * 30.f) * 1.f;
-    const float qx = px * 0.2000f, qz = pz * 0.2000f;
-
     const float top = (float)MMGEN_SEA_LEVEL + 0.15f * (maxHeight - (float)MMGEN_SEA_LEVEL);
+    const float sx = fx * 0.0470f, sy = fy * 0.0470f, sz = fz * 0.0470f;
+    // fbm3From3<3> component by component (rng.hpp:180-186), y first; one rolled loop = one inlined simplex body (code size)
+    float o[3], py = 0.f;
+#pragma unroll 1
+    for (int it = 0; it < 3; ++it) {
+        const int k = it == 0 ? 1 : (it == 1 ? 0 : 2);
+        const float ax = k == 0 ? 0.f : (k == 1 ? 5923.45f : 1765.68f), ay = k == 0 ? 0.f : (k == 1 ? 4129.42f : 4704.36f),
+                    az = k == 0 ? 0.f : (k == 1 ? 5790.48f : 5692.12f);
+        o[k] = k == 0 ? fbm3<3>(sx, sy, sz) : fbm3<3>(sx + ax, sy + ay, sz + az);
+        if (it == 0) {
+            py = (fy + o[1] * 24.f) * 1.f;
+#if MM_CAVE_BIOME_PRUNE
+            constexpr float kA2 = 0.875f * 1.06f;
+            if (py >= (top - 19.f) + 23.f * kA2 + 0.05f) return MMCB_NONE;
+            if (!wantDeep && py <= ((top - 72.f) - 18.f * kA2 - 10.f) - 7.f * kA2 - 0.05f) return MMCB_NONE;
+#endif
+        }
+    }
+    const float ox = o[0], oz = o[2];
+    const float px = (fx + ox * 30.f) * 1.f, pz = (fz + oz * 30.f) * 1.f;
+    const float qx = px * 0.2000f, qz = pz * 0.2000f;
 
     MinStd rng = rng4(wx, wy, wz, seed);
     float rand = rng.u01();

@@ -205,3 +205,36 @@ def test_minstd_matches_real_thrust(oracle, golden):
         for want in r:
             x = 48271 * x % m
             assert x == want
+
+
+def test_simplex_bounds(oracle):
+    """cave_biome on the device (csrc/mm_biome.cuh) skips evaluations whose outcome is decided by |fbm2<3>| <= 0.875 * B2 with B2 = 1.06.
+    The bound is adversarial, not statistical: simplex2 = 130 * sum_k m_k^4 (g_k . x_k) <= 130 * max|g| * sup sum_k (0.5 - r_k^2)_+^4 r_k
+    (every gradient aligned with its corner offset).  max|g| comes from the 289-entry gradient table exactly as the device builds it;
+    the supremum over the simplex is taken on a 3000 x 3000 grid of the skewed unit cell plus the Lipschitz slack of the grid
+    (|d/dr (0.5 - r^2)^4 r| <= 0.0625, three corners, half a cell diagonal).  A sample of the oracle's simplex2 stays below it, too."""
+    f = np.float32
+    p = np.arange(0, 289, dtype=f)
+    t = p * f(0.024390243902439)
+    X = f(2) * (t - np.floor(t)) - f(1)
+    h = np.abs(X) - f(0.5)
+    a = X - np.floor(X + f(0.5))
+    nrm = f(1.79284291400159) - f(0.85373472095314) * (a * a + h * h)
+    gmax = float((np.sqrt(a.astype(np.float64) ** 2 + h.astype(np.float64) ** 2) * nrm.astype(np.float64)).max())
+    n = 3000
+    u = (np.arange(n) + 0.5) / n
+    U, V = np.meshgrid(u, u, indexing="ij")
+    c0 = (3 - np.sqrt(3)) / 6
+    tt = (U + V) * c0
+    x0, y0 = U - tt, V - tt
+    i1x = (x0 > y0).astype(np.float64)
+    hk = lambda x, y: np.maximum(0.5 - (x * x + y * y), 0) ** 4 * np.sqrt(x * x + y * y)
+    F = hk(x0, y0) + hk(x0 - i1x + c0, y0 - (1 - i1x) + c0) + hk(x0 - 1 + 2 * c0, y0 - 1 + 2 * c0)
+    slack = 3 * 0.0625 * (np.sqrt(2) / n) / 2
+    bound = 130.0 * gmax * (float(F.max()) + slack)
+    assert bound < 1.06, bound
+    rs = np.random.RandomState(3)
+    xy = (rs.rand(2_000_000, 2).astype(f) - f(0.5)) * f(2000.0)
+    out = np.zeros(len(xy), f)
+    oracle.lib.mmo_simplex2(len(xy), _p(xy), _p(out))
+    assert float(np.abs(out).max()) < bound
