@@ -142,12 +142,17 @@ MM_DEV void de_casteljau(const v3* ctrl, v3* spline)      // :40-66
 // =========================================================================================================
 // surface features
 // =========================================================================================================
-MM_DEV bool place_feature(int feature, int fx, int fy, int fz, int wx, int wy, int wz, uint8_t& out)
+// `fstate` = the placement's own stream right after seeding (surface_feature_stream): it depends on the placement alone, so a caller that
+// evaluates many voxels of one placement seeds it once instead of hashing twice per voxel.
+MM_DEV uint32_t surface_feature_stream(int fx, int fy, int fz) { return rng4(fx, fy, fz, 1293012).x; }
+MM_DEV uint32_t cave_feature_stream(int fx, int fy, int fz) { return rng4(fx, fy, fz, 398132).x; }
+
+MM_DEV bool place_feature(int feature, int fx, int fy, int fz, int wx, int wy, int wz, uint32_t fstate, uint8_t& out)
 {
     const i3 fp = {wx - fx, wy - fy, wz - fz};
     v3 pos = V3((float)fp.x, (float)fp.y, (float)fp.z);
     const v3 wbp = V3((float)wx, (float)wy, (float)wz);
-    MinStd frng = rng4(fx, fy, fz, 1293012);
+    MinStd frng; frng.x = fstate;                 // = rng4(fx, fy, fz, 1293012) (featurePlacement.hpp:153)
     LazyRng brng = {wx, wy, wz, 57847812};       // the per-voxel stream (featurePlacement.hpp:154): seeded only where a rule draws from it
 
     switch (feature) {
@@ -591,13 +596,13 @@ MM_DEV bool place_feature(int feature, int fx, int fy, int fz, int wx, int wy, i
 // =========================================================================================================
 // cave features
 // =========================================================================================================
-MM_DEV bool place_cave_feature(int feature, int fx, int fy, int fz, int layerHeight, int wx, int wy, int wz, uint8_t& out)
+MM_DEV bool place_cave_feature(int feature, int fx, int fy, int fz, int layerHeight, int wx, int wy, int wz, uint32_t fstate, uint8_t& out)
 {
     const i3 fp = {wx - fx, wy - fy, wz - fz};
     const i3 ftp = {wx - fx, wy - (fy + layerHeight), wz - fz};
     const v3 pos = V3((float)fp.x, (float)fp.y, (float)fp.z);
     v3 topPos = V3((float)ftp.x, (float)ftp.y, (float)ftp.z);
-    MinStd frng = rng4(fx, fy, fz, 398132);
+    MinStd frng; frng.x = fstate;                 // = rng4(fx, fy, fz, 398132) (featurePlacement.hpp:1119)
     LazyRng brng = {wx, wy, wz, 9322743};        // the per-voxel stream (featurePlacement.hpp:1120): seeded only where a rule draws from it
 
     switch (feature) {

@@ -455,7 +455,7 @@ MM_DEV void surface_extent(int feat, int fx, int fy, int fz, int& reach, int& dl
 // so that the voxel loop never goes back to global memory: 64 entries per round, ballot + popcount prefix, no workgroup barrier.
 // Returns the number of candidates, or -1 when they do not fit CAND_CAP (caller falls back to the full scan).
 template <class Entry, int LIST_CAP, bool CAVE>
-MM_DEV int filter_column(const Entry* __restrict__ list, int wx, int wz, int2* s_cand, unsigned& featureMask)
+MM_DEV int filter_column(const Entry* __restrict__ list, int wx, int wz, int2* s_cand, uint32_t* s_seed, unsigned& featureMask)
 {
     const int lane = threadIdx.x & 63;
     int base = 0;
@@ -483,7 +483,11 @@ MM_DEV int filter_column(const Entry* __restrict__ list, int wx, int wz, int2* s
             featureMask |= 1u << feat;
             const int w = (fx - wx + 128) | ((fz - wz + 128) << 8) | ((fy & 511) << 16) | (feat << 25) | ((int)(list[i].can_replace_blocks != 0) << 30);
             const int slot = base + __popcll(cm & ((1ull << lane) - 1ull));
-            if (slot < CAND_CAP) s_cand[slot] = make_int2(w, lh);
+            if (slot < CAND_CAP) {
+                s_cand[slot] = make_int2(w, lh);
+                // the placement's own random stream, seeded once per (column, candidate) instead of once per voxel
+                s_seed[slot] = CAVE ? cave_feature_stream(fx, fy, fz) : surface_feature_stream(fx, fy, fz);
+            }
         }
         base += __popcll(cm);
         if (firstNone < 64) break;
@@ -513,6 +517,7 @@ k_apply_features(uint8_t* __restrict__ blocks, const int2* __restrict__ chunkPos
 {
     __shared__ int2 s_cand[APPLY_COLS][2 * CAND_CAP];      // per wave: surface candidates, then cave candidates
     __shared__ int s_pref[APPLY_COLS][2 * CAND_CAP + 1];   // exclusive prefix of the candidates' voxel counts
+    __shared__ uint32_t s_seed[APPLY_COLS][2 * CAND_CAP];  // the candidates' random streams right after seeding
     __shared__ unsigned s_claim[APPLY_COLS][384];          // per voxel: smallest (candidate << 8 | block) that claimed it
     __shared__ uint8_t s_blk[APPLY_COLS][384];             // the column's base blocks
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -521,6 +526,9 @@ k_apply_features(uint8_t* __restrict__ blocks, const int2* __restrict__ chunkPos
     const int b0 = bounds[4 * chunk], b1 = bounds[4 * chunk + 1], b2 = bounds[4 * chunk + 2], b3 = bounds[4 * chunk + 3];
     const bool doS = gfp && b0 <= b1, doC = gcfp && b2 <= b3;      // workgroup-uniform (one chunk per workgroup)
     if (!doS && !doC) return;
+#if MM_APPLY_EXP == 3
+    return;                                                             // timing experiment: launch + bounds only
+#endif
 
     const int2 cp = chunkPos[srcIdx ? srcIdx[chunk] : chunk];
     const int wx = cp.x + (idx2d & 15), wz = cp.y + (idx2d >> 4);
@@ -529,14 +537,17 @@ k_apply_features(uint8_t* __restrict__ blocks, const int2* __restrict__ chunkPos
     int2* cand = s_cand[wave];
     int nS = 0, nC = 0;
     unsigned maskS = 0u, maskC = 0u;
-    if (doS) nS = filter_column<mmgen_feature_placement, MMGEN_MAX_GATHERED_FEATURES_PER_CHUNK, false>(listS, wx, wz, cand, maskS);
-    if (doC) nC = filter_column<mmgen_cave_feature_placement, MMGEN_MAX_GATHERED_CAVE_FEATURES_PER_CHUNK, true>(listC, wx, wz, cand + imax(nS, 0), maskC);
+    if (doS) nS = filter_column<mmgen_feature_placement, MMGEN_MAX_GATHERED_FEATURES_PER_CHUNK, false>(listS, wx, wz, cand, s_seed[wave], maskS);
+    if (doC) nC = filter_column<mmgen_cave_feature_placement, MMGEN_MAX_GATHERED_CAVE_FEATURES_PER_CHUNK, true>(listC, wx, wz, cand + imax(nS, 0), s_seed[wave] + imax(nS, 0), maskC);
     // two workgroup-uniform decisions (the only workgroup barriers): nothing reaches these four columns -> done; the simplex tables
     // (12 KB from L2 per workgroup) are only staged when a candidate's rasteriser evaluates simplex noise (coral, iceberg, redwood,
     // cypress; glowstone, the two fungi) or the gathered lists must be scanned directly
     constexpr unsigned kNoiseS = (1u << MMF_CORAL) | (1u << MMF_ICEBERG) | (1u << MMF_REDWOOD_TREE) | (1u << MMF_CYPRESS_TREE);
     constexpr unsigned kNoiseC = (1u << MMCF_GLOWSTONE_CLUSTER) | (1u << MMCF_WARPED_FUNGUS) | (1u << MMCF_AMBER_FUNGUS);
     if (!__syncthreads_or(nS != 0 || nC != 0)) return;
+#if MM_APPLY_EXP == 4
+    return;                                                             // timing experiment: launch + filters only
+#endif
     if (__syncthreads_or((__ballot((maskS & kNoiseS) || (maskC & kNoiseC)) != 0ull) || nS < 0 || nC < 0)) noise_tables_init();
     if (nS == 0 && nC == 0) return;
     uint8_t* colBlocks = blocks + (size_t)MMGEN_BLOCKS_PER_CHUNK * chunk + 384 * idx2d;
@@ -555,7 +566,7 @@ k_apply_features(uint8_t* __restrict__ blocks, const int2* __restrict__ chunkPos
                     if (block != MMB_AIR && !listS[i].can_replace_blocks) continue;
                     const int fy = listS[i].pos[1];
                     if (y < fy + kFeatureBounds[feature][0] || y > fy + kFeatureBounds[feature][1]) continue;
-                    if (place_feature(feature, listS[i].pos[0], fy, listS[i].pos[2], wx, y, wz, fb)) { placed = true; break; }
+                    if (place_feature(feature, listS[i].pos[0], fy, listS[i].pos[2], wx, y, wz, surface_feature_stream(listS[i].pos[0], fy, listS[i].pos[2]), fb)) { placed = true; break; }
                 }
             }
             if (doC && !placed && y >= cLo && y <= cHi) {
@@ -565,7 +576,7 @@ k_apply_features(uint8_t* __restrict__ blocks, const int2* __restrict__ chunkPos
                     if (block != MMB_AIR && !listC[i].can_replace_blocks) continue;
                     const int fy = listC[i].pos[1], lh = listC[i].layer_height;
                     if (y < fy + kCaveFeatureBounds[feature][0] || y > fy + lh + kCaveFeatureBounds[feature][1]) continue;
-                    if (place_cave_feature(feature, listC[i].pos[0], fy, listC[i].pos[2], lh, wx, y, wz, fb)) { placed = true; break; }
+                    if (place_cave_feature(feature, listC[i].pos[0], fy, listC[i].pos[2], lh, wx, y, wz, cave_feature_stream(listC[i].pos[0], fy, listC[i].pos[2]), fb)) { placed = true; break; }
                 }
             }
             if (placed) colBlocks[y] = fb;
@@ -620,7 +631,8 @@ k_apply_features(uint8_t* __restrict__ blocks, const int2* __restrict__ chunkPos
 #if MM_APPLY_EXP == 2
         const bool placed = (fx + fy + fz + y) == 0x7fffffff;          // timing experiment: no rasteriser
 #else
-        const bool placed = cave ? place_cave_feature(feature, fx, fy, fz, e.y, wx, y, wz, fb) : place_feature(feature, fx, fy, fz, wx, y, wz, fb);
+        const uint32_t fstate = s_seed[wave][k];
+        const bool placed = cave ? place_cave_feature(feature, fx, fy, fz, e.y, wx, y, wz, fstate, fb) : place_feature(feature, fx, fy, fz, wx, y, wz, fstate, fb);
 #endif
         if (placed) atomicMin(&s_claim[wave][y], ((unsigned)k << 8) | fb);
     }
@@ -717,8 +729,8 @@ k_feature_box(int isCave, int feature, int fx, int fy, int fz, int layerHeight, 
     if (i >= sx * sy * sz) return;
     const int y = i % sy, x = (i / sy) % sx, z = i / (sy * sx);
     uint8_t b = 0;
-    const bool placed = isCave ? place_cave_feature(feature, fx, fy, fz, layerHeight, bx + x, by + y, bz + z, b)
-                               : place_feature(feature, fx, fy, fz, bx + x, by + y, bz + z, b);
+    const bool placed = isCave ? place_cave_feature(feature, fx, fy, fz, layerHeight, bx + x, by + y, bz + z, cave_feature_stream(fx, fy, fz), b)
+                               : place_feature(feature, fx, fy, fz, bx + x, by + y, bz + z, surface_feature_stream(fx, fy, fz), b);
     out[i] = placed ? b : 255;
 }
 
