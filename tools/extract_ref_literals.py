@@ -1,0 +1,147 @@
+#!/usr/bin/env python3
+"""Numeric literals of the reference's arithmetic functions, per function and per switch case, as DATA (numbers only):
+tests/golden/ref_literals.json = {"<file>::<function>[::<case>]": [sorted distinct float32 values]}.
+
+The function bodies of biomeFuncs.hpp / featurePlacement.hpp / rng.hpp / chunk.cu cannot be compiled here (cuda / thrust headers), and the
+oracle and the device code restate them from the same reading.  A mistyped or dropped constant is the kind of common-mode error no
+HIP-vs-oracle test can see; this fixture lets a CPU test hold every section of the oracle (same function and case names) and of the device
+code (MMBIO_ / MMF_ / MMCF_ / MMCB_ case labels) to the set of constants the reference's own text uses: every value the reference writes
+in a section must appear in ours.  (Control flow and operation order stay unpinned: DESIGN.md §2.)
+
+Run in the build container: python tools/extract_ref_literals.py   (reads /root/reference, writes tests/golden/ref_literals.json).
+The section parser (`sections`, `literals`) is imported by tests/test_ref_literals.py to parse OUR sources the same way.
+"""
+import json
+import os
+import re
+import sys
+
+import numpy as np
+
+REF = "/root/reference/src"
+NUM = re.compile(r"(?<![\w.])(?:0[xX][0-9a-fA-F]*\.?[0-9a-fA-F]*(?:[pP][-+]?\d+)?|\d+\.\d*(?:[eE][-+]?\d+)?|\.\d+(?:[eE][-+]?\d+)?|\d+(?:[eE][-+]?\d+)?)(?:f|F|u|U|ull|ULL|ll|LL|l|L)?(?![\w.])")
+
+
+def strip_comments(text):
+    text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+    return re.sub(r"//[^\n]*", " ", text)
+
+
+def literals(code):
+    """sorted distinct numeric literal values of a piece of code, as float32 (hex ints as ints); template arguments count like any number"""
+    vals = set()
+    for m in NUM.finditer(code):
+        tok = m.group(0)
+        if tok.lower().startswith("0x"):
+            body = tok.rstrip("uUlL")
+            if "p" in body.lower():
+                v = float.fromhex(body.rstrip("fF"))               # hex float (0x1.8p+1f)
+            else:
+                v = float(int(body, 16))                           # hex integer: a trailing f is a digit here
+        else:
+            v = float(tok.rstrip("fFuUlL"))
+        vals.add(float(np.float32(v)))
+    return sorted(vals)
+
+
+def body_after(text, start):
+    """text of the brace block that starts at the first '{' after `start`"""
+    i = text.index("{", start)
+    depth = 0
+    for j in range(i, len(text)):
+        if text[j] == "{":
+            depth += 1
+        elif text[j] == "}":
+            depth -= 1
+            if depth == 0:
+                return text[i:j + 1]
+    raise ValueError("unbalanced braces")
+
+
+def sections(text, signature, case_prefixes=()):
+    """{section: code}.  `signature` is a regex matching the start of the function definition; with case_prefixes the body is cut at
+    `case <prefix>NAME:` labels (consecutive labels share the code that follows; code before the first label is section '')."""
+    out = {}
+    for m in re.finditer(signature, text):
+        try:
+            body = body_after(text, m.end() - 1 if text[m.end() - 1] == "{" else m.end())
+        except ValueError:
+            continue
+        if not case_prefixes:
+            out[""] = out.get("", "") + body
+            continue
+        label = re.compile(r"case\s+(?:" + "|".join(re.escape(p) for p in case_prefixes) + r")(\w+)\s*:")
+        pos, names = 0, [""]
+        pieces = []
+        for lm in label.finditer(body):
+            between = body[pos:lm.start()]
+            if between.strip():
+                pieces.append((names, between))
+                names = []
+            names = names + [lm.group(1)]
+            pos = lm.end()
+        pieces.append((names, body[pos:]))
+        for nm, code in pieces:
+            for n in nm:
+                out[n] = out.get(n, "") + code
+    return out
+
+
+# (file, key, signature regex, case prefixes)
+REFERENCE_SECTIONS = [
+    ("terrain/biomeFuncs.hpp", "getSingleBiomeNoise", r"float\s+getSingleBiomeNoise\s*\([^)]*\)\s*\{", ()),
+    ("terrain/biomeFuncs.hpp", "getBiomeNoise", r"BiomeNoise\s+getBiomeNoise\s*\([^)]*\)\s*\{", ()),
+    ("terrain/biomeFuncs.hpp", "getSingleCaveBiomeNoise", r"float\s+getSingleCaveBiomeNoise\s*\([^)]*\)\s*\{", ()),
+    ("terrain/biomeFuncs.hpp", "getCaveBiomeNoise", r"CaveBiomeNoise\s+getCaveBiomeNoise\s*\([^)]*\)\s*\{", ()),
+    ("terrain/biomeFuncs.hpp", "getHeight", r"float\s+getHeight\s*\([^)]*\)\s*\{", ("Biome::",)),
+    ("terrain/biomeFuncs.hpp", "biomeBlockPreProcess", r"bool\s+biomeBlockPreProcess\s*\([^)]*\)\s*\{", ("Biome::",)),
+    ("terrain/biomeFuncs.hpp", "biomeBlockPostProcess", r"bool\s+biomeBlockPostProcess\s*\([^)]*\)\s*\{", ("Biome::",)),
+    ("terrain/biomeFuncs.hpp", "caveBiomeBlockPostProcess", r"bool\s+caveBiomeBlockPostProcess\s*\([^)]*\)\s*\{", ("CaveBiome::",)),
+    ("terrain/featurePlacement.hpp", "sdCappedCylinder", r"float\s+sdCappedCylinder\s*\([^)]*\)\s*\{", ()),
+    ("terrain/featurePlacement.hpp", "isInRasterizedLine", r"bool\s+isInRasterizedLine\s*\([^)]*\)\s*\{", ()),
+    ("terrain/featurePlacement.hpp", "jungleLeaves", r"bool\s+jungleLeaves\s*\([^)]*\)\s*\{", ()),
+    ("terrain/featurePlacement.hpp", "getCrystalRadius", r"float\s+getCrystalRadius\s*\([^)]*\)\s*\{", ()),
+    ("terrain/featurePlacement.hpp", "isInCrystal", r"bool\s+isInCrystal\s*\([^)]*\)\s*\{", ()),
+    ("terrain/featurePlacement.hpp", "getRandomCrystalBlock", r"Block\s+getRandomCrystalBlock\s*\([^)]*\)\s*\{", ()),
+    ("terrain/featurePlacement.hpp", "placeFeature", r"bool\s+placeFeature\s*\([^)]*\)\s*\{", ("Feature::",)),
+    ("terrain/featurePlacement.hpp", "placeCaveFeature", r"bool\s+placeCaveFeature\s*\([^)]*\)\s*\{", ("CaveFeature::",)),
+    ("util/rng.hpp", "hash", r"unsigned\s+int\s+hash\s*\([^)]*\)\s*\{", ()),
+    ("util/rng.hpp", "makeSeededRandomEngine", r"makeSeededRandomEngine\s*\([^)]*\)\s*\{", ()),
+    ("util/rng.hpp", "rand1From1", r"float\s+rand1From1\s*\([^)]*\)\s*\{", ()),
+    ("util/rng.hpp", "rand1From2", r"float\s+rand1From2\s*\([^)]*\)\s*\{", ()),
+    ("util/rng.hpp", "rand1From3", r"float\s+rand1From3\s*\([^)]*\)\s*\{", ()),
+    ("util/rng.hpp", "rand2From2", r"vec2\s+rand2From2\s*\([^)]*\)\s*\{", ()),
+    ("util/rng.hpp", "rand2From3", r"vec2\s+rand2From3\s*\([^)]*\)\s*\{", ()),
+    ("util/rng.hpp", "rand3From2", r"vec3\s+rand3From2\s*\([^)]*\)\s*\{", ()),
+    ("util/rng.hpp", "rand3From3", r"vec3\s+rand3From3\s*\([^)]*\)\s*\{", ()),
+    ("util/rng.hpp", "fbm2From2", r"vec2\s+fbm2From2\s*\([^)]*\)\s*\{", ()),
+    ("util/rng.hpp", "fbm3From3", r"vec3\s+fbm3From3\s*\([^)]*\)\s*\{", ()),
+    ("util/rng.hpp", "simplex2From2", r"vec2\s+simplex2From2\s*\([^)]*\)\s*\{", ()),
+    ("util/rng.hpp", "specialCaveNoise", r"float\s+specialCaveNoise\s*\([^)]*\)\s*\{", ()),
+    ("terrain/chunk.cu", "shouldGenerateCaveAtBlock", r"bool\s+shouldGenerateCaveAtBlock\s*\([^)]*\)\s*\{", ()),
+    ("terrain/chunk.cu", "getStratifiedMaterialThickness", r"float\s+getStratifiedMaterialThickness\s*\([^)]*\)\s*\{", ()),
+    ("terrain/chunk.cu", "isFeaturePos", r"bool\s+isFeaturePos\s*\([^)]*\)\s*\{", ()),
+    ("terrain/chunk.cu", "generateColumnFeaturePlacements", r"void\s+Chunk::generateColumnFeaturePlacements\s*\([^)]*\)\s*\{", ()),
+    ("terrain/chunk.cu", "placeDecorators", r"void\s+Chunk::placeDecorators\s*\([^)]*\)\s*\{", ()),
+    ("terrain/chunk.cu", "kernGenerateCaves", r"void\s+kernGenerateCaves\s*\([^{]*\)\s*\{", ()),
+]
+
+
+def main(out_path):
+    out = {}
+    cache = {}
+    for rel, key, sig, prefixes in REFERENCE_SECTIONS:
+        if rel not in cache:
+            cache[rel] = strip_comments(open(os.path.join(REF, rel)).read())
+        secs = sections(cache[rel], sig, prefixes)
+        assert secs, (rel, key)
+        for name, code in secs.items():
+            vals = literals(code)
+            if vals:
+                out[f"{os.path.basename(rel)}::{key}" + (f"::{name}" if name else "")] = vals
+    json.dump(out, open(out_path, "w"), indent=0, sort_keys=True)
+    print(f"wrote {out_path}: {len(out)} sections, {sum(len(v) for v in out.values())} literal values")
+
+
+if __name__ == "__main__":
+    main(sys.argv[1] if len(sys.argv) > 1 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "ref_literals.json"))
