@@ -289,6 +289,33 @@ MM_DEV int cave_biome(int wx, int wy, int wz, float maxHeight, int seed, bool wa
     MinStd rng = rng4(wx, wy, wz, seed);
     float rand = rng.u01();
 
+    // The two depth bands: none = smoothstep(n2sEnd, n2sStart, py), shallow = smoothstep(s2dEnd, s2dStart, py), each edge pair built from
+    // two fbm2<3>.  A smoothstep is exactly 0 at or below its lower edge and exactly 1 at or above its upper edge, and the edges are
+    // confined by the same bound as above, so py decides which band can be strictly inside its transition:
+    //   py <= (top - 19 - 23 A) - 5 - 3 A - slack  =>  none == 0 exactly (rand - 0 == rand)          py >= (top - 72) + 18 A + slack  =>  shallow == 1 exactly
+    // The first limit lies 7 blocks above the second, so at most ONE band needs its 6 simplex2 (the reference evaluates 12); lanes that
+    // need the upper band and lanes that need the lower one run the same instructions on per-lane constants.
+#if MM_CAVE_BIOME_PRUNE
+    constexpr float kA = 0.875f * 1.06f;
+    static_assert((((-19.f - 23.f * kA) - 5.f) - 3.f * kA) - 0.05f > ((-72.f + 18.f * kA) + 0.05f) + 1.f, "the two transition bands must not overlap");
+    const bool noneZero = py <= ((((top - 19.f) - 23.f * kA) - 5.f) - 3.f * kA) - 0.05f;
+    const bool shallowOne = py >= ((top - 72.f) + 18.f * kA) + 0.05f;
+    const bool shallowZero = py <= ((((top - 72.f) - 18.f * kA) - 10.f) - 7.f * kA) - 0.05f;
+    const int band = !noneZero ? 0 : ((shallowOne || shallowZero) ? -1 : 1);
+    float bandVal = 0.f;
+    if (band >= 0) {
+        const bool b0 = band == 0;
+        const float f1 = b0 ? fbm2<3>(qx, qz) : fbm2<3>(qx + -4921.34f, qz + 8402.13f);
+        const float edge1 = (b0 ? (top - 19.f) : (top - 72.f)) + (b0 ? 23.f : 18.f) * f1;
+        const float f2 = fbm2<3>(qx + (b0 ? 3821.34f : 9411.32f), qz + (b0 ? 4920.32f : -3921.34f));
+        const float edge0 = (edge1 - (b0 ? 5.f : 10.f)) + (b0 ? 3.f : 7.f) * f2;
+        bandVal = smoothstep(edge0, edge1, py);
+    }
+    const float none = band == 0 ? bandVal : 0.f;
+    rand -= none;                                   // NONE
+    if (rand <= 0.f) return MMCB_NONE;
+    const float shallow = band == 1 ? bandVal : (shallowZero ? 0.f : 1.f);
+#else
     const float n2sStart = (top - 19.f) + 23.f * fbm2<3>(qx, qz);
     const float n2sEnd = (n2sStart - 5.f) + 3.f * fbm2<3>(qx + 3821.34f, qz + 4920.32f);
     const float none = smoothstep(n2sEnd, n2sStart, py);
@@ -299,6 +326,7 @@ MM_DEV int cave_biome(int wx, int wy, int wz, float maxHeight, int seed, bool wa
     const float s2dStart = (top - 72.f) + 18.f * fbm2<3>(qx + -4921.34f, qz + 8402.13f);
     const float s2dEnd = (s2dStart - 10.f) + 7.f * fbm2<3>(qx + 9411.32f, qz + -3921.34f);
     const float shallow = smoothstep(s2dEnd, s2dStart, py);
+#endif
 
     // rand > 0 here.  A weight that is exactly 0 (rocky, warped are in [0, 1]) subtracts +0 and cannot select its biome, so
     // the simplex3 behind it is only evaluated when its factor is non-zero (outside the transition bands one of the two is 0).

@@ -16,7 +16,10 @@ struct ErosionPhase {       // state of the relaxation loop of one zone as seen 
     int passes;             // relaxation passes the reference's loop would have executed before this launch
     int accSel;             // which accumulator buffer is current
     int fresh;              // written by k_erode_init: the first launch takes it as is
-    int sel[8];             // which of a layer's three planes holds its current start plane (2 = state after its first pass)
+    unsigned sel;           // 2 bits per layer: which of the layer's three planes holds its current start plane (2 = state after its first
+                            // pass).  Packed, not an array: a dynamically indexed member would put the whole phase in scratch
+    __host__ __device__ int plane(int l) const { return (int)((sel >> (2 * l)) & 3u); }
+    __host__ __device__ void setPlane(int l, int v) { sel = (sel & ~(3u << (2 * l))) | ((unsigned)v << (2 * l)); }
 };
 // Per-zone device-side state machine: launch t reads the phase launch t-1 ran with (slot[(t-1) & 1]) and launch t-1's "changed" mask
 // (changed[(t-1) & 3], bit j = pass j altered a column), derives its own phase (every workgroup redundantly, a few scalar ops), and

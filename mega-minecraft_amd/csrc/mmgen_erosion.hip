@@ -49,17 +49,17 @@ MM_DEV ErosionPhase next_phase(const ErosionPhase& prev, unsigned maskPrev)
     if (prev.fresh) { cur.fresh = 0; return cur; }
     if (prev.done) return cur;
     const int L = prev.layer;
-    const int outSel = prev.isFirst ? 0 : 1 - prev.sel[L];           // plane the previous launch wrote its final state to
+    const int outSel = prev.isFirst ? 0 : 1 - prev.plane(L);           // plane the previous launch wrote its final state to
     const unsigned full = (1u << EROSION_K) - 1u;
     if ((maskPrev & full) == full) {                                 // every pass changed something: not converged yet
         cur.passes = prev.passes + EROSION_K;
-        cur.sel[L] = outSel; cur.accSel = 1 - prev.accSel; cur.isFirst = 0;
+        cur.setPlane(L, outSel); cur.accSel = 1 - prev.accSel; cur.isFirst = 0;
         return cur;
     }
     const int firstUnchanged = __builtin_ctz(~maskPrev);             // the pass at which the reference's loop stops
     cur.passes = prev.passes + firstUnchanged + 1;
-    if (prev.isFirst && firstUnchanged == 0) cur.sel[L] = 2;         // unchanged first pass: its own output is final, acc untouched
-    else { cur.sel[L] = outSel; cur.accSel = 1 - prev.accSel; }
+    if (prev.isFirst && firstUnchanged == 0) cur.setPlane(L, 2);         // unchanged first pass: its own output is final, acc untouched
+    else { cur.setPlane(L, outSel); cur.accSel = 1 - prev.accSel; }
     if (L == 0) cur.done = 1;
     else { cur.layer = L - 1; cur.isFirst = 1; }
     return cur;
@@ -142,12 +142,12 @@ k_erode_pass(const float* __restrict__ gatheredBase, size_t gatheredStride, floa
     float* work = workBase + ZONE_WORK_FLOATS * zone;
     const float* accIn = work + (size_t)24 * ZN + (size_t)ph.accSel * ZN;
     float* accOut = work + (size_t)24 * ZN + (size_t)(1 - ph.accSel) * ZN;
-    const float* startIn = isFirst ? (gathered + (size_t)layer * ZN) : (work + ((size_t)layer * 3 + ph.sel[layer]) * ZN);
-    float* startOut = work + ((size_t)layer * 3 + (isFirst ? 0 : 1 - ph.sel[layer])) * ZN;
+    const float* startIn = isFirst ? (gathered + (size_t)layer * ZN) : (work + ((size_t)layer * 3 + ph.plane(layer)) * ZN);
+    float* startOut = work + ((size_t)layer * 3 + (isFirst ? 0 : 1 - ph.plane(layer))) * ZN;
     float* startFirst = work + ((size_t)layer * 3 + 2) * ZN;
     // end plane = final start plane of the layer above (already eroded), or the heightfield plane for the top layer
     const float* endIn = (layer == MMGEN_NUM_ERODED_MATERIALS - 1) ? (gathered + (size_t)8 * ZN)
-                                                                   : (work + ((size_t)(layer + 1) * 3 + ph.sel[layer + 1]) * ZN);
+                                                                   : (work + ((size_t)(layer + 1) * 3 + ph.plane(layer + 1)) * ZN);
 
     // extended tile: ex, ez in [0, EXT) <-> grid (gx0 + ex, gz0 + ez); cells beyond the grid do not exist (neighbours clamp to the edge)
     const int gx0 = blockIdx.x * 32 - EROSION_K, gz0 = blockIdx.y * 32 - EROSION_K;
@@ -222,7 +222,7 @@ k_erode_writeback(float* __restrict__ gatheredBase, size_t gatheredStride, const
     const float* work = workBase + ZONE_WORK_FLOATS * zone;
     float* gathered = gatheredBase + gatheredStride * zone;
 #pragma unroll
-    for (int l = 0; l < 8; ++l) gathered[(size_t)l * ZN + c] = work[((size_t)l * 3 + st->sel[l]) * ZN + c];
+    for (int l = 0; l < 8; ++l) gathered[(size_t)l * ZN + c] = work[((size_t)l * 3 + st->plane(l)) * ZN + c];
     if (accOutBase) accOutBase[accStride * zone + c] = work[(size_t)24 * ZN + (size_t)st->accSel * ZN + c];
 }
 
@@ -237,7 +237,7 @@ __global__ void k_erode_init(ErosionState* states, float* workBase, int zones)
     if (i == 0) {
         ErosionPhase s;
         s.layer = MMGEN_NUM_ERODED_MATERIALS - 1; s.isFirst = 1; s.done = 0; s.passes = 0; s.accSel = 0; s.fresh = 1;
-        for (int l = 0; l < 8; ++l) s.sel[l] = 0;
+        s.sel = 0u;
         states[zone].slot[1] = s;            // launch 0 reads slot[(0 - 1) & 1]
         states[zone].slot[0] = s;
         for (int k = 0; k < 4; ++k) states[zone].changed[k] = 0u;

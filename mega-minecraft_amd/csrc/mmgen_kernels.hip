@@ -193,6 +193,32 @@ k_cave_columns(const float* __restrict__ bw, const int2* __restrict__ chunkPos, 
     colInfo[(size_t)256 * chunk + t] = make_float2(obw, ravineY);
 }
 
+// smoothstep(0.2, 0.4, fbm3<4>(p)) of the cave threshold (chunk.cu shouldGenerateCaveAtBlock).  Exact pruning: the smoothstep is exactly 0
+// for an argument <= 0.2 and exactly 1 for one >= 0.4, the octaves still to come after octave i add at most amp_i * B3 in magnitude
+// (their amplitudes sum to < amp_i; B3 = 1.23 >= sup |simplex3| = 42 * sup_g |g| * sup sum (0.6 - r^2)^4 r = 42 * 1.00001 * 0.029187,
+// adversarially aligned gradients: tests/test_oracle_math.py::test_simplex3_bound), so once the partial sum is that far on either
+// side the remaining octaves cannot move the result.  The partial sums are the reference's own (same order of additions).  This noise
+// varies over thousands of blocks: a workgroup's voxels nearly always leave the loop together.
+#ifndef MM_CAVE_HUGE_PRUNE
+#define MM_CAVE_HUGE_PRUNE 1
+#endif
+MM_DEV float cave_huge(float x, float y, float z)
+{
+    float acc = 0.f, amp = 1.f;
+#pragma unroll 1
+    for (int i = 0; i < 4; ++i) {
+        amp *= 0.5f;
+        acc += amp * simplex3_inl(x, y, z);
+        x *= 2.f; y *= 2.f; z *= 2.f;
+#if MM_CAVE_HUGE_PRUNE
+        const float rest = amp * 1.23f;
+        if (acc + rest <= 0.2f - 0.001f) return 0.f;
+        if (acc - rest >= 0.4f + 0.001f) return 1.f;
+#endif
+    }
+    return smoothstep(0.2f, 0.4f, acc);
+}
+
 #define CELL_NX 8          // 4 adjacent columns share one tile: +1 cell in x over the single-column reach
 #define CELL_NY 8
 #define CELL_NZ 7
@@ -334,7 +360,7 @@ k_cave_voxels(const float* __restrict__ hf, const float2* __restrict__ colInfo, 
         const float topRatio = smoothstep(142.f, 95.f, fy + obw * 50.f);
         const float bottomRatio = smoothstep(5.f, 20.f, fy);
         float thr = 0.24f + 0.12f * fbm3<4>(npx * 4.f, npy * 4.f, npz * 4.f);
-        const float huge = smoothstep(0.2f, 0.4f, fbm3<4>(npx * 0.0700f, npy * 0.0700f, npz * 0.0700f));
+        const float huge = cave_huge(npx * 0.0700f, npy * 0.0700f, npz * 0.0700f);
         thr *= (1.f + 1.4f * huge);
         thr *= topRatio * (0.3f + 0.7f * bottomRatio);
         if (thr > 0.04f) {

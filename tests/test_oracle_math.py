@@ -238,3 +238,49 @@ def test_simplex_bounds(oracle):
     out = np.zeros(len(xy), f)
     oracle.lib.mmo_simplex2(len(xy), _p(xy), _p(out))
     assert float(np.abs(out).max()) < bound
+
+
+def test_simplex3_bound(oracle):
+    """cave_huge on the device (csrc/mmgen_kernels.hip) leaves its octave loop once the octaves still to come cannot move the result,
+    using |simplex3| <= B3 = 1.23.  Adversarial bound like test_simplex_bounds: simplex3 = 42 * sum_k m_k^4 (g_k . x_k)
+    <= 42 * sup|g| * sup sum_k (0.6 - r_k^2)_+^4 r_k.  sup|g|: a gradient is p * (1.79284291400159 - 0.85373472095314 |p|^2), whose length
+    s (1.7928... - 0.8537... s^2) is at most 1.00001 whatever p is.  The supremum over the simplex: coarse grid of the unit cell (160^3),
+    then 8^3 sub-grids of every coarse cell that could still hold the maximum, plus the Lipschitz slack of the fine grid
+    (|d/dr (0.6 - r^2)^4 r| <= 0.1296, four corners, half a cell diagonal).  A sample of the oracle's simplex3 stays below it, too."""
+    s_ = np.linspace(0.0, 2.0, 2_000_001)
+    gmax = float((s_ * (1.79284291400159 - 0.85373472095314 * s_ * s_)).max())
+    assert gmax < 1.00001
+
+    def F(v):
+        i = np.floor(v + v.sum(-1, keepdims=True) / 3.0)
+        x0 = v - i + i.sum(-1, keepdims=True) / 6.0
+        g = (x0[..., [1, 2, 0]] <= x0).astype(np.float64)         # step(x0.yzx, x0.xyz)
+        lz = (1.0 - g)[..., [2, 0, 1]]
+        i1, i2 = np.minimum(g, lz), np.maximum(g, lz)
+        tot = 0.0
+        for x in (x0, x0 - i1 + 1 / 6.0, x0 - i2 + 1 / 3.0, x0 - 0.5):
+            r2 = (x * x).sum(-1)
+            tot = tot + np.maximum(0.6 - r2, 0) ** 4 * np.sqrt(r2)
+        return tot
+
+    n, m = 160, 8
+    h = 1.0 / n
+    u = (np.arange(n) + 0.5) * h
+    slack = 4 * 0.1296 * (np.sqrt(3) * h / 2)
+    vals, pts = [], []
+    for a in u:
+        V = np.stack(np.meshgrid([a], u, u, indexing="ij"), -1).reshape(-1, 3)
+        vals.append(F(V)); pts.append(V)
+    vals, pts = np.concatenate(vals), np.concatenate(pts)
+    sel = pts[vals + slack > vals.max()]
+    sub = (np.arange(m) + 0.5) / m * h - h / 2
+    S = np.stack(np.meshgrid(sub, sub, sub, indexing="ij"), -1).reshape(-1, 3)
+    fine = max(float(F((sel[k:k + 2000, None, :] + S[None]).reshape(-1, 3)).max()) for k in range(0, len(sel), 2000))
+    bound = 42.0 * 1.00001 * (fine + 4 * 0.1296 * (np.sqrt(3) * h / m / 2))
+    assert bound < 1.23, bound
+    f = np.float32
+    rs = np.random.RandomState(4)
+    xyz = (rs.rand(2_000_000, 3).astype(f) - f(0.5)) * f(2000.0)
+    out = np.zeros(len(xyz), f)
+    oracle.lib.mmo_simplex3(len(xyz), _p(xyz), _p(out))
+    assert float(np.abs(out).max()) < bound

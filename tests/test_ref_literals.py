@@ -115,7 +115,7 @@ DEVICE_MAP = {
     "rng.hpp::fbm3From3": ([CS + "mm_noise.cuh"], [r"f3\s+fbm3from3\s*\([^)]*\)\s*\{"], None),
     "rng.hpp::simplex2From2": ([CS + "mm_noise.cuh"], [r"f2\s+simplex2from2\s*\([^)]*\)\s*\{"], None),
     "rng.hpp::specialCaveNoise": ([CS + "mm_noise.cuh"], [r"float\s+special_cave_noise\s*\([^)]*\)\s*\{"], None),
-    "chunk.cu::shouldGenerateCaveAtBlock": ([CS + "mmgen_kernels.hip"], [r"\bk_cave_columns\s*\([^)]*\)\s*\{", r"\bk_cave_voxels\s*\([^{]*\)\s*\{"], None),
+    "chunk.cu::shouldGenerateCaveAtBlock": ([CS + "mmgen_kernels.hip"], [r"\bk_cave_columns\s*\([^)]*\)\s*\{", r"\bk_cave_voxels\s*\([^{]*\)\s*\{", r"float\s+cave_huge\s*\([^)]*\)\s*\{"], None),
     "chunk.cu::getStratifiedMaterialThickness": ([CS + "mmgen_kernels.hip"], [r"float\s+stratified_thickness\s*\([^)]*\)\s*\{"], None),
     "chunk.cu::isFeaturePos": ([CS + "mmgen_features.hip"], [r"bool\s+is_feature_pos\s*\([^)]*\)\s*\{"], None),
     "chunk.cu::generateColumnFeaturePlacements": ([CS + "mmgen_features.hip"], [r"void\s+column_placements\s*\([^{]*\)\s*\{"], None),
@@ -127,6 +127,7 @@ DEVICE_BENIGN = {0.0, 0.5, 1.0, 2.0, 3.0, 4.0, 5.0, 6.0, 9.0, 16.0, 63.0, 64.0, 
 DEVICE_EXTRA = {
     "biomeFuncs.hpp::getBiomeNoise": (float(np.float32(0.32)),),         # overallBiomeScale, a file-level constant in the reference (biomeFuncs.hpp:105)
     # cave_biome: fbm3From3's component offsets (rng.hpp:188-191, rolled into the loop) and the exact-pruning bound 0.875 * 1.06
+    "chunk.cu::shouldGenerateCaveAtBlock": (float(np.float32(1.23)), float(np.float32(0.001))),    # cave_huge: exact-pruning bound B3 and its slack
     "biomeFuncs.hpp::getCaveBiomeNoise": tuple(float(np.float32(v)) for v in (0.875, 1.06, 5923.45, 4129.42, 5790.48, 1765.68, 4704.36, 5692.12)),
 }
 DEVICE_ALLOW = {
