@@ -260,7 +260,7 @@ MM_DEV float column_height(int wxi, int wzi, float* w24 /* nullable */)
 #ifndef MM_CAVE_BIOME_PRUNE
 #define MM_CAVE_BIOME_PRUNE 1
 #endif
-MM_DEV int cave_biome(int wx, int wy, int wz, float maxHeight, int seed, bool wantDeep = true)
+MM_DEV int cave_biome(int wx, int wy, int wz, float maxHeight, int seed, bool wantDeep = true, bool crystalOnly = false)
 {
     const float fx = (float)wx, fy = (float)wy, fz = (float)wz;
     const float top = (float)MMGEN_SEA_LEVEL + 0.15f * (maxHeight - (float)MMGEN_SEA_LEVEL);
@@ -288,6 +288,22 @@ MM_DEV int cave_biome(int wx, int wy, int wz, float maxHeight, int seed, bool wa
 
     MinStd rng = rng4(wx, wy, wz, seed);
     float rand = rng.u01();
+
+    // crystalOnly: the caller only needs to know whether the result is CRYSTAL_CAVES (k_fill: a voxel further than 7 blocks from every cave
+    // surface - LUSH_CAVES only converts within 1.5 + 4.5 simplex3 <= 7.04 blocks of one - that is not the top of a cave floor).  CRYSTAL's
+    // weight is (1 - none) shallow rocky, and rocky = smoothstep(-0.05, 0.05, simplex3(p * 0.0022)) is exactly 0 over half the world in
+    // patches hundreds of blocks wide: there the draw cannot select CRYSTAL (it subtracts +0) and neither depth band is evaluated.  rocky
+    // is therefore evaluated BEFORE the bands (same value, same place in the draw).
+    float rocky = 0.f;
+#if MM_CAVE_BIOME_PRUNE
+    const bool rockyMatters = !(py <= ((((top - 72.f) - 18.f * (0.875f * 1.06f)) - 10.f) - 7.f * (0.875f * 1.06f)) - 0.05f);      // shallow can be non-zero
+#else
+    const bool rockyMatters = true;
+#endif
+    if (rockyMatters) {
+        rocky = smoothstep(-0.05f, 0.05f, simplex3(px * 0.0022f + -9193.23f, py * 0.0022f + -6813.39f, pz * 0.0022f + (float)-2171.23));
+        if (crystalOnly && rocky == 0.f) return MMCB_NONE;
+    }
 
     // The two depth bands: none = smoothstep(n2sEnd, n2sStart, py), shallow = smoothstep(s2dEnd, s2dStart, py), each edge pair built from
     // two fbm2<3>.  A smoothstep is exactly 0 at or below its lower edge and exactly 1 at or above its upper edge, and the edges are
@@ -329,14 +345,13 @@ MM_DEV int cave_biome(int wx, int wy, int wz, float maxHeight, int seed, bool wa
 #endif
 
     // rand > 0 here.  A weight that is exactly 0 (rocky, warped are in [0, 1]) subtracts +0 and cannot select its biome, so
-    // the simplex3 behind it is only evaluated when its factor is non-zero (outside the transition bands one of the two is 0).
+    // the simplex3 behind warped is only evaluated when its factor is non-zero (shallowW != 0 implies rockyMatters: rocky was evaluated).
     const float shallowW = (1.f - none) * shallow;
     if (shallowW != 0.f) {
-        const float rocky = smoothstep(-0.05f, 0.05f, simplex3(px * 0.0022f + -9193.23f, py * 0.0022f + -6813.39f, pz * 0.0022f + (float)-2171.23));
         rand -= shallowW * rocky;                   // CRYSTAL_CAVES
         if (rand <= 0.f) return MMCB_CRYSTAL_CAVES;
         rand -= shallowW * (1.f - rocky);           // LUSH_CAVES
-        if (rand <= 0.f) return MMCB_LUSH_CAVES;
+        if (rand <= 0.f) return crystalOnly ? MMCB_NONE : MMCB_LUSH_CAVES;
     }
     const float deepW = 1.f - shallow;
     // wantDeep = false: the caller has no use for WARPED_FOREST / AMBER_FOREST (k_fill: those two only re-skin the top DEEPSLATE /

@@ -158,7 +158,7 @@ __global__ void __launch_bounds__(256) k_fix_backward(float* __restrict__ layers
 //                    (ocean+beach weight, the whole ravine branch → one y threshold)
 //   k_cave_voxels  : one workgroup (3 waves, 3 passes) per 4 columns, lane = voxel; Worley cell points of the columns' reachable
 //                    8x8x7 cell box staged in LDS; solid/air bits → LDS bit words → popcount ranks → (start,end) runs
-//   k_cave_biomes  : the occupied layer slots' (bottom, top) cave-biome evaluations, compacted per 32 columns and walked densely
+//   k_cave_biomes  : the occupied layer slots' (bottom, top) cave-biome evaluations, compacted per 128 columns and walked densely
 // =========================================================================================================
 __global__ void __launch_bounds__(256)
 k_cave_columns(const float* __restrict__ bw, const int2* __restrict__ chunkPos, float2* __restrict__ colInfo, const int* __restrict__ chunkList)
@@ -324,8 +324,9 @@ k_cave_voxels(const float* __restrict__ hf, const float2* __restrict__ colInfo, 
     // need the noise only below y ~ 92 and most voxels that pass the first test pass the second, so without compaction 4 - 40 %
     // of the lanes idle through the 23 simplex evaluations.
     //   A  every voxel: everything that needs no noise; solid bit set as if the noise said "no cave"; voxels that need it -> list 1
-    //   B  list 1: threshold (2 x fbm3<4>); voxels whose threshold can carve (> 0.04) -> list 2 with their threshold
-    //   C  list 2: position warp (fbm3from3<5>) + Worley; "cave" clears the solid bit again
+    //   B  list 1: position warp (fbm3from3<5>) + Worley = the cave noise; voxels whose noise is below the largest threshold the voxel can
+    //      have -> list 2 with their noise
+    //   C  list 2: the threshold (huge, then fbm3<4> only if the noise is still below the bound); "cave" clears the solid bit again
     for (int e = t; e < CAVE_VOXELS; e += CAVE_THREADS) {
         const int c = e / CAVE_YEVAL, y = e - c * CAVE_YEVAL;
         if (!((needMask >> c) & 1u)) continue;
@@ -347,6 +348,12 @@ k_cave_voxels(const float* __restrict__ hf, const float2* __restrict__ colInfo, 
         }
     }
     __syncthreads();
+    // The reference evaluates  cave = threshold > 0.04 && caveNoise < threshold  with threshold = ((0.24 + 0.12 fa) (1 + 1.4 huge)) T,
+    // fa = fbm3<4>, huge in [0, 1], T = topRatio (0.3 + 0.7 bottomRatio) >= 0.  Every operation of that expression is monotone in fa and
+    // in huge (IEEE rounding is monotone, the other factors are non-negative), so the SAME expression with fa := kCaveFaMax >= sup |fbm3<4>|
+    // = 0.9375 * 1.23 and huge := 1 is >= threshold bit for bit: a voxel whose cave noise is not below that bound is solid whatever the
+    // two fbm3<4> are, and they are never evaluated for it (56 % of the voxels; half of the rest is decided once huge is known).
+    constexpr float kCaveFaMax = 1.16f;
     const int count1 = s_count[0];
     for (int i = t; i < count1; i += CAVE_THREADS) {
         const int e = s_list1[i];
@@ -359,28 +366,41 @@ k_cave_voxels(const float* __restrict__ hf, const float2* __restrict__ colInfo, 
         const float npy = fy * 0.0050f;
         const float topRatio = smoothstep(142.f, 95.f, fy + obw * 50.f);
         const float bottomRatio = smoothstep(5.f, 20.f, fy);
-        float thr = 0.24f + 0.12f * fbm3<4>(npx * 4.f, npy * 4.f, npz * 4.f);
-        const float huge = cave_huge(npx * 0.0700f, npy * 0.0700f, npz * 0.0700f);
-        thr *= (1.f + 1.4f * huge);
-        thr *= topRatio * (0.3f + 0.7f * bottomRatio);
-        if (thr > 0.04f) {
+        float bound = 0.24f + 0.12f * kCaveFaMax;
+        bound *= (1.f + 1.4f * 1.f);
+        bound *= topRatio * (0.3f + 0.7f * bottomRatio);
+        if (!(bound > 0.04f)) continue;                        // threshold <= bound <= 0.04: no noise cave
+        const f3 o = fbm3from3<5>(npx * 0.8000f, npy * 0.8000f, npz * 0.8000f);
+        const float n = special_cave_noise(npx * 1.f + o.x * 1.8f, npy * 1.6f + o.y * 1.8f, npz * 1.f + o.z * 1.8f, tile);
+        if (n < bound) {
             const int k = atomicAdd(&s_count[1], 1);
             s_list2[k] = (unsigned short)e;
-            s_thr[k] = thr;
+            s_thr[k] = n;
         }
     }
     __syncthreads();
     const int count2 = s_count[1];
     for (int i = t; i < count2; i += CAVE_THREADS) {
         const int e = s_list2[i];
-        const float thr = s_thr[i];
+        const float n = s_thr[i];
         const int c = e / CAVE_YEVAL, y = e - c * CAVE_YEVAL;
         const int idx2d = 4 * group + c;
+        const float obw = colInfo[chunk * 256 + idx2d].x;
         const int wx = cp.x + (idx2d & 15), wz = cp.y + (idx2d >> 4);
-        const float npx = (float)wx * 0.0050f, npz = (float)wz * 0.0050f, npy = (float)y * 0.0050f;
-        const f3 o = fbm3from3<5>(npx * 0.8000f, npy * 0.8000f, npz * 0.8000f);
-        const float n = special_cave_noise(npx * 1.f + o.x * 1.8f, npy * 1.6f + o.y * 1.8f, npz * 1.f + o.z * 1.8f, tile);
-        if (n < thr) atomicAnd(&s_solid[c][y >> 6], ~(1ull << (y & 63)));
+        const float npx = (float)wx * 0.0050f, npz = (float)wz * 0.0050f;
+        const float fy = (float)y;
+        const float npy = fy * 0.0050f;
+        const float topRatio = smoothstep(142.f, 95.f, fy + obw * 50.f);
+        const float bottomRatio = smoothstep(5.f, 20.f, fy);
+        const float huge = cave_huge(npx * 0.0700f, npy * 0.0700f, npz * 0.0700f);
+        float bound = 0.24f + 0.12f * kCaveFaMax;
+        bound *= (1.f + 1.4f * huge);
+        bound *= topRatio * (0.3f + 0.7f * bottomRatio);
+        if (!(n < bound)) continue;                            // (a further compaction of the survivors into a fourth phase measured 0 %)
+        float thr = 0.24f + 0.12f * fbm3<4>(npx * 4.f, npy * 4.f, npz * 4.f);
+        thr *= (1.f + 1.4f * huge);
+        thr *= topRatio * (0.3f + 0.7f * bottomRatio);
+        if (thr > 0.04f && n < thr) atomicAnd(&s_solid[c][y >> 6], ~(1ull << (y & 63)));
     }
     // analytic part, y in [144, 384): solid iff y <= topSolid and not (y > ravineY)   (topRatio == 0 there)
     if (t < CAVE_COLS * 4) {   // 4 lanes per column fill words 2..5 (word 2 holds y 128..191: bits >= 16 only)
@@ -430,10 +450,10 @@ k_cave_voxels(const float* __restrict__ hf, const float2* __restrict__ colInfo, 
 // 32 slots are occupied.  One workgroup = CB_COLS columns of a chunk: the (column, slot, bottom | top) evaluations that exist are
 // compacted into an LDS list and walked densely, so that every lane of every pass carries one.
 #ifndef CB_COLS
-#define CB_COLS 32
+#define CB_COLS 128        // measured (columns x threads): 32 x 128 1.35 ms, 64 x 128 1.31, 128 x 128 1.71, 128 x 256 1.17, 256 x 256 1.48
 #endif
 #ifndef CB_THREADS
-#define CB_THREADS 128
+#define CB_THREADS 256
 #endif
 __global__ void __launch_bounds__(CB_THREADS)
 k_cave_biomes(const float* __restrict__ hf, const int2* __restrict__ chunkPos, mmgen_cave_layer* __restrict__ caveLayers,
@@ -659,7 +679,11 @@ k_fill(const float* __restrict__ hf, const float* __restrict__ bw, const float* 
 #if MM_FILL_EXP != 1
         // WARPED / AMBER only act on the top DEEPSLATE / BLACKSTONE block of a cave floor (caveBottomDepth == 0)
         const bool wantDeep = bdc == 0 && (block == MMB_DEEPSLATE || block == MMB_BLACKSTONE);
-        const int cb = cave_biome(wx, y, wz, s_lh[cRow + c][MMGEN_NUM_MATERIALS], 190249401, wantDeep);
+        // LUSH_CAVES only converts within 1.5 + 4.5 simplex3 <= 1.5 + 4.5 * 1.23 = 7.04 blocks of a cave surface: further away only CRYSTAL_CAVES
+        // can change the block (depth codes: 63 = no such surface)
+        const int tdc = (e >> 25) & 63;
+        const bool crystalOnly = !wantDeep && bdc > 7 && tdc > 7;
+        const int cb = cave_biome(wx, y, wz, s_lh[cRow + c][MMGEN_NUM_MATERIALS], 190249401, wantDeep, crystalOnly);
         if (MM_FILL_EXP != 2 && (cb == MMCB_CRYSTAL_CAVES || cb == MMCB_LUSH_CAVES)) {
             s_list2[atomicAdd(&s_count[1], 1)] = (unsigned short)(i | (cb == MMCB_LUSH_CAVES ? 2048 : 0));
             continue;

@@ -127,7 +127,8 @@ DEVICE_BENIGN = {0.0, 0.5, 1.0, 2.0, 3.0, 4.0, 5.0, 6.0, 9.0, 16.0, 63.0, 64.0, 
 DEVICE_EXTRA = {
     "biomeFuncs.hpp::getBiomeNoise": (float(np.float32(0.32)),),         # overallBiomeScale, a file-level constant in the reference (biomeFuncs.hpp:105)
     # cave_biome: fbm3From3's component offsets (rng.hpp:188-191, rolled into the loop) and the exact-pruning bound 0.875 * 1.06
-    "chunk.cu::shouldGenerateCaveAtBlock": (float(np.float32(1.23)), float(np.float32(0.001))),    # cave_huge: exact-pruning bound B3 and its slack
+    # cave_huge: exact-pruning bound B3 and its slack; k_cave_voxels: kCaveFaMax >= sup |fbm3<4>| = 0.9375 * B3
+    "chunk.cu::shouldGenerateCaveAtBlock": (float(np.float32(1.23)), float(np.float32(0.001)), float(np.float32(1.16))),
     "biomeFuncs.hpp::getCaveBiomeNoise": tuple(float(np.float32(v)) for v in (0.875, 1.06, 5923.45, 4129.42, 5790.48, 1765.68, 4704.36, 5692.12)),
 }
 DEVICE_ALLOW = {
