@@ -431,27 +431,92 @@ MM_DEV void wave_lds_sync()
 MM_DEV int wave_min(int v) { for (int o = 32; o > 0; o >>= 1) v = imin(v, __shfl_xor(v, o)); return v; }
 MM_DEV int wave_max(int v) { for (int o = 32; o > 0; o >>= 1) v = imax(v, __shfl_xor(v, o)); return v; }
 
-// Horizontal reach and vertical extent (relative to pos.y) of ONE surface placement.  The tables are per-feature worst cases; for
-// PURPLE_MUSHROOM the worst case (reach 127, 121 voxels tall: the smallest universal scale AND the 20 % half-scale draw) makes a single
-// placement visit 7.9 M voxels, 10 x all other features of the bench world together, while the typical one claims nothing beyond
-// 16 - 35 blocks.  Its first three draws (featurePlacement.hpp:705-709: universal scale, half-scale, height) bound what it can
-// claim exactly: |pos.xz| <= 35 and -1 <= pos.y <= height + 12 in the scaled frame, or the rasteriser returns false.
-MM_DEV void surface_extent(int feat, int fx, int fy, int fz, int& reach, int& dlo, int& dhi)
+// What ONE placement can claim in ONE column (dx, dz) = column - placement position: false when nothing, else the vertical extent relative
+// to pos.y.  The tables are per-feature worst cases over every random draw; for the features that own most (voxel, placement) pairs of a
+// generated world the rasteriser's own early-outs bound the claim much more tightly once the placement's first draws are known
+// (fstate = its stream right after seeding; the draws below are the ones the rasteriser makes, in its order).  Everything excluded here
+// returns false in the rasteriser: tests/test_gpu_features.py::test_tight_extents_lose_nothing.
+//   PURPLE_MUSHROOM (featurePlacement.hpp:705-709): worst case reach 127 / 121 voxels tall (smallest universal scale AND the 20 % half-scale
+//     draw: 7.9 M voxels per placement, 10 x all other features of the bench world together); the first three draws bound it to
+//     |pos.xz| <= 35 and -1 <= pos.y <= height + 12 in the scaled frame.
+//   CORAL: the first draw picks one of five shapes: two noisy ellipsoids (radius <= base + amplitude * 1.23, |simplex3| <= 1.23), two
+//     bundles of six rasterised segments inside [-6.5, 6.5] x [0, 8.5] x [-6.5, 6.5], one tube field that is empty from radius 3.7 on.
+MM_DEV bool surface_extent(int feat, int fy, int dx, int dz, uint32_t fstate, int& dlo, int& dhi)
 {
-    reach = kFeatureReach[feat]; dlo = kFeatureBounds[feat][0]; dhi = kFeatureBounds[feat][1];
+    dlo = kFeatureBounds[feat][0]; dhi = kFeatureBounds[feat][1];
     if (feat == MMF_PURPLE_MUSHROOM) {
-        MinStd frng = rng4(fx, fy, fz, 1293012);
+        MinStd frng; frng.x = fstate;
         float sc = 1.f + frng.u01() * 1.2f;
         if (frng.u01() < 0.2f) sc *= 0.5f;
         const float height = 25.f + frng.u01() * 30.f;
-        reach = imin(reach, (int)(35.f / sc) + 2);                        // + 2: rounding of the scaled coordinates and of this division
+        const int reach = imin(kFeatureReach[feat], (int)(35.f / sc) + 2);      // + 2: rounding of the scaled coordinates and of this division
         dhi = imin(dhi, (int)((height + 12.f) / sc) + 2);
+        return iabs(dx) <= reach && iabs(dz) <= reach;
     }
+    if (feat == MMF_CORAL) {
+        if (fy > MMGEN_SEA_LEVEL - 6) return false;
+        const int d2 = dx * dx + dz * dz;
+        if (d2 > 64) return false;                                              // len2(pos.xz) > 8
+        MinStd frng; frng.x = fstate;
+        const int kind = (int)(frng.u01() * 5.f);
+        if (kind == 0 || kind == 1) {
+            // len3(x, y * ys, z) < radius, radius < base + amp * 1.23 (+ 0.01: rounding)
+            const float rmax = (kind == 0 ? (2.8f + 1.4f * frng.u01()) + 0.4f * 1.23f : (2.2f + 1.7f * frng.u01()) + 1.2f * 1.23f) + 0.01f;
+            const float rest = rmax * rmax - (float)d2;
+            if (rest <= 0.f) return false;
+            const int dy = (int)(__builtin_sqrtf(rest) / (kind == 0 ? 1.15f : 1.25f)) + 1;
+            dlo = imax(dlo, -dy); dhi = imin(dhi, dy);
+            return true;
+        }
+        if (kind == 2 || kind == 3) {                                           // floor of a point of a segment inside the box above
+            dlo = imax(dlo, -1); dhi = imin(dhi, 9);
+            return iabs(dx) <= 7 && iabs(dz) <= 7;
+        }
+        if (kind == 4) {                                                        // h <= (1 + d2nd / 2) * 3.5 - 2 with d2nd <= sqrt(5); 0 * ... - 2 from radius 3.7
+            dlo = imax(dlo, -1); dhi = imin(dhi, 6);
+            return d2 <= 13;
+        }
+        return true;
+    }
+    return true;
+}
+
+//   WARPED_FUNGUS: stem in its own column, shroomlights in the four neighbours, cap only within radius 3.7 and, within radius 2.3, exactly
+//     one voxel thick (capStart == capEnd); AMBER_FUNGUS: stem, and a cap ring at Manhattan distance 1 or 2.  Neither depends on the
+//     layer height, which the table bound adds.
+MM_DEV bool cave_extent(int feat, int lh, int dx, int dz, uint32_t fstate, int& dlo, int& dhi)
+{
+    dlo = kCaveFeatureBounds[feat][0]; dhi = lh + kCaveFeatureBounds[feat][1];
+    const int ml = iabs(dx) + iabs(dz);
+    if (feat == MMCF_WARPED_FUNGUS) {
+        if (ml > 6) return false;
+        MinStd frng; frng.x = fstate;
+        const int height = (int)(2.5f + 3.0f * frng.u01());
+        // (the table bounds are the reference's own per-feature height test, chunk.cu:1438-1509: part of the result, only ever narrowed)
+        dhi = imin(dhi, height + 1);                                            // stem <= height, shroomlight <= height, cap <= capEnd <= height + 1
+        if (ml <= 1) return true;
+        const float capRadius = len2((float)dx, (float)dz);
+        if (capRadius > 3.7f) return false;
+        const int capEnd = height + 1 - (int)(capRadius / 2.5f);
+        dhi = imin(dhi, capEnd);
+        if (!(capRadius - 2.3f > 0.f)) dlo = imax(dlo, capEnd);                 // capStart = (int)((float)capEnd - (4.2 s) * 0) = capEnd
+        return true;
+    }
+    if (feat == MMCF_AMBER_FUNGUS) {
+        if (ml > 2) return false;                                               // the cap needs ml == capDist, 1 or 2
+        MinStd frng; frng.x = fstate;
+        const int height = (int)(4.5f + 4.5f * frng.u01());
+        if (ml == 0) { dlo = imax(dlo, 0); dhi = imin(dhi, height + 1); }
+        else { dlo = imax(dlo, height / 2 - 1); dhi = imin(dhi, height); }
+        return true;
+    }
+    return true;
 }
 
 // Stable WAVE-wide compaction of the list entries that can reach column (wx, wz), as packed copies
 //   .x = (fx - wx + 128) | (fz - wz + 128) << 8 | fy << 16 | feature << 25 | canReplace << 30,
-//   .y = layerHeight (cave entries) or the placement's own vertical extent (dlo + 128) | dhi << 8 relative to fy (surface entries)
+//   .y = the vertical extent this placement can claim in this column, relative to fy: (dlo + 128) | dhi << 8 (surface entries),
+//        layerHeight | (dlo + 128) << 9 | dhi << 17 (cave entries)
 // so that the voxel loop never goes back to global memory: 64 entries per round, ballot + popcount prefix, no workgroup barrier.
 // Returns the number of candidates, or -1 when they do not fit CAND_CAP (caller falls back to the full scan).
 template <class Entry, int LIST_CAP, bool CAVE>
@@ -465,16 +530,21 @@ MM_DEV int filter_column(const Entry* __restrict__ list, int wx, int wz, int2* s
         if (i < LIST_CAP) { feat = list[i].feature; fx = list[i].pos[0]; fz = list[i].pos[2]; }
         const unsigned long long noneMask = __ballot(feat == 0);
         const int firstNone = noneMask ? (int)__builtin_ctzll(noneMask) : 64;
-        int reach = CAVE ? kCaveFeatureReach[feat] : kFeatureReach[feat];
+        const int reach = CAVE ? kCaveFeatureReach[feat] : kFeatureReach[feat];
         bool cand = lane < firstNone && iabs(wx - fx) <= reach && iabs(wz - fz) <= reach;
         int fy = 0, lh = 0;
+        uint32_t fstate = 0u;
         if (cand) {
             fy = list[i].pos[1];
-            if constexpr (CAVE) lh = list[i].layer_height;
-            else {
-                int dlo, dhi;
-                surface_extent(feat, fx, fy, fz, reach, dlo, dhi);
-                cand = iabs(wx - fx) <= reach && iabs(wz - fz) <= reach;
+            // the placement's own random stream, seeded once per (column, candidate) instead of once per voxel
+            fstate = CAVE ? cave_feature_stream(fx, fy, fz) : surface_feature_stream(fx, fy, fz);
+            int dlo, dhi;
+            if constexpr (CAVE) {
+                const int layerHeight = list[i].layer_height;
+                cand = cave_extent(feat, layerHeight, wx - fx, wz - fz, fstate, dlo, dhi);
+                lh = layerHeight | ((dlo + 128) << 9) | (dhi << 17);
+            } else {
+                cand = surface_extent(feat, fy, wx - fx, wz - fz, fstate, dlo, dhi);
                 lh = (dlo + 128) | (dhi << 8);
             }
         }
@@ -485,8 +555,7 @@ MM_DEV int filter_column(const Entry* __restrict__ list, int wx, int wz, int2* s
             const int slot = base + __popcll(cm & ((1ull << lane) - 1ull));
             if (slot < CAND_CAP) {
                 s_cand[slot] = make_int2(w, lh);
-                // the placement's own random stream, seeded once per (column, candidate) instead of once per voxel
-                s_seed[slot] = CAVE ? cave_feature_stream(fx, fy, fz) : surface_feature_stream(fx, fy, fz);
+                s_seed[slot] = fstate;
             }
         }
         base += __popcll(cm);
@@ -594,10 +663,10 @@ k_apply_features(uint8_t* __restrict__ blocks, const int2* __restrict__ chunkPos
         int n = 0;
         if (k < nTot) {
             const int2 e = cand[k];
-            const int fy = (e.x >> 16) & 511, feature = (e.x >> 25) & 31;
+            const int fy = (e.x >> 16) & 511;
             int lo, hi;
             if (k < nS) { lo = imax(fy + (e.y & 255) - 128, sLo); hi = imin(fy + (e.y >> 8), sHi); }
-            else { lo = imax(fy + kCaveFeatureBounds[feature][0], cLo); hi = imin(fy + e.y + kCaveFeatureBounds[feature][1], cHi); }
+            else { lo = imax(fy + ((e.y >> 9) & 255) - 128, cLo); hi = imin(fy + (e.y >> 17), cHi); }
             n = imax(hi - lo + 1, 0);
             if (n > 0) { yLo = imin(yLo, lo); yHi = imax(yHi, hi); }
         }
@@ -624,7 +693,7 @@ k_apply_features(uint8_t* __restrict__ blocks, const int2* __restrict__ chunkPos
         const int2 e = cand[k];
         const int fx = wx + (e.x & 255) - 128, fz = wz + ((e.x >> 8) & 255) - 128, fy = (e.x >> 16) & 511, feature = (e.x >> 25) & 31;
         const bool cave = k >= nS;
-        const int lo = cave ? imax(fy + kCaveFeatureBounds[feature][0], cLo) : imax(fy + (e.y & 255) - 128, sLo);
+        const int lo = cave ? imax(fy + ((e.y >> 9) & 255) - 128, cLo) : imax(fy + (e.y & 255) - 128, sLo);
         const int y = lo + (j - pref[k]);
         if (s_blk[wave][y] != MMB_AIR && !((e.x >> 30) & 1)) continue;
         uint8_t fb = 0;
@@ -632,7 +701,7 @@ k_apply_features(uint8_t* __restrict__ blocks, const int2* __restrict__ chunkPos
         const bool placed = (fx + fy + fz + y) == 0x7fffffff;          // timing experiment: no rasteriser
 #else
         const uint32_t fstate = s_seed[wave][k];
-        const bool placed = cave ? place_cave_feature(feature, fx, fy, fz, e.y, wx, y, wz, fstate, fb) : place_feature(feature, fx, fy, fz, wx, y, wz, fstate, fb);
+        const bool placed = cave ? place_cave_feature(feature, fx, fy, fz, e.y & 511, wx, y, wz, fstate, fb) : place_feature(feature, fx, fy, fz, wx, y, wz, fstate, fb);
 #endif
         if (placed) atomicMin(&s_claim[wave][y], ((unsigned)k << 8) | fb);
     }
