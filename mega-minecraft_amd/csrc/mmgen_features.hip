@@ -478,6 +478,72 @@ MM_DEV bool surface_extent(int feat, int fy, int dx, int dz, uint32_t fstate, in
         }
         return true;
     }
+    const int d2 = dx * dx + dz * dz;
+    if (feat == MMF_REDWOOD_TREE) {
+        // pos *= sc; out when pos.y > height + 8, hd > 12, or below leavesStart - 4 outside the trunk's radius of 3
+        MinStd frng; frng.x = fstate;
+        const float sc = 0.6f + 0.3f * frng.u01();
+        const float height = 27.f + 13.f * frng.u01();
+        const float leavesStart = 10.f + 4.f * frng.u01();
+        const float hd = len2((float)dx * sc, (float)dz * sc);
+        if (hd > 12.f) return false;
+        dhi = imin(dhi, (int)((height + 8.f) / sc) + 1);
+        if (hd > 3.f) dlo = imax(dlo, (int)((leavesStart - 4.f) / sc) - 1);
+        return true;
+    }
+    if (feat == MMF_BIRCH_TREE) {
+        MinStd frng; frng.x = fstate;
+        int height = (int)(6.2f + 4.f * frng.u01());
+        if (frng.u01() < 0.08f) height = (int)((float)height * 1.9f);
+        dlo = imax(dlo, 0); dhi = imin(dhi, height + 6);
+        if (d2 == 0) return true;
+        // leaves: height - 4.5 <= y <= height + 8.1, radius <= 5 * max(0.5 x^3 - 1.5 x^2 + x) * 3.6 = 3.4642
+        if (d2 > 13) return false;
+        dlo = imax(dlo, height - 5);
+        return true;
+    }
+    if (feat == MMF_PINE_TREE) {
+        MinStd frng; frng.x = fstate;
+        const int height = (int)(7.f + 4.f * frng.u01());
+        dlo = imax(dlo, 0); dhi = imin(dhi, height + 4);
+        if (d2 == 0) return true;
+        if (d2 > 8) return false;                                              // leaves: len2 < mix(3, 1, ratio) <= 3, height - 6.5 <= y <= height + 3
+        dlo = imax(dlo, height - 7); dhi = imin(dhi, height + 3);
+        return true;
+    }
+    if (feat == MMF_PINE_SHRUB) {
+        MinStd frng; frng.x = fstate;
+        const int height = (int)(2.f + 2.f * frng.u01());
+        dlo = imax(dlo, 0); dhi = imin(dhi, height + 4);
+        if (d2 == 0) return true;
+        if (d2 > 8) return false;                                              // jungle_leaves: radius <= 2.5 * 1.2 = 3, 0 <= y - (height - 1) <= 2.5
+        dlo = imax(dlo, height - 1); dhi = imin(dhi, height + 2);
+        return true;
+    }
+    if (feat == MMF_MEDIUM_PURPLE_MUSHROOM) {
+        MinStd frng; frng.x = fstate;
+        const int height = (int)(1.5f + 2.3f * frng.u01());
+        dhi = imin(dhi, height + 1);
+        if (d2 == 0) return true;
+        if (d2 > 6) return false;                                              // cap: y == height + 1 within radius 1.8 or 2.5
+        dlo = imax(dlo, height + 1);
+        return true;
+    }
+    if (feat == MMF_MEDIUM_CRYSTAL || feat == MMF_CRYSTAL) {
+        if (fy > 180) return false;
+        // pos = (fp + (0, 2, 0)) * scale.  Main crystal: within 1.0 * 5.2 of the segment to endPos (|endPos.xz| <= 12, endPos.y = 18 + 8 r1);
+        // small crystals: 0.8 pos within 3.0 of a segment of horizontal length <= 9: |pos.xz| <= 17.3, -5.3 <= pos.y <= endPos.y + 2
+        MinStd frng; frng.x = fstate;
+        float scale = 0.55f + 0.4f * frng.u01();
+        if (feat == MMF_MEDIUM_CRYSTAL) scale *= 2.f;
+        frng.u01();
+        const float endY = 18.f + 8.f * frng.u01();
+        const int reach = (int)(17.3f / scale) + 1;
+        if (iabs(dx) > reach || iabs(dz) > reach) return false;
+        dhi = imin(dhi, (int)((endY + 2.f) / scale) - 1);                       // (dy + 2) * scale <= endY + 2; + 1 for the rounding
+        dlo = imax(dlo, -(int)(5.3f / scale) - 3);
+        return true;
+    }
     return true;
 }
 
@@ -508,6 +574,38 @@ MM_DEV bool cave_extent(int feat, int lh, int dx, int dz, uint32_t fstate, int& 
         const int height = (int)(4.5f + 4.5f * frng.u01());
         if (ml == 0) { dlo = imax(dlo, 0); dhi = imin(dhi, height + 1); }
         else { dlo = imax(dlo, height / 2 - 1); dhi = imin(dhi, height); }
+        return true;
+    }
+    const int d2 = dx * dx + dz * dz;
+    if (feat == MMCF_CAVE_VINE) {                                               // hangs height <= min(14, layerHeight) blocks from the ceiling
+        MinStd frng; frng.x = fstate;
+        const int height = imin((int)(3.f + 12.f * frng.u01()), lh);
+        dlo = imax(dlo, lh - height); dhi = imin(dhi, lh);
+        return true;
+    }
+    if (feat == MMCF_GLOWSTONE_CLUSTER) {
+        // r = |(dx, 1.35 dyTop, dz)| * s < 3.5 + 2 simplex2 <= 5.62 (|simplex2| <= 1.06)
+        MinStd frng; frng.x = fstate;
+        const float sc = 1.f + 0.5f * frng.u01();
+        const float rest = 31.7f - (float)d2 * (sc * sc);
+        if (rest <= 0.f) return false;
+        const int m = (int)(__builtin_sqrtf(rest) / (1.35f * sc)) + 1;
+        dlo = imax(dlo, lh - m); dhi = imin(dhi, lh + m);
+        return true;
+    }
+    if (feat == MMCF_STORMLIGHT_SPHERE || feat == MMCF_CEILING_STORMLIGHT_SPHERE) {
+        MinStd frng; frng.x = fstate;
+        const float radius = 3.5f + 4.f * frng.u01();
+        const float rest = radius * radius - (float)d2;
+        if (rest < 0.f) return false;
+        const int m = (int)__builtin_sqrtf(rest) + 1;
+        const int c = feat == MMCF_STORMLIGHT_SPHERE ? 0 : lh;
+        dlo = imax(dlo, c - m); dhi = imin(dhi, c + m);
+        return true;
+    }
+    if (feat == MMCF_CRYSTAL_PILLAR && lh != 0) {                               // d <= 4 (2 (hr - 0.5)^2 + 0.5) <= 4, spherical caps of that radius at both ends
+        if (d2 > 16) return false;                                              // (layerHeight 0: hr = 0 / 0, every comparison with the radius is false: table bounds)
+        dlo = imax(dlo, -5); dhi = imin(dhi, lh + 5);
         return true;
     }
     return true;
