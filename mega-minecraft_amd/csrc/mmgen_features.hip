@@ -446,12 +446,53 @@ MM_DEV bool surface_extent(int feat, int fy, int dx, int dz, uint32_t fstate, in
     dlo = kFeatureBounds[feat][0]; dhi = kFeatureBounds[feat][1];
     if (feat == MMF_PURPLE_MUSHROOM) {
         MinStd frng; frng.x = fstate;
-        float sc = 1.f + frng.u01() * 1.2f;
-        if (frng.u01() < 0.2f) sc *= 0.5f;
+        const float universalScale = 1.f + frng.u01() * 1.2f;
+        const bool half = frng.u01() < 0.2f;
+        const float sc = half ? universalScale * 0.5f : universalScale;         // (p * s) * 0.5 == p * (s * 0.5): a power of two
         const float height = 25.f + frng.u01() * 30.f;
         const int reach = imin(kFeatureReach[feat], (int)(35.f / sc) + 2);      // + 2: rounding of the scaled coordinates and of this division
         dhi = imin(dhi, (int)((height + 12.f) / sc) + 2);
-        return iabs(dx) <= reach && iabs(dz) <= reach;
+        if (iabs(dx) > reach || iabs(dz) > reach) return false;
+        // the column in the rasteriser's scaled frame, computed the way it computes pos
+        float px = (float)dx * universalScale, pz = (float)dz * universalScale;
+        if (half) { px *= 0.5f; pz *= 0.5f; }
+        const float hd = len2(px, pz);
+        if (!(hd > 8.f)) return true;
+        // beyond radius 8: pos.y >= height - 12 and |pos - top| <= 35, or the rasteriser returns false
+        const float rest = 35.f * 35.f - hd * hd;
+        if (rest < 0.f) return false;
+        const float vr = __builtin_sqrtf(rest);
+        dlo = imax(dlo, (int)((height - gmin(12.f, vr)) / sc) - 1);             // height - 12 >= 13
+        dhi = imin(dhi, (int)((height + vr) / sc) + 2);
+        if (!(hd > 11.6f)) return true;
+        // beyond radius 11.6 the stem cannot reach (its spline stays inside the hull of the control points, |x|, |z| <= 6, radius <= 3):
+        // only the cap is left, the points between the two planes through p1 and p2 = p1 + dir * len perpendicular to dir, within
+        // `radius` of the axis.  p1, p2 and radius depend on the placement alone; they are rebuilt here with the rasteriser's own
+        // statements (featurePlacement.hpp:712-760), and the slab 0 <= (pos - p1) . v <= v . v bounds this column's y.
+        v3 ctrl[5];
+        ctrl[0] = V3(0.f, 0.f, 0.f);
+        const v3 endPoint = V3(0.f, height, 0.f);
+#pragma unroll
+        for (int i = 1; i < 5; ++i) {
+            const float r0 = u11(frng), r1 = u11(frng), r2 = u11(frng);
+            v3 off = V3(r0, r1, r2) * V3(6.f, 2.f, 6.f);
+            if (i == 4) off = off * 0.6f;
+            ctrl[i] = (endPoint * ((float)i / 4.f)) + off;
+        }
+        v3 spline[7];
+        de_casteljau<5, 7>(ctrl, spline);
+        const v3 p1 = spline[6];
+        const v3 p2 = p1 + norm3(p1 - spline[5]) * (3.f + frng.u01() * 1.5f);
+        const float radius = (7.f * frng.u01() + 12.f) * mixf(0.8f, 1.2f, (height - 33.f) / 40.f);
+        const v3 v = p2 - p1;
+        const float vv = dot3(v, v);
+        if (len2(px - p1.x, pz - p1.z) > (radius + __builtin_sqrtf(vv)) + 0.01f) return false;     // farther than radius from every axis point
+        if (!(v.y > 0.2f)) return true;                                          // (nearly) horizontal axis: the slab does not bound y
+        const float a = (px - p1.x) * v.x + (pz - p1.z) * v.z;
+        const float ysLo = p1.y + (0.f - a) / v.y, ysHi = p1.y + (vv - a) / v.y;
+        dlo = imax(dlo, (int)__builtin_floorf(ysLo / sc) - 1);
+        dhi = imin(dhi, (int)__builtin_floorf(ysHi / sc) + 2);
+        return dlo <= dhi;
     }
     if (feat == MMF_CORAL) {
         if (fy > MMGEN_SEA_LEVEL - 6) return false;

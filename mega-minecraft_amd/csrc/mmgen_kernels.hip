@@ -223,7 +223,9 @@ MM_DEV float cave_huge(float x, float y, float z)
 #define CELL_NY 8
 #define CELL_NZ 7
 #define CELL_N (CELL_NX * CELL_NY * CELL_NZ)
-#define CAVE_COLS 4        // columns per workgroup (same z row of the chunk, x = 4g .. 4g+3)
+#ifndef CAVE_COLS
+#define CAVE_COLS 4        // columns per batch (same z row of the chunk); 16 / CAVE_COLS batches per workgroup
+#endif
 #define CAVE_YEVAL 144     // voxels y < 144 may need the noise (threshold is 0 once y + 50*obw >= 142); 144 = 2.25 waves
 #define CAVE_VOXELS (CAVE_COLS * CAVE_YEVAL)      // 576 = 9 full waves: no partially filled wave
 #ifndef CAVE_THREADS
@@ -311,10 +313,10 @@ k_cave_voxels(const float* __restrict__ hf, const float2* __restrict__ colInfo, 
     }
     noise_tables_init<false>();                                // no simplex2 in this kernel; ends with the workgroup barrier
 
-  for (int sub = 0; sub < 4; ++sub) {
-    const int group = 4 * row + sub;                           // 64 groups of 4 columns per chunk: x = 4 (group % 4) + c, z = group / 4
-    const unsigned needMask = (rowNeed >> (4 * sub)) & 0xfu;
-    if (t < CAVE_COLS * 6) s_solid[t / 6][t % 6] = 0ull;
+  for (int sub = 0; sub < 16 / CAVE_COLS; ++sub) {
+    const int colBase = 16 * row + CAVE_COLS * sub;            // first column of the batch: x = CAVE_COLS * sub + c, z = row
+    const unsigned needMask = (rowNeed >> (CAVE_COLS * sub)) & ((1u << CAVE_COLS) - 1u);
+    for (int i = t; i < CAVE_COLS * 6; i += CAVE_THREADS) s_solid[i / 6][i % 6] = 0ull;
     if (t < 2) s_count[t] = 0;
     for (int i = t; i < CAVE_COLS * 3 * MMGEN_MAX_CAVE_LAYERS_PER_COLUMN; i += CAVE_THREADS)
         (&s_layers[0][0])[i] = ((i % 3) == 2) ? 0 : 384;       // {384, 384, biomes = 0}
@@ -330,7 +332,7 @@ k_cave_voxels(const float* __restrict__ hf, const float2* __restrict__ colInfo, 
     for (int e = t; e < CAVE_VOXELS; e += CAVE_THREADS) {
         const int c = e / CAVE_YEVAL, y = e - c * CAVE_YEVAL;
         if (!((needMask >> c) & 1u)) continue;
-        const int col = chunk * 256 + 4 * group + c;
+        const int col = chunk * 256 + colBase + c;
         const float maxHeight = hf[col];
         const float2 ci = colInfo[col];
         const float obw = ci.x, ravineY = ci.y;
@@ -358,7 +360,7 @@ k_cave_voxels(const float* __restrict__ hf, const float2* __restrict__ colInfo, 
     for (int i = t; i < count1; i += CAVE_THREADS) {
         const int e = s_list1[i];
         const int c = e / CAVE_YEVAL, y = e - c * CAVE_YEVAL;
-        const int idx2d = 4 * group + c;
+        const int idx2d = colBase + c;
         const float obw = colInfo[chunk * 256 + idx2d].x;
         const int wx = cp.x + (idx2d & 15), wz = cp.y + (idx2d >> 4);
         const float npx = (float)wx * 0.0050f, npz = (float)wz * 0.0050f;
@@ -384,7 +386,7 @@ k_cave_voxels(const float* __restrict__ hf, const float2* __restrict__ colInfo, 
         const int e = s_list2[i];
         const float n = s_thr[i];
         const int c = e / CAVE_YEVAL, y = e - c * CAVE_YEVAL;
-        const int idx2d = 4 * group + c;
+        const int idx2d = colBase + c;
         const float obw = colInfo[chunk * 256 + idx2d].x;
         const int wx = cp.x + (idx2d & 15), wz = cp.y + (idx2d >> 4);
         const float npx = (float)wx * 0.0050f, npz = (float)wz * 0.0050f;
@@ -405,7 +407,7 @@ k_cave_voxels(const float* __restrict__ hf, const float2* __restrict__ colInfo, 
     // analytic part, y in [144, 384): solid iff y <= topSolid and not (y > ravineY)   (topRatio == 0 there)
     if (t < CAVE_COLS * 4) {   // 4 lanes per column fill words 2..5 (word 2 holds y 128..191: bits >= 16 only)
         const int c = t >> 2, w = 2 + (t & 3);
-        const int col = chunk * 256 + 4 * group + c;
+        const int col = chunk * 256 + colBase + c;
         const int topSolid = ((needMask >> c) & 1u) ? imax((int)hf[col], MMGEN_SEA_LEVEL) : -1;
         const float ravineY = colInfo[col].y;
         unsigned long long m = 0ull;
@@ -440,7 +442,7 @@ k_cave_voxels(const float* __restrict__ hf, const float2* __restrict__ colInfo, 
     __syncthreads();
     for (int i = t; i < CAVE_COLS * 3 * MMGEN_MAX_CAVE_LAYERS_PER_COLUMN; i += CAVE_THREADS) {
         const int cc = i / (3 * MMGEN_MAX_CAVE_LAYERS_PER_COLUMN), k = i % (3 * MMGEN_MAX_CAVE_LAYERS_PER_COLUMN);
-        ((int*)(caveLayers + (size_t)MMGEN_MAX_CAVE_LAYERS_PER_COLUMN * (chunk * 256 + 4 * group + cc)))[k] = s_layers[cc][k];
+        ((int*)(caveLayers + (size_t)MMGEN_MAX_CAVE_LAYERS_PER_COLUMN * (chunk * 256 + colBase + cc)))[k] = s_layers[cc][k];
     }
     __syncthreads();                                           // the bit words, lists and layer slots are re-used by the next batch
   }

@@ -493,6 +493,7 @@ TIGHT_CASES = [
     (([6], 14), ([4, 7], 150)),                                        # REDWOOD_TREE; GLOWSTONE_CLUSTER, CRYSTAL_PILLAR
     (([8, 9, 10], 90), ([5, 6], 90)),                                  # BIRCH / PINE_TREE / PINE_SHRUB; STORMLIGHT spheres (floor, ceiling)
     (([17, 18], 9), ([3], 250)),                                       # MEDIUM_CRYSTAL, CRYSTAL; CAVE_VINE
+    (([16], 4), ([3], 30)),                                            # PURPLE_MUSHROOM alone (stem hull, cap slab); they reach up to 72 blocks
 ]
 
 
