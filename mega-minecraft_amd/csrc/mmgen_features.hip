@@ -527,9 +527,12 @@ MM_DEV bool surface_extent(int feat, int fy, int dx, int dz, uint32_t fstate, in
         const float height = 27.f + 13.f * frng.u01();
         const float leavesStart = 10.f + 4.f * frng.u01();
         const float hd = len2((float)dx * sc, (float)dz * sc);
-        if (hd > 12.f) return false;
-        dhi = imin(dhi, (int)((height + 8.f) / sc) + 1);
-        if (hd > 3.f) dlo = imax(dlo, (int)((leavesStart - 4.f) / sc) - 1);
+        // leaf clusters: |pos - center| <= 5 horizontally, |center.xz| <= 3.75 hr, hr = 1.1 - 0.5 ratio <= 1.307 (the cell is at most 6 below
+        // leavesStart, leavesEnd - leavesStart >= 14.5): 9.9; branches stay within 0.5 of the segment to the centre; the trunk's radius is < 3
+        if (hd > 10.f) return false;
+        // trunk up to pos.y = height, leaves up to leavesEnd = height + 1.5 + u < height + 2.5
+        dhi = imin(dhi, (int)((height + 2.5f) / sc) + 1);
+        if (hd > 3.f) dlo = imax(dlo, (int)(leavesStart / sc) - 1);              // outside the trunk: leaves and branches, pos.y >= leavesStart
         return true;
     }
     if (feat == MMF_BIRCH_TREE) {
