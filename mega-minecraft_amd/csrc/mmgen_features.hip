@@ -668,8 +668,13 @@ MM_DEV int filter_column(const Entry* __restrict__ list, int wx, int wz, int2* s
     int base = 0;
     for (int r0 = 0; r0 < LIST_CAP; r0 += 64) {
         const int i = r0 + lane;
-        int feat = 0, fx = 0, fz = 0;
-        if (i < LIST_CAP) { feat = list[i].feature; fx = list[i].pos[0]; fz = list[i].pos[2]; }
+        // the whole entry in one round trip (this kernel runs at 3 waves per SIMD: every dependent global load is ~1 us nobody hides)
+        int feat = 0, fx = 0, fz = 0, fyRaw = 0, lhRaw = 0, canReplace = 0;
+        if (i < LIST_CAP) {
+            const Entry en = list[i];
+            feat = en.feature; fx = en.pos[0]; fyRaw = en.pos[1]; fz = en.pos[2]; canReplace = en.can_replace_blocks != 0;
+            if constexpr (CAVE) lhRaw = en.layer_height;
+        }
         const unsigned long long noneMask = __ballot(feat == 0);
         const int firstNone = noneMask ? (int)__builtin_ctzll(noneMask) : 64;
         const int reach = CAVE ? kCaveFeatureReach[feat] : kFeatureReach[feat];
@@ -677,12 +682,12 @@ MM_DEV int filter_column(const Entry* __restrict__ list, int wx, int wz, int2* s
         int fy = 0, lh = 0;
         uint32_t fstate = 0u;
         if (cand) {
-            fy = list[i].pos[1];
+            fy = fyRaw;
             // the placement's own random stream, seeded once per (column, candidate) instead of once per voxel
             fstate = CAVE ? cave_feature_stream(fx, fy, fz) : surface_feature_stream(fx, fy, fz);
             int dlo, dhi;
             if constexpr (CAVE) {
-                const int layerHeight = list[i].layer_height;
+                const int layerHeight = lhRaw;
                 cand = cave_extent(feat, layerHeight, wx - fx, wz - fz, fstate, dlo, dhi);
                 lh = layerHeight | ((dlo + 128) << 9) | (dhi << 17);
             } else {
@@ -693,7 +698,7 @@ MM_DEV int filter_column(const Entry* __restrict__ list, int wx, int wz, int2* s
         const unsigned long long cm = __ballot(cand);
         if (cand) {
             featureMask |= 1u << feat;
-            const int w = (fx - wx + 128) | ((fz - wz + 128) << 8) | ((fy & 511) << 16) | (feat << 25) | ((int)(list[i].can_replace_blocks != 0) << 30);
+            const int w = (fx - wx + 128) | ((fz - wz + 128) << 8) | ((fy & 511) << 16) | (feat << 25) | (canReplace << 30);
             const int slot = base + __popcll(cm & ((1ull << lane) - 1ull));
             if (slot < CAND_CAP) {
                 s_cand[slot] = make_int2(w, lh);
@@ -724,22 +729,24 @@ MM_DEV int filter_column(const Entry* __restrict__ list, int wx, int wz, int2* s
 __attribute__((amdgpu_waves_per_eu(MM_APPLY_WAVES, MM_APPLY_WAVES)))
 __global__ void __launch_bounds__(APPLY_THREADS)
 k_apply_features(uint8_t* __restrict__ blocks, const int2* __restrict__ chunkPos, const mmgen_feature_placement* __restrict__ gfp,
-                 const mmgen_cave_feature_placement* __restrict__ gcfp, const int* __restrict__ bounds, const int* __restrict__ srcIdx)
+                 const mmgen_cave_feature_placement* __restrict__ gcfp, const int* __restrict__ bounds, const int* __restrict__ srcIdx, int nGroups)
 {
     __shared__ int2 s_cand[APPLY_COLS][2 * CAND_CAP];      // per wave: surface candidates, then cave candidates
     __shared__ int s_pref[APPLY_COLS][2 * CAND_CAP + 1];   // exclusive prefix of the candidates' voxel counts
     __shared__ uint32_t s_seed[APPLY_COLS][2 * CAND_CAP];  // the candidates' random streams right after seeding
     __shared__ unsigned s_claim[APPLY_COLS][384];          // per voxel: smallest (candidate << 8 | block) that claimed it
     __shared__ uint8_t s_blk[APPLY_COLS][384];             // the column's base blocks
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int col = APPLY_COLS * blockIdx.x + wave;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;      // wave index in an SGPR: so are chunk and column
+    // Persistent workgroups: the simplex tables (12 KB) are staged ONCE per workgroup, not once per four columns (most four-column groups
+    // of a generated world have a coral, a fungus or a redwood in reach: 6 GB of L2 -> LDS copies per launch).  After that barrier every
+    // wave walks its own columns (group g -> column 4 g + wave, groups strided over the grid); no workgroup barrier inside the loop.
+    noise_tables_init();
+  for (int group = blockIdx.x; group < nGroups; group += gridDim.x) {
+    const int col = APPLY_COLS * group + wave;
     const int chunk = col >> 8, idx2d = col & 255;      // dense output / list index; positions are read at srcIdx[chunk]; 256 % APPLY_COLS == 0
     const int b0 = bounds[4 * chunk], b1 = bounds[4 * chunk + 1], b2 = bounds[4 * chunk + 2], b3 = bounds[4 * chunk + 3];
-    const bool doS = gfp && b0 <= b1, doC = gcfp && b2 <= b3;      // workgroup-uniform (one chunk per workgroup)
-    if (!doS && !doC) return;
-#if MM_APPLY_EXP == 3
-    return;                                                             // timing experiment: launch + bounds only
-#endif
+    const bool doS = gfp && b0 <= b1, doC = gcfp && b2 <= b3;
+    if (!doS && !doC) continue;
 
     const int2 cp = chunkPos[srcIdx ? srcIdx[chunk] : chunk];
     const int wx = cp.x + (idx2d & 15), wz = cp.y + (idx2d >> 4);
@@ -750,17 +757,7 @@ k_apply_features(uint8_t* __restrict__ blocks, const int2* __restrict__ chunkPos
     unsigned maskS = 0u, maskC = 0u;
     if (doS) nS = filter_column<mmgen_feature_placement, MMGEN_MAX_GATHERED_FEATURES_PER_CHUNK, false>(listS, wx, wz, cand, s_seed[wave], maskS);
     if (doC) nC = filter_column<mmgen_cave_feature_placement, MMGEN_MAX_GATHERED_CAVE_FEATURES_PER_CHUNK, true>(listC, wx, wz, cand + imax(nS, 0), s_seed[wave] + imax(nS, 0), maskC);
-    // two workgroup-uniform decisions (the only workgroup barriers): nothing reaches these four columns -> done; the simplex tables
-    // (12 KB from L2 per workgroup) are only staged when a candidate's rasteriser evaluates simplex noise (coral, iceberg, redwood,
-    // cypress; glowstone, the two fungi) or the gathered lists must be scanned directly
-    constexpr unsigned kNoiseS = (1u << MMF_CORAL) | (1u << MMF_ICEBERG) | (1u << MMF_REDWOOD_TREE) | (1u << MMF_CYPRESS_TREE);
-    constexpr unsigned kNoiseC = (1u << MMCF_GLOWSTONE_CLUSTER) | (1u << MMCF_WARPED_FUNGUS) | (1u << MMCF_AMBER_FUNGUS);
-    if (!__syncthreads_or(nS != 0 || nC != 0)) return;
-#if MM_APPLY_EXP == 4
-    return;                                                             // timing experiment: launch + filters only
-#endif
-    if (__syncthreads_or((__ballot((maskS & kNoiseS) || (maskC & kNoiseC)) != 0ull) || nS < 0 || nC < 0)) noise_tables_init();
-    if (nS == 0 && nC == 0) return;
+    if (nS == 0 && nC == 0) continue;
     uint8_t* colBlocks = blocks + (size_t)MMGEN_BLOCKS_PER_CHUNK * chunk + 384 * idx2d;
     const int sLo = imax(b0, 0), sHi = imin(b1, 383), cLo = imax(b2, 0), cHi = imin(b3, 383);   // the chunk's height bounds (chunk.cu:1555-1570)
 
@@ -792,7 +789,7 @@ k_apply_features(uint8_t* __restrict__ blocks, const int2* __restrict__ chunkPos
             }
             if (placed) colBlocks[y] = fb;
         }
-        return;
+        continue;
     }
 
     // items: exclusive scan of the candidates' vertical extents (clipped to the column and to the chunk's bounds)
@@ -819,7 +816,7 @@ k_apply_features(uint8_t* __restrict__ blocks, const int2* __restrict__ chunkPos
         total += __shfl(incl, 63);
     }
     if (lane == 0) pref[nTot] = total;
-    if (total == 0) return;
+    if (total == 0) continue;
     yLo = wave_min(yLo); yHi = wave_max(yHi);
     for (int y = yLo + lane; y <= yHi; y += 64) { s_blk[wave][y] = colBlocks[y]; s_claim[wave][y] = 0xffffffffu; }
     wave_lds_sync();
@@ -852,6 +849,8 @@ k_apply_features(uint8_t* __restrict__ blocks, const int2* __restrict__ chunkPos
         const unsigned c = s_claim[wave][y];
         if (c != 0xffffffffu) colBlocks[y] = (uint8_t)(c & 255u);
     }
+    wave_lds_sync();                                       // the wave's LDS rows are re-used by its next column
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1050,8 +1049,18 @@ int launch_apply_features(uint8_t* blocks, const int32_t* pos, int n, const mmge
                           const int* bounds, const int* srcIdx, hipStream_t s)
 {
     if (n <= 0) return 0;
-    LAUNCH(KID_APPLY_FEATURES, mm::k_apply_features, dim3(n * (256 / APPLY_COLS)), dim3(APPLY_THREADS), s, blocks, (const int2*)pos, gfp, gcfp, bounds,
-           srcIdx);
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return (int)hipErrorInvalidDevice;
+        cus = prop.multiProcessorCount;
+    }
+    // persistent: MM_APPLY_WAVES waves per SIMD = that many 4-wave workgroups per CU
+    const long long groups = (long long)n * (256 / APPLY_COLS), fit = (long long)cus * MM_APPLY_WAVES;
+    if (groups > 0x7fffffffLL) return (int)hipErrorInvalidValue;
+    LAUNCH(KID_APPLY_FEATURES, mm::k_apply_features, dim3((unsigned)(groups < fit ? groups : fit)), dim3(APPLY_THREADS), s, blocks, (const int2*)pos, gfp, gcfp,
+           bounds, srcIdx, (int)groups);
     return 0;
 }
 
