@@ -12,7 +12,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
-from extract_ref_literals import REFERENCE_SECTIONS, literals, sections, strip_comments   # noqa: E402
+from extract_ref_literals import REFERENCE_SECTIONS, literals, sections, skeleton_digest, strip_comments   # noqa: E402
 
 REF = json.load(open(os.path.join(ROOT, "tests", "golden", "ref_literals.json")))
 
@@ -186,3 +186,57 @@ def test_device_sections_hold_every_reference_constant():
     not_mapped = sorted(k for k in REF if k not in covered and not k.startswith("chunk.cu::kernGenerateCaves"))
     assert not not_mapped, f"reference sections without a device counterpart in DEVICE_MAP: {not_mapped}"
     assert not problems, "\n".join(problems)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# statement skeletons: tests/golden/ref_skeletons.json holds one SHA-256 per reference section (the digest of its normalised token stream,
+# tools/extract_ref_literals.py::skeleton; a digest, not text).  Where the oracle's same-named section has the same digest it IS the
+# reference's code statement for statement - control flow, operation order, operands - up to the documented table of renamed helpers.
+SKEL = json.load(open(os.path.join(ROOT, "tests", "golden", "ref_skeletons.json")))
+# sections whose oracle form differs in more than names (each group with its reason); everything else must be token-identical
+SKELETON_DIFFERS = {
+    # vector expressions written per component, explicit evaluation order of constructor arguments that draw from the stream
+    # (float r0 = u11(rng), r1 = ..., r2 = ...; vec3(r0, r1, r2)), closures u01f() / u01b() for u01(featureRng) / u01(blockRng), integer
+    # literals in float vectors written as floats, ivec helpers: every rasteriser
+    "featurePlacement.hpp::placeFeature", "featurePlacement.hpp::placeCaveFeature", "featurePlacement.hpp::sdCappedCylinder",
+    "featurePlacement.hpp::isInRasterizedLine", "featurePlacement.hpp::isInCrystal", "featurePlacement.hpp::getCrystalRadius",
+    "featurePlacement.hpp::getRandomCrystalBlock",
+    *("featurePlacement.hpp::placeFeature::" + f for f in (
+        "SPHERE", "CORAL", "KELP", "ICEBERG", "ACACIA_TREE", "REDWOOD_TREE", "CYPRESS_TREE", "BIRCH_TREE", "PINE_TREE", "PINE_SHRUB",
+        "RAFFLESIA", "LARGE_JUNGLE_TREE", "SMALL_JUNGLE_TREE", "TINY_JUNGLE_TREE", "MEDIUM_PURPLE_MUSHROOM", "PURPLE_MUSHROOM",
+        "MEDIUM_CRYSTAL", "CRYSTAL", "PALM_TREE", "CACTUS")),
+    *("featurePlacement.hpp::placeCaveFeature::" + f for f in (
+        "CAVE_VINE", "GLOWSTONE_CLUSTER", "STORMLIGHT_SPHERE", "CEILING_STORMLIGHT_SPHERE", "CRYSTAL_PILLAR", "WARPED_FUNGUS", "AMBER_FUNGUS")),
+    # the sin hashes return fract(sin(v) * c) per component; the engine is our own Rng over uint32_t; specialCaveNoise floors explicitly
+    "rng.hpp::hash", "rng.hpp::makeSeededRandomEngine", "rng.hpp::rand2From2", "rng.hpp::rand2From3", "rng.hpp::rand3From2",
+    "rng.hpp::rand3From3", "rng.hpp::specialCaveNoise",
+    # host / kernel orchestration restated over plain arrays (tables through T(), no shared memory, no thread indices)
+    "chunk.cu::getStratifiedMaterialThickness", "chunk.cu::isFeaturePos", "chunk.cu::generateColumnFeaturePlacements",
+    "chunk.cu::placeDecorators", "chunk.cu::kernGenerateCaves",
+    # isInRange() written as two comparisons on floats, explicit parentheses around int -> float operands, an unused local dropped
+    "biomeFuncs.hpp::caveBiomeBlockPostProcess", "biomeFuncs.hpp::caveBiomeBlockPostProcess::CRYSTAL_CAVES",
+    "biomeFuncs.hpp::caveBiomeBlockPostProcess::LUSH_CAVES", "biomeFuncs.hpp::caveBiomeBlockPostProcess::AMBER_FOREST",
+    "biomeFuncs.hpp::biomeBlockPostProcess::CRYSTALS",
+}
+
+
+def test_oracle_sections_are_token_identical_to_the_reference():
+    cache, identical, differs = {}, [], []
+    for rel, key, sig, prefixes in REFERENCE_SECTIONS:
+        base = os.path.basename(rel)
+        if base not in cache:
+            cache[base] = _read(ORACLE_FILES[base])
+        sig_o = sig.replace(r"void\s+Chunk::", r"void\s+").replace(r"void\s+kernGenerateCaves", r"void\s+generateCaves")
+        secs = sections(cache[base], sig_o, prefixes)
+        for k in SKEL:
+            parts = k.split("::")
+            if parts[0] != base or parts[1] != key:
+                continue
+            mine = skeleton_digest(secs.get(parts[2] if len(parts) == 3 else "", ""))
+            (identical if mine["sha256"] == SKEL[k]["sha256"] else differs).append(k)
+    unexpected = sorted(set(differs) - SKELETON_DIFFERS)
+    assert not unexpected, "oracle sections that no longer match the reference's statement skeleton: " + ", ".join(unexpected)
+    stale = sorted(SKELETON_DIFFERS - set(differs))
+    assert not stale, "sections listed as different that are identical now (move them out of SKELETON_DIFFERS): " + ", ".join(stale)
+    # what is pinned this way: every getHeight case, both biome-noise functions, the surface block rules, fbm / simplex-from helpers, ...
+    assert len(identical) >= 53 and sum(k.startswith("biomeFuncs.hpp::getHeight::") for k in identical) == 24

@@ -8,7 +8,13 @@ HIP-vs-oracle test can see; this fixture lets a CPU test hold every section of t
 code (MMBIO_ / MMF_ / MMCF_ / MMCB_ case labels) to the set of constants the reference's own text uses: every value the reference writes
 in a section must appear in ours.  (Control flow and operation order stay unpinned: DESIGN.md §2.)
 
-Run in the build container: python tools/extract_ref_literals.py   (reads /root/reference, writes tests/golden/ref_literals.json).
+A second fixture, tests/golden/ref_skeletons.json, holds ONE SHA-256 per section: the digest of the section's token stream after a
+fixed normalisation (`skeleton`: comments, qualifiers, braces, (float) casts and printf statements dropped, numbers by value, a table of
+renamed helpers).  The oracle's same-named section is normalised the same way; equal digests mean the oracle's section is the reference's
+statement for statement - control flow, operation order, operands - up to that table.  A digest is not the text: nothing of the source
+can be read back from it.
+
+Run in the build container: python tools/extract_ref_literals.py   (reads /root/reference, writes both fixtures).
 The section parser (`sections`, `literals`) is imported by tests/test_ref_literals.py to parse OUR sources the same way.
 """
 import json
@@ -87,6 +93,54 @@ def sections(text, signature, case_prefixes=()):
     return out
 
 
+# ---- statement skeletons -------------------------------------------------------------------------------------------------------
+TOKEN = re.compile(r"0[xX][0-9a-fA-F]+[uUlL]*|\d+\.\d*(?:[eE][-+]?\d+)?[fF]?|\.\d+(?:[eE][-+]?\d+)?[fF]?|\d+(?:[eE][-+]?\d+)?[fFuUlL]*|[A-Za-z_]\w*|::|->|<<=|>>=|<<|>>"
+                   r"|<=|>=|==|!=|&&|\|\||\+=|-=|\*=|/=|%=|\+\+|--|[-+*/%<>=!&|^~?:;,.()\[\]{}]")
+# helpers the oracle names differently (its own deterministic libm, glm look-alikes with a g_ prefix, typed overloads)
+RENAME = {"g_smoothstep": "smoothstep", "g_mix": "mix", "g_clamp": "clamp", "g_max": "max", "g_min": "min", "g_floor": "floor", "g_fract": "fract",
+          "g_length": "length", "g_normalize": "normalize", "g_dot": "dot", "g_cross": "cross", "g_distance": "distance", "g_mod": "mod",
+          "g_abs": "abs", "g_sqrt": "sqrt", "mm_powf": "powf", "mm_sinf": "sin", "mm_cosf": "cos", "mm_acosf": "acos", "mm_atan2f": "atan2",
+          "mm_fmodf": "fmod", "mm_sqrtf": "sqrt", "mm_sincosf": "sincosf", "sinf": "sin", "cosf": "cos", "acosf": "acos", "atan2f": "atan2",
+          "fmodf": "fmod", "fabsf": "abs", "fmaxf": "max", "fminf": "min", "fmax": "max", "fmin": "min", "floorf": "floor", "sqrtf": "sqrt",
+          "isInRangeF": "isInRange", "isInRangeI": "isInRange"}
+DROPPED = {"const", "__device__", "__host__", "static", "inline", "{", "}", "glm", "thrust", "std", "::"}
+
+
+def _number(tok):
+    if tok.lower().startswith("0x"):
+        return "#%d" % int(tok.rstrip("uUlL"), 16)
+    body = tok.rstrip("fFuUlL")
+    if any(c in body for c in ".eE") or tok[-1] in "fF":
+        return "#%r" % float(np.float32(float(body)))
+    return "#%d" % int(body)                                         # an integer literal stays an integer: 2 / 3 is not 2.f / 3.f
+
+
+def skeleton(code):
+    """normalised token list of a piece of (comment-free) code"""
+    toks = [m.group(0) for m in TOKEN.finditer(code)]
+    out, i = [], 0
+    while i < len(toks):
+        t = toks[i]
+        if t == "(" and i + 2 < len(toks) and toks[i + 1] == "float" and toks[i + 2] == ")":      # (float) casts the oracle makes explicit
+            i += 3
+            continue
+        if t not in DROPPED:
+            out.append(_number(t) if (t[0].isdigit() or (t[0] == "." and len(t) > 1)) else RENAME.get(t, t))
+        i += 1
+    txt = " " + " ".join(out) + " "
+    txt = re.sub(r" printf \( [^;]* \) ;", " ", txt)                    # "reached an unreachable section" diagnostics
+    txt = txt.replace(" default : break ;", " ")
+    txt = re.sub(r" \( void \) \w+ ;", " ", txt)
+    txt = txt.replace(" . r ", " . x ").replace(" . g ", " . y ").replace(" . b ", " . z ")      # glm colour aliases of the components
+    return txt.split()
+
+
+def skeleton_digest(code):
+    import hashlib
+    toks = skeleton(code)
+    return {"sha256": hashlib.sha256(" ".join(toks).encode()).hexdigest(), "tokens": len(toks)}
+
+
 # (file, key, signature regex, case prefixes)
 REFERENCE_SECTIONS = [
     ("terrain/biomeFuncs.hpp", "getSingleBiomeNoise", r"float\s+getSingleBiomeNoise\s*\([^)]*\)\s*\{", ()),
@@ -141,6 +195,13 @@ def main(out_path):
                 out[f"{os.path.basename(rel)}::{key}" + (f"::{name}" if name else "")] = vals
     json.dump(out, open(out_path, "w"), indent=0, sort_keys=True)
     print(f"wrote {out_path}: {len(out)} sections, {sum(len(v) for v in out.values())} literal values")
+    skel = {}
+    for rel, key, sig, prefixes in REFERENCE_SECTIONS:
+        for name, code in sections(cache[rel], sig, prefixes).items():
+            skel[f"{os.path.basename(rel)}::{key}" + (f"::{name}" if name else "")] = skeleton_digest(code)
+    skel_path = os.path.join(os.path.dirname(out_path), "ref_skeletons.json")
+    json.dump(skel, open(skel_path, "w"), indent=0, sort_keys=True)
+    print(f"wrote {skel_path}: {len(skel)} section digests")
 
 
 if __name__ == "__main__":
