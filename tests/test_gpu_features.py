@@ -1,5 +1,8 @@
 """GPU parity tests for the feature stages (F1 placements, F2 gather, L2 rasterisers, D1 decorators) and the full region
 pipeline (all stages, device resident) against the CPU oracle.  Bit-exact block ids is the bar."""
+import os
+import sys
+
 import numpy as np
 import pytest
 from conftest import assert_bit_equal
@@ -536,3 +539,24 @@ def test_tight_extents_lose_nothing(gen, oracle, case):
         plain = oracle.generate_region(cx0, cz0, 1, 1, erosion=True, features=True, decorators=True)["blocks"]
         total_diff_from_plain += int((ref != plain).sum())
     assert total_diff_from_plain > 1000                                       # the synthetic placements really claim voxels
+
+
+@pytest.mark.gpu
+def test_bench_n2_rehearsal_on_one_gpu():
+    """bench.py's N > 1 path (parent spawns torch.distributed.run before touching HIP, two ranks, 2 x 1 tile layout, TileContext, two-phase
+    ring exchange overlapped with the base fill, max-over-ranks timing, the border spot check against the oracle) rehearsed with both
+    ranks on ONE GPU: gloo group + host-staged p2p (tests/host_staged_dist.py) instead of RCCL, which refuses two ranks on one device.
+    Small tiles; the line must carry n_gpus = 2, be marked dry_run, and its blocks at the tile border must be bit-exact."""
+    import json, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MMGEN_BENCH_ONE_GPU_DRYRUN="1")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--tile-nx", "24",
+                        "--tile-nz", "24", "--cpu-side", "12"], env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and "dry_run" in line and line["config"]["tiles"] == "2x1"
+    assert line["halo_bytes_received_per_step_all_ranks"] > 0
+    assert line["parity_spot_check"] == "bit-exact"
+    assert "roofline" in line and "cpu_baseline" in line and line["scaling"] == "weak"
