@@ -650,8 +650,11 @@ k_fill(const float* __restrict__ hf, const float* __restrict__ bw, const float* 
     // phase 1: base blocks.  The two cave-surface distances only matter as "== 0" and "0 .. threshold" with threshold = 1.5 + 4.5 * simplex3
     // (|simplex3| < 3.5 by the crudest bound: 42 * 4 corners * max((0.6 - r^2)^4 r) = 3.5), so they travel as 6-bit codes:
     // negative -> 63, 62 and beyond -> 62.
-    for (int v = t; v < FILL_COLS * 384; v += FILL_THREADS) {
-        const int c = v / 384, y = v - 384 * c;
+    // y-major walk (lane -> column t % 4, y = t / 4): a wave covers 16 consecutive y of all four columns, so the list that phase 2 walks
+    // is ordered by depth, and its exits - which go by depth zone - retire whole waves instead of idling lanes
+    for (int u = t; u < FILL_COLS * 384; u += FILL_THREADS) {
+        const int c = u % FILL_COLS, y = u / FILL_COLS;
+        const int v = 384 * c + y;                                  // position in the batch's 1 536 output bytes
         const int idx2d = idxBase + c;
         const int wx = cp.x + (idx2d & 15), wz = cp.y + (idx2d >> 4);
         const ColumnBiomes cbi = {s_nzN[cRow + c], s_ocean[cRow + c] != 0, s_nzIdx[cRow + c], s_nzW[cRow + c], s_bw[cRow + c]};
