@@ -470,7 +470,10 @@ k_cave_biomes(const float* __restrict__ hf, const int2* __restrict__ chunkPos, m
     mmgen_cave_layer* L0 = caveLayers + ((size_t)256 * chunk + col0) * MMGEN_MAX_CAVE_LAYERS_PER_COLUMN;
     if (t == 0) s_count = 0;
     noise_tables_init();                                       // ends with the workgroup barrier
-    for (int i = t; i < CB_COLS * MMGEN_MAX_CAVE_LAYERS_PER_COLUMN; i += CB_THREADS) {
+    // slot-major walk (lane -> column u % CB_COLS, slot u / CB_COLS): the item list comes out ordered by depth (slot 0 = the lowest layer of
+    // every column first), and cave_biome's exits go by depth zone
+    for (int u = t; u < CB_COLS * MMGEN_MAX_CAVE_LAYERS_PER_COLUMN; u += CB_THREADS) {
+        const int i = (u % CB_COLS) * MMGEN_MAX_CAVE_LAYERS_PER_COLUMN + u / CB_COLS;
         const int start = L0[i].start, end = L0[i].end;
         if (start == 384) continue;                            // unused slot: biomes stay NONE (0)
         const int n = (end == 384) ? 1 : 2;                    // a layer open to the sky has no top block: top biome NONE
@@ -580,7 +583,11 @@ MM_DEV BaseBlock place_block_base(const ColumnBiomes& cbi, const float* s_lh, co
 #ifndef MM_FILL_EXP
 #define MM_FILL_EXP 0      // timing experiments only (tools/build_variant.sh): 1 = no cave-biome phase, 2 = no cave-biome block rules
 #endif
+#ifndef FILL_COLS
 #define FILL_COLS 4          // columns per batch
+#endif
+#define FILL_VBITS (FILL_COLS == 4 ? 11 : (FILL_COLS == 8 ? 12 : 13))      // bits of a voxel's position in the batch (FILL_COLS * 384 voxels)
+#define FILL_VMASK ((1 << FILL_VBITS) - 1)
 #define FILL_ROW 16          // columns per workgroup: one row of the chunk, staged with whole-line loads
 #define FILL_L3_CAP 256      // deferred lush voxels per batch (typically 0 - 30)
 #ifndef FILL_THREADS
@@ -600,8 +607,8 @@ k_fill(const float* __restrict__ hf, const float* __restrict__ bw, const float* 
     __shared__ float s_bw[FILL_ROW][MMGEN_NUM_BIOMES];
     __shared__ float s_lh[FILL_ROW][MMGEN_NUM_MATERIALS + 1];
     __shared__ mmgen_cave_layer s_cl[FILL_COLS][MMGEN_MAX_CAVE_LAYERS_PER_COLUMN];
-    __shared__ unsigned int s_list[FILL_COLS * 384];          // voxel (11 bits) | block (8) << 11 | bottomDepth code (6) << 19 | topDepth code (6) << 25
-    __shared__ unsigned short s_list2[FILL_COLS * 384];       // index into s_list (11 bits) | isLush << 11: voxels whose cave biome has a noise rule
+    __shared__ unsigned int s_list[FILL_COLS * 384];          // voxel (FILL_VBITS) | block (8) | bottomDepth code (6) | topDepth code (6), from the low bits up
+    __shared__ unsigned short s_list2[FILL_COLS * 384];       // index into s_list (FILL_VBITS) | isLush << FILL_VBITS: voxels whose cave biome has a noise rule
     __shared__ unsigned short s_list3[FILL_L3_CAP];           // index into s_list: lush voxels close enough to a cave surface for clay / moss
     __shared__ int s_count[3];
     __shared__ unsigned s_qbase;
@@ -663,7 +670,7 @@ k_fill(const float* __restrict__ hf, const float* __restrict__ bw, const float* 
             const int slot = atomicAdd(&s_count[0], 1);
             const unsigned bdc = r.bottomDepth < 0 ? 63u : (unsigned)imin(r.bottomDepth, 62);
             const unsigned tdc = r.topDepth < 0 ? 63u : (unsigned)imin(r.topDepth, 62);
-            s_list[slot] = (unsigned)v | ((unsigned)r.block << 11) | (bdc << 19) | (tdc << 25);
+            s_list[slot] = (unsigned)v | ((unsigned)r.block << FILL_VBITS) | (bdc << (FILL_VBITS + 8)) | (tdc << (FILL_VBITS + 14));
         } else {
             outBase[v] = r.block;
         }
@@ -675,9 +682,9 @@ k_fill(const float* __restrict__ hf, const float* __restrict__ bw, const float* 
     const int count = s_count[0];
     for (int i = t; i < count; i += FILL_THREADS) {
         const unsigned e = s_list[i];
-        const int v = e & 2047;
-        uint8_t block = (uint8_t)((e >> 11) & 255);
-        const int bdc = (e >> 19) & 63;
+        const int v = e & FILL_VMASK;
+        uint8_t block = (uint8_t)((e >> FILL_VBITS) & 255);
+        const int bdc = (e >> (FILL_VBITS + 8)) & 63;
         const int c = v / 384, y = v - 384 * c;
         const int idx2d = idxBase + c;
         const int wx = cp.x + (idx2d & 15), wz = cp.y + (idx2d >> 4);
@@ -686,11 +693,11 @@ k_fill(const float* __restrict__ hf, const float* __restrict__ bw, const float* 
         const bool wantDeep = bdc == 0 && (block == MMB_DEEPSLATE || block == MMB_BLACKSTONE);
         // LUSH_CAVES only converts within 1.5 + 4.5 simplex3 <= 1.5 + 4.5 * 1.23 = 7.04 blocks of a cave surface: further away only CRYSTAL_CAVES
         // can change the block (depth codes: 63 = no such surface)
-        const int tdc = (e >> 25) & 63;
+        const int tdc = (e >> (FILL_VBITS + 14)) & 63;
         const bool crystalOnly = !wantDeep && bdc > 7 && tdc > 7;
         const int cb = cave_biome(wx, y, wz, s_lh[cRow + c][MMGEN_NUM_MATERIALS], 190249401, wantDeep, crystalOnly);
         if (MM_FILL_EXP != 2 && (cb == MMCB_CRYSTAL_CAVES || cb == MMCB_LUSH_CAVES)) {
-            s_list2[atomicAdd(&s_count[1], 1)] = (unsigned short)(i | (cb == MMCB_LUSH_CAVES ? 2048 : 0));
+            s_list2[atomicAdd(&s_count[1], 1)] = (unsigned short)(i | (cb == MMCB_LUSH_CAVES ? (1 << FILL_VBITS) : 0));
             continue;
         }
         if (wantDeep && cb != MMCB_NONE) cave_biome_block_post(block, cb, wx, y, wz, 0, -1);      // WARPED / AMBER re-skin, no noise
@@ -703,11 +710,11 @@ k_fill(const float* __restrict__ hf, const float* __restrict__ bw, const float* 
     const int count2 = s_count[1];
     for (int k = t; k < count2; k += FILL_THREADS) {
         const int item = s_list2[k];
-        const int i = item & 2047, cb = (item & 2048) ? MMCB_LUSH_CAVES : MMCB_CRYSTAL_CAVES;
+        const int i = item & FILL_VMASK, cb = (item & (1 << FILL_VBITS)) ? MMCB_LUSH_CAVES : MMCB_CRYSTAL_CAVES;
         const unsigned e = s_list[i];
-        const int v = e & 2047;
-        uint8_t block = (uint8_t)((e >> 11) & 255);
-        const int bdc = (e >> 19) & 63, tdc = (e >> 25) & 63;
+        const int v = e & FILL_VMASK;
+        uint8_t block = (uint8_t)((e >> FILL_VBITS) & 255);
+        const int bdc = (e >> (FILL_VBITS + 8)) & 63, tdc = (e >> (FILL_VBITS + 14)) & 63;
         const int c = v / 384, y = v - 384 * c;
         const int idx2d = idxBase + c;
         const int wx = cp.x + (idx2d & 15), wz = cp.y + (idx2d >> 4);
@@ -734,7 +741,7 @@ k_fill(const float* __restrict__ hf, const float* __restrict__ bw, const float* 
     const bool queued = lushQueue && qbase <= lushCap && (unsigned)count3 <= lushCap - qbase;
     for (int k = t; k < count3; k += FILL_THREADS) {
         const unsigned e = s_list[s_list3[k]];
-        const int v = e & 2047;
+        const int v = e & FILL_VMASK;
         const int c = v / 384, y = v - 384 * c;
         const int idx2d = idxBase + c;
         if (queued) { lushQueue[1 + qbase + k] = ((unsigned)outChunk << 17) | ((unsigned)idx2d << 9) | (unsigned)y; continue; }
