@@ -329,8 +329,9 @@ k_cave_voxels(const float* __restrict__ hf, const float2* __restrict__ colInfo, 
     //   B  list 1: position warp (fbm3from3<5>) + Worley = the cave noise; voxels whose noise is below the largest threshold the voxel can
     //      have -> list 2 with their noise
     //   C  list 2: the threshold (huge, then fbm3<4> only if the noise is still below the bound); "cave" clears the solid bit again
-    for (int e = t; e < CAVE_VOXELS; e += CAVE_THREADS) {
-        const int c = e / CAVE_YEVAL, y = e - c * CAVE_YEVAL;
+    for (int u = t; u < CAVE_VOXELS; u += CAVE_THREADS) {
+        const int c = u % CAVE_COLS, y = u / CAVE_COLS;              // y-major: the lists come out ordered by depth
+        const int e = c * CAVE_YEVAL + y;
         if (!((needMask >> c) & 1u)) continue;
         const int col = chunk * 256 + colBase + c;
         const float maxHeight = hf[col];
