@@ -251,20 +251,25 @@ MM_DEV float column_height(int wxi, int wzi, float* w24 /* nullable */)
 //   the values used are identical to evaluating all four up front, the unused ones are simply never computed.
 // ---------------------------------------------------------------------------------------------------------
 // Exact pruning (the values that ARE computed are the reference's; what is skipped provably cannot change the result): the depth bands
-// are smoothsteps of the warped height py between band edges that are fbm2<3> offsets around fixed levels, and |fbm2<3>| <= 0.875 B2 with
-// B2 = 1.06 >= sup |simplex2| (130 * max table gradient 0.7897 * sup sum (0.5 - r^2)^4 r over the simplex 0.010080 = 1.0348: adversarially
-// aligned gradients, tests/test_oracle_math.py::test_simplex_bounds).  So once py (3 of the 9 warp evaluations) is known:
-//   py >= top - 19 + 23 * 0.9275 + slack  =>  none == 1 exactly  =>  the draw minus 1 is <= 0  =>  NONE   (skips 6 simplex3 + 6 simplex2)
-//   py <= top - 82 - 25 * 0.9275 - slack  =>  none == 0 and shallow == 0 exactly  =>  only the two deep biomes remain; a caller that has no
-//                                            use for them (wantDeep = false) gets NONE                         (skips 6 simplex3 + 12 simplex2)
+// are smoothsteps of the warped height py between band edges that are fbm2<3> offsets around fixed levels, and |fbm2<3>| <= A = 0.875 *
+// MM_SIMPLEX2_BOUND (mm_noise.cuh: the adversarial supremum of simplex2 plus the rounding slack, valid inside the pruning domain).
+// So once py (3 of the 9 warp evaluations) is known:
+//   py >= top - 19 + 23 A + slack  =>  none == 1 exactly  =>  the draw minus 1 is <= 0  =>  NONE         (skips 6 simplex3 + 6 simplex2)
+//   py <= top - 82 - 25 A - slack  =>  none == 0 and shallow == 0 exactly  =>  only the two deep biomes remain; a caller that has no
+//                                     use for them (wantDeep = false) gets NONE                          (skips 6 simplex3 + 12 simplex2)
 #ifndef MM_CAVE_BIOME_PRUNE
 #define MM_CAVE_BIOME_PRUNE 1
 #endif
-MM_DEV int cave_biome(int wx, int wy, int wz, float maxHeight, int seed, bool wantDeep = true, bool crystalOnly = false)
+// PRUNE = the column lies inside the pruning domain (prune_domain(wx, wz), mm_noise.cuh): a compile-time switch, so that the pruned path
+// carries no trace of the plain one (k_fill sits exactly at its register budget); kernels pick the instantiation per workgroup or per lane.
+template <bool PRUNE>
+MM_DEV int cave_biome_t(int wx, int wy, int wz, float maxHeight, int seed, bool wantDeep, bool crystalOnly)
 {
     const float fx = (float)wx, fy = (float)wy, fz = (float)wz;
     const float top = (float)MMGEN_SEA_LEVEL + 0.15f * (maxHeight - (float)MMGEN_SEA_LEVEL);
     const float sx = fx * 0.0470f, sy = fy * 0.0470f, sz = fz * 0.0470f;
+    constexpr float kA = 0.875f * MM_SIMPLEX2_BOUND;            // >= |fbm2<3>| inside the pruning domain (mm_noise.cuh)
+    constexpr bool prune = PRUNE && MM_CAVE_BIOME_PRUNE;
     // fbm3From3<3> component by component (rng.hpp:180-186), y first; one rolled loop = one inlined simplex body (code size)
     float o[3], py = 0.f;
 #pragma unroll 1
@@ -275,11 +280,10 @@ MM_DEV int cave_biome(int wx, int wy, int wz, float maxHeight, int seed, bool wa
         o[k] = k == 0 ? fbm3<3>(sx, sy, sz) : fbm3<3>(sx + ax, sy + ay, sz + az);
         if (it == 0) {
             py = (fy + o[1] * 24.f) * 1.f;
-#if MM_CAVE_BIOME_PRUNE
-            constexpr float kA2 = 0.875f * 1.06f;
-            if (py >= (top - 19.f) + 23.f * kA2 + 0.05f) return MMCB_NONE;
-            if (!wantDeep && py <= ((top - 72.f) - 18.f * kA2 - 10.f) - 7.f * kA2 - 0.05f) return MMCB_NONE;
-#endif
+            if constexpr (prune) {
+                if (py >= (top - 19.f) + 23.f * kA + 0.05f) return MMCB_NONE;
+                if (!wantDeep && py <= ((top - 72.f) - 18.f * kA - 10.f) - 7.f * kA - 0.05f) return MMCB_NONE;
+            }
         }
     }
     const float ox = o[0], oz = o[2];
@@ -290,16 +294,12 @@ MM_DEV int cave_biome(int wx, int wy, int wz, float maxHeight, int seed, bool wa
     float rand = rng.u01();
 
     // crystalOnly: the caller only needs to know whether the result is CRYSTAL_CAVES (k_fill: a voxel further than 7 blocks from every cave
-    // surface - LUSH_CAVES only converts within 1.5 + 4.5 simplex3 <= 7.04 blocks of one - that is not the top of a cave floor).  CRYSTAL's
+    // surface - LUSH_CAVES only converts within 1.5 + 4.5 simplex3 <= 7.67 blocks of one - that is not the top of a cave floor).  CRYSTAL's
     // weight is (1 - none) shallow rocky, and rocky = smoothstep(-0.05, 0.05, simplex3(p * 0.0022)) is exactly 0 over half the world in
     // patches hundreds of blocks wide: there the draw cannot select CRYSTAL (it subtracts +0) and neither depth band is evaluated.  rocky
     // is therefore evaluated BEFORE the bands (same value, same place in the draw).
     float rocky = 0.f;
-#if MM_CAVE_BIOME_PRUNE
-    const bool rockyMatters = !(py <= ((((top - 72.f) - 18.f * (0.875f * 1.06f)) - 10.f) - 7.f * (0.875f * 1.06f)) - 0.05f);      // shallow can be non-zero
-#else
-    const bool rockyMatters = true;
-#endif
+    const bool rockyMatters = !prune || !(py <= ((((top - 72.f) - 18.f * kA) - 10.f) - 7.f * kA) - 0.05f);      // shallow can be non-zero
     if (rockyMatters) {
         rocky = smoothstep(-0.05f, 0.05f, simplex3(px * 0.0022f + -9193.23f, py * 0.0022f + -6813.39f, pz * 0.0022f + (float)-2171.23));
         if (crystalOnly && rocky == 0.f) return MMCB_NONE;
@@ -311,38 +311,36 @@ MM_DEV int cave_biome(int wx, int wy, int wz, float maxHeight, int seed, bool wa
     //   py <= (top - 19 - 23 A) - 5 - 3 A - slack  =>  none == 0 exactly (rand - 0 == rand)          py >= (top - 72) + 18 A + slack  =>  shallow == 1 exactly
     // The first limit lies 7 blocks above the second, so at most ONE band needs its 6 simplex2 (the reference evaluates 12); lanes that
     // need the upper band and lanes that need the lower one run the same instructions on per-lane constants.
-#if MM_CAVE_BIOME_PRUNE
-    constexpr float kA = 0.875f * 1.06f;
-    static_assert((((-19.f - 23.f * kA) - 5.f) - 3.f * kA) - 0.05f > ((-72.f + 18.f * kA) + 0.05f) + 1.f, "the two transition bands must not overlap");
-    const bool noneZero = py <= ((((top - 19.f) - 23.f * kA) - 5.f) - 3.f * kA) - 0.05f;
-    const bool shallowOne = py >= ((top - 72.f) + 18.f * kA) + 0.05f;
-    const bool shallowZero = py <= ((((top - 72.f) - 18.f * kA) - 10.f) - 7.f * kA) - 0.05f;
-    const int band = !noneZero ? 0 : ((shallowOne || shallowZero) ? -1 : 1);
-    float bandVal = 0.f;
-    if (band >= 0) {
-        const bool b0 = band == 0;
-        const float f1 = b0 ? fbm2<3>(qx, qz) : fbm2<3>(qx + -4921.34f, qz + 8402.13f);
-        const float edge1 = (b0 ? (top - 19.f) : (top - 72.f)) + (b0 ? 23.f : 18.f) * f1;
-        const float f2 = fbm2<3>(qx + (b0 ? 3821.34f : 9411.32f), qz + (b0 ? 4920.32f : -3921.34f));
-        const float edge0 = (edge1 - (b0 ? 5.f : 10.f)) + (b0 ? 3.f : 7.f) * f2;
-        bandVal = smoothstep(edge0, edge1, py);
+    static_assert((((-19.f - 23.f * kA) - 5.f) - 3.f * kA) - 0.05f > ((-72.f + 18.f * kA) + 0.05f) + 0.5f, "the two transition bands must not overlap");
+    float none, shallow;
+    if constexpr (prune) {
+        const bool noneZero = py <= ((((top - 19.f) - 23.f * kA) - 5.f) - 3.f * kA) - 0.05f;
+        const bool shallowOne = py >= ((top - 72.f) + 18.f * kA) + 0.05f;
+        const bool shallowZero = py <= ((((top - 72.f) - 18.f * kA) - 10.f) - 7.f * kA) - 0.05f;
+        const int band = !noneZero ? 0 : ((shallowOne || shallowZero) ? -1 : 1);
+        float bandVal = 0.f;
+        if (band >= 0) {
+            const bool b0 = band == 0;
+            const float f1 = b0 ? fbm2<3>(qx, qz) : fbm2<3>(qx + -4921.34f, qz + 8402.13f);
+            const float edge1 = (b0 ? (top - 19.f) : (top - 72.f)) + (b0 ? 23.f : 18.f) * f1;
+            const float f2 = fbm2<3>(qx + (b0 ? 3821.34f : 9411.32f), qz + (b0 ? 4920.32f : -3921.34f));
+            const float edge0 = (edge1 - (b0 ? 5.f : 10.f)) + (b0 ? 3.f : 7.f) * f2;
+            bandVal = smoothstep(edge0, edge1, py);
+        }
+        none = band == 0 ? bandVal : 0.f;
+        rand -= none;                                   // NONE
+        if (rand <= 0.f) return MMCB_NONE;
+        shallow = band == 1 ? bandVal : (shallowZero ? 0.f : 1.f);
+    } else {
+        const float n2sStart = (top - 19.f) + 23.f * fbm2<3>(qx, qz);
+        const float n2sEnd = (n2sStart - 5.f) + 3.f * fbm2<3>(qx + 3821.34f, qz + 4920.32f);
+        none = smoothstep(n2sEnd, n2sStart, py);
+        rand -= none;                                   // NONE
+        if (rand <= 0.f) return MMCB_NONE;
+        const float s2dStart = (top - 72.f) + 18.f * fbm2<3>(qx + -4921.34f, qz + 8402.13f);
+        const float s2dEnd = (s2dStart - 10.f) + 7.f * fbm2<3>(qx + 9411.32f, qz + -3921.34f);
+        shallow = smoothstep(s2dEnd, s2dStart, py);
     }
-    const float none = band == 0 ? bandVal : 0.f;
-    rand -= none;                                   // NONE
-    if (rand <= 0.f) return MMCB_NONE;
-    const float shallow = band == 1 ? bandVal : (shallowZero ? 0.f : 1.f);
-#else
-    const float n2sStart = (top - 19.f) + 23.f * fbm2<3>(qx, qz);
-    const float n2sEnd = (n2sStart - 5.f) + 3.f * fbm2<3>(qx + 3821.34f, qz + 4920.32f);
-    const float none = smoothstep(n2sEnd, n2sStart, py);
-
-    rand -= none;                                   // NONE
-    if (rand <= 0.f) return MMCB_NONE;
-
-    const float s2dStart = (top - 72.f) + 18.f * fbm2<3>(qx + -4921.34f, qz + 8402.13f);
-    const float s2dEnd = (s2dStart - 10.f) + 7.f * fbm2<3>(qx + 9411.32f, qz + -3921.34f);
-    const float shallow = smoothstep(s2dEnd, s2dStart, py);
-#endif
 
     // rand > 0 here.  A weight that is exactly 0 (rocky, warped are in [0, 1]) subtracts +0 and cannot select its biome, so
     // the simplex3 behind warped is only evaluated when its factor is non-zero (shallowW != 0 implies rockyMatters: rocky was evaluated).
@@ -364,6 +362,11 @@ MM_DEV int cave_biome(int wx, int wy, int wz, float maxHeight, int seed, bool wa
         if (rand <= 0.f) return MMCB_AMBER_FOREST;
     }
     return MMCB_NONE;
+}
+
+MM_DEV int cave_biome(int wx, int wy, int wz, float maxHeight, int seed)
+{
+    return prune_domain(wx, wz) ? cave_biome_t<true>(wx, wy, wz, maxHeight, seed, true, false) : cave_biome_t<false>(wx, wy, wz, maxHeight, seed, true, false);
 }
 
 // ---------------------------------------------------------------------------------------------------------

@@ -204,6 +204,20 @@ MM_DEV float simplex2_inl(float vx, float vy)
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// Bounds the exact prunings rely on (cave_biome's depth zones, the cave threshold, the rasterisers' extents).  Adversarially aligned
+// gradients give sup |simplex2| <= 1.0348 and sup |simplex3| <= 1.2259 over a lattice cell (tests/test_oracle_math.py::test_simplex_bounds,
+// test_simplex3_bound).  In floating point the skew sum that picks the cell is rounded, so the evaluated point can lie outside its cell by
+// a few ulp of the ARGUMENT: the prunings are therefore only applied where the arguments are small - columns within MM_PRUNE_DOMAIN
+// blocks of the origin (a 4 096 x 4 096-chunk world; the largest simplex2 argument there is 2.6e4, the largest simplex3 argument 1e4, the
+// point at most 0.006 outside its cell, which can add at most 0.006 * 3 * 0.0625 * 130 * 0.79 = 0.115 resp. 0.006 * 4 * 0.1296 * 42 =
+// 0.13) - and with the slack folded into the constants.  Beyond the domain every voxel takes the unpruned path: same values, more work.
+// ---------------------------------------------------------------------------------------------------------
+#define MM_SIMPLEX2_BOUND 1.16f
+#define MM_SIMPLEX3_BOUND 1.37f
+#define MM_PRUNE_DOMAIN 32768
+MM_DEV bool prune_domain(int wx, int wz) { return wx > -MM_PRUNE_DOMAIN && wx < MM_PRUNE_DOMAIN && wz > -MM_PRUNE_DOMAIN && wz < MM_PRUNE_DOMAIN; }
+
+// ---------------------------------------------------------------------------------------------------------
 // simplex3 split at the lattice: part1 (skewed cell + offsets inside it) -> gradients of the cell's 4 simplex corners
 // -> part3 (falloff * gradient . offset).  The gradients are a function of (cell, corner ordering) ONLY and come from the
 // LDS tables.  simplex3 = part3(part1(v), gradients(part1(v))): glm's operations in glm's order, merely regrouped (checked by

@@ -166,7 +166,7 @@ int mmgen_fill(const float* d_hf, const float* d_bw, const float* d_layers, cons
     if (!sc) return (int)hipErrorInvalidDevice;
     int e = ensure_fill_queue(*sc, n, stream);
     if (e) return e;
-    e = mmk::launch_fill(d_hf, d_bw, d_layers, d_cl, d_pos, n, d_blocks, nullptr, sc->fillQueue, mmk::fill_queue_bytes(n), (hipStream_t)stream);
+    e = mmk::launch_fill(d_hf, d_bw, d_layers, d_cl, d_pos, n, d_blocks, nullptr, sc->fillQueue, mmk::fill_queue_bytes(n), false /* positions live on the device */, (hipStream_t)stream);
     if (e || !(d_fp || d_cfp)) return e;
     return mmk::launch_apply_features(d_blocks, d_pos, n, d_fp, d_cfp, d_bounds, nullptr, (hipStream_t)stream);
 }

@@ -439,9 +439,9 @@ MM_DEV int wave_max(int v) { for (int o = 32; o > 0; o >>= 1) v = imax(v, __shfl
 //   PURPLE_MUSHROOM (featurePlacement.hpp:705-709): worst case reach 127 / 121 voxels tall (smallest universal scale AND the 20 % half-scale
 //     draw: 7.9 M voxels per placement, 10 x all other features of the bench world together); the first three draws bound it to
 //     |pos.xz| <= 35 and -1 <= pos.y <= height + 12 in the scaled frame.
-//   CORAL: the first draw picks one of five shapes: two noisy ellipsoids (radius <= base + amplitude * 1.23, |simplex3| <= 1.23), two
+//   CORAL: the first draw picks one of five shapes: two noisy ellipsoids (radius <= base + amplitude * MM_SIMPLEX3_BOUND), two
 //     bundles of six rasterised segments inside [-6.5, 6.5] x [0, 8.5] x [-6.5, 6.5], one tube field that is empty from radius 3.7 on.
-MM_DEV bool surface_extent(int feat, int fy, int dx, int dz, uint32_t fstate, int& dlo, int& dhi)
+MM_DEV bool surface_extent(int feat, int fy, int dx, int dz, uint32_t fstate, bool noiseBounds, int& dlo, int& dhi)
 {
     dlo = kFeatureBounds[feat][0]; dhi = kFeatureBounds[feat][1];
     if (feat == MMF_PURPLE_MUSHROOM) {
@@ -501,8 +501,9 @@ MM_DEV bool surface_extent(int feat, int fy, int dx, int dz, uint32_t fstate, in
         MinStd frng; frng.x = fstate;
         const int kind = (int)(frng.u01() * 5.f);
         if (kind == 0 || kind == 1) {
-            // len3(x, y * ys, z) < radius, radius < base + amp * 1.23 (+ 0.01: rounding)
-            const float rmax = (kind == 0 ? (2.8f + 1.4f * frng.u01()) + 0.4f * 1.23f : (2.2f + 1.7f * frng.u01()) + 1.2f * 1.23f) + 0.01f;
+            if (!noiseBounds) return true;                                          // outside the pruning domain the simplex bound is not used
+            // len3(x, y * ys, z) < radius, radius < base + amp * MM_SIMPLEX3_BOUND (+ 0.01: rounding)
+            const float rmax = (kind == 0 ? (2.8f + 1.4f * frng.u01()) + 0.4f * MM_SIMPLEX3_BOUND : (2.2f + 1.7f * frng.u01()) + 1.2f * MM_SIMPLEX3_BOUND) + 0.01f;
             const float rest = rmax * rmax - (float)d2;
             if (rest <= 0.f) return false;
             const int dy = (int)(__builtin_sqrtf(rest) / (kind == 0 ? 1.15f : 1.25f)) + 1;
@@ -594,7 +595,7 @@ MM_DEV bool surface_extent(int feat, int fy, int dx, int dz, uint32_t fstate, in
 //   WARPED_FUNGUS: stem in its own column, shroomlights in the four neighbours, cap only within radius 3.7 and, within radius 2.3, exactly
 //     one voxel thick (capStart == capEnd); AMBER_FUNGUS: stem, and a cap ring at Manhattan distance 1 or 2.  Neither depends on the
 //     layer height, which the table bound adds.
-MM_DEV bool cave_extent(int feat, int lh, int dx, int dz, uint32_t fstate, int& dlo, int& dhi)
+MM_DEV bool cave_extent(int feat, int lh, int dx, int dz, uint32_t fstate, bool noiseBounds, int& dlo, int& dhi)
 {
     dlo = kCaveFeatureBounds[feat][0]; dhi = lh + kCaveFeatureBounds[feat][1];
     const int ml = iabs(dx) + iabs(dz);
@@ -627,11 +628,12 @@ MM_DEV bool cave_extent(int feat, int lh, int dx, int dz, uint32_t fstate, int& 
         dlo = imax(dlo, lh - height); dhi = imin(dhi, lh);
         return true;
     }
-    if (feat == MMCF_GLOWSTONE_CLUSTER) {
-        // r = |(dx, 1.35 dyTop, dz)| * s < 3.5 + 2 simplex2 <= 5.62 (|simplex2| <= 1.06)
+    if (feat == MMCF_GLOWSTONE_CLUSTER && noiseBounds) {
+        // r = |(dx, 1.35 dyTop, dz)| * s < 3.5 + 2 simplex2 <= 3.5 + 2 MM_SIMPLEX2_BOUND = 5.82
         MinStd frng; frng.x = fstate;
         const float sc = 1.f + 0.5f * frng.u01();
-        const float rest = 31.7f - (float)d2 * (sc * sc);
+        constexpr float rMax = 3.5f + 2.f * MM_SIMPLEX2_BOUND + 0.01f;
+        const float rest = rMax * rMax - (float)d2 * (sc * sc);
         if (rest <= 0.f) return false;
         const int m = (int)(__builtin_sqrtf(rest) / (1.35f * sc)) + 1;
         dlo = imax(dlo, lh - m); dhi = imin(dhi, lh + m);
@@ -665,6 +667,7 @@ template <class Entry, int LIST_CAP, bool CAVE>
 MM_DEV int filter_column(const Entry* __restrict__ list, int wx, int wz, int2* s_cand, uint32_t* s_seed, unsigned& featureMask)
 {
     const int lane = threadIdx.x & 63;
+    const bool noiseBounds = prune_domain(wx, wz);                  // the two extents that use a simplex bound (coral ellipsoids, glowstone)
     int base = 0;
     for (int r0 = 0; r0 < LIST_CAP; r0 += 64) {
         const int i = r0 + lane;
@@ -688,10 +691,10 @@ MM_DEV int filter_column(const Entry* __restrict__ list, int wx, int wz, int2* s
             int dlo, dhi;
             if constexpr (CAVE) {
                 const int layerHeight = lhRaw;
-                cand = cave_extent(feat, layerHeight, wx - fx, wz - fz, fstate, dlo, dhi);
+                cand = cave_extent(feat, layerHeight, wx - fx, wz - fz, fstate, noiseBounds, dlo, dhi);
                 lh = layerHeight | ((dlo + 128) << 9) | (dhi << 17);
             } else {
-                cand = surface_extent(feat, fy, wx - fx, wz - fz, fstate, dlo, dhi);
+                cand = surface_extent(feat, fy, wx - fx, wz - fz, fstate, noiseBounds, dlo, dhi);
                 lh = (dlo + 128) | (dhi << 8);
             }
         }

@@ -195,14 +195,13 @@ k_cave_columns(const float* __restrict__ bw, const int2* __restrict__ chunkPos, 
 
 // smoothstep(0.2, 0.4, fbm3<4>(p)) of the cave threshold (chunk.cu shouldGenerateCaveAtBlock).  Exact pruning: the smoothstep is exactly 0
 // for an argument <= 0.2 and exactly 1 for one >= 0.4, the octaves still to come after octave i add at most amp_i * B3 in magnitude
-// (their amplitudes sum to < amp_i; B3 = 1.23 >= sup |simplex3| = 42 * sup_g |g| * sup sum (0.6 - r^2)^4 r = 42 * 1.00001 * 0.029187,
-// adversarially aligned gradients: tests/test_oracle_math.py::test_simplex3_bound), so once the partial sum is that far on either
+// (their amplitudes sum to < amp_i; B3 = MM_SIMPLEX3_BOUND, mm_noise.cuh), so once the partial sum is that far on either
 // side the remaining octaves cannot move the result.  The partial sums are the reference's own (same order of additions).  This noise
 // varies over thousands of blocks: a workgroup's voxels nearly always leave the loop together.
 #ifndef MM_CAVE_HUGE_PRUNE
 #define MM_CAVE_HUGE_PRUNE 1
 #endif
-MM_DEV float cave_huge(float x, float y, float z)
+MM_DEV float cave_huge(float x, float y, float z, float b3 /* MM_SIMPLEX3_BOUND inside the pruning domain, FLT_MAX outside: no early exit */)
 {
     float acc = 0.f, amp = 1.f;
 #pragma unroll 1
@@ -211,7 +210,7 @@ MM_DEV float cave_huge(float x, float y, float z)
         acc += amp * simplex3_inl(x, y, z);
         x *= 2.f; y *= 2.f; z *= 2.f;
 #if MM_CAVE_HUGE_PRUNE
-        const float rest = amp * 1.23f;
+        const float rest = amp * b3;
         if (acc + rest <= 0.2f - 0.001f) return 0.f;
         if (acc - rest >= 0.4f + 0.001f) return 1.f;
 #endif
@@ -354,9 +353,11 @@ k_cave_voxels(const float* __restrict__ hf, const float2* __restrict__ colInfo, 
     // The reference evaluates  cave = threshold > 0.04 && caveNoise < threshold  with threshold = ((0.24 + 0.12 fa) (1 + 1.4 huge)) T,
     // fa = fbm3<4>, huge in [0, 1], T = topRatio (0.3 + 0.7 bottomRatio) >= 0.  Every operation of that expression is monotone in fa and
     // in huge (IEEE rounding is monotone, the other factors are non-negative), so the SAME expression with fa := kCaveFaMax >= sup |fbm3<4>|
-    // = 0.9375 * 1.23 and huge := 1 is >= threshold bit for bit: a voxel whose cave noise is not below that bound is solid whatever the
+    // = 0.9375 * MM_SIMPLEX3_BOUND and huge := 1 is >= threshold bit for bit: a voxel whose cave noise is not below that bound is solid whatever the
     // two fbm3<4> are, and they are never evaluated for it (56 % of the voxels; half of the rest is decided once huge is known).
-    constexpr float kCaveFaMax = 1.16f;
+    const bool prune = prune_domain(cp.x, cp.y + row);          // the row's 16 columns: x in [cp.x, cp.x + 15] (cp.x a multiple of 16), z = cp.y + row
+    const float b3 = prune ? MM_SIMPLEX3_BOUND : 3.402823466e+38f;
+    const float kCaveFaMax = prune ? 0.9375f * MM_SIMPLEX3_BOUND : 1e30f;      // outside the domain: a bound no noise reaches
     const int count1 = s_count[0];
     for (int i = t; i < count1; i += CAVE_THREADS) {
         const int e = s_list1[i];
@@ -395,7 +396,7 @@ k_cave_voxels(const float* __restrict__ hf, const float2* __restrict__ colInfo, 
         const float npy = fy * 0.0050f;
         const float topRatio = smoothstep(142.f, 95.f, fy + obw * 50.f);
         const float bottomRatio = smoothstep(5.f, 20.f, fy);
-        const float huge = cave_huge(npx * 0.0700f, npy * 0.0700f, npz * 0.0700f);
+        const float huge = cave_huge(npx * 0.0700f, npy * 0.0700f, npz * 0.0700f, b3);
         float bound = 0.24f + 0.12f * kCaveFaMax;
         bound *= (1.f + 1.4f * huge);
         bound *= topRatio * (0.3f + 0.7f * bottomRatio);
@@ -598,12 +599,18 @@ MM_DEV BaseBlock place_block_base(const ColumnBiomes& cbi, const float* s_lh, co
 #define MM_FILL_WAVES 6
 #endif
 
-__attribute__((amdgpu_waves_per_eu(MM_FILL_WAVES, MM_FILL_WAVES)))
-__global__ void __launch_bounds__(FILL_THREADS)
-k_fill(const float* __restrict__ hf, const float* __restrict__ bw, const float* __restrict__ layers,
-       const mmgen_cave_layer* __restrict__ caveLayers, const int2* __restrict__ chunkPos, uint8_t* __restrict__ blocks,
-       const int* __restrict__ srcIdx, unsigned* __restrict__ lushQueue /*[0] = count, entries from [1]; nullable*/, unsigned lushCap)
+// NEAR = the rows inside the pruning domain (mm_noise.cuh), evaluated with the exact prunings; k_fill_far takes the rows beyond it the
+// plain way.  Two kernels rather than a flag: the pruned path sits exactly at its register budget, and a row belongs to one of them.
+template <bool NEAR>
+MM_DEV void fill_body(const float* __restrict__ hf, const float* __restrict__ bw, const float* __restrict__ layers,
+                      const mmgen_cave_layer* __restrict__ caveLayers, const int2* __restrict__ chunkPos, uint8_t* __restrict__ blocks,
+                      const int* __restrict__ srcIdx, unsigned* __restrict__ lushQueue /*[0] = count, entries from [1]; nullable*/, unsigned lushCap)
 {
+    {
+        const int bid0 = xcd_block(blockIdx.x, gridDim.x);
+        const int2 cp0 = chunkPos[srcIdx ? srcIdx[bid0 >> 4] : (bid0 >> 4)];
+        if (prune_domain(cp0.x, cp0.y + (bid0 & 15)) != NEAR) return;       // (the row's x range is [cp.x, cp.x + 15], cp.x a multiple of 16)
+    }
     noise_tables_init();
     __shared__ float s_bw[FILL_ROW][MMGEN_NUM_BIOMES];
     __shared__ float s_lh[FILL_ROW][MMGEN_NUM_MATERIALS + 1];
@@ -692,11 +699,12 @@ k_fill(const float* __restrict__ hf, const float* __restrict__ bw, const float* 
 #if MM_FILL_EXP != 1
         // WARPED / AMBER only act on the top DEEPSLATE / BLACKSTONE block of a cave floor (caveBottomDepth == 0)
         const bool wantDeep = bdc == 0 && (block == MMB_DEEPSLATE || block == MMB_BLACKSTONE);
-        // LUSH_CAVES only converts within 1.5 + 4.5 simplex3 <= 1.5 + 4.5 * 1.23 = 7.04 blocks of a cave surface: further away only CRYSTAL_CAVES
-        // can change the block (depth codes: 63 = no such surface)
+        // LUSH_CAVES only converts within 1.5 + 4.5 simplex3 <= 1.5 + 4.5 * 1.37 = 7.67 blocks of a cave surface: further away only CRYSTAL_CAVES
+        // can change the block (depth codes: 63 = no such surface; MM_SIMPLEX3_BOUND holds inside the pruning domain)
         const int tdc = (e >> (FILL_VBITS + 14)) & 63;
-        const bool crystalOnly = !wantDeep && bdc > 7 && tdc > 7;
-        const int cb = cave_biome(wx, y, wz, s_lh[cRow + c][MMGEN_NUM_MATERIALS], 190249401, wantDeep, crystalOnly);
+        static_assert(1.5f + 4.5f * MM_SIMPLEX3_BOUND < 8.f, "depth beyond which LUSH_CAVES cannot convert");
+        const bool crystalOnly = NEAR && !wantDeep && bdc > 7 && tdc > 7;
+        const int cb = cave_biome_t<NEAR>(wx, y, wz, s_lh[cRow + c][MMGEN_NUM_MATERIALS], 190249401, wantDeep, crystalOnly);
         if (MM_FILL_EXP != 2 && (cb == MMCB_CRYSTAL_CAVES || cb == MMCB_LUSH_CAVES)) {
             s_list2[atomicAdd(&s_count[1], 1)] = (unsigned short)(i | (cb == MMCB_LUSH_CAVES ? (1 << FILL_VBITS) : 0));
             continue;
@@ -752,6 +760,21 @@ k_fill(const float* __restrict__ hf, const float* __restrict__ bw, const float* 
     }
     __syncthreads();                                               // the lists and s_cl are re-used by the next batch
   }
+}
+
+__attribute__((amdgpu_waves_per_eu(MM_FILL_WAVES, MM_FILL_WAVES)))
+__global__ void __launch_bounds__(FILL_THREADS)
+k_fill(const float* __restrict__ hf, const float* __restrict__ bw, const float* __restrict__ layers, const mmgen_cave_layer* __restrict__ caveLayers,
+       const int2* __restrict__ chunkPos, uint8_t* __restrict__ blocks, const int* __restrict__ srcIdx, unsigned* __restrict__ lushQueue, unsigned lushCap)
+{
+    fill_body<true>(hf, bw, layers, caveLayers, chunkPos, blocks, srcIdx, lushQueue, lushCap);
+}
+
+__global__ void __launch_bounds__(FILL_THREADS)
+k_fill_far(const float* __restrict__ hf, const float* __restrict__ bw, const float* __restrict__ layers, const mmgen_cave_layer* __restrict__ caveLayers,
+           const int2* __restrict__ chunkPos, uint8_t* __restrict__ blocks, const int* __restrict__ srcIdx, unsigned* __restrict__ lushQueue, unsigned lushCap)
+{
+    fill_body<false>(hf, bw, layers, caveLayers, chunkPos, blocks, srcIdx, lushQueue, lushCap);
 }
 
 // The queued lush voxels of a whole k_fill launch, 64 to a wave (entry = outChunk << 17 | column << 9 | y).
@@ -826,7 +849,7 @@ __global__ void __launch_bounds__(256) k_probe(int fn, const float* __restrict__
 // =========================================================================================================
 namespace mmk {
 
-using mmk::KID_HEIGHTFIELD; using mmk::KID_LAYERS; using mmk::KID_FIX_BACKWARD; using mmk::KID_CAVE_COLUMNS; using mmk::KID_CAVE_VOXELS;
+using mmk::KID_FILL_FAR; using mmk::KID_HEIGHTFIELD; using mmk::KID_LAYERS; using mmk::KID_FIX_BACKWARD; using mmk::KID_CAVE_COLUMNS; using mmk::KID_CAVE_VOXELS;
 using mmk::KID_CAVE_BIOMES; using mmk::KID_FILL; using mmk::KID_PROBE; using mmk::KID_FILL_LUSH;
 
 // every kernel of this translation unit can reach simplex noise: make sure the per-device table image exists, then launch (timed when
@@ -872,7 +895,7 @@ int launch_caves(const float* hf, const float* bw, const int32_t* pos, int n, mm
 }
 
 int launch_fill(const float* hf, const float* bw, const float* layers, const mmgen_cave_layer* caveLayers, const int32_t* pos, int n,
-                uint8_t* blocks, const int* srcIdx, unsigned* lushQueue, size_t lushQueueBytes, hipStream_t s)
+                uint8_t* blocks, const int* srcIdx, unsigned* lushQueue, size_t lushQueueBytes, bool allInPruneDomain, hipStream_t s)
 {
     if (n <= 0) return 0;
     const unsigned cap = lushQueue && lushQueueBytes >= 8 ? (unsigned)(lushQueueBytes / 4 - 1) : 0u;
@@ -891,6 +914,9 @@ int launch_fill(const float* hf, const float* bw, const float* layers, const mmg
         }
         LAUNCH(KID_FILL, mm::k_fill, dim3(nb * (256 / FILL_ROW)), dim3(FILL_THREADS), s, hf + 256 * in0, bw + (size_t)MMGEN_BIOME_WEIGHTS_SIZE * in0,
                layers + (size_t)MMGEN_LAYERS_SIZE * in0, caveLayers + (size_t)MMGEN_CAVE_LAYERS_SIZE * in0, p, out, idx, lushQueue, cap);
+        if (!allInPruneDomain)             // rows beyond the pruning domain (each kernel leaves the other's rows alone)
+            LAUNCH(KID_FILL_FAR, mm::k_fill_far, dim3(nb * (256 / FILL_ROW)), dim3(FILL_THREADS), s, hf + 256 * in0, bw + (size_t)MMGEN_BIOME_WEIGHTS_SIZE * in0,
+                   layers + (size_t)MMGEN_LAYERS_SIZE * in0, caveLayers + (size_t)MMGEN_CAVE_LAYERS_SIZE * in0, p, out, idx, lushQueue, cap);
         if (lushQueue) {
             const unsigned grid = (unsigned)nb * 4 < 2048u ? (unsigned)nb * 4 : 2048u;
             LAUNCH(KID_FILL_LUSH, mm::k_fill_lush, dim3(grid), dim3(256), s, (const unsigned*)lushQueue, cap, p, idx, out);

@@ -363,6 +363,13 @@ int mmgen_region_placement_buffers(mmgen_region* r, mmgen_feature_placement** d_
 
 // Base blocks of the rectangle (kernFill without the feature lists).  Needs nothing from the placement ring, so a tiling caller runs
 // it while the ring exchange with the neighbouring GPUs is in flight; mmgen_region_finish then only gathers / rasterises / decorates.
+// the rectangle's blocks all lie within the pruning domain of the exact prunings (mm_noise.cuh): the plain kernels are not launched
+static bool region_in_prune_domain(const mmgen_region* r)
+{
+    const long long lim = 32768;      // MM_PRUNE_DOMAIN
+    return 16LL * r->cx0 > -lim && 16LL * (r->cx0 + r->nx) - 1 < lim && 16LL * r->cz0 > -lim && 16LL * (r->cz0 + r->nz) - 1 < lim;
+}
+
 int mmgen_region_fill(mmgen_region* r, uint8_t* d_blocks, void* stream)
 {
     if (!r || !r->began || !d_blocks) return (int)hipErrorInvalidValue;
@@ -375,7 +382,7 @@ int mmgen_region_fill(mmgen_region* r, uint8_t* d_blocks, void* stream)
     mmk::StageRange sr("mmgen:fill");
     CK(r->fillQueue.ensure(mmk::fill_queue_bytes(r->nx * r->nz)));
     CK(mmk::launch_fill(hfP, bwP, layersP, r->caveP.as<mmgen_cave_layer>(), posP, r->nx * r->nz, d_blocks, r->targets.as<int>(),
-                        r->fillQueue.as<unsigned>(), mmk::fill_queue_bytes(r->nx * r->nz), s));
+                        r->fillQueue.as<unsigned>(), mmk::fill_queue_bytes(r->nx * r->nz), region_in_prune_domain(r), s));
     r->filled = true; r->filledInto = d_blocks;
     return 0;
 }

@@ -208,7 +208,8 @@ def test_minstd_matches_real_thrust(oracle, golden):
 
 
 def test_simplex_bounds(oracle):
-    """cave_biome on the device (csrc/mm_biome.cuh) skips evaluations whose outcome is decided by |fbm2<3>| <= 0.875 * B2 with B2 = 1.06.
+    """cave_biome on the device (csrc/mm_biome.cuh) skips evaluations whose outcome is decided by |fbm2<3>| <= 0.875 * B2 (the supremum computed here is 1.035; the device
+    uses 1.16, slack for rounding included).
     The bound is adversarial, not statistical: simplex2 = 130 * sum_k m_k^4 (g_k . x_k) <= 130 * max|g| * sup sum_k (0.5 - r_k^2)_+^4 r_k
     (every gradient aligned with its corner offset).  max|g| comes from the 289-entry gradient table exactly as the device builds it;
     the supremum over the simplex is taken on a 3000 x 3000 grid of the skewed unit cell plus the Lipschitz slack of the grid
@@ -233,6 +234,9 @@ def test_simplex_bounds(oracle):
     slack = 3 * 0.0625 * (np.sqrt(2) / n) / 2
     bound = 130.0 * gmax * (float(F.max()) + slack)
     assert bound < 1.06, bound
+    # the device uses MM_SIMPLEX2_BOUND = 1.16 and only within 32 768 blocks of the origin: a point evaluated up to 0.006 outside its cell (the
+    # rounding of the skew sum at arguments up to 2.6e4) adds at most 0.006 * 3 * 0.0625 to the sum (csrc/mm_noise.cuh)
+    assert 130.0 * gmax * (float(F.max()) + slack + 0.006 * 3 * 0.0625) < 1.16
     rs = np.random.RandomState(3)
     xy = (rs.rand(2_000_000, 2).astype(f) - f(0.5)) * f(2000.0)
     out = np.zeros(len(xy), f)
@@ -242,7 +246,7 @@ def test_simplex_bounds(oracle):
 
 def test_simplex3_bound(oracle):
     """cave_huge on the device (csrc/mmgen_kernels.hip) leaves its octave loop once the octaves still to come cannot move the result,
-    using |simplex3| <= B3 = 1.23.  Adversarial bound like test_simplex_bounds: simplex3 = 42 * sum_k m_k^4 (g_k . x_k)
+    using |simplex3| <= B3 (the supremum computed here is 1.226; the device uses 1.37, slack for rounding included).  Adversarial bound like test_simplex_bounds: simplex3 = 42 * sum_k m_k^4 (g_k . x_k)
     <= 42 * sup|g| * sup sum_k (0.6 - r_k^2)_+^4 r_k.  sup|g|: a gradient is p * (1.79284291400159 - 0.85373472095314 |p|^2), whose length
     s (1.7928... - 0.8537... s^2) is at most 1.00001 whatever p is.  The supremum over the simplex: coarse grid of the unit cell (160^3),
     then 8^3 sub-grids of every coarse cell that could still hold the maximum, plus the Lipschitz slack of the fine grid
@@ -278,6 +282,8 @@ def test_simplex3_bound(oracle):
     fine = max(float(F((sel[k:k + 2000, None, :] + S[None]).reshape(-1, 3)).max()) for k in range(0, len(sel), 2000))
     bound = 42.0 * 1.00001 * (fine + 4 * 0.1296 * (np.sqrt(3) * h / m / 2))
     assert bound < 1.23, bound
+    # the device uses MM_SIMPLEX3_BOUND = 1.37 inside its pruning domain: 0.006 outside the cell adds at most 0.006 * 4 * 0.1296 to the sum
+    assert 42.0 * 1.00001 * (fine + 4 * 0.1296 * (np.sqrt(3) * h / m / 2) + 0.006 * 4 * 0.1296) < 1.37
     f = np.float32
     rs = np.random.RandomState(4)
     xyz = (rs.rand(2_000_000, 3).astype(f) - f(0.5)) * f(2000.0)

@@ -88,7 +88,7 @@ CS = "mega-minecraft_amd/csrc/"
 DEVICE_MAP = {
     "biomeFuncs.hpp::getSingleBiomeNoise": ([CS + "mm_biome.cuh"], [r"float\s+single_biome_noise\s*\([^)]*\)\s*\{"], None),
     "biomeFuncs.hpp::getBiomeNoise": ([CS + "mm_biome.cuh"], [r"BiomeNoise\s+biome_noise\s*\([^)]*\)\s*\{"], None),
-    "biomeFuncs.hpp::getCaveBiomeNoise": ([CS + "mm_biome.cuh"], [r"int\s+cave_biome\s*\([^)]*\)\s*\{"], None),
+    "biomeFuncs.hpp::getCaveBiomeNoise": ([CS + "mm_biome.cuh"], [r"int\s+cave_biome_t\s*\([^)]*\)\s*\{"], None),
     "biomeFuncs.hpp::getHeight": ([CS + "mm_biome.cuh"], [r"float\s+biome_height\s*\([^)]*\)\s*\{"], "MMBIO_"),
     "biomeFuncs.hpp::biomeBlockPreProcess": ([CS + "mm_biome.cuh"], [r"bool\s+biome_block_pre\s*\([^)]*\)\s*\{"], None),
     "biomeFuncs.hpp::biomeBlockPostProcess": ([CS + "mm_biome.cuh"], [r"void\s+biome_block_post\s*\([^)]*\)\s*\{"], "MMBIO_"),
@@ -126,10 +126,11 @@ DEVICE_BENIGN = {0.0, 0.5, 1.0, 2.0, 3.0, 4.0, 5.0, 6.0, 9.0, 16.0, 63.0, 64.0, 
                  float(np.float32(3.402823466e+38))}
 DEVICE_EXTRA = {
     "biomeFuncs.hpp::getBiomeNoise": (float(np.float32(0.32)),),         # overallBiomeScale, a file-level constant in the reference (biomeFuncs.hpp:105)
-    # cave_biome: fbm3From3's component offsets (rng.hpp:188-191, rolled into the loop) and the exact-pruning bound 0.875 * 1.06
-    # cave_huge: exact-pruning bound B3 and its slack; k_cave_voxels: kCaveFaMax >= sup |fbm3<4>| = 0.9375 * B3
-    "chunk.cu::shouldGenerateCaveAtBlock": (float(np.float32(1.23)), float(np.float32(0.001)), float(np.float32(1.16))),
-    "biomeFuncs.hpp::getCaveBiomeNoise": tuple(float(np.float32(v)) for v in (0.875, 1.06, 5923.45, 4129.42, 5790.48, 1765.68, 4704.36, 5692.12)),
+    # cave_huge: slack of its exact pruning; k_cave_voxels: kCaveFaMax = 0.9375 * MM_SIMPLEX3_BOUND (the octave amplitudes of fbm3<4> sum to
+    # 0.9375), 1e30 = "no bound" outside the pruning domain (the bounds themselves are macros of mm_noise.cuh)
+    "chunk.cu::shouldGenerateCaveAtBlock": (float(np.float32(0.001)), 0.9375, float(np.float32(1e30))),
+    # cave_biome: fbm3From3's component offsets (rng.hpp:188-191, rolled into the loop) and 0.875 = the octave amplitudes of fbm2<3>
+    "biomeFuncs.hpp::getCaveBiomeNoise": tuple(float(np.float32(v)) for v in (0.875, 5923.45, 4129.42, 5790.48, 1765.68, 4704.36, 5692.12)),
 }
 DEVICE_ALLOW = {
     "featurePlacement.hpp::placeFeature": (0.0, 1.0),
