@@ -52,6 +52,8 @@ REGIONS = [
     (1767, -1044, 1, 1), (3227, 152, 1, 1), (1602, 977, 1, 1), (3946, -3906, 1, 1), (-2105, -2470, 1, 1), (-88, -3971, 1, 1),
     # world edge: block coordinates 6.4e8 (fp32 ulp 64), noise lattice cells beyond the LDS tables' domain
     (40_000_000, -40_000_000, 1, 1),
+    # across the border of the pruning domain (|block x|, |z| < 32 768 = chunk 2048, csrc/mm_noise.cuh): pruned and plain kernels in one launch
+    (2046, -2050, 4, 3), (-2049, 2047, 2, 2),
 ]
 
 
