@@ -170,10 +170,8 @@ MM_DEV float simplex2_inl(float vx, float vy)
     const float ax = (x0x + C0) - i1x, ay = (x0y + C0) - i1y;     // x12.xy
     const float bx = x0x + C2, by = x0y + C2;                     // x12.zw
 
-    // table domain: lattice coordinates below 2^24 in magnitude (then glm::mod(x, 289) is an integer in [0, 288]); NaN fails the test
-    const bool inDomain = __builtin_fabsf(ix) < 16777216.f && __builtin_fabsf(iy) < 16777216.f;
-    ix = gmod(ix, 289.f);
-    iy = gmod(iy, 289.f);
+    // table domain: lattice coordinates below 2^24 - 512 in magnitude (then glm::mod(x, 289) is an integer in [0, 288]); NaN fails the test
+    const bool inDomain = __builtin_fabsf(ix) < 16776704.f && __builtin_fabsf(iy) < 16776704.f;      // 2^24 - 512, see below
 
     float m0 = gmax(0.5f - (x0x * x0x + x0y * x0y), 0.f);
     float m1 = gmax(0.5f - (ax * ax + ay * ay), 0.f);
@@ -183,13 +181,22 @@ MM_DEV float simplex2_inl(float vx, float vy)
 
     f3 c0, c1, c2;
     if (inDomain) {
-        const int x4 = 4 * (int)ix, y4 = 4 * (int)iy;
+        // glm::mod(i, 289) = i - 289 floor(i / 289) with an IEEE division (two of them are a quarter of this function's instructions).  For an
+        // integer |i| < 2^24 - 512 the correctly rounded quotient has the true quotient's floor (the nearest multiple of 289 is 1 / 289 =
+        // 0.0035 away, more than half an ulp of any quotient below 2^16), 289 * floor is at most |i| + 288 < 2^24 and therefore exact (for a
+        // negative i just below -2^24 + 288 it is not: found by test_device_simplex_lattice_hash_shortcuts), so is the subtraction: the
+        // integer remainder IS glm's value.
+        int xi = (int)ix % 289, yi = (int)iy % 289;
+        xi += xi < 0 ? 289 : 0; yi += yi < 0 ? 289 : 0;
+        const int x4 = 4 * xi, y4 = 4 * yi;
         const int py0 = perm4(y4), py1 = perm4(y4 + 4);              // i1.y is 0 or 1: the middle corner re-uses one of the two
         const f4v t0 = grad2_at(py0 + x4);
         const f4v t1 = grad2_at(gt ? (py0 + x4) + 4 : (py1 + x4));
         const f4v t2 = grad2_at((py1 + x4) + 4);
         c0 = mk3(t0.x, t0.y, t0.z); c1 = mk3(t1.x, t1.y, t1.z); c2 = mk3(t2.x, t2.y, t2.z);
     } else {
+        ix = gmod(ix, 289.f);
+        iy = gmod(iy, 289.f);
         c0 = simplex2_corner(permute((permute(iy + 0.f) + ix) + 0.f));
         c1 = simplex2_corner(permute((permute(iy + i1y) + ix) + i1x));
         c2 = simplex2_corner(permute((permute(iy + 1.f) + ix) + 1.f));
@@ -258,10 +265,15 @@ MM_DEV void simplex3_gradients_direct(float ix, float iy, float iz, bool gxb, bo
 // Same values through the LDS tables (see the header); falls back to the arithmetic outside the tables' domain.
 MM_DEV void simplex3_gradients(float ix, float iy, float iz, bool gx, bool gy, bool gz, float* __restrict__ q)
 {
-    // table domain: lattice coordinates below 2^24 in magnitude (then mod289 is an integer in [-1, 289]); NaN fails the test
-    const bool inDomain = __builtin_fabsf(ix) < 16777216.f && __builtin_fabsf(iy) < 16777216.f && __builtin_fabsf(iz) < 16777216.f;
-    ix = mod289(ix); iy = mod289(iy); iz = mod289(iz);
+    // table domain: lattice coordinates below 2^23 in magnitude (then mod289 is an integer in [-1, 289]); NaN fails the test
+    // (2^23: below it 289 * floor(i / 289) is exact, see below)
+    const bool inDomain = __builtin_fabsf(ix) < 8388608.f && __builtin_fabsf(iy) < 8388608.f && __builtin_fabsf(iz) < 8388608.f;
     if (inDomain) {
+        // mod289(i) = i - floor(i * (1 / 289)) * 289: for |i| < 2^23 the product floor * 289 is an integer below 2^24, hence exact, and so is the
+        // difference: one fused multiply-add returns the same value as the multiply and the subtraction
+        ix = __builtin_fmaf(-289.f, __builtin_floorf(ix * (1.f / 289.f)), ix);
+        iy = __builtin_fmaf(-289.f, __builtin_floorf(iy * (1.f / 289.f)), iy);
+        iz = __builtin_fmaf(-289.f, __builtin_floorf(iz * (1.f / 289.f)), iz);
         const bool i1x = gx && !gz, i1y = gy && !gx, i1z = gz && !gy;
         const bool i2x = gx || !gz, i2y = gy || !gx, i2z = gz || !gy;
         const int x4 = 4 * (int)ix, y4 = 4 * (int)iy, z4 = 4 * (int)iz;
@@ -276,6 +288,7 @@ MM_DEV void simplex3_gradients(float ix, float iy, float iz, bool gx, bool gy, b
             q[3 * k] = g.x; q[3 * k + 1] = g.y; q[3 * k + 2] = g.z;
         }
     } else {
+        ix = mod289(ix); iy = mod289(iy); iz = mod289(iz);
         simplex3_gradients_direct(ix, iy, iz, gx, gy, gz, q);
     }
 }

@@ -28,6 +28,33 @@ def test_device_simplex_matches_real_glm(gen, golden):
     assert_bit_equal(gen.debug_probe("simplex3_split", g["xyz"], len(g["xyz"]))[:, 0], g["simplex3"], "device split simplex3 vs glm")
 
 
+def test_device_simplex_lattice_hash_shortcuts(gen, oracle):
+    """The device replaces glm::mod(i, 289)'s IEEE division by an integer remainder (simplex2, |i| < 2^24) and mod289's multiply + subtract by
+    one fused multiply-add (simplex3, |i| < 2^23): exact by the arguments in csrc/mm_noise.cuh.  Held to the oracle (itself held to the real
+    glm on 1.6 M points) where those arguments are tight: lattice coordinates around multiples of 289, negative, up to and across the
+    two domain limits."""
+    import ctypes
+    f = np.float32
+    rs = np.random.RandomState(9)
+
+    def pts(dim, scale, n):
+        base = (rs.randint(-scale // 289, scale // 289, (n, dim)) * 289 + rs.randint(-2, 3, (n, dim))).astype(np.float64)
+        return np.concatenate([(base + rs.rand(n, dim)).astype(f), ((rs.rand(n, dim) - 0.5) * 2 * scale).astype(f)])
+
+    def ref(fn, a):
+        out = np.zeros(len(a), f)
+        a = np.ascontiguousarray(a)
+        fn(len(a), a.ctypes.data_as(ctypes.c_void_p), out.ctypes.data_as(ctypes.c_void_p))
+        return out
+
+    for scale in (5000, 4_000_000, 8_388_000 * 2, 16_777_000 * 2):             # small; large; across 2^23; across 2^24 (arguments are ~ 1.4 x the lattice coordinate)
+        a2 = pts(2, scale, 20000)
+        assert_bit_equal(gen.debug_probe("simplex2", a2, len(a2))[:, 0], ref(oracle.lib.mmo_simplex2, a2), f"simplex2 at scale {scale}")
+        a3 = pts(3, scale, 20000)
+        assert_bit_equal(gen.debug_probe("simplex3", a3, len(a3))[:, 0], ref(oracle.lib.mmo_simplex3, a3), f"simplex3 at scale {scale}")
+        assert_bit_equal(gen.debug_probe("simplex3_split", a3, len(a3))[:, 0], ref(oracle.lib.mmo_simplex3, a3), f"split simplex3 at scale {scale}")
+
+
 def test_device_math_matches_kat(gen, golden):
     k = golden["oracle_kat"]
     n = len(k["trig_in"])
