@@ -671,7 +671,11 @@ MM_DEV void fill_body(const float* __restrict__ hf, const float* __restrict__ bw
         const int c = u % FILL_COLS, y = u / FILL_COLS;
         const int v = 384 * c + y;                                  // position in the batch's 1 536 output bytes
         const int idx2d = idxBase + c;
-        const int wx = cp.x + (idx2d & 15), wz = cp.y + (idx2d >> 4);
+        const int wx = cp.x + (idx2d & 15);
+        int wz = cp.y + (idx2d >> 4);
+        // wz is the same for the whole workgroup (one row of a chunk): left visible, the compiler hoists (float)wz * scale for each of the six
+        // block-rule noises out of the loop into six VGPRs it then has to spill (the kernel sits at its register budget)
+        asm volatile("" : "+v"(wz));
         const ColumnBiomes cbi = {s_nzN[cRow + c], s_ocean[cRow + c] != 0, s_nzIdx[cRow + c], s_nzW[cRow + c], s_bw[cRow + c]};
         const BaseBlock r = place_block_base(cbi, s_lh[cRow + c], s_cl[c], y, s_lh[cRow + c][MMGEN_NUM_MATERIALS], wx, wz);
         if (r.needCave) {
