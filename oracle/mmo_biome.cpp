@@ -46,19 +46,19 @@ Tables::Tables()
 #undef CW
 
     // biomeFuncs.hpp:786-801 (BiomeBlocks default grassBlock = DIRT, biome.hpp:60-63)
-    for (int i = 0; i < numBiomes; ++i) grassBlock[i] = Block::DIRT;
-    grassBlock[(int)Biome::TROPICAL_BEACH] = Block::JUNGLE_GRASS_BLOCK;
-    grassBlock[(int)Biome::SAVANNA] = Block::SAVANNA_GRASS_BLOCK;
-    grassBlock[(int)Biome::FROZEN_WASTELAND] = Block::SNOWY_GRASS_BLOCK;
-    grassBlock[(int)Biome::REDWOOD_FOREST] = Block::GRASS_BLOCK;
-    grassBlock[(int)Biome::SHREKS_SWAMP] = Block::JUNGLE_GRASS_BLOCK;
-    grassBlock[(int)Biome::LUSH_BIRCH_FOREST] = Block::GRASS_BLOCK;
-    grassBlock[(int)Biome::TIANZI_MOUNTAINS] = Block::GRASS_BLOCK;
-    grassBlock[(int)Biome::JUNGLE] = Block::JUNGLE_GRASS_BLOCK;
-    grassBlock[(int)Biome::PURPLE_MUSHROOMS] = Block::MYCELIUM;
-    grassBlock[(int)Biome::OASIS] = Block::JUNGLE_GRASS_BLOCK;
-    grassBlock[(int)Biome::PLAINS] = Block::GRASS_BLOCK;
-    grassBlock[(int)Biome::MOUNTAINS] = Block::GRASS_BLOCK;
+    for (int i = 0; i < numBiomes; ++i) biomeBlocks[i].grassBlock = Block::DIRT;
+    biomeBlocks[(int)Biome::TROPICAL_BEACH].grassBlock = Block::JUNGLE_GRASS_BLOCK;
+    biomeBlocks[(int)Biome::SAVANNA].grassBlock = Block::SAVANNA_GRASS_BLOCK;
+    biomeBlocks[(int)Biome::FROZEN_WASTELAND].grassBlock = Block::SNOWY_GRASS_BLOCK;
+    biomeBlocks[(int)Biome::REDWOOD_FOREST].grassBlock = Block::GRASS_BLOCK;
+    biomeBlocks[(int)Biome::SHREKS_SWAMP].grassBlock = Block::JUNGLE_GRASS_BLOCK;
+    biomeBlocks[(int)Biome::LUSH_BIRCH_FOREST].grassBlock = Block::GRASS_BLOCK;
+    biomeBlocks[(int)Biome::TIANZI_MOUNTAINS].grassBlock = Block::GRASS_BLOCK;
+    biomeBlocks[(int)Biome::JUNGLE].grassBlock = Block::JUNGLE_GRASS_BLOCK;
+    biomeBlocks[(int)Biome::PURPLE_MUSHROOMS].grassBlock = Block::MYCELIUM;
+    biomeBlocks[(int)Biome::OASIS].grassBlock = Block::JUNGLE_GRASS_BLOCK;
+    biomeBlocks[(int)Biome::PLAINS].grassBlock = Block::GRASS_BLOCK;
+    biomeBlocks[(int)Biome::MOUNTAINS].grassBlock = Block::GRASS_BLOCK;
 
     // biomeFuncs.hpp:808-837: material/block, thickness, noise amplitude, noise scale
 #define MI(m, v1, v2, v3) materialInfos[(int)Material::m] = {Block::m, v1, v2, v3}
@@ -335,45 +335,60 @@ CaveBiomeNoise getCaveBiomeNoise(const vec3 worldBlockPos, float maxHeight)    /
     return noise;
 }
 
-static inline void applySingleBiomeNoise(float& totalWeight, const W weight, const float noise)
+static inline void applySingleBiomeNoise(float& totalWeight, const BiomeWeightType weight, const float noise)
 {
     switch (weight) {
-    case wP: totalWeight *= noise; break;
-    case wN: totalWeight *= 1.f - noise; break;
+    case BiomeWeightType::W_POSITIVE: totalWeight *= noise; break;
+    case BiomeWeightType::W_NEGATIVE: totalWeight *= 1.f - noise; break;
     default: break;
     }
 }
 
+// the reference's __constant__ copies of the rule tables (biomeFuncs.hpp:105-107)
+#define dev_biomeNoiseWeights (T().biomeNoiseWeights)
+#define dev_caveBiomeNoiseWeights (T().caveBiomeNoiseWeights)
+
 float getBiomeWeight(Biome biome, const BiomeNoise& noise)     // biomeFuncs.hpp:171-185
 {
-    const auto& w = T().biomeNoiseWeights[(int)biome];
+    const auto& biomeWeights = dev_biomeNoiseWeights[(int)biome];
+
     float totalWeight = 1.f;
-    applySingleBiomeNoise(totalWeight, w.ocean, noise.ocean);
-    applySingleBiomeNoise(totalWeight, w.beach, noise.beach);
-    applySingleBiomeNoise(totalWeight, w.rocky, noise.rocky);
-    applySingleBiomeNoise(totalWeight, w.magic, noise.magic);
-    applySingleBiomeNoise(totalWeight, w.temperature, noise.temperature);
-    applySingleBiomeNoise(totalWeight, w.moisture, noise.moisture);
+
+#define applyNoise(type) applySingleBiomeNoise(totalWeight, biomeWeights.type, noise.type)
+    applyNoise(ocean);
+    applyNoise(beach);
+    applyNoise(rocky);
+    applyNoise(magic);
+    applyNoise(temperature);
+    applyNoise(moisture);
+#undef applyNoise
+
     return totalWeight;
 }
 
 float getCaveBiomeWeight(CaveBiome biome, const CaveBiomeNoise& noise)     // biomeFuncs.hpp:187-199
 {
-    const auto& w = T().caveBiomeNoiseWeights[(int)biome];
+    const auto& caveBiomeWeights = dev_caveBiomeNoiseWeights[(int)biome];
+
     float totalWeight = 1.f;
-    applySingleBiomeNoise(totalWeight, w.none, noise.none);
-    applySingleBiomeNoise(totalWeight, w.shallow, noise.shallow);
-    applySingleBiomeNoise(totalWeight, w.warped, noise.warped);
-    applySingleBiomeNoise(totalWeight, w.rocky, noise.rocky);
+
+#define applyNoise(type) applySingleBiomeNoise(totalWeight, caveBiomeWeights.type, noise.type)
+    applyNoise(none);
+    applyNoise(shallow);
+    applyNoise(warped);
+    applyNoise(rocky);
+#undef applyNoise
+
     return totalWeight;
 }
 
 CaveBiome getCaveBiome(ivec3 worldBlockPos, float maxHeight, int seed)     // biomeFuncs.hpp:201-220
 {
-    CaveBiomeNoise noise = getCaveBiomeNoise(vec3(worldBlockPos), maxHeight);
+    CaveBiomeNoise noise = getCaveBiomeNoise(worldBlockPos, maxHeight);
 
-    Rng rng = makeSeededRandomEngine(worldBlockPos.x, worldBlockPos.y, worldBlockPos.z, seed);
-    float rand = rng.u01();
+    auto rng = makeSeededRandomEngine(worldBlockPos.x, worldBlockPos.y, worldBlockPos.z, seed);
+    uniform_real_distribution<float> u01(0, 1);
+    float rand = u01(rng);
     for (int caveBiomeIdx = 0; caveBiomeIdx < numCaveBiomes; ++caveBiomeIdx) {
         CaveBiome caveBiome = (CaveBiome)caveBiomeIdx;
         float weight = getCaveBiomeWeight(caveBiome, noise);
@@ -602,7 +617,7 @@ bool biomeBlockPostProcess(Block* blockPtr, Biome biome, ivec3 worldBlockPos, fl
     }
     case Biome::CRYSTALS: {
         if (!isTopBlock || *blockPtr == Block::QUARTZ) return false;
-        if (rand1From2(vec2((float)(worldBlockPos.x + 913213), (float)(worldBlockPos.z + 85941))) < 0.1f) {
+        if (rand1From2(vec2(worldBlockPos.x + 913213, worldBlockPos.z + 85941)) < 0.1f) {
             *blockPtr = Block::MYCELIUM;
             return true;
         }
@@ -625,14 +640,14 @@ bool caveBiomeBlockPostProcess(Block* blockPtr, CaveBiome caveBiome, ivec3 world
     if (caveBiome == CaveBiome::NONE) return false;
 
     bool isTopBlock = caveBottomDepth == 0;
-    // bool isBottomBlock = caveTopDepth == 0;   (unused in the reference too)
+    bool isBottomBlock = caveTopDepth == 0;
+    (void)isBottomBlock;                                  // unused in the reference too
 
     switch (caveBiome) {
     case CaveBiome::CRYSTAL_CAVES: {
         if (*blockPtr != Block::STONE && *blockPtr != Block::DEEPSLATE && *blockPtr != Block::BLACKSTONE) return false;
 
-        vec3 noisePos = vec3((float)(worldBlockPos.x + worldBlockPos.y), (float)(worldBlockPos.z + 5819323),
-                             (float)(worldBlockPos.x + worldBlockPos.z) * 2.0f) * 0.05f;
+        vec3 noisePos = vec3(worldBlockPos.x + worldBlockPos.y, worldBlockPos.z + 5819323, (worldBlockPos.x + worldBlockPos.z) * 2.0f) * 0.05f;
         float quartzNoise = simplex(noisePos);
         if (quartzNoise < -0.25f) {
             *blockPtr = Block::QUARTZ;
@@ -651,7 +666,7 @@ bool caveBiomeBlockPostProcess(Block* blockPtr, CaveBiome caveBiome, ivec3 world
             cobblestoneBlock = Block::COBBLED_DEEPSLATE;
         }
 
-        if (rand1From3(vec3(worldBlockPos)) < cobblestoneChance) {
+        if (rand1From3(worldBlockPos) < cobblestoneChance) {
             *blockPtr = cobblestoneBlock;
             return true;
         }
@@ -662,8 +677,7 @@ bool caveBiomeBlockPostProcess(Block* blockPtr, CaveBiome caveBiome, ivec3 world
 
         vec3 noisePos = vec3(worldBlockPos) * 0.025f;
         float threshold = 1.5f + 4.5f * simplex(noisePos);
-        const float bd = (float)caveBottomDepth, td = (float)caveTopDepth;
-        if (!(bd >= 0.f && bd <= threshold) && !(td >= 0.f && td <= threshold)) return false;
+        if (!isInRange((float)caveBottomDepth, 0.f, threshold) && !isInRange((float)caveTopDepth, 0.f, threshold)) return false;
 
         noisePos.y += 192031.9821f;
         vec3 noiseOffset = fbm3From3<3>(noisePos * 0.4f) * 2.f;
@@ -686,7 +700,7 @@ bool caveBiomeBlockPostProcess(Block* blockPtr, CaveBiome caveBiome, ivec3 world
     }
     default: break;
     }
-    return false;
+    __builtin_unreachable();      // the reference falls off the end here (biomeFuncs.hpp:706-707); every CaveBiome value returns above
 }
 
 }  // namespace mmo

@@ -9,6 +9,8 @@
 //   src/terrain/biomeFuncs.hpp:385-707 biomeBlockPreProcess / biomeBlockPostProcess / caveBiomeBlockPostProcess
 //   src/terrain/biomeFuncs.hpp:725-1256 BiomeUtils::init (tables)
 #pragma once
+#include <algorithm>
+#include <initializer_list>
 #include <vector>
 #include <array>
 #include <initializer_list>
@@ -151,28 +153,41 @@ struct CaveFeaturePlacement {   // biome.hpp:239-245, 24 bytes
 };
 static_assert(sizeof(CaveFeaturePlacement) == 24, "CaveFeaturePlacement wire size");
 
-struct DecoratorGen {           // biome.hpp:247-287; sets become small vectors (membership only)
+// std::unordered_set<Block> of the reference (biome.hpp:251-252) as a small vector with the three members the path uses
+// (empty / find / end: membership only, iteration order never matters)
+struct BlockSet {
+    std::vector<Block> v;
+    BlockSet() {}
+    BlockSet(std::initializer_list<Block> l) : v(l) {}
+    BlockSet(const std::vector<Block>& l) : v(l) {}
+    bool empty() const { return v.empty(); }
+    std::vector<Block>::const_iterator end() const { return v.end(); }
+    std::vector<Block>::const_iterator find(Block b) const { return std::find(v.begin(), v.end(), b); }
+};
+
+struct DecoratorGen {           // biome.hpp:247-287
     Block decoratorBlock;
     float chance;
-    std::vector<Block> possibleUnderBlocks;
-    std::vector<Block> possibleReplaceBlocks{Block::AIR};
+    BlockSet possibleUnderBlocks;
+    BlockSet possibleReplaceBlocks{Block::AIR};
     Block secondDecoratorBlock = Block::AIR;
     bool generatesFromCeiling = false;
     DecoratorGen(Block b, float c, std::vector<Block> under) : decoratorBlock(b), chance(c), possibleUnderBlocks(under) {}
-    DecoratorGen& setWater() { possibleReplaceBlocks = {Block::WATER}; return *this; }
+    DecoratorGen& setWater() { possibleReplaceBlocks = BlockSet{Block::WATER}; return *this; }
     DecoratorGen& setSecondDecoratorBlock(Block b) { secondDecoratorBlock = b; return *this; }
     DecoratorGen& setGeneratesFromCeiling() { generatesFromCeiling = true; return *this; }
 };
 
 // ------------------------------------------------------------------ tables (BiomeUtils::init, biomeFuncs.hpp:725-1256)
-enum W : unsigned char { wI, wP, wN };
+enum W : unsigned char { wI, wP, wN, W_IGNORED = wI, W_POSITIVE = wP, W_NEGATIVE = wN };
+typedef W BiomeWeightType;               // biome.hpp's enum class BiomeWeightType; the short names keep the 24 x 6 rule table readable
 struct BiomeWeights { W ocean, beach, rocky, magic, temperature, moisture; };
 struct CaveBiomeWeights { W none, shallow, warped, rocky; };
 
 struct Tables {
     BiomeWeights biomeNoiseWeights[numBiomes];
     CaveBiomeWeights caveBiomeNoiseWeights[numCaveBiomes];
-    Block grassBlock[numBiomes];
+    struct BiomeBlocks { Block grassBlock; } biomeBlocks[numBiomes];    // biome.hpp:60-63
     MaterialInfo materialInfos[numMaterials];
     float biomeMaterialWeights[numBiomes * numMaterials];
     ivec2 dirVecs2d[8];

@@ -160,11 +160,11 @@ void mmo_tables_gens(int* featureBounds /*[21][2]*/, int* caveFeatureBounds /*[1
             const DecoratorGen& g = gens[k];
             float* o = base + k * 10;
             std::vector<int> under;
-            for (Block u : g.possibleUnderBlocks) under.push_back((int)u);
+            for (Block u : g.possibleUnderBlocks.v) under.push_back((int)u);
             std::sort(under.begin(), under.end());
             o[0] = 1; o[1] = (float)(int)g.decoratorBlock; o[2] = g.chance; o[3] = (float)under.size();
             for (size_t j = 0; j < under.size() && j < 3; ++j) o[4 + j] = (float)under[j];
-            o[7] = (float)(int)g.possibleReplaceBlocks[0]; o[8] = (float)(int)g.secondDecoratorBlock; o[9] = g.generatesFromCeiling ? 1.f : 0.f;
+            o[7] = (float)(int)g.possibleReplaceBlocks.v[0]; o[8] = (float)(int)g.secondDecoratorBlock; o[9] = g.generatesFromCeiling ? 1.f : 0.f;
         }
     };
     std::memset(decoGens, 0, sizeof(float) * numBiomes * 7 * 10);
@@ -177,7 +177,7 @@ void mmo_tables_rules(uint8_t* biome144, uint8_t* cave20, uint8_t* grass24)
     for (int b = 0; b < numBiomes; ++b) {
         const auto& w = T().biomeNoiseWeights[b];
         uint8_t* o = biome144 + 6 * b; o[0] = w.ocean; o[1] = w.beach; o[2] = w.rocky; o[3] = w.magic; o[4] = w.temperature; o[5] = w.moisture;
-        grass24[b] = (uint8_t)T().grassBlock[b];
+        grass24[b] = (uint8_t)T().biomeBlocks[b].grassBlock;
     }
     for (int b = 0; b < numCaveBiomes; ++b) {
         const auto& w = T().caveBiomeNoiseWeights[b];
@@ -242,7 +242,7 @@ void mmo_decorators(int n, const int* posXZ, const float* hf, const float* bw, c
 // single-voxel feature probes (fixture 11 of SURVEY §8c): rasterise one placement into a box
 void mmo_place_feature_box(int feature, const int* fpos, int canReplace, const int* boxMin, const int* boxSize, uint8_t* out)
 {
-    FeaturePlacement p; std::memset(&p, 0, sizeof(p));
+    FeaturePlacement p; std::memset((void*)&p, 0, sizeof(p));
     p.feature = (Feature)feature; p.pos = ivec3{fpos[0], fpos[1], fpos[2]}; p.canReplaceBlocks = canReplace != 0;
     size_t k = 0;
     for (int z = 0; z < boxSize[2]; ++z) for (int x = 0; x < boxSize[0]; ++x) for (int y = 0; y < boxSize[1]; ++y, ++k) {
@@ -253,7 +253,7 @@ void mmo_place_feature_box(int feature, const int* fpos, int canReplace, const i
 }
 void mmo_place_cave_feature_box(int feature, const int* fpos, int layerHeight, int canReplace, const int* boxMin, const int* boxSize, uint8_t* out)
 {
-    CaveFeaturePlacement p; std::memset(&p, 0, sizeof(p));
+    CaveFeaturePlacement p; std::memset((void*)&p, 0, sizeof(p));
     p.feature = (CaveFeature)feature; p.pos = ivec3{fpos[0], fpos[1], fpos[2]}; p.layerHeight = layerHeight; p.canReplaceBlocks = canReplace != 0;
     size_t k = 0;
     for (int z = 0; z < boxSize[2]; ++z) for (int x = 0; x < boxSize[0]; ++x) for (int y = 0; y < boxSize[1]; ++y, ++k) {

@@ -17,6 +17,33 @@
 
 namespace mmo {
 
+// ---------------------------------------------------------------- utility functions (rng.hpp:9-63)
+template <class T> static inline int manhattanLength(T v) { return compAdd(g_abs(v)); }
+template <class T> static inline int manhattanDistance(T a, T b) { return compAdd(g_abs(a - b)); }
+template <class T> static inline bool isInRange(T v, T min, T max) { return v >= min && v <= max; }
+template <class T> static inline bool isPosInRange(T pos, T corner1, T corner2)
+{
+    T minPos = g_min(corner1, corner2);
+    T maxPos = g_max(corner1, corner2);
+    return pos.x >= minPos.x && pos.x <= maxPos.x
+        && pos.y >= minPos.y && pos.y <= maxPos.y
+        && pos.z >= minPos.z && pos.z <= maxPos.z;
+}
+static inline float getRatio(float v, float minVal, float maxVal) { return (v - minVal) / (maxVal - minVal); }
+static inline float saturate(float v) { return g_clamp(v, 0.f, 1.f); }
+static inline bool isSaturated(float v) { return v >= 0.f && v <= 1.f; }
+
+static bool calculateLineParams(const vec3 pos, const vec3 linePos1, const vec3 linePos2, float* ratio, float* distFromLine)
+{
+    vec3 vecLine = linePos2 - linePos1;
+    vec3 pointPos = pos - linePos1;
+    *ratio = g_dot(pointPos, vecLine) / g_dot(vecLine, vecLine);
+    vec3 pointLine = vecLine * (*ratio);
+    *distFromLine = g_distance(pointPos, pointLine);
+    return isSaturated(*ratio);
+}
+
+
 // ---------------------------------------------------------------- integer hash + minstd (rng.hpp:69-96)
 static inline uint32_t hash_u32(uint32_t a)
 {
@@ -54,15 +81,37 @@ struct Rng {           // thrust::minstd_rand: x <- 48271 x mod (2^31-1), min 1,
     }
 };
 
-static inline Rng makeSeededRandomEngine(int x) { return Rng(hash_u32((uint32_t)x)); }
+// thrust::uniform_real_distribution<T>(a, b), thrust/random/detail/uniform_real_distribution.inl operator(): the engine's draw minus
+// its minimum, over 1 + (max - min) in T, scaled to [a, b).  Declared the way the reference declares them
+// (`thrust::uniform_real_distribution<float> u01(0, 1);`, featurePlacement.hpp:155-156) and called the same way (`u01(featureRng)`).
+template <class T>
+struct uniform_real_distribution {
+    T a, b;
+    uniform_real_distribution(T a_, T b_) : a(a_), b(b_) {}
+    T operator()(Rng& urng) const
+    {
+        T result = (T)(urng.next() - 1u);
+        result /= ((T)1 + (T)(2147483646u - 1u));
+        return (result * (b - a)) + a;
+    }
+};
+
+// The reference seeds in `int` arithmetic: (1 << 31) | (x << 22) | y shifts bits out of and into the sign bit, which is modular two's
+// complement arithmetic since C++20 (the oracle is built with -std=c++20; CUDA's nvcc computes the same bits); the int converts to the
+// unsigned parameter of hash() and the int result to the engine's unsigned seed modulo 2^32.
+static inline Rng makeSeededRandomEngine(int x)
+{
+    int h = hash_u32(x);
+    return Rng(h);
+}
 static inline Rng makeSeededRandomEngine(int x, int y, int z)
 {
-    uint32_t h = hash_u32(0x80000000u | ((uint32_t)x << 22) | (uint32_t)y) ^ hash_u32((uint32_t)z);
+    int h = hash_u32((1 << 31) | (x << 22) | y) ^ hash_u32(z);
     return Rng(h);
 }
 static inline Rng makeSeededRandomEngine(int x, int y, int z, int w)
 {
-    uint32_t h = hash_u32(0x80000000u | ((uint32_t)x << 22) | ((uint32_t)y << 11) | (uint32_t)w) ^ hash_u32((uint32_t)z);
+    int h = hash_u32((1 << 31) | (x << 22) | (y << 11) | w) ^ hash_u32(z);
     return Rng(h);
 }
 
@@ -70,27 +119,37 @@ static inline Rng makeSeededRandomEngine(int x, int y, int z, int w)
 static inline float rand1From1(float v) { return g_fract(mm_sinf(v * 238.68f) * 39021.426f); }
 static inline float rand1From2(vec2 v) { return g_fract(mm_sinf(g_dot(v, vec2(238.68f, 491.28f))) * 39021.426f); }
 static inline float rand1From3(vec3 v) { return g_fract(mm_sinf(g_dot(v, vec3(238.68f, 491.28f, 640.88f))) * 39021.426f); }
+static inline vec2 mm_sinf(vec2 v) { return vec2(mm_sinf(v.x), mm_sinf(v.y)); }             // glm::sin(vecN): component-wise
+static inline vec3 mm_sinf(vec3 v) { return vec3(mm_sinf(v.x), mm_sinf(v.y), mm_sinf(v.z)); }
 static inline vec2 rand2From2(vec2 v)
 {
-    return vec2(g_fract(mm_sinf(g_dot(v, vec2(238.68f, 491.28f))) * 39021.426f),
-                g_fract(mm_sinf(g_dot(v, vec2(654.37f, 560.45f))) * 39021.426f));
+    return g_fract(mm_sinf(vec2(
+        g_dot(v, vec2(238.68f, 491.28f)),
+        g_dot(v, vec2(654.37f, 560.45f))
+    )) * 39021.426f);
 }
 static inline vec2 rand2From3(vec3 v)
 {
-    return vec2(g_fract(mm_sinf(g_dot(v, vec3(238.68f, 491.28f, 640.88f))) * 39021.426f),
-                g_fract(mm_sinf(g_dot(v, vec3(654.37f, 560.45f, 151.81f))) * 39021.426f));
+    return g_fract(mm_sinf(vec2(
+        g_dot(v, vec3(238.68f, 491.28f, 640.88f)),
+        g_dot(v, vec3(654.37f, 560.45f, 151.81f))
+    )) * 39021.426f);
 }
 static inline vec3 rand3From2(vec2 v)
 {
-    return vec3(g_fract(mm_sinf(g_dot(v, vec2(238.68f, 491.28f))) * 39021.426f),
-                g_fract(mm_sinf(g_dot(v, vec2(654.37f, 560.45f))) * 39021.426f),
-                g_fract(mm_sinf(g_dot(v, vec2(640.88f, 151.81f))) * 39021.426f));
+    return g_fract(mm_sinf(vec3(
+        g_dot(v, vec2(238.68f, 491.28f)),
+        g_dot(v, vec2(654.37f, 560.45f)),
+        g_dot(v, vec2(640.88f, 151.81f))
+    )) * 39021.426f);
 }
 static inline vec3 rand3From3(vec3 v)
 {
-    return vec3(g_fract(mm_sinf(g_dot(v, vec3(238.68f, 491.28f, 402.98f))) * 39021.426f),
-                g_fract(mm_sinf(g_dot(v, vec3(654.37f, 560.45f, 747.42f))) * 39021.426f),
-                g_fract(mm_sinf(g_dot(v, vec3(640.88f, 151.81f, 674.81f))) * 39021.426f));
+    return g_fract(mm_sinf(vec3(
+        g_dot(v, vec3(238.68f, 491.28f, 402.98f)),
+        g_dot(v, vec3(654.37f, 560.45f, 747.42f)),
+        g_dot(v, vec3(640.88f, 151.81f, 674.81f))
+    )) * 39021.426f);
 }
 
 // ---------------------------------------------------------------- glm simplex (noise.inl:591-721)
@@ -202,14 +261,14 @@ static inline vec2 simplex2From2(vec2 pos) { return vec2(simplex(pos), simplex(p
 template <int octaves = 5, class T>
 static inline float fbm(T pos)
 {
-    float f = 0.f;
+    float fbm = 0.f;
     float amplitude = 1.f;
     for (int i = 0; i < octaves; ++i) {
         amplitude *= 0.5f;
-        f += amplitude * simplex(pos);
+        fbm += amplitude * simplex(pos);
         pos *= 2.f;
     }
-    return f;
+    return fbm;
 }
 
 template <int octaves = 5>
@@ -228,8 +287,7 @@ static inline vec3 fbm3From3(vec3 pos)
 // ---------------------------------------------------------------- worley (rng.hpp:193-320)
 static inline float worley(vec2 pos, vec3* colorPtr = nullptr, float* edgeDistPtr = nullptr)
 {
-    vec2 fl = g_floor(pos);
-    ivec2 uvInt = {(int)fl.x, (int)fl.y};
+    ivec2 uvInt = ivec2(g_floor(pos));
     vec2 uvFract = g_fract(pos);
 
     float minDist1 = FLT_MAX;
@@ -237,8 +295,8 @@ static inline float worley(vec2 pos, vec3* colorPtr = nullptr, float* edgeDistPt
     vec2 closestPoint;
     for (int x = -1; x <= 1; ++x) {
         for (int y = -1; y <= 1; ++y) {
-            ivec2 neighbor = {x, y};
-            vec2 point = rand2From2(vec2(uvInt + neighbor));
+            ivec2 neighbor = ivec2(x, y);
+            vec2 point = rand2From2(uvInt + neighbor);
             vec2 diff = vec2(neighbor) + point - uvFract;
             float dist = g_length(diff);
             if (dist < minDist1) {
@@ -257,8 +315,7 @@ static inline float worley(vec2 pos, vec3* colorPtr = nullptr, float* edgeDistPt
 
 static inline float worley(vec3 pos, vec3* colorPtr = nullptr, float* edgeDistPtr = nullptr)
 {
-    vec3 fl = g_floor(pos);
-    ivec3 uvInt = {(int)fl.x, (int)fl.y, (int)fl.z};
+    ivec3 uvInt = ivec3(g_floor(pos));
     vec3 uvFract = g_fract(pos);
 
     float minDist1 = FLT_MAX;
@@ -267,8 +324,8 @@ static inline float worley(vec3 pos, vec3* colorPtr = nullptr, float* edgeDistPt
     for (int x = -1; x <= 1; ++x) {
         for (int y = -1; y <= 1; ++y) {
             for (int z = -1; z <= 1; ++z) {
-                ivec3 neighbor = {x, y, z};
-                vec3 point = rand3From3(vec3(uvInt + neighbor));
+                ivec3 neighbor = ivec3(x, y, z);
+                vec3 point = rand3From3(uvInt + neighbor);
                 vec3 diff = vec3(neighbor) + point - uvFract;
                 float dist = g_length(diff);
                 if (dist < minDist1) {
@@ -288,8 +345,7 @@ static inline float worley(vec3 pos, vec3* colorPtr = nullptr, float* edgeDistPt
 
 static inline float specialCaveNoise(vec3 pos)
 {
-    vec3 fl = g_floor(pos);
-    ivec3 uvInt = {(int)fl.x, (int)fl.y, (int)fl.z};
+    ivec3 uvInt = ivec3(g_floor(pos));
     vec3 uvFract = g_fract(pos);
 
     float minDist1 = FLT_MAX;
@@ -298,8 +354,8 @@ static inline float specialCaveNoise(vec3 pos)
     for (int x = -1; x <= 1; ++x) {
         for (int y = -1; y <= 1; ++y) {
             for (int z = -1; z <= 1; ++z) {
-                ivec3 neighbor = {x, y, z};
-                vec3 point = rand3From3(vec3(uvInt + neighbor));
+                ivec3 neighbor = ivec3(x, y, z);
+                vec3 point = rand3From3(uvInt + neighbor);
                 vec3 diff = vec3(neighbor) + point - uvFract;
                 float dist = g_length(diff);
                 if (dist < minDist1) {

@@ -9,6 +9,20 @@ namespace mmo {
 UbCounters g_ub = {0, 0, 0};
 
 static inline int posTo2dIndex16(int x, int z) { return x + 16 * z; }
+static inline int posTo2dIndex(int x, int z) { return x + 16 * z; }                          // posTo2dIndex<16>, biomeFuncs.hpp:11-16
+static inline int posTo3dIndex(ivec3 pos) { return pos.y + 384 * posTo2dIndex(pos.x, pos.z); }   // biomeFuncs.hpp:25-37
+// the three places where the canonical semantics add a statement to a member function of the reference; all are named
+// macros so that tools/extract_ref_literals.py can list and drop exactly these
+#define CANONICAL_RETURN_FALSE return false
+#define CANONICAL_NO_LAYER_FOUND(idx, blockPtr) if ((idx) < 0) { ++g_ub.noLayerFound; *(blockPtr) = Block::STONE; } else
+#define CANONICAL_DECORATOR_RANGE(pos) if ((pos).y < 0 || (pos).y > 383) { ++g_ub.decoratorOutOfRange; return; }
+// the reference's __constant__ / host copies of BiomeUtils' tables (biomeFuncs.hpp:709-723)
+#define dev_materialInfos (T().materialInfos)
+#define dev_biomeBlocks (T().biomeBlocks)
+#define host_biomeFeatureGens (T().biomeFeatureGens)
+#define host_caveBiomeFeatureGens (T().caveBiomeFeatureGens)
+#define host_biomeDecoratorGens (T().biomeDecoratorGens)
+#define host_caveBiomeDecoratorGens (T().caveBiomeDecoratorGens)
 static inline int posTo2dIndex18(int x, int z) { return x + 18 * z; }
 
 // ===================================================================================================
@@ -64,11 +78,11 @@ void gatherHeightfield(ivec2 chunkWorldBlockPos, const float* heightfield, float
 static float getStratifiedMaterialThickness(int layerIdx, float materialWeight, vec2 worldPos)
 {
     if (materialWeight > 0) {
-        const auto& materialInfo = T().materialInfos[layerIdx];
+        const auto& materialInfo = dev_materialInfos[layerIdx];
         vec2 noisePos = worldPos * materialInfo.noiseScaleOrMaxSlope + vec2((float)layerIdx * 5283.64f);
         return g_max(0.f, materialInfo.thickness + materialInfo.noiseAmplitudeOrTanAngleOfRepose * fbm(noisePos)) * materialWeight;
     }
-    return 0;
+    else return 0;
 }
 
 void generateLayers(ivec2 chunkWorldBlockPos, const float* gatheredHeightfield, const float* biomeWeights, float* layers)
@@ -298,115 +312,194 @@ void generateCaves(ivec2 chunkWorldBlockPos, const float* heightfield, const flo
 // ===================================================================================================
 // F1 — feature placements chunk.cu:999-1156
 // ===================================================================================================
-static bool isFeaturePos(ivec2 worldBlockPos2d, int gridCellSize, int gridCellPadding, int seed)     // chunk.cu:999-1008
+bool isFeaturePos(ivec2 worldBlockPos2d, int gridCellSize, int gridCellPadding, int seed)     // chunk.cu:999-1008
 {
-    const vec2 fl = g_floor(vec2(worldBlockPos2d) / (float)gridCellSize) * (float)gridCellSize;
-    const ivec2 gridCornerWorldPos = {(int)fl.x, (int)fl.y};
+    const ivec2 gridCornerWorldPos = ivec2(g_floor(vec2(worldBlockPos2d) / (float)gridCellSize) * (float)gridCellSize);
     const int gridCellInternalSideLength = gridCellSize - (2 * gridCellPadding);
-    vec2 randPos = rand2From3(vec3((float)gridCornerWorldPos.x, (float)gridCornerWorldPos.y, (float)seed));
-    const vec2 off = g_floor(randPos * (float)gridCellInternalSideLength);
-    const ivec2 gridPlaceWorldPos = gridCornerWorldPos + ivec2{gridCellPadding, gridCellPadding} + ivec2{(int)off.x, (int)off.y};
+    vec2 randPos = rand2From3(vec3(gridCornerWorldPos, seed));
+    const ivec2 gridPlaceWorldPos = gridCornerWorldPos
+        + ivec2(gridCellPadding)
+        + ivec2(g_floor(randPos * (float)gridCellInternalSideLength));
     return worldBlockPos2d == gridPlaceWorldPos;
 }
 
-static bool tryGenerateCaveFeaturePlacement(const CaveFeatureGen& gen, const CaveLayer& caveLayer, bool top, int seed, float rand,
-                                            ivec2 worldBlockPos2d, std::vector<CaveFeaturePlacement>& out)    // chunk.cu:1010-1038
+// The reference's Chunk as the host stages see it: the same member names over the caller's per-chunk staging arrays, so that the
+// member functions below can be stated as they are written (this->caveLayers.data(), this->featurePlacements.push_back({...})).
+template <class E> struct Staging {
+    E* p;
+    E* data() const { return p; }
+    E& operator[](size_t i) const { return p[i]; }
+};
+struct Chunk {
+    ivec3 worldBlockPos;
+    Staging<const float> heightfield, biomeWeights, layers;
+    Staging<const CaveLayer> caveLayers;
+    Staging<Block> blocks;
+    std::vector<FeaturePlacement>& featurePlacements;
+    std::vector<CaveFeaturePlacement>& caveFeaturePlacements;
+
+    bool tryGenerateCaveFeaturePlacement(const CaveFeatureGen& caveFeatureGen, const CaveLayer& caveLayer, bool top, int caveFeaturePlacementSeed,
+                                         float rand, ivec2 worldBlockPos2d);
+    void generateColumnFeaturePlacements(int localX, int localZ);
+    void tryPlaceSingleDecorator(ivec3 pos, const DecoratorGen& gen);
+    void placeDecorators();
+};
+
+bool Chunk::tryGenerateCaveFeaturePlacement(const CaveFeatureGen& caveFeatureGen, const CaveLayer& caveLayer, bool top,
+                                            int caveFeaturePlacementSeed, float rand, ivec2 worldBlockPos2d)    // chunk.cu:1010-1038
 {
     int layerHeight = caveLayer.end - caveLayer.start;
-    if (rand >= gen.chancePerGridCell
-        || (top != gen.generatesFromCeiling)
-        || (!gen.canGenerateInLava && (top ? caveLayer.end : (caveLayer.start + 1)) <= LAVA_LEVEL)
-        || layerHeight < gen.minLayerHeight)
-        return false;
 
-    if (isFeaturePos(worldBlockPos2d, gen.gridCellSize, gen.gridCellPadding, seed)) {
-        CaveFeaturePlacement p;
-        std::memset(&p, 0, sizeof(p));
-        p.feature = gen.caveFeature;
-        p.pos = ivec3{worldBlockPos2d.x, caveLayer.start + 1, worldBlockPos2d.y};
-        p.layerHeight = layerHeight;
-        p.canReplaceBlocks = gen.canReplaceBlocks;
-        out.push_back(p);
+    if (rand >= caveFeatureGen.chancePerGridCell
+        || (top != caveFeatureGen.generatesFromCeiling)
+        || (!caveFeatureGen.canGenerateInLava && (top ? caveLayer.end : (caveLayer.start + 1)) <= LAVA_LEVEL)
+        || layerHeight < caveFeatureGen.minLayerHeight)
+    {
+        return false;
+    }
+
+    if (isFeaturePos(worldBlockPos2d, caveFeatureGen.gridCellSize, caveFeatureGen.gridCellPadding, caveFeaturePlacementSeed))
+    {
+        this->caveFeaturePlacements.push_back({
+            caveFeatureGen.caveFeature,
+            ivec3(worldBlockPos2d.x, caveLayer.start + 1, worldBlockPos2d.y),
+            layerHeight,
+            caveFeatureGen.canReplaceBlocks
+        });
         return true;
     }
-    return false;   // CANONICAL: the reference falls off the end of the function here (chunk.cu:1028-1038)
+    CANONICAL_RETURN_FALSE;      // the reference falls off the end of the function here (chunk.cu:1028-1038); canonical: false
 }
 
-static void generateColumnFeaturePlacements(ivec2 chunkWorldBlockPos, int localX, int localZ, const float* heightfield, const float* biomeWeights,
-                                            const float* layers, const CaveLayer* caveLayers, std::vector<FeaturePlacement>& out,
-                                            std::vector<CaveFeaturePlacement>& caveOut)     // chunk.cu:1041-1145
+void Chunk::generateColumnFeaturePlacements(int localX, int localZ)     // chunk.cu:1041-1145
 {
-    const Tables& t = T();
-    const int idx2d = posTo2dIndex16(localX, localZ);
-    const float* columnBiomeWeights = biomeWeights + idx2d;
+    const int idx2d = posTo2dIndex(localX, localZ);
+
+    const float* columnBiomeWeights = biomeWeights.data() + idx2d;
+
     const float height = heightfield[idx2d];
     const int groundHeight = (int)height;
-    const ivec2 worldBlockPos2d = chunkWorldBlockPos + ivec2{localX, localZ};
 
-    Rng blockRng = makeSeededRandomEngine(worldBlockPos2d.x, worldBlockPos2d.y, 329828101);
+    const ivec2 localBlockPos2d = ivec2(localX, localZ);
+    const ivec2 worldBlockPos2d = ivec2(this->worldBlockPos.x, this->worldBlockPos.z) + localBlockPos2d;
+
+    auto blockRng = makeSeededRandomEngine(worldBlockPos2d.x, worldBlockPos2d.y, 329828101);
+    uniform_real_distribution<float> u01(0, 1);
 
     bool surfaceIsCave = false;
-    const CaveLayer* columnCaveLayers = caveLayers + idx2d * MAX_CAVE_LAYERS_PER_COLUMN;
-    for (int caveLayerIdx = 0; caveLayerIdx < MAX_CAVE_LAYERS_PER_COLUMN; ++caveLayerIdx) {
-        const CaveLayer& caveLayer = columnCaveLayers[caveLayerIdx];
-        if (caveLayer.start == 384 || groundHeight <= caveLayer.start) break;
+    const auto columnCaveLayers = this->caveLayers.data() + (idx2d * MAX_CAVE_LAYERS_PER_COLUMN);
+    for (int caveLayerIdx = 0; caveLayerIdx < MAX_CAVE_LAYERS_PER_COLUMN; ++caveLayerIdx)
+    {
+        const auto& caveLayer = columnCaveLayers[caveLayerIdx];
 
-        for (const auto& gen : t.caveBiomeFeatureGens[(int)caveLayer.bottomBiome]) {
-            int seed = (int)gen.caveFeature * 98239 + caveLayerIdx * 191702;
-            if (tryGenerateCaveFeaturePlacement(gen, caveLayer, false, seed, blockRng.u01(), worldBlockPos2d, caveOut)) break;
+        if (caveLayer.start == 384 || groundHeight <= caveLayer.start)
+        {
+            break;
         }
-        if (caveLayer.end != 384) {
-            for (const auto& gen : t.caveBiomeFeatureGens[(int)caveLayer.topBiome]) {
-                int seed = (int)gen.caveFeature * 58321 + caveLayerIdx * 871503;
-                if (tryGenerateCaveFeaturePlacement(gen, caveLayer, true, seed, blockRng.u01(), worldBlockPos2d, caveOut)) break;
+
+        for (const auto& caveFeatureGen : host_caveBiomeFeatureGens[(int)caveLayer.bottomBiome])
+        {
+            int caveFeaturePlacementSeed = (int)caveFeatureGen.caveFeature * 98239 + caveLayerIdx * 191702;
+            if (tryGenerateCaveFeaturePlacement(caveFeatureGen, caveLayer, false, caveFeaturePlacementSeed, u01(blockRng), worldBlockPos2d))
+            {
+                break;
             }
         }
-        if (groundHeight > caveLayer.start && groundHeight <= caveLayer.end) {
+
+        if (caveLayer.end != 384)
+        {
+            for (const auto& caveFeatureGen : host_caveBiomeFeatureGens[(int)caveLayer.topBiome])
+            {
+                int caveFeaturePlacementSeed = (int)caveFeatureGen.caveFeature * 58321 + caveLayerIdx * 871503;
+                if (tryGenerateCaveFeaturePlacement(caveFeatureGen, caveLayer, true, caveFeaturePlacementSeed, u01(blockRng), worldBlockPos2d))
+                {
+                    break;
+                }
+            }
+        }
+
+        if (groundHeight > caveLayer.start && groundHeight <= caveLayer.end)
+        {
             surfaceIsCave = true;
             break;
         }
     }
 
-    if (!surfaceIsCave) {
-        Biome biome = getRandomBiome<256>(columnBiomeWeights, blockRng.u01());
-        const auto& featureGens = t.biomeFeatureGens[(int)biome];
-        const float* columnLayers = layers + idx2d;
-        for (const auto& featureGen : featureGens) {
-            if (blockRng.u01() >= featureGen.chancePerGridCell) continue;
+    if (!surfaceIsCave)
+    {
+        Biome biome = getRandomBiome<256>(columnBiomeWeights, u01(blockRng));
+        const auto& featureGens = host_biomeFeatureGens[(int)biome];
 
-            if (!featureGen.possibleTopLayers.empty()) {
+        const float* columnLayers = this->layers.data() + idx2d;
+
+        for (const auto& featureGen : featureGens)
+        {
+            if (u01(blockRng) >= featureGen.chancePerGridCell)
+            {
+                continue;
+            }
+
+            if (!featureGen.possibleTopLayers.empty())
+            {
                 bool canPlace = false;
-                for (const auto& possibleTopLayer : featureGen.possibleTopLayers) {
+                for (const auto& possibleTopLayer : featureGen.possibleTopLayers)
+                {
+                    // layerIdx + 1 == numMaterials (SNOW) would read past `layers`: no gen table lists SNOW as a top layer (the
+                    // sanitizer job would see the read)
                     int layerIdx = (int)possibleTopLayer.material;
                     float layerStart = columnLayers[256 * layerIdx];
-                    // layerIdx + 1 == numMaterials (SNOW) would read past `layers`; no gen table lists SNOW as a top layer.
-                    float layerEnd = (layerIdx + 1 < numMaterials) ? columnLayers[256 * (layerIdx + 1)] : height;
-                    if (layerStart > height || layerEnd < height || g_min(layerEnd, height) - layerStart < possibleTopLayer.minThickness) continue;
+                    float layerEnd = columnLayers[256 * (layerIdx + 1)];
+
+                    if (layerStart > height || layerEnd < height || g_min(layerEnd, height) - layerStart < possibleTopLayer.minThickness)
+                    {
+                        continue;
+                    }
+
                     canPlace = true;
                     break;
                 }
-                if (!canPlace) continue;
+
+                if (!canPlace)
+                {
+                    continue;
+                }
             }
 
-            if (isFeaturePos(worldBlockPos2d, featureGen.gridCellSize, featureGen.gridCellPadding, (int)featureGen.feature * 518721)) {
-                FeaturePlacement p;
-                std::memset(&p, 0, sizeof(p));
-                p.feature = featureGen.feature;
-                p.pos = ivec3{worldBlockPos2d.x, groundHeight + 1, worldBlockPos2d.y};
-                p.canReplaceBlocks = featureGen.canReplaceBlocks;
-                out.push_back(p);
+            if (isFeaturePos(worldBlockPos2d, featureGen.gridCellSize, featureGen.gridCellPadding, (int)featureGen.feature * 518721))
+            {
+                this->featurePlacements.push_back({
+                    featureGen.feature,
+                    ivec3(worldBlockPos2d.x, groundHeight + 1, worldBlockPos2d.y),
+                    featureGen.canReplaceBlocks
+                });
                 break;
             }
         }
     }
 }
 
+// the 20 / 24-byte records are compared and shipped as bytes: the padding after the bool is zeroed (aggregate initialisation leaves it unspecified)
+template <class P> static void zeroPadding(std::vector<P>& v, size_t from)
+{
+    for (size_t i = from; i < v.size(); ++i) {
+        P q;
+        std::memset((void*)&q, 0, sizeof(q));
+        q.feature = v[i].feature; q.pos = v[i].pos; q.canReplaceBlocks = v[i].canReplaceBlocks;
+        if constexpr (sizeof(P) == 24) q.layerHeight = v[i].layerHeight;
+        std::memcpy((void*)&v[i], &q, sizeof(q));
+    }
+}
+
 void generateFeaturePlacements(ivec2 chunkWorldBlockPos, const float* heightfield, const float* biomeWeights, const float* layers,
                                const CaveLayer* caveLayers, std::vector<FeaturePlacement>& out, std::vector<CaveFeaturePlacement>& caveOut)
 {
-    for (int localZ = 0; localZ < 16; ++localZ)
+    const size_t n0 = out.size(), c0 = caveOut.size();
+    Chunk chunk{ivec3(chunkWorldBlockPos.x, 0, chunkWorldBlockPos.y), {heightfield}, {biomeWeights}, {layers}, {caveLayers}, {nullptr}, out, caveOut};
+    for (int localZ = 0; localZ < 16; ++localZ)                           // chunk.cu:1147-1156
         for (int localX = 0; localX < 16; ++localX)
-            generateColumnFeaturePlacements(chunkWorldBlockPos, localX, localZ, heightfield, biomeWeights, layers, caveLayers, out, caveOut);
+            chunk.generateColumnFeaturePlacements(localX, localZ);
+    zeroPadding(out, n0);
+    zeroPadding(caveOut, c0);
 }
 
 // F2 — chunk.cu:1158-1167
@@ -423,85 +516,143 @@ const ivec2 gatherFeaturePlacementsChunkOffsets[49] = {
 // ===================================================================================================
 // L1 — chunkFillPlaceBlock chunk.cu:1202-1380
 // ===================================================================================================
-static void chunkFillPlaceBlock(Block* blockPtr, const float* biomeWeights24, const float* layersAndHeight, const CaveLayer* caveLayers32,
-                                int y, float height, ivec3 worldBlockPos, Rng& rng)
+static void chunkFillPlaceBlock(
+    Block* blockPtr,
+    const float* shared_biomeWeights,
+    const float* shared_layersAndHeight,
+    const CaveLayer* shared_caveLayers,
+    int y,
+    float height,
+    ivec3 worldBlockPos,
+    Rng& rng)
 {
-    const Tables& t = T();
-    if (y == 0) { *blockPtr = Block::BEDROCK; return; }
-    if ((float)y > height && y > SEA_LEVEL) { *blockPtr = Block::AIR; return; }
-
-    bool isOcean = false;
-    for (int biomeIdx = 0; biomeIdx < numOceanBiomes; ++biomeIdx) {
-        if (biomeWeights24[biomeIdx] > 0.f) { isOcean = true; break; }
+    if (y == 0)
+    {
+        *blockPtr = Block::BEDROCK;
+        return;
     }
 
-    Biome randBiome = getRandomBiome(biomeWeights24, rng.u01());
-    bool isTopBlock = (float)y >= height - 1.f;
+    if (y > height && y > SEA_LEVEL)
+    {
+        *blockPtr = Block::AIR;
+        return;
+    }
 
-    if ((float)y > height && y <= SEA_LEVEL) {
+    bool isOcean = false;
+    for (int biomeIdx = 0; biomeIdx < numOceanBiomes; ++biomeIdx)
+    {
+        if (shared_biomeWeights[biomeIdx] > 0.f)
+        {
+            isOcean = true;
+            break;
+        }
+    }
+
+    uniform_real_distribution<float> u01(0, 1);
+
+    Biome randBiome = getRandomBiome(shared_biomeWeights, u01(rng));
+    bool isTopBlock = y >= height - 1.f;
+
+#define doBlockPostProcess() biomeBlockPostProcess(blockPtr, randBiome, worldBlockPos, height, isTopBlock)
+#define postProcessCaveBiome getCaveBiome(worldBlockPos, height, 190249401)
+#define doCaveBlockPostProcess() caveBiomeBlockPostProcess(blockPtr, postProcessCaveBiome, worldBlockPos, caveBottomDepth, caveTopDepth)
+
+    if (y > height && y <= SEA_LEVEL)
+    {
         *blockPtr = Block::WATER;
-        biomeBlockPostProcess(blockPtr, randBiome, worldBlockPos, height, isTopBlock);
-        if (isOcean) return;
+        doBlockPostProcess();
+
+        if (isOcean)
+        {
+            return;
+        }
     }
 
     int caveBottomDepth = -384;
     int caveTopDepth = -384;
     int caveLayerIdx = 0;
-    for (; caveLayerIdx < MAX_CAVE_LAYERS_PER_COLUMN; ++caveLayerIdx) {
-        const auto& caveLayer = caveLayers32[caveLayerIdx];
-        if (caveLayer.start == 384) {
+    for ( ; caveLayerIdx < MAX_CAVE_LAYERS_PER_COLUMN; ++caveLayerIdx)
+    {
+        const auto& caveLayer = shared_caveLayers[caveLayerIdx];
+        if (caveLayer.start == 384)
+        {
             caveBottomDepth = -384;
             break;
         }
+
         caveBottomDepth = caveLayer.start - y;
-        if (y <= caveLayer.start) break;
-        if (y <= caveLayer.end) {
+
+        if (y <= caveLayer.start)
+        {
+            break;
+        }
+
+        if (y <= caveLayer.end)
+        {
             caveBottomDepth = caveLayer.start - y;
             caveTopDepth = y - (caveLayer.end + 1);
             *blockPtr = (y <= LAVA_LEVEL) ? Block::LAVA : Block::AIR;
-            caveBiomeBlockPostProcess(blockPtr, getCaveBiome(worldBlockPos, height, 190249401), worldBlockPos, caveBottomDepth, caveTopDepth);
+            doCaveBlockPostProcess();
             return;
         }
+
         caveTopDepth = y - (caveLayer.end + 1);
     }
 
-    if ((float)y > height) return;
+    if (y > height)
+    {
+        return;
+    }
 
     bool wasBlockPreProcessed = biomeBlockPreProcess(blockPtr, randBiome, worldBlockPos, height);
-    if (wasBlockPreProcessed) {
-        biomeBlockPostProcess(blockPtr, randBiome, worldBlockPos, height, isTopBlock);
+    if (wasBlockPreProcessed)
+    {
+        doBlockPostProcess();
         return;
     }
 
     int layerIdxStart;
-    if ((float)y >= layersAndHeight[numForwardMaterials]) layerIdxStart = numForwardMaterials;
-    else layerIdxStart = 0;
+    if (y >= shared_layersAndHeight[numForwardMaterials])
+    {
+        layerIdxStart = numForwardMaterials;
+    }
+    else
+    {
+        layerIdxStart = 0;
+    }
 
     int thisLayerIdx = -1;
-    for (int layerIdx = layerIdxStart; layerIdx < numMaterials; ++layerIdx) {
-        float layerStart = layersAndHeight[layerIdx];
-        float layerEnd = layersAndHeight[layerIdx + 1];
-        if (layerStart <= (float)y && (float)y < layerEnd) {
+    for (int layerIdx = layerIdxStart; layerIdx < numMaterials; ++layerIdx)
+    {
+        float layerStart = shared_layersAndHeight[layerIdx];
+        float layerEnd = shared_layersAndHeight[layerIdx + 1];
+
+        if (layerStart <= y && y < layerEnd)
+        {
             thisLayerIdx = layerIdx;
             break;
         }
     }
 
-    if (thisLayerIdx < 0) {
-        // CANONICAL: the reference reads dev_materialInfos[-1] here (chunk.cu:1349-1363), which happens when y == height
-        // exactly; canonical block is STONE. Counted.
-        ++g_ub.noLayerFound;
-        *blockPtr = Block::STONE;
-    } else {
-        *blockPtr = t.materialInfos[thisLayerIdx].block;
+    // CANONICAL: the reference reads dev_materialInfos[-1] when no layer contains y (chunk.cu:1349-1363), which happens when
+    // y == height exactly; canonical block is STONE. Counted.
+    CANONICAL_NO_LAYER_FOUND(thisLayerIdx, blockPtr)
+    *blockPtr = dev_materialInfos[thisLayerIdx].block;
+
+    if (isTopBlock)
+    {
+        if (*blockPtr == Block::DIRT)
+        {
+            *blockPtr = dev_biomeBlocks[(int)randBiome].grassBlock;
+        }
     }
 
-    if (isTopBlock) {
-        if (*blockPtr == Block::DIRT) *blockPtr = t.grassBlock[(int)randBiome];
-    }
+    doBlockPostProcess();
+    doCaveBlockPostProcess();
 
-    biomeBlockPostProcess(blockPtr, randBiome, worldBlockPos, height, isTopBlock);
-    caveBiomeBlockPostProcess(blockPtr, getCaveBiome(worldBlockPos, height, 190249401), worldBlockPos, caveBottomDepth, caveTopDepth);
+#undef doBlockPostProcess
+#undef doCaveBlockPostProcess
+#undef postProcessCaveBiome
 }
 
 // ===================================================================================================
@@ -583,77 +734,131 @@ void fillChunk(ivec3 chunkWorldBlockPos, const float* heightfield, const float* 
 // ===================================================================================================
 // D1 — tryPlaceSingleDecorator chunk.cu:1634-1677, placeDecorators chunk.cu:1679-1747
 // ===================================================================================================
-static bool contains(const std::vector<Block>& v, Block b) { return std::find(v.begin(), v.end(), b) != v.end(); }
-
-static void tryPlaceSingleDecorator(Block* blocks, ivec3 pos, const DecoratorGen& gen)
+void Chunk::tryPlaceSingleDecorator(ivec3 pos, const DecoratorGen& gen)
 {
     // CANONICAL: a ceiling decorator of a cave layer that is open to the sky has pos.y == 384 (chunk.cu:1728 with
     // caveLayer.end == 384); the reference then indexes the next column's bedrock (rejected: not replaceable) or, for
     // the last column, reads past the array. Canonical = no-op. Counted.
-    if (pos.y < 0 || pos.y > 383) { ++g_ub.decoratorOutOfRange; return; }
+    CANONICAL_DECORATOR_RANGE(pos);
 
-    const int decoratorIdx = pos.y + 384 * posTo2dIndex16(pos.x, pos.z);
-    Block& currentBlock = blocks[decoratorIdx];
-    if (!gen.possibleReplaceBlocks.empty() && !contains(gen.possibleReplaceBlocks, currentBlock)) return;
+    const int decoratorIdx = posTo3dIndex(pos);
+    Block& currentBlock = this->blocks[decoratorIdx];
+    if (!gen.possibleReplaceBlocks.empty()
+        && gen.possibleReplaceBlocks.find(currentBlock) == gen.possibleReplaceBlocks.end())
+    {
+        return;
+    }
 
     int underBlockOffset = gen.generatesFromCeiling ? 1 : -1;
-    if (!(pos.y + underBlockOffset >= 0 && pos.y + underBlockOffset <= 383)) return;
+    if (!isInRange(pos.y + underBlockOffset, 0, 383))
+    {
+        return;
+    }
 
     const Block underBlock = blocks[decoratorIdx + underBlockOffset];
-    if ((int)underBlock < numNonSolidBlocks || (!gen.possibleUnderBlocks.empty() && !contains(gen.possibleUnderBlocks, underBlock))) return;
+    if ((int)underBlock < numNonSolidBlocks
+        || (!gen.possibleUnderBlocks.empty() && gen.possibleUnderBlocks.find(underBlock) == gen.possibleUnderBlocks.end()))
+    {
+        return;
+    }
 
-    if (gen.secondDecoratorBlock != Block::AIR) {
+    if (gen.secondDecoratorBlock != Block::AIR)
+    {
         int overBlockOffset = -underBlockOffset;
-        if (!(pos.y + overBlockOffset >= 0 && pos.y + overBlockOffset <= 383)) return;
-        Block& overBlock = blocks[decoratorIdx + overBlockOffset];
-        if (!gen.possibleReplaceBlocks.empty() && !contains(gen.possibleReplaceBlocks, overBlock)) return;
+        if (!isInRange(pos.y + overBlockOffset, 0, 383))
+        {
+            return;
+        }
+
+        Block& overBlock = this->blocks[decoratorIdx + overBlockOffset];
+        if (!gen.possibleReplaceBlocks.empty() && gen.possibleReplaceBlocks.find(overBlock) == gen.possibleReplaceBlocks.end())
+        {
+            return;
+        }
+
         overBlock = gen.secondDecoratorBlock;
     }
+
     currentBlock = gen.decoratorBlock;
 }
 
-void placeDecorators(ivec3 chunkWorldBlockPos, const float* heightfield, const float* biomeWeights, const CaveLayer* caveLayers, Block* blocks)
+void Chunk::placeDecorators()
 {
-    const Tables& t = T();
-    Rng rng = makeSeededRandomEngine(chunkWorldBlockPos.x, chunkWorldBlockPos.y, chunkWorldBlockPos.z, 7589341);
+    auto rng = makeSeededRandomEngine(this->worldBlockPos.x, this->worldBlockPos.y, this->worldBlockPos.z, 7589341);
+    uniform_real_distribution<float> u01(0, 1);
 
-    for (int z = 0; z < 16; ++z) {
-        for (int x = 0; x < 16; ++x) {
-            const int idx2d = posTo2dIndex16(x, z);
-            const float* columnBiomeWeights = biomeWeights + idx2d;
-            Biome biome = getRandomBiome<256>(columnBiomeWeights, rng.u01());
+    for (int z = 0; z < 16; ++z)
+    {
+        for (int x = 0; x < 16; ++x)
+        {
+            const int idx2d = posTo2dIndex(x, z);
 
-            float rand = rng.u01();
-            const auto& biomeDecoratorGens = t.biomeDecoratorGens[(int)biome];
-            for (size_t genIdx = 0; genIdx < biomeDecoratorGens.size(); ++genIdx) {
+            const float* columnBiomeWeights = biomeWeights.data() + idx2d;
+            Biome biome = getRandomBiome<256>(columnBiomeWeights, u01(rng));
+
+            float rand = u01(rng);
+            const auto& biomeDecoratorGens = host_biomeDecoratorGens[(int)biome];
+            for (int genIdx = 0; genIdx < biomeDecoratorGens.size(); ++genIdx)
+            {
                 const auto& gen = biomeDecoratorGens[genIdx];
-                if ((rand -= gen.chance) < 0.f) {
-                    tryPlaceSingleDecorator(blocks, ivec3{x, ((int)heightfield[idx2d]) + 1, z}, gen);
+
+                if ((rand -= gen.chance) < 0.f)
+                {
+                    tryPlaceSingleDecorator(ivec3(x, ((int)this->heightfield[idx2d]) + 1, z), gen);
                     break;
                 }
             }
 
-            const CaveLayer* columnCaveLayers = caveLayers + MAX_CAVE_LAYERS_PER_COLUMN * idx2d;
-            for (int caveLayerIdx = 0; caveLayerIdx < MAX_CAVE_LAYERS_PER_COLUMN; ++caveLayerIdx) {
+            const CaveLayer* columnCaveLayers = this->caveLayers.data() + (MAX_CAVE_LAYERS_PER_COLUMN * idx2d);
+            for (int caveLayerIdx = 0; caveLayerIdx < MAX_CAVE_LAYERS_PER_COLUMN; ++caveLayerIdx)
+            {
                 const auto& caveLayer = columnCaveLayers[caveLayerIdx];
-                if (caveLayer.start == 384) break;
 
-                float bottomRand = rng.u01();
-                float topRand = rng.u01();
-                // placedBottom / placedTop are never set in the reference (chunk.cu:1718-1743): every gen whose
-                // cumulative chance is passed fires. Reproduced as is.
-                const auto& caveBiomeDecoratorGens = t.caveBiomeDecoratorGens[(int)caveLayer.bottomBiome];
-                for (size_t genIdx = 0; genIdx < caveBiomeDecoratorGens.size(); ++genIdx) {
+                if (caveLayer.start == 384)
+                {
+                    break;
+                }
+
+                float bottomRand = u01(rng);
+                float topRand = u01(rng);
+                // placedBottom / placedTop are never set (chunk.cu:1718-1743): every gen whose cumulative chance is passed fires
+                bool placedBottom = false;
+                bool placedTop = false;
+                const auto& caveBiomeDecoratorGens = host_caveBiomeDecoratorGens[(int)caveLayer.bottomBiome];
+                for (int genIdx = 0; genIdx < caveBiomeDecoratorGens.size(); ++genIdx)
+                {
                     const auto& gen = caveBiomeDecoratorGens[genIdx];
-                    if (gen.generatesFromCeiling) {
-                        if ((topRand -= gen.chance) < 0.f) tryPlaceSingleDecorator(blocks, ivec3{x, caveLayer.end, z}, gen);
-                    } else {
-                        if ((bottomRand -= gen.chance) < 0.f) tryPlaceSingleDecorator(blocks, ivec3{x, caveLayer.start + 1, z}, gen);
+                    if (gen.generatesFromCeiling)
+                    {
+                        if (!placedTop && (topRand -= gen.chance) < 0.f)
+                        {
+                            tryPlaceSingleDecorator(ivec3(x, caveLayer.end, z), gen);
+                        }
+                    }
+                    else
+                    {
+                        if (!placedBottom && (bottomRand -= gen.chance) < 0.f)
+                        {
+                            tryPlaceSingleDecorator(ivec3(x, caveLayer.start + 1, z), gen);
+                        }
+                    }
+
+                    if (placedTop && placedBottom)
+                    {
+                        break;
                     }
                 }
             }
         }
     }
+}
+
+void placeDecorators(ivec3 chunkWorldBlockPos, const float* heightfield, const float* biomeWeights, const CaveLayer* caveLayers, Block* blocks)
+{
+    std::vector<FeaturePlacement> none;
+    std::vector<CaveFeaturePlacement> caveNone;
+    Chunk chunk{chunkWorldBlockPos, {heightfield}, {biomeWeights}, {nullptr}, {caveLayers}, {blocks}, none, caveNone};
+    chunk.placeDecorators();
 }
 
 }  // namespace mmo

@@ -11,27 +11,50 @@
 #pragma once
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
+#include <type_traits>
 
 namespace mmo {
 
-struct ivec2 { int x, y; };
-struct ivec3 { int x, y, z; };
+// Like glm's, the constructors take any arithmetic type per component (vec3(0, trunkHeight, 0), vec2(worldBlockPos.x, leavesSeed)) and
+// convert it with a static_cast; vectors of another component type convert implicitly (glm declares those constructors explicit only
+// under GLM_FORCE_EXPLICIT_CTOR, which the reference does not define: `vec3 pos = floorPos;`, isInRasterizedLine(pos, ...) with a
+// float position truncating to ivec3).  With these the oracle can state the reference's expressions as they are written.
+struct vec2;
+struct vec3;
+struct ivec2 {
+    int x, y;
+    ivec2() : x(0), y(0) {}
+    template <class A, class = std::enable_if_t<std::is_arithmetic<A>::value>> explicit ivec2(A s) : x((int)s), y((int)s) {}
+    template <class A, class B> ivec2(A x_, B y_) : x((int)x_), y((int)y_) {}
+    inline ivec2(const vec2& v);
+};
+struct ivec3 {
+    int x, y, z;
+    ivec3() : x(0), y(0), z(0) {}
+    template <class A, class = std::enable_if_t<std::is_arithmetic<A>::value>> explicit ivec3(A s) : x((int)s), y((int)s), z((int)s) {}
+    template <class A, class B, class C> ivec3(A x_, B y_, C z_) : x((int)x_), y((int)y_), z((int)z_) {}
+    inline ivec3(const vec3& v);
+};
 
 struct vec2 {
     float x, y;
     vec2() : x(0), y(0) {}
-    explicit vec2(float s) : x(s), y(s) {}
-    vec2(float x_, float y_) : x(x_), y(y_) {}
-    explicit vec2(ivec2 v) : x((float)v.x), y((float)v.y) {}
+    template <class A, class = std::enable_if_t<std::is_arithmetic<A>::value>> explicit vec2(A s) : x((float)s), y((float)s) {}
+    template <class A, class B> vec2(A x_, B y_) : x((float)x_), y((float)y_) {}
+    vec2(ivec2 v) : x((float)v.x), y((float)v.y) {}
 };
 struct vec3 {
     float x, y, z;
     vec3() : x(0), y(0), z(0) {}
-    explicit vec3(float s) : x(s), y(s), z(s) {}
-    vec3(float x_, float y_, float z_) : x(x_), y(y_), z(z_) {}
-    vec3(vec2 v, float z_) : x(v.x), y(v.y), z(z_) {}
-    explicit vec3(ivec3 v) : x((float)v.x), y((float)v.y), z((float)v.z) {}
+    template <class A, class = std::enable_if_t<std::is_arithmetic<A>::value>> explicit vec3(A s) : x((float)s), y((float)s), z((float)s) {}
+    template <class A, class B, class C> vec3(A x_, B y_, C z_) : x((float)x_), y((float)y_), z((float)z_) {}
+    template <class C> vec3(vec2 v, C z_) : x(v.x), y(v.y), z((float)z_) {}
+    template <class C> vec3(ivec2 v, C z_) : x((float)v.x), y((float)v.y), z((float)z_) {}
+    vec3(ivec3 v) : x((float)v.x), y((float)v.y), z((float)v.z) {}
 };
+inline ivec2::ivec2(const vec2& v) : x((int)v.x), y((int)v.y) {}
+inline ivec3::ivec3(const vec3& v) : x((int)v.x), y((int)v.y), z((int)v.z) {}
 struct vec4 {
     float x, y, z, w;
     vec4() : x(0), y(0), z(0), w(0) {}
@@ -45,7 +68,15 @@ static inline ivec2 operator*(ivec2 a, int s) { return {a.x * s, a.y * s}; }
 static inline bool operator==(ivec2 a, ivec2 b) { return a.x == b.x && a.y == b.y; }
 static inline ivec3 operator+(ivec3 a, ivec3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
 static inline ivec3 operator-(ivec3 a, ivec3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+static inline ivec3 operator*(ivec3 a, int s) { return {a.x * s, a.y * s, a.z * s}; }
+static inline ivec3 operator/(ivec3 a, int s) { return {a.x / s, a.y / s, a.z / s}; }
 static inline bool operator==(ivec3 a, ivec3 b) { return a.x == b.x && a.y == b.y && a.z == b.z; }
+static inline ivec2 g_abs(ivec2 v) { return {std::abs(v.x), std::abs(v.y)}; }
+static inline ivec3 g_abs(ivec3 v) { return {std::abs(v.x), std::abs(v.y), std::abs(v.z)}; }
+static inline int compAdd(ivec2 v) { return v.x + v.y; }                  // glm/gtx/component_wise.inl
+static inline int compAdd(ivec3 v) { return v.x + v.y + v.z; }
+static inline ivec3 g_min(ivec3 a, ivec3 b) { return {(b.x < a.x) ? b.x : a.x, (b.y < a.y) ? b.y : a.y, (b.z < a.z) ? b.z : a.z}; }
+static inline ivec3 g_max(ivec3 a, ivec3 b) { return {(a.x < b.x) ? b.x : a.x, (a.y < b.y) ? b.y : a.y, (a.z < b.z) ? b.z : a.z}; }
 
 // ---- vec2
 static inline vec2 operator+(vec2 a, vec2 b) { return vec2(a.x + b.x, a.y + b.y); }
@@ -109,11 +140,14 @@ static inline float g_radians(float deg) { return deg * 0.0174532925199432957692
 static inline vec2 g_floor(vec2 v) { return vec2(floorf(v.x), floorf(v.y)); }
 static inline vec3 g_floor(vec3 v) { return vec3(floorf(v.x), floorf(v.y), floorf(v.z)); }
 static inline vec4 g_floor(vec4 v) { return vec4(floorf(v.x), floorf(v.y), floorf(v.z), floorf(v.w)); }
+static inline vec2 g_ceil(vec2 v) { return vec2(ceilf(v.x), ceilf(v.y)); }
+static inline vec3 g_ceil(vec3 v) { return vec3(ceilf(v.x), ceilf(v.y), ceilf(v.z)); }
 static inline vec2 g_fract(vec2 v) { return vec2(g_fract(v.x), g_fract(v.y)); }
 static inline vec3 g_fract(vec3 v) { return vec3(g_fract(v.x), g_fract(v.y), g_fract(v.z)); }
 static inline vec2 g_abs(vec2 v) { return vec2(fabsf(v.x), fabsf(v.y)); }
 static inline vec3 g_abs(vec3 v) { return vec3(fabsf(v.x), fabsf(v.y), fabsf(v.z)); }
 static inline vec4 g_abs(vec4 v) { return vec4(fabsf(v.x), fabsf(v.y), fabsf(v.z), fabsf(v.w)); }
+static inline vec2 g_max(vec2 a, vec2 b) { return vec2(g_max(a.x, b.x), g_max(a.y, b.y)); }
 static inline vec3 g_min(vec3 a, vec3 b) { return vec3(g_min(a.x, b.x), g_min(a.y, b.y), g_min(a.z, b.z)); }
 static inline vec3 g_max(vec3 a, vec3 b) { return vec3(g_max(a.x, b.x), g_max(a.y, b.y), g_max(a.z, b.z)); }
 static inline vec4 g_max(vec4 a, vec4 b) { return vec4(g_max(a.x, b.x), g_max(a.y, b.y), g_max(a.z, b.z), g_max(a.w, b.w)); }
@@ -138,5 +172,10 @@ static inline vec3 g_cross(vec3 x, vec3 y) {
 
 static inline ivec2 to_ivec2(vec2 v) { return {(int)v.x, (int)v.y}; }
 static inline ivec3 to_ivec3(vec3 v) { return {(int)v.x, (int)v.y, (int)v.z}; }
+
+// C++ leaves the evaluation order of function-call arguments unspecified, and the reference draws from one random stream in several
+// arguments of one constructor call (featurePlacement.hpp:224,700,991,1066).  The canonical order is left to right; a
+// braced initialiser list guarantees it.  tools/extract_ref_literals.py reads `vec3_ltr` as `vec3`.
+#define vec3_ltr(...) vec3{__VA_ARGS__}
 
 }  // namespace mmo

@@ -12,12 +12,10 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
-from extract_ref_literals import REFERENCE_SECTIONS, literals, sections, skeleton_digest, strip_comments   # noqa: E402
+from extract_ref_literals import ORACLE_FILES, REFERENCE_SECTIONS, literals, oracle_signature, sections, skeleton_digest, strip_comments   # noqa: E402
 
 REF = json.load(open(os.path.join(ROOT, "tests", "golden", "ref_literals.json")))
 
-ORACLE_FILES = {"biomeFuncs.hpp": ["oracle/mmo_biome.cpp"], "featurePlacement.hpp": ["oracle/mmo_features.cpp"],
-                "rng.hpp": ["oracle/mmo_noise.h"], "chunk.cu": ["oracle/mmo_stages.cpp"]}
 
 
 def _read(paths):
@@ -37,8 +35,7 @@ def _oracle_sections():
         base = os.path.basename(rel)
         if base not in cache:
             cache[base] = _read(ORACLE_FILES[base])
-        sig_o = sig.replace(r"void\s+Chunk::", r"void\s+").replace(r"void\s+kernGenerateCaves", r"void\s+generateCaves")
-        secs = sections(cache[base], sig_o, prefixes)
+        secs = sections(cache[base], oracle_signature(f"{base}::{key}", sig), prefixes)
         for name, code in secs.items():
             out[f"{base}::{key}" + (f"::{name}" if name else "")] = literals(code)
     return out
@@ -49,22 +46,14 @@ ORACLE_ALLOW = {
     "chunk.cu::kernGenerateCaves": (12.0, 32.0, 383.0, 4095.0),       # thread-block geometry of the CUDA kernel (12 threads, 32-layer shared arrays, y = 383 - 32 k, 0xFFF flip mask)
     "featurePlacement.hpp::placeFeature": (0.0, 1.0),        # preamble before the switch: vec3 / ivec3 helpers
     "featurePlacement.hpp::placeCaveFeature": (1.0,),
-    "rng.hpp::makeSeededRandomEngine": (1.0, 31.0),           # (1 << 31) is written 0x80000000u
 }
 ORACLE_EXTRA = {
     "chunk.cu::kernGenerateCaves": (2.0, 385.0),              # isFilled[385] + the flip loop replace the shared-memory bit words
-    "rng.hpp::makeSeededRandomEngine": (2147483648.0,),       # 0x80000000u = the reference's (1 << 31)
 }
-ORACLE_SIGNATURES = {"rng.hpp::hash": r"uint32_t\s+hash_u32\s*\([^)]*\)\s*\{"}
 
 
 def test_oracle_sections_hold_every_reference_constant():
     ours = _oracle_sections()
-    for key, sig in ORACLE_SIGNATURES.items():
-        base = key.split("::")[0]
-        secs = sections(_read(ORACLE_FILES[base]), sig, ())
-        if secs:
-            ours[key] = literals(secs[""])
     problems = []
     for key in sorted(REF):
         if key not in ours:
@@ -102,6 +91,20 @@ DEVICE_MAP = {
     "featurePlacement.hpp::getRandomCrystalBlock": ([CS + "mm_features.cuh"], [r"uint8_t\s+random_crystal_block\s*\([^)]*\)\s*\{"], None),
     "featurePlacement.hpp::placeFeature": ([CS + "mm_features.cuh"], [r"bool\s+place_feature\s*\([^)]*\)\s*\{", r"uint32_t\s+surface_feature_stream\s*\([^)]*\)\s*\{"], "MMF_"),
     "featurePlacement.hpp::placeCaveFeature": ([CS + "mm_features.cuh"], [r"bool\s+place_cave_feature\s*\([^)]*\)\s*\{", r"uint32_t\s+cave_feature_stream\s*\([^)]*\)\s*\{"], "MMCF_"),
+    "biomeFuncs.hpp::getRandomBiome": ([CS + "mm_biome.cuh"], [r"int\s+random_biome\s*\([^)]*\)\s*\{"], None),
+    "biomeFuncs.hpp::applySingleBiomeNoise": ([CS + "mm_biome.cuh"], [r"float\s+biome_weight\s*\([^)]*\)\s*\{"], None),
+    "biomeFuncs.hpp::getBiomeWeight": ([CS + "mm_biome.cuh"], [r"float\s+biome_weight\s*\([^)]*\)\s*\{"], None),
+    "biomeFuncs.hpp::getCaveBiomeWeight": ([CS + "mm_biome.cuh"], [r"int\s+cave_biome_t\s*\([^)]*\)\s*\{"], None),
+    "biomeFuncs.hpp::getCaveBiome": ([CS + "mm_biome.cuh"], [r"int\s+cave_biome_t\s*\([^)]*\)\s*\{"], None),
+    "featurePlacement.hpp::deCasteljau": ([CS + "mm_features.cuh"], [r"void\s+de_casteljau\s*\([^)]*\)\s*\{"], None),
+    "rng.hpp::saturate": ([CS + "mm_features.cuh"], [r"bool\s+saturated\s*\([^)]*\)\s*\{"], None),
+    "rng.hpp::isSaturated": ([CS + "mm_features.cuh"], [r"bool\s+saturated\s*\([^)]*\)\s*\{"], None),
+    "rng.hpp::fbm": ([CS + "mm_noise.cuh"], [r"float\s+fbm2\s*\([^)]*\)\s*\{", r"float\s+fbm3\s*\([^)]*\)\s*\{"], None),
+    "rng.hpp::worley2": ([CS + "mm_noise.cuh"], [r"Worley2\s+worley2\s*\([^)]*\)\s*\{"], None),
+    "rng.hpp::worley3": ([CS + "mm_noise.cuh"], [r"Worley3\s+worley3\s*\([^)]*\)\s*\{"], None),
+    "chunk.cu::chunkFillPlaceBlock": ([CS + "mmgen_kernels.hip"], [r"BaseBlock\s+place_block_base\s*\([^)]*\)\s*\{", r"void\s+fill_body\s*\([^{]*\)\s*\{"], None),
+    "chunk.cu::tryGenerateCaveFeaturePlacement": ([CS + "mmgen_features.hip"], [r"void\s+column_placements\s*\([^{]*\)\s*\{"], None),
+    "chunk.cu::tryPlaceSingleDecorator": ([CS + "mmgen_features.hip"], [r"void\s+try_place_decorator\s*\([^)]*\)\s*\{"], None),
     "rng.hpp::hash": ([CS + "mm_math.cuh"], [r"uint32_t\s+hash32\s*\([^)]*\)\s*\{"], None),
     "rng.hpp::makeSeededRandomEngine": ([CS + "mm_math.cuh"], [r"MinStd\s+rng3\s*\([^)]*\)\s*\{", r"MinStd\s+rng4\s*\([^)]*\)\s*\{"], None),
     "rng.hpp::rand1From1": ([CS + "mm_features.cuh", CS + "mm_noise.cuh"], [r"float\s+rand1from1\s*\([^)]*\)\s*\{", r"float\s+hash_unit\s*\([^)]*\)\s*\{"], None),
@@ -125,6 +128,9 @@ DEVICE_MAP = {
 DEVICE_BENIGN = {0.0, 0.5, 1.0, 2.0, 3.0, 4.0, 5.0, 6.0, 9.0, 16.0, 63.0, 64.0, 255.0, 256.0, 384.0, 65535.0, 2147483648.0, 48271.0,
                  float(np.float32(3.402823466e+38))}
 DEVICE_EXTRA = {
+    # fill_body: lane / batch geometry of the row workgroup (4 columns x 96 y per batch, 16-byte store pieces, 2^32 list keys) and the
+    # "further than 7 blocks from every cave surface" test of the CRYSTAL-only evaluations (LUSH_CAVES converts within 1.5 + 4.5 |simplex3|)
+    "chunk.cu::chunkFillPlaceBlock": (1.5, 4.5, 7.0, 8.0, 14.0, 15.0, 17.0, 45.0, 62.0, 96.0, 4294967296.0),
     "biomeFuncs.hpp::getBiomeNoise": (float(np.float32(0.32)),),         # overallBiomeScale, a file-level constant in the reference (biomeFuncs.hpp:105)
     # cave_huge: slack of its exact pruning; k_cave_voxels: kCaveFaMax = 0.9375 * MM_SIMPLEX3_BOUND (the octave amplitudes of fbm3<4> sum to
     # 0.9375), 1e30 = "no bound" outside the pruning domain (the bounds themselves are macros of mm_noise.cuh)
@@ -133,6 +139,8 @@ DEVICE_EXTRA = {
     "biomeFuncs.hpp::getCaveBiomeNoise": tuple(float(np.float32(v)) for v in (0.875, 5923.45, 4129.42, 5790.48, 1765.68, 4704.36, 5692.12)),
 }
 DEVICE_ALLOW = {
+    "rng.hpp::worley2": (0.5,),                                        # the edge distance (d2 - d1) * 0.5 is formed by the callers from the returned pair
+    "rng.hpp::worley3": (0.5,),
     "featurePlacement.hpp::placeFeature": (0.0, 1.0),
     "featurePlacement.hpp::placeCaveFeature": (0.0, 1.0),
     "rng.hpp::makeSeededRandomEngine": (1.0, 31.0),                    # 0x80000000u
@@ -144,6 +152,14 @@ DEVICE_ALLOW = {
 def test_device_sections_hold_every_reference_constant():
     problems = []
     covered = set()
+    # one device function often restates several functions of the reference (cave_biome_t = getCaveBiomeNoise + getCaveBiomeWeight +
+    # getCaveBiome, column_placements = generateColumnFeaturePlacements + tryGenerateCaveFeaturePlacement, ...): a value of the device
+    # code is an "extra" only if none of the reference functions mapped onto that device function contains it
+    shared_want = {}
+    for ref_fn, (files, sigs, prefix) in DEVICE_MAP.items():
+        vals = set(v for k in REF if k == ref_fn or k.startswith(ref_fn + "::") for v in REF[k])
+        for sig in sigs:
+            shared_want.setdefault(sig, set()).update(vals)
     for ref_fn, (files, sigs, prefix) in DEVICE_MAP.items():
         text = _read(files)
         ref_keys = [k for k in REF if k == ref_fn or k.startswith(ref_fn + "::")]
@@ -162,7 +178,8 @@ def test_device_sections_hold_every_reference_constant():
             missing = sorted(v for v in want - ours if not any(abs(v - a) <= 1e-6 * max(1.0, abs(a)) for a in allow))
             if missing:
                 problems.append(f"{ref_fn} -> {sigs}: values of the reference missing from the device code: {missing}")
-            extra = sorted(ours - want - DEVICE_BENIGN - set(DEVICE_EXTRA.get(ref_fn, ())))
+            shared = set().union(*(shared_want[sig] for sig in sigs))
+            extra = sorted(ours - want - shared - DEVICE_BENIGN - set(v for fn in DEVICE_MAP if set(DEVICE_MAP[fn][1]) & set(sigs) for v in DEVICE_EXTRA.get(fn, ())))
             if extra:
                 problems.append(f"{ref_fn}: values in the device code that the reference's function does not contain: {extra}")
             continue
@@ -194,50 +211,90 @@ def test_device_sections_hold_every_reference_constant():
 # tools/extract_ref_literals.py::skeleton; a digest, not text).  Where the oracle's same-named section has the same digest it IS the
 # reference's code statement for statement - control flow, operation order, operands - up to the documented table of renamed helpers.
 SKEL = json.load(open(os.path.join(ROOT, "tests", "golden", "ref_skeletons.json")))
-# sections whose oracle form differs in more than names (each group with its reason); everything else must be token-identical
+# sections whose oracle form differs in more than names (each with its reason); everything else must be token-identical
 SKELETON_DIFFERS = {
-    # vector expressions written per component, explicit evaluation order of constructor arguments that draw from the stream
-    # (float r0 = u11(rng), r1 = ..., r2 = ...; vec3(r0, r1, r2)), closures u01f() / u01b() for u01(featureRng) / u01(blockRng), integer
-    # literals in float vectors written as floats, ivec helpers: every rasteriser
-    "featurePlacement.hpp::placeFeature", "featurePlacement.hpp::placeCaveFeature", "featurePlacement.hpp::sdCappedCylinder",
-    "featurePlacement.hpp::isInRasterizedLine", "featurePlacement.hpp::isInCrystal", "featurePlacement.hpp::getCrystalRadius",
-    "featurePlacement.hpp::getRandomCrystalBlock",
-    *("featurePlacement.hpp::placeFeature::" + f for f in (
-        "SPHERE", "CORAL", "KELP", "ICEBERG", "ACACIA_TREE", "REDWOOD_TREE", "CYPRESS_TREE", "BIRCH_TREE", "PINE_TREE", "PINE_SHRUB",
-        "RAFFLESIA", "LARGE_JUNGLE_TREE", "SMALL_JUNGLE_TREE", "TINY_JUNGLE_TREE", "MEDIUM_PURPLE_MUSHROOM", "PURPLE_MUSHROOM",
-        "MEDIUM_CRYSTAL", "CRYSTAL", "PALM_TREE", "CACTUS")),
-    *("featurePlacement.hpp::placeCaveFeature::" + f for f in (
-        "CAVE_VINE", "GLOWSTONE_CLUSTER", "STORMLIGHT_SPHERE", "CEILING_STORMLIGHT_SPHERE", "CRYSTAL_PILLAR", "WARPED_FUNGUS", "AMBER_FUNGUS")),
-    # the sin hashes return fract(sin(v) * c) per component; the engine is our own Rng over uint32_t; specialCaveNoise floors explicitly
-    "rng.hpp::hash", "rng.hpp::makeSeededRandomEngine", "rng.hpp::rand2From2", "rng.hpp::rand2From3", "rng.hpp::rand3From2",
-    "rng.hpp::rand3From3", "rng.hpp::specialCaveNoise",
-    # host / kernel orchestration restated over plain arrays (tables through T(), no shared memory, no thread indices)
-    "chunk.cu::getStratifiedMaterialThickness", "chunk.cu::isFeaturePos", "chunk.cu::generateColumnFeaturePlacements",
-    "chunk.cu::placeDecorators", "chunk.cu::kernGenerateCaves",
-    # isInRange() written as two comparisons on floats, explicit parentheses around int -> float operands, an unused local dropped
-    "biomeFuncs.hpp::caveBiomeBlockPostProcess", "biomeFuncs.hpp::caveBiomeBlockPostProcess::CRYSTAL_CAVES",
-    "biomeFuncs.hpp::caveBiomeBlockPostProcess::LUSH_CAVES", "biomeFuncs.hpp::caveBiomeBlockPostProcess::AMBER_FOREST",
-    "biomeFuncs.hpp::biomeBlockPostProcess::CRYSTALS",
+    # the one CUDA kernel among the sections: a thread block of 12 threads x 32 voxels per column with shared-memory bit words, a
+    # __syncthreads() between the noise phase and the run extraction; the oracle walks the column with a plain array of 385 flags.  The
+    # arithmetic it calls (shouldGenerateCaveAtBlock, getCaveBiome) IS pinned; what differs is thread-index orchestration.
+    "chunk.cu::kernGenerateCaves",
 }
+# What the normaliser (tools/extract_ref_literals.py::skeleton) treats as equal, all of it listed there: comments, qualifiers
+# (const / static / inline / __device__ / __host__), braces, (float) casts, namespaces (glm:: thrust:: std::), printf diagnostics,
+# `default: break;`, `(void)x;`, `#pragma unroll`, the reference's own compile-time switches resolved as its `#define`s set them, the
+# table of renamed helpers (g_* glm look-alikes, mm_* libm, hash_u32, Rng = default_random_engine), and four named oracle-only
+# insertions: vec3_ltr (= vec3 with the canonical left-to-right evaluation of its arguments), CANONICAL_RETURN_FALSE,
+# CANONICAL_DECORATOR_RANGE, CANONICAL_NO_LAYER_FOUND (where the reference's behaviour is undefined).
 
 
-def test_oracle_sections_are_token_identical_to_the_reference():
+def _skeleton_report():
     cache, identical, differs = {}, [], []
     for rel, key, sig, prefixes in REFERENCE_SECTIONS:
         base = os.path.basename(rel)
         if base not in cache:
             cache[base] = _read(ORACLE_FILES[base])
-        sig_o = sig.replace(r"void\s+Chunk::", r"void\s+").replace(r"void\s+kernGenerateCaves", r"void\s+generateCaves")
-        secs = sections(cache[base], sig_o, prefixes)
+        secs = sections(cache[base], oracle_signature(f"{base}::{key}", sig), prefixes)
         for k in SKEL:
             parts = k.split("::")
             if parts[0] != base or parts[1] != key:
                 continue
             mine = skeleton_digest(secs.get(parts[2] if len(parts) == 3 else "", ""))
             (identical if mine["sha256"] == SKEL[k]["sha256"] else differs).append(k)
+    return identical, differs
+
+
+def test_oracle_sections_are_token_identical_to_the_reference():
+    identical, differs = _skeleton_report()
     unexpected = sorted(set(differs) - SKELETON_DIFFERS)
     assert not unexpected, "oracle sections that no longer match the reference's statement skeleton: " + ", ".join(unexpected)
     stale = sorted(SKELETON_DIFFERS - set(differs))
     assert not stale, "sections listed as different that are identical now (move them out of SKELETON_DIFFERS): " + ", ".join(stale)
-    # what is pinned this way: every getHeight case, both biome-noise functions, the surface block rules, fbm / simplex-from helpers, ...
-    assert len(identical) >= 53 and sum(k.startswith("biomeFuncs.hpp::getHeight::") for k in identical) == 24
+    # what is pinned this way: every function and switch case on the path except the one kernel above
+    assert len(SKEL) >= 127 and len(identical) == len(SKEL) - 1
+    count = lambda prefix: sum(k.startswith(prefix) for k in identical)
+    assert count("biomeFuncs.hpp::getHeight::") == 24
+    assert count("featurePlacement.hpp::placeFeature::") == 21 and count("featurePlacement.hpp::placeCaveFeature::") == 10
+    assert count("rng.hpp::") == 24 and count("chunk.cu::") == 8 and count("biomeFuncs.hpp::") == 51 and count("featurePlacement.hpp::") == 43
+    assert all(SKEL[k]["tokens"] > 0 for k in SKEL)
+
+
+# one mutation per family of sections: a change of operation order, of an operand or of control flow in the oracle must break the digest
+MUTATIONS = [
+    ("oracle/mmo_biome.cpp", "136.f + 6.f * fbm", "6.f * fbm + 136.f", "biomeFuncs.hpp::getHeight::"),                      # operand order
+    ("oracle/mmo_features.cpp", "float icebergCenterRatio = 1.f - (horizontalDistance / icebergRadius);",
+     "float icebergCenterRatio = (icebergRadius - horizontalDistance) / icebergRadius;", "featurePlacement.hpp::placeFeature::ICEBERG"),
+    ("oracle/mmo_features.cpp", "vec3_ltr(u11(featureRng), u01(featureRng), u11(featureRng)) * vec3(2.5f, 3.5f, 2.5f)",
+     "vec3_ltr(u11(featureRng), u11(featureRng), u01(featureRng)) * vec3(2.5f, 3.5f, 2.5f)", "featurePlacement.hpp::placeFeature::CORAL"),   # draw order
+    ("oracle/mmo_features.cpp", "if (radiusRatio < 0.4f) *blockPtr = Block::GLOWSTONE;", "if (radiusRatio <= 0.4f) *blockPtr = Block::GLOWSTONE;",
+     "featurePlacement.hpp::placeCaveFeature::CRYSTAL_PILLAR"),                                                                  # comparison
+    ("oracle/mmo_noise.h", "g_dot(v, vec3(654.37f, 560.45f, 747.42f)),\n        g_dot(v, vec3(640.88f, 151.81f, 674.81f))",
+     "g_dot(v, vec3(640.88f, 151.81f, 674.81f)),\n        g_dot(v, vec3(654.37f, 560.45f, 747.42f))", "rng.hpp::rand3From3"),        # component order
+    ("oracle/mmo_noise.h", "return minDist3 / minDist1 - 1.f;", "return minDist3 / (minDist1 - 1.f);", "rng.hpp::specialCaveNoise"),
+    ("oracle/mmo_noise.h", "int h = hash_u32((1 << 31) | (x << 22) | (y << 11) | w) ^ hash_u32(z);",
+     "int h = hash_u32((1 << 31) | (x << 22) | (z << 11) | w) ^ hash_u32(y);", "rng.hpp::makeSeededRandomEngine"),
+    ("oracle/mmo_stages.cpp", "+ ivec2(gridCellPadding)\n        + ivec2(g_floor(randPos * (float)gridCellInternalSideLength));",
+     "+ ivec2(g_floor(randPos * (float)gridCellInternalSideLength + (float)gridCellPadding));", "chunk.cu::isFeaturePos"),
+    ("oracle/mmo_stages.cpp", "if (!placedTop && (topRand -= gen.chance) < 0.f)", "if (!placedTop && (topRand -= gen.chance) <= 0.f)", "chunk.cu::placeDecorators"),
+    ("oracle/mmo_stages.cpp", "if (u01(blockRng) >= featureGen.chancePerGridCell)", "if (u01(blockRng) > featureGen.chancePerGridCell)",
+     "chunk.cu::generateColumnFeaturePlacements"),
+    ("oracle/mmo_stages.cpp", "if (layerStart <= y && y < layerEnd)", "if (layerStart < y && y <= layerEnd)", "chunk.cu::chunkFillPlaceBlock"),
+    ("oracle/mmo_biome.cpp", "if (rand <= 0.f) return caveBiome;", "if (rand < 0.f) return caveBiome;", "biomeFuncs.hpp::getCaveBiome"),
+]
+
+
+@pytest.mark.parametrize("path,old,new,prefix", MUTATIONS, ids=[m[3].split("::", 1)[1] for m in MUTATIONS])
+def test_skeleton_digest_sees_a_mutated_oracle_statement(path, old, new, prefix, monkeypatch):
+    """the digests are not vacuous: each listed one-statement change of the oracle's TEXT (never built) moves a section of that family
+    out of the identical set"""
+    full = os.path.join(ROOT, path)
+    text = open(full).read()
+    assert text.count(old) >= 1, f"mutation target not found in {path}: {old!r}"
+    real_open = open
+
+    def fake_read(paths):
+        return "\n".join(strip_comments(text.replace(old, new, 1) if os.path.join(ROOT, p) == full else real_open(os.path.join(ROOT, p)).read())
+                         for p in paths)
+
+    monkeypatch.setitem(globals(), "_read", fake_read)
+    _, differs = _skeleton_report()
+    hit = [k for k in differs if k.startswith(prefix)]
+    assert hit, f"mutating {old!r} -> {new!r} left every {prefix}* digest unchanged"

@@ -30,7 +30,47 @@ NUM = re.compile(r"(?<![\w.])(?:0[xX][0-9a-fA-F]*\.?[0-9a-fA-F]*(?:[pP][-+]?\d+)
 
 def strip_comments(text):
     text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
-    return re.sub(r"//[^\n]*", " ", text)
+    return resolve_conditionals(re.sub(r"//[^\n]*", " ", text))
+
+
+def resolve_conditionals(text):
+    """keep the active branch of #if / #ifdef / #ifndef ... #else ... #endif for the object-like macros the (comment-free) text itself
+    defines (`#define DEBUG_USE_CONTRIBUTION_FILL_METHOD 0` at the top of chunk.cu; a commented-out #define is not defined); the
+    directive lines themselves are dropped.  Conditions: NAME, !NAME, defined(NAME); anything else is kept as written."""
+    defs = {}
+    for m in re.finditer(r"^[ \t]*#[ \t]*define[ \t]+(\w+)[ \t]+(-?\d+)[ \t]*$", text, flags=re.M):
+        defs[m.group(1)] = int(m.group(2))
+    out, stack = [], []                                     # stack of (active_before, this_branch_taken, currently_active)
+    for line in text.split("\n"):
+        m = re.match(r"[ \t]*#[ \t]*(ifdef|ifndef|if|else|endif)\b[ \t]*(.*)", line)
+        active = all(s[2] for s in stack)
+        if not m:
+            if active:
+                out.append(line)
+            continue
+        kind, cond = m.group(1), m.group(2).strip()
+        if kind in ("ifdef", "ifndef"):
+            val = (cond in defs) != (kind == "ifndef")
+            stack.append([active, val, val])
+        elif kind == "if":
+            neg = cond.startswith("!")
+            name = cond.lstrip("! ").strip()
+            dm = re.match(r"defined\s*\(?\s*(\w+)\s*\)?$", name)
+            if dm:
+                val = dm.group(1) in defs
+            elif re.fullmatch(r"\w+", name):
+                val = bool(defs.get(name, 0))
+            else:
+                out.append(line)                                # not ours to decide: leave the construct in the token stream
+                stack.append([active, True, True])
+                continue
+            val = val != neg
+            stack.append([active, val, val])
+        elif kind == "else" and stack:
+            stack[-1][2] = not stack[-1][1]
+        elif kind == "endif" and stack:
+            stack.pop()
+    return "\n".join(out)
 
 
 def literals(code):
@@ -102,7 +142,11 @@ RENAME = {"g_smoothstep": "smoothstep", "g_mix": "mix", "g_clamp": "clamp", "g_m
           "g_abs": "abs", "g_sqrt": "sqrt", "mm_powf": "powf", "mm_sinf": "sin", "mm_cosf": "cos", "mm_acosf": "acos", "mm_atan2f": "atan2",
           "mm_fmodf": "fmod", "mm_sqrtf": "sqrt", "mm_sincosf": "sincosf", "sinf": "sin", "cosf": "cos", "acosf": "acos", "atan2f": "atan2",
           "fmodf": "fmod", "fabsf": "abs", "fmaxf": "max", "fminf": "min", "fmax": "max", "fmin": "min", "floorf": "floor", "sqrtf": "sqrt",
-          "isInRangeF": "isInRange", "isInRangeI": "isInRange"}
+          "isInRangeF": "isInRange", "isInRangeI": "isInRange", "g_ceil": "ceil", "ceilf": "ceil", "g_angle": "angle", "g_sin": "sin",
+          "hash_u32": "hash", "Rng": "default_random_engine",
+          # C++ leaves the order of evaluation of call arguments unspecified; where the reference draws from one random stream in several
+          # arguments of one vec3(...) the oracle fixes the canonical left-to-right order with a braced list behind this macro (mmo_vec.h)
+          "vec3_ltr": "vec3"}
 DROPPED = {"const", "__device__", "__host__", "static", "inline", "{", "}", "glm", "thrust", "std", "::"}
 
 
@@ -129,7 +173,10 @@ def skeleton(code):
         i += 1
     txt = " " + " ".join(out) + " "
     txt = re.sub(r" printf \( [^;]* \) ;", " ", txt)                    # "reached an unreachable section" diagnostics
-    txt = txt.replace(" default : break ;", " ")
+    txt = txt.replace(" default : break ;", " ").replace(" pragma unroll ", " ").replace(" __builtin_unreachable ( ) ;", " ")
+    # the two statements the canonical semantics add to member functions of the reference (oracle/mmo_stages.cpp)
+    txt = txt.replace(" CANONICAL_RETURN_FALSE ;", " ").replace(" CANONICAL_DECORATOR_RANGE ( pos ) ;", " ")
+    txt = txt.replace(" CANONICAL_NO_LAYER_FOUND ( thisLayerIdx , blockPtr )", " ")
     txt = re.sub(r" \( void \) \w+ ;", " ", txt)
     txt = txt.replace(" . r ", " . x ").replace(" . g ", " . y ").replace(" . b ", " . z ")      # glm colour aliases of the components
     return txt.split()
@@ -159,6 +206,26 @@ REFERENCE_SECTIONS = [
     ("terrain/featurePlacement.hpp", "getRandomCrystalBlock", r"Block\s+getRandomCrystalBlock\s*\([^)]*\)\s*\{", ()),
     ("terrain/featurePlacement.hpp", "placeFeature", r"bool\s+placeFeature\s*\([^)]*\)\s*\{", ("Feature::",)),
     ("terrain/featurePlacement.hpp", "placeCaveFeature", r"bool\s+placeCaveFeature\s*\([^)]*\)\s*\{", ("CaveFeature::",)),
+    ("terrain/biomeFuncs.hpp", "getRandomBiome", r"Biome\s+getRandomBiome\s*\([^)]*\)\s*\{", ()),
+    ("terrain/biomeFuncs.hpp", "applySingleBiomeNoise", r"void\s+applySingleBiomeNoise\s*\([^)]*\)\s*\{", ()),
+    ("terrain/biomeFuncs.hpp", "getBiomeWeight", r"float\s+getBiomeWeight\s*\([^)]*\)\s*\{", ()),
+    ("terrain/biomeFuncs.hpp", "getCaveBiomeWeight", r"float\s+getCaveBiomeWeight\s*\([^)]*\)\s*\{", ()),
+    ("terrain/biomeFuncs.hpp", "getCaveBiome", r"CaveBiome\s+getCaveBiome\s*\([^)]*\)\s*\{", ()),
+    ("terrain/featurePlacement.hpp", "sdSphere", r"float\s+sdSphere\s*\([^)]*\)\s*\{", ()),
+    ("terrain/featurePlacement.hpp", "opSubtraction", r"float\s+opSubtraction\s*\([^)]*\)\s*\{", ()),
+    ("terrain/featurePlacement.hpp", "opOnion", r"float\s+opOnion\s*\([^)]*\)\s*\{", ()),
+    ("terrain/featurePlacement.hpp", "deCasteljau", r"void\s+deCasteljau\s*\([^)]*\)\s*\{", ()),
+    ("util/rng.hpp", "manhattanLength", r"int\s+manhattanLength\s*\([^)]*\)\s*\{", ()),
+    ("util/rng.hpp", "manhattanDistance", r"int\s+manhattanDistance\s*\([^)]*\)\s*\{", ()),
+    ("util/rng.hpp", "isInRange", r"bool\s+isInRange\s*\([^)]*\)\s*\{", ()),
+    ("util/rng.hpp", "isPosInRange", r"bool\s+isPosInRange\s*\([^)]*\)\s*\{", ()),
+    ("util/rng.hpp", "getRatio", r"float\s+getRatio\s*\([^)]*\)\s*\{", ()),
+    ("util/rng.hpp", "saturate", r"float\s+saturate\s*\([^)]*\)\s*\{", ()),
+    ("util/rng.hpp", "isSaturated", r"(?:float|bool)\s+isSaturated\s*\([^)]*\)\s*\{", ()),
+    ("util/rng.hpp", "calculateLineParams", r"bool\s+calculateLineParams\s*\([^)]*\)\s*\{", ()),
+    ("util/rng.hpp", "fbm", r"float\s+fbm\s*\([^)]*\)\s*\{", ()),
+    ("util/rng.hpp", "worley2", r"float\s+worley\s*\(\s*vec2[^)]*\)\s*\{", ()),
+    ("util/rng.hpp", "worley3", r"float\s+worley\s*\(\s*vec3[^)]*\)\s*\{", ()),
     ("util/rng.hpp", "hash", r"unsigned\s+int\s+hash\s*\([^)]*\)\s*\{", ()),
     ("util/rng.hpp", "makeSeededRandomEngine", r"makeSeededRandomEngine\s*\([^)]*\)\s*\{", ()),
     ("util/rng.hpp", "rand1From1", r"float\s+rand1From1\s*\([^)]*\)\s*\{", ()),
@@ -175,10 +242,27 @@ REFERENCE_SECTIONS = [
     ("terrain/chunk.cu", "shouldGenerateCaveAtBlock", r"bool\s+shouldGenerateCaveAtBlock\s*\([^)]*\)\s*\{", ()),
     ("terrain/chunk.cu", "getStratifiedMaterialThickness", r"float\s+getStratifiedMaterialThickness\s*\([^)]*\)\s*\{", ()),
     ("terrain/chunk.cu", "isFeaturePos", r"bool\s+isFeaturePos\s*\([^)]*\)\s*\{", ()),
+    ("terrain/chunk.cu", "tryGenerateCaveFeaturePlacement", r"bool\s+Chunk::tryGenerateCaveFeaturePlacement\s*\([^)]*\)\s*\{", ()),
+    ("terrain/chunk.cu", "tryPlaceSingleDecorator", r"void\s+Chunk::tryPlaceSingleDecorator\s*\([^)]*\)\s*\{", ()),
     ("terrain/chunk.cu", "generateColumnFeaturePlacements", r"void\s+Chunk::generateColumnFeaturePlacements\s*\([^)]*\)\s*\{", ()),
     ("terrain/chunk.cu", "placeDecorators", r"void\s+Chunk::placeDecorators\s*\([^)]*\)\s*\{", ()),
+    ("terrain/chunk.cu", "chunkFillPlaceBlock", r"void\s+chunkFillPlaceBlock\s*\([^{]*\)\s*\{", ()),
     ("terrain/chunk.cu", "kernGenerateCaves", r"void\s+kernGenerateCaves\s*\([^{]*\)\s*\{", ()),
 ]
+
+
+# where the oracle restates each reference file
+ORACLE_FILES = {"biomeFuncs.hpp": ["oracle/mmo_biome.h", "oracle/mmo_biome.cpp"], "featurePlacement.hpp": ["oracle/mmo_features.cpp"],
+                "rng.hpp": ["oracle/mmo_noise.h"], "chunk.cu": ["oracle/mmo_stages.cpp"]}
+
+# the oracle's spelling of a reference signature (free functions instead of Chunk:: members, its own kernel-less stage names)
+ORACLE_SIGNATURES = {"rng.hpp::hash": r"uint32_t\s+hash_u32\s*\([^)]*\)\s*\{"}
+
+
+def oracle_signature(key, sig):
+    if key in ORACLE_SIGNATURES:
+        return ORACLE_SIGNATURES[key]
+    return sig.replace(r"void\s+kernGenerateCaves", r"void\s+generateCaves")
 
 
 def main(out_path):
