@@ -32,6 +32,11 @@ const char* mmgen_error_string(int code);
 /* pre-size the library-internal scratch of the per-stage calls on `stream` (per-column cave info, deferred-voxel queue) so that later
  * calls on that stream allocate nothing (graph capture).  Scratch is keyed by (device, stream). */
 int mmgen_reserve(int max_chunks_per_call, void* stream);
+/* frees the library-internal scratch kept for `stream` on the current device (synchronises it first): call before destroying a stream,
+ * so that the entry does not outlive it and a recycled handle does not inherit its buffers.  mmgen_release_all: every stream, every
+ * device entry (synchronises the current device). */
+int mmgen_release(void* stream);
+int mmgen_release_all(void);
 
 /* Chunk::generateHeightfields, device part (chunk.cu:150-185,207-213): kernGenerateHeightfield.
  * in : d_chunk_world_block_pos [n][2] int32 (x, z) world block position of each chunk's (0,0) column
@@ -132,6 +137,25 @@ int mmgen_region_fill(mmgen_region* region, uint8_t* d_blocks, void* stream);
 int mmgen_region_finish(mmgen_region* region, uint8_t* d_blocks, float* d_heightfields /*nullable*/, float* d_layers /*[n][20][256], nullable*/,
                         mmgen_cave_layer* d_cave_layers /*[n][256][32], nullable*/, void* stream);
 int mmgen_region_last_erosion_passes(const mmgen_region* region);
+/* The one capacity of this library that the reference does not have: a chunk's cave placement list holds MMGEN_CFP_CAP entries (the
+ * reference pushes into an unbounded vector, chunk.cu:1028-1038; a chunk of a generated world carries < 100, the worst case the
+ * algorithm allows is 16 384).  Entries beyond the capacity are dropped, which would change blocks - so it is reported, not hidden:
+ * mmgen_region_finish checks every list length it is about to gather (its own and the ones that arrived from other GPUs) on the device
+ * and records the largest in host-visible memory; from then on mmgen_region_begin / _finish return MMGEN_ERROR_PLACEMENT_OVERFLOW
+ * until the caller acknowledges it.  mmgen_region_max_cave_placements synchronises `stream`, returns the largest cave list length seen
+ * since the last call (<= MMGEN_CFP_CAP means nothing was dropped) and clears the record.  (Surface lists cannot overflow: at most one
+ * placement per column, MMGEN_FP_CAP = 256.  The per-stage call mmgen_generate_feature_placements returns the raw counts to its caller.) */
+#define MMGEN_ERROR_PLACEMENT_OVERFLOW 20001
+int mmgen_region_max_cave_placements(mmgen_region* region, int* out_max, void* stream);
+/* How the region schedules its stages.  Default (serial = 0): a stage DAG over the caller's stream and three
+ * internal ones - the erosion branch (select, gather, ~25 dependent relaxation launches with their host reads, scatter, fix-up) beside
+ * the caves, which need none of it (the reference rotates five streams over its stages, terrain.cpp:129,179-182); the base fill on its
+ * own stream, ordered behind whatever the caller's stream holds when d_blocks is first passed in; the rectangle optionally cut into
+ * `slices` z slices (0 = automatic = 1) with the rasterisers / decorators of slice i beside the fill of slice i + 1.  Every internal
+ * stream is joined into the caller's stream before mmgen_region_finish returns, so callers order against that one stream only.  serial = 1:
+ * every kernel on the caller's stream in the reference's stage order (what per-kernel timing and the counters want); also selected
+ * by MMGEN_REGION_SERIAL=1 in the environment.  Results are identical. */
+int mmgen_region_set_serial(mmgen_region* region, int serial, int slices);
 /* Copies the placement lists of n whole cells between two placement grids with the per-cell layout of mmgen_region_placement_buffers
  * (fp [cells][MMGEN_FP_CAP], cfp [cells][MMGEN_CFP_CAP], counts [cells][2]): cell d_dst_idx[i] of dst <- cell d_src_idx[i] of src.  A streaming
  * caller keeps the lists of chunks it has generated in its own grid and feeds them back as ring cells of later regions (mask 0 in

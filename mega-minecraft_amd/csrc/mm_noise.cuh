@@ -82,17 +82,21 @@ MM_DEV f3 simplex3_corner(float p)
 // One dependent LDS read less per corner (4 per simplex3, 3 per simplex2) for two integer VALU.
 // two objects (known LDS bases, immediate offsets in the non-inlined callees): a kernel that never reaches simplex2 does not
 // reference s_noise2 and does not pay its 4.6 KB
-struct alignas(16) NoiseTables3 { f4v grad3[MM_GRAD_N]; int perm4[MM_PERM_N]; };
+// perm16[i] = 16 * permute(i - MM_PERM_LO): the value is used twice - shifted right by 2 it is the byte offset of the next level's entry
+// in this table, as it stands it is the byte offset of the corner's gradient in grad3 / grad2 (16-byte entries)
+struct alignas(16) NoiseTables3 { f4v grad3[MM_GRAD_N]; int perm16[MM_PERM_N]; };
 struct alignas(16) NoiseTables2 { f4v grad2[MM_GRAD_N]; };
 static __shared__ NoiseTables3 s_noise;
 static __shared__ NoiseTables2 s_noise2;
 
 typedef __attribute__((address_space(3))) const char* lds_bytes;
-MM_DEV int perm4(int off) { return *(__attribute__((address_space(3))) const int*)((lds_bytes)s_noise.perm4 + 4 * MM_PERM_LO + off); }
-// s4 = 4 * (b + x + o): byte offset of the index that the last permute would have taken
-MM_DEV int grad_wrap(int s4) { const unsigned j4 = (unsigned)(s4 + 4); const unsigned w = j4 - 4u * 289u; return (int)((w < j4 ? w : j4) << 2); }
-MM_DEV f4v grad3_at(int s4) { return *(__attribute__((address_space(3))) const f4v*)((lds_bytes)s_noise.grad3 + grad_wrap(s4)); }
-MM_DEV f4v grad2_at(int s4) { return *(__attribute__((address_space(3))) const f4v*)((lds_bytes)s_noise2.grad2 + grad_wrap(s4)); }
+// off = 4 * index (a byte offset into the table); returns 16 * permute(index)
+MM_DEV int perm16(int off) { return *(__attribute__((address_space(3))) const int*)((lds_bytes)s_noise.perm16 + 4 * MM_PERM_LO + off); }
+// s16 = 16 * (b + x + o + 1): 16 x the table index of the gradient of permute(b + x + o), before the wrap at 289 (j' = min_u32(j, j - 289));
+// the callers fold the "+ 1" into the corner constant, so a corner costs add3 + add + min
+MM_DEV int grad_wrap16(int s16) { const unsigned j = (unsigned)s16; const unsigned w = j - 16u * 289u; return (int)(w < j ? w : j); }
+MM_DEV f4v grad3_at16(int s16) { return *(__attribute__((address_space(3))) const f4v*)((lds_bytes)s_noise.grad3 + grad_wrap16(s16)); }
+MM_DEV f4v grad2_at16(int s16) { return *(__attribute__((address_space(3))) const f4v*)((lds_bytes)s_noise2.grad2 + grad_wrap16(s16)); }
 
 // The tables are built ONCE per device and translation unit by k_noise_tables_build (below, with the arithmetic functions above)
 // into this global image; every workgroup then just copies the 12 KB image into LDS at kernel entry (16-byte words, L2 resident)
@@ -103,7 +107,7 @@ static __device__ NoiseTables2 g_noise2;
 static __global__ void __launch_bounds__(256) k_noise_tables_build()
 {
     const int t = threadIdx.x;
-    for (int i = t; i < MM_PERM_N; i += 256) g_noise.perm4[i] = 4 * (int)permute((float)(i - MM_PERM_LO));
+    for (int i = t; i < MM_PERM_N; i += 256) g_noise.perm16[i] = 16 * (int)permute((float)(i - MM_PERM_LO));
     for (int i = t; i < MM_GRAD_N; i += 256) {
         const float p = permute((float)(i - 1));
         const f3 g3 = simplex3_corner(p);
@@ -155,6 +159,9 @@ MM_DEV void noise_tables_init()
     __syncthreads();
 }
 
+MM_DEV float falloff_max0(float x) { return __builtin_fmaxf(x, 0.f); }
+
+template <bool KNOWN_IN = false>
 MM_DEV float simplex2_inl(float vx, float vy)
 {
     const float C0 = (float)0.211324865405187, C1 = (float)0.366025403784439;
@@ -171,11 +178,13 @@ MM_DEV float simplex2_inl(float vx, float vy)
     const float bx = x0x + C2, by = x0y + C2;                     // x12.zw
 
     // table domain: lattice coordinates below 2^24 - 512 in magnitude (then glm::mod(x, 289) is an integer in [0, 288]); NaN fails the test
-    const bool inDomain = __builtin_fabsf(ix) < 16776704.f && __builtin_fabsf(iy) < 16776704.f;      // 2^24 - 512, see below
+    const bool inDomain = KNOWN_IN || (__builtin_fabsf(ix) < 16776704.f && __builtin_fabsf(iy) < 16776704.f);      // 2^24 - 512, see below
 
-    float m0 = gmax(0.5f - (x0x * x0x + x0y * x0y), 0.f);
-    float m1 = gmax(0.5f - (ax * ax + ay * ay), 0.f);
-    float m2 = gmax(0.5f - (bx * bx + by * by), 0.f);
+    // glm::max(x, 0) = (x < 0) ? 0 : x keeps a -0 that v_max_f32 turns into +0; the value is squared next, (-0)^2 = (+0)^2 = +0, and NaN
+    // positions are outside every caller's domain: one instruction instead of compare + select
+    float m0 = falloff_max0(0.5f - (x0x * x0x + x0y * x0y));
+    float m1 = falloff_max0(0.5f - (ax * ax + ay * ay));
+    float m2 = falloff_max0(0.5f - (bx * bx + by * by));
     m0 = m0 * m0; m1 = m1 * m1; m2 = m2 * m2;
     m0 = m0 * m0; m1 = m1 * m1; m2 = m2 * m2;
 
@@ -188,11 +197,11 @@ MM_DEV float simplex2_inl(float vx, float vy)
         // integer remainder IS glm's value.
         int xi = (int)ix % 289, yi = (int)iy % 289;
         xi += xi < 0 ? 289 : 0; yi += yi < 0 ? 289 : 0;
-        const int x4 = 4 * xi, y4 = 4 * yi;
-        const int py0 = perm4(y4), py1 = perm4(y4 + 4);              // i1.y is 0 or 1: the middle corner re-uses one of the two
-        const f4v t0 = grad2_at(py0 + x4);
-        const f4v t1 = grad2_at(gt ? (py0 + x4) + 4 : (py1 + x4));
-        const f4v t2 = grad2_at((py1 + x4) + 4);
+        const int x16 = 16 * xi, y4 = 4 * yi;
+        const int py0 = perm16(y4), py1 = perm16(y4 + 4);            // i1.y is 0 or 1: the middle corner re-uses one of the two
+        const f4v t0 = grad2_at16((py0 + x16) + 16);
+        const f4v t1 = grad2_at16(gt ? (py0 + x16) + 32 : (py1 + x16) + 16);
+        const f4v t2 = grad2_at16((py1 + x16) + 32);
         c0 = mk3(t0.x, t0.y, t0.z); c1 = mk3(t1.x, t1.y, t1.z); c2 = mk3(t2.x, t2.y, t2.z);
     } else {
         ix = gmod(ix, 289.f);
@@ -230,7 +239,26 @@ MM_DEV bool prune_domain(int wx, int wz) { return wx > -MM_PRUNE_DOMAIN && wx < 
 // LDS tables.  simplex3 = part3(part1(v), gradients(part1(v))): glm's operations in glm's order, merely regrouped (checked by
 // the probe tests against real glm).
 // ---------------------------------------------------------------------------------------------------------
-struct Sx3Cell { float ix, iy, iz; float x0x, x0y, x0z; bool gx, gy, gz; };      // g = step(x0.yzx, x0) as three predicates
+// The corner ordering: g = step(x0.yzx, x0), l = 1 - g, i1 = min(g, l.zxy), i2 = max(g, l.zxy) are all in {0, 1}, so min / max are AND /
+// OR of the three order predicates: a AND NOT b is "a > b", a OR NOT b is "a >= b" on {0, 1}.  Written as comparisons on purpose: the
+// compiler turns them into AND / OR of two lane masks (one s_andn2 / s_orn2 on the scalar unit for the whole wave, each use a single
+// v_cndmask), whereas `a && !b` becomes select(a, !b, false) in its IR and from there a NESTED per-lane select (9 VALU for the six), and
+// `a & !b` is carried out in per-lane integers.
+struct Sx3Cell {
+    float ix, iy, iz; float x0x, x0y, x0z;
+    bool gx, gy, gz;
+    MM_DEV bool i1x() const { return gx > gz; }
+    MM_DEV bool i1y() const { return gy > gx; }
+    MM_DEV bool i1z() const { return gz > gy; }
+    MM_DEV bool i2x() const { return gx >= gz; }
+    MM_DEV bool i2y() const { return gy >= gx; }
+    MM_DEV bool i2z() const { return gz >= gy; }
+};
+
+MM_DEV float sel_f(bool m, float ifSet, float ifClear) { return m ? ifSet : ifClear; }
+MM_DEV int sel_i(bool m, int ifSet, int ifClear) { return m ? ifSet : ifClear; }
+MM_DEV int sel_4_0(bool m) { return m ? 4 : 0; }
+MM_DEV int sel_32_16(bool m) { return m ? 32 : 16; }
 
 MM_DEV Sx3Cell simplex3_part1(float vx, float vy, float vz)
 {
@@ -246,13 +274,10 @@ MM_DEV Sx3Cell simplex3_part1(float vx, float vy, float vz)
 }
 
 // 12 floats: (qx, qy, qz) of the 4 corners, already scaled by taylorInvSqrt.  Arithmetic form; ix, iy, iz already mod289'd.
-MM_DEV void simplex3_gradients_direct(float ix, float iy, float iz, bool gxb, bool gyb, bool gzb, float* __restrict__ q)
+MM_DEV void simplex3_gradients_direct(float ix, float iy, float iz, const Sx3Cell& c, float* __restrict__ q)
 {
-    // l = 1 - g; i1 = min(g, l.zxy); i2 = max(g, l.zxy)
-    const int gx = gxb, gy = gyb, gz = gzb;
-    const int i1x = gx & (gz ^ 1), i1y = gy & (gx ^ 1), i1z = gz & (gy ^ 1);
-    const int i2x = gx | (gz ^ 1), i2y = gy | (gx ^ 1), i2z = gz | (gy ^ 1);
-    const float oz[4] = {0.f, (float)i1z, (float)i2z, 1.f}, oy[4] = {0.f, (float)i1y, (float)i2y, 1.f}, ox[4] = {0.f, (float)i1x, (float)i2x, 1.f};
+    const float oz[4] = {0.f, sel_f(c.i1z(), 1.f, 0.f), sel_f(c.i2z(), 1.f, 0.f), 1.f}, oy[4] = {0.f, sel_f(c.i1y(), 1.f, 0.f), sel_f(c.i2y(), 1.f, 0.f), 1.f},
+                ox[4] = {0.f, sel_f(c.i1x(), 1.f, 0.f), sel_f(c.i2x(), 1.f, 0.f), 1.f};
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const float a = permute(iz + oz[k]);
@@ -262,51 +287,52 @@ MM_DEV void simplex3_gradients_direct(float ix, float iy, float iz, bool gxb, bo
     }
 }
 
-// Same values through the LDS tables (see the header); falls back to the arithmetic outside the tables' domain.
-MM_DEV void simplex3_gradients(float ix, float iy, float iz, bool gx, bool gy, bool gz, float* __restrict__ q)
+// table domain of the gradients: lattice coordinates below 2^23 in magnitude (then mod289 is an integer in [-1, 289] and 289 * floor(i /
+// 289) is exact, see below); NaN fails the test
+MM_DEV bool simplex3_in_domain(float ix, float iy, float iz) { return __builtin_fabsf(ix) < 8388608.f && __builtin_fabsf(iy) < 8388608.f && __builtin_fabsf(iz) < 8388608.f; }
+
+// Same values through the LDS tables (see the header); falls back to the arithmetic outside the tables' domain.  KNOWN_IN = the caller
+// has established the domain for this evaluation (the fbm stacks test their last octave once instead of every octave).
+template <bool KNOWN_IN = false>
+MM_DEV void simplex3_gradients(const Sx3Cell& c, float* __restrict__ q)
 {
-    // table domain: lattice coordinates below 2^23 in magnitude (then mod289 is an integer in [-1, 289]); NaN fails the test
-    // (2^23: below it 289 * floor(i / 289) is exact, see below)
-    const bool inDomain = __builtin_fabsf(ix) < 8388608.f && __builtin_fabsf(iy) < 8388608.f && __builtin_fabsf(iz) < 8388608.f;
-    if (inDomain) {
+    float ix = c.ix, iy = c.iy, iz = c.iz;
+    if (KNOWN_IN || simplex3_in_domain(ix, iy, iz)) {
         // mod289(i) = i - floor(i * (1 / 289)) * 289: for |i| < 2^23 the product floor * 289 is an integer below 2^24, hence exact, and so is the
         // difference: one fused multiply-add returns the same value as the multiply and the subtraction
         ix = __builtin_fmaf(-289.f, __builtin_floorf(ix * (1.f / 289.f)), ix);
         iy = __builtin_fmaf(-289.f, __builtin_floorf(iy * (1.f / 289.f)), iy);
         iz = __builtin_fmaf(-289.f, __builtin_floorf(iz * (1.f / 289.f)), iz);
-        const bool i1x = gx && !gz, i1y = gy && !gx, i1z = gz && !gy;
-        const bool i2x = gx || !gz, i2y = gy || !gx, i2z = gz || !gy;
-        const int x4 = 4 * (int)ix, y4 = 4 * (int)iy, z4 = 4 * (int)iz;
-        // level z: the four corners only ever need permute(z) and permute(z + 1)
-        const int pz0 = perm4(z4), pz1 = perm4(z4 + 4);
-        const int a[4] = {pz0, i1z ? pz1 : pz0, i2z ? pz1 : pz0, pz1};
-        const int oy[4] = {0, i1y ? 4 : 0, i2y ? 4 : 0, 4}, ox[4] = {0, i1x ? 4 : 0, i2x ? 4 : 0, 4};
+        const int x16 = 16 * (int)ix, y4 = 4 * (int)iy, z4 = 4 * (int)iz;
+        // level z: the four corners only ever need permute(z) and permute(z + 1); as byte offsets of the next level's entries (16 p -> 4 p)
+        const int pz0 = perm16(z4) >> 2, pz1 = perm16(z4 + 4) >> 2;
+        const int a[4] = {pz0, sel_i(c.i1z(), pz1, pz0), sel_i(c.i2z(), pz1, pz0), pz1};
+        const int oy[4] = {0, sel_4_0(c.i1y()), sel_4_0(c.i2y()), 4}, ox[4] = {16, sel_32_16(c.i1x()), sel_32_16(c.i2x()), 32};      // ox: 16 * (o + 1)
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const int b = perm4((a[k] + y4) + oy[k]);
-            const f4v g = grad3_at((b + x4) + ox[k]);       // fused: gradient of permute(b + x + o)
+            const int b = perm16((a[k] + y4) + oy[k]);
+            const f4v g = grad3_at16((b + x16) + ox[k]);    // fused: gradient of permute(b + x + o)
             q[3 * k] = g.x; q[3 * k + 1] = g.y; q[3 * k + 2] = g.z;
         }
     } else {
         ix = mod289(ix); iy = mod289(iy); iz = mod289(iz);
-        simplex3_gradients_direct(ix, iy, iz, gx, gy, gz, q);
+        simplex3_gradients_direct(ix, iy, iz, c, q);
     }
 }
 
 MM_DEV float simplex3_part3(const Sx3Cell& c, const float* __restrict__ q)
 {
     const float Cx = (float)(1.0 / 6.0), Cy = (float)(1.0 / 3.0);
-    // g = step(x0.yzx, x0), l = 1 - g, i1 = min(g, l.zxy), i2 = max(g, l.zxy): all in {0, 1}, so min / max are AND / OR of the order
-    // bits (the same integers simplex3_gradients indexes the tables with) and the floats are exact conversions of them
-    const float i1x = (c.gx && !c.gz) ? 1.f : 0.f, i1y = (c.gy && !c.gx) ? 1.f : 0.f, i1z = (c.gz && !c.gy) ? 1.f : 0.f;
-    const float i2x = (c.gx || !c.gz) ? 1.f : 0.f, i2y = (c.gy || !c.gx) ? 1.f : 0.f, i2z = (c.gz || !c.gy) ? 1.f : 0.f;
-    const float cx[4] = {c.x0x, (c.x0x - i1x) + Cx, (c.x0x - i2x) + Cy, c.x0x - 0.5f};
-    const float cy[4] = {c.x0y, (c.x0y - i1y) + Cx, (c.x0y - i2y) + Cy, c.x0y - 0.5f};
-    const float cz[4] = {c.x0z, (c.x0z - i1z) + Cx, (c.x0z - i2z) + Cy, c.x0z - 0.5f};
+    // x0 - i1 with i1 in {0, 1}: x0 - 0 is x0 itself (exact, sign of zero included), so both middle corners select between x0 and the ONE
+    // difference x0 - 1 per axis
+    const float dx = c.x0x - 1.f, dy = c.x0y - 1.f, dz = c.x0z - 1.f;
+    const float cx[4] = {c.x0x, sel_f(c.i1x(), dx, c.x0x) + Cx, sel_f(c.i2x(), dx, c.x0x) + Cy, c.x0x - 0.5f};
+    const float cy[4] = {c.x0y, sel_f(c.i1y(), dy, c.x0y) + Cx, sel_f(c.i2y(), dy, c.x0y) + Cy, c.x0y - 0.5f};
+    const float cz[4] = {c.x0z, sel_f(c.i1z(), dz, c.x0z) + Cx, sel_f(c.i2z(), dz, c.x0z) + Cy, c.x0z - 0.5f};
     float mm4[4], pd[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        float m = gmax(0.6f - ((cx[k] * cx[k] + cy[k] * cy[k]) + cz[k] * cz[k]), 0.f);
+        float m = falloff_max0(0.6f - ((cx[k] * cx[k] + cy[k] * cy[k]) + cz[k] * cz[k]));      // see simplex2_inl
         m = m * m;
         mm4[k] = m * m;
         pd[k] = (q[3 * k] * cx[k] + q[3 * k + 1] * cy[k]) + q[3 * k + 2] * cz[k];
@@ -314,43 +340,80 @@ MM_DEV float simplex3_part3(const Sx3Cell& c, const float* __restrict__ q)
     return 42.f * ((mm4[0] * pd[0] + mm4[1] * pd[1]) + (mm4[2] * pd[2] + mm4[3] * pd[3]));
 }
 
+template <bool KNOWN_IN = false>
 MM_DEV float simplex3_inl(float vx, float vy, float vz)
 {
     const Sx3Cell c = simplex3_part1(vx, vy, vz);
     float q[12];
-    simplex3_gradients(c.ix, c.iy, c.iz, c.gx, c.gy, c.gz, q);
+    simplex3_gradients<KNOWN_IN>(c, q);
     return simplex3_part3(c, q);
 }
 
 // One shared (non-inlined) body per translation unit for the scattered call sites (block rules, rasterisers); the fbm stacks
 // below inline the body ONCE inside a rolled octave loop instead: no call, no callee-saved register pressure around it.
-MM_SIMPLEX_ATTR float simplex2(float vx, float vy) { return simplex2_inl(vx, vy); }
-MM_SIMPLEX_ATTR float simplex3(float vx, float vy, float vz) { return simplex3_inl(vx, vy, vz); }
+MM_SIMPLEX_ATTR float simplex2(float vx, float vy) { return simplex2_inl<false>(vx, vy); }
+MM_SIMPLEX_ATTR float simplex3(float vx, float vy, float vz) { return simplex3_inl<false>(vx, vy, vz); }
 
 // ---------------------------------------------------------------------------------------------------------
 // fbm stacks (rng.hpp:166-191): amplitude halves, frequency doubles, octaves summed in order
 // ---------------------------------------------------------------------------------------------------------
-template <int OCT>
-MM_DEV float fbm2(float x, float y)
+template <int OCT, bool KNOWN_IN>
+MM_DEV float fbm2_loop(float x, float y)
 {
     float acc = 0.f, amp = 1.f;
 #pragma unroll 1
     for (int i = 0; i < OCT; ++i) {
         amp *= 0.5f;
-        acc += amp * simplex2_inl(x, y);
+        acc += amp * simplex2_inl<KNOWN_IN>(x, y);
         x *= 2.f; y *= 2.f;
     }
     return acc;
 }
 
+// domain test once per stack (see fbm3 below): |floor(v + (vx + vy) * 0.366)| < 2 max|v| + 1, the last octave evaluates at 2^(OCT - 1) v
 template <int OCT>
-MM_DEV float fbm3(float x, float y, float z)
+MM_DEV float fbm2(float x, float y)
+{
+    const float m = __builtin_fmaxf(__builtin_fabsf(x), __builtin_fabsf(y));
+    if (__builtin_expect(m < (float)(1 << (22 - OCT)), 1)) return fbm2_loop<OCT, true>(x, y);
+    // beyond the table domain (block coordinates of hundreds of millions): the shared out-of-line simplex2 with its per-call test, so that
+    // the call sites carry ONE inlined loop body (k_heightfield inlines dozens of stacks: a second body each cost it 50 % of its time)
+    float acc = 0.f, amp = 1.f;
+#pragma unroll 1
+    for (int i = 0; i < OCT; ++i) {
+        amp *= 0.5f;
+        acc += amp * simplex2(x, y);
+        x *= 2.f; y *= 2.f;
+    }
+    return acc;
+}
+
+template <int OCT, bool KNOWN_IN>
+MM_DEV float fbm3_loop(float x, float y, float z)
 {
     float acc = 0.f, amp = 1.f;
 #pragma unroll 1
     for (int i = 0; i < OCT; ++i) {
         amp *= 0.5f;
-        acc += amp * simplex3_inl(x, y, z);
+        acc += amp * simplex3_inl<KNOWN_IN>(x, y, z);
+        x *= 2.f; y *= 2.f; z *= 2.f;
+    }
+    return acc;
+}
+
+// The table-domain test of the gradients (|lattice coordinate| < 2^23) once per stack instead of once per octave: a lattice coordinate is
+// floor(v + (vx + vy + vz) / 3), at most 2 max|v| + 1 in magnitude, and the last octave evaluates at 2^(OCT - 1) times the argument - so
+// max|v| < 2^(22 - OCT) puts every octave inside the domain (NaN fails the test and takes the per-octave check).  Same values either way.
+template <int OCT>
+MM_DEV float fbm3(float x, float y, float z)
+{
+    const float m = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(x), __builtin_fabsf(y)), __builtin_fabsf(z));
+    if (__builtin_expect(m < (float)(1 << (22 - OCT)), 1)) return fbm3_loop<OCT, true>(x, y, z);
+    float acc = 0.f, amp = 1.f;                 // beyond the domain: the shared out-of-line simplex3 (see fbm2)
+#pragma unroll 1
+    for (int i = 0; i < OCT; ++i) {
+        amp *= 0.5f;
+        acc += amp * simplex3(x, y, z);
         x *= 2.f; y *= 2.f; z *= 2.f;
     }
     return acc;

@@ -97,7 +97,47 @@ int mmgen_init(int device)
     return mmk::prepare_features();
 }
 
-const char* mmgen_error_string(int code) { return hipGetErrorString((hipError_t)code); }
+const char* mmgen_error_string(int code)
+{
+    if (code == MMGEN_ERROR_PLACEMENT_OVERFLOW)
+        return "a chunk's cave placement list exceeded MMGEN_CFP_CAP and lost entries (mmgen_region_max_cave_placements acknowledges)";
+    return hipGetErrorString((hipError_t)code);
+}
+
+// Library scratch of the per-stage calls is kept per (device, stream) and only grows.  A host that creates and destroys streams calls
+// mmgen_release(stream) before destroying one (a recycled handle would otherwise inherit the old buffers, and the entry would stay
+// for good); mmgen_release_all() frees everything, e.g. before unloading the library.  Both synchronise the streams they release.
+int mmgen_release(void* stream)
+{
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return (int)e;
+    Scratch sc;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        auto it = g_scratch.find({dev, stream});
+        if (it == g_scratch.end()) return 0;
+        sc = it->second;
+        g_scratch.erase(it);
+    }
+    e = hipStreamSynchronize((hipStream_t)stream);
+    if (e != hipSuccess) return (int)e;
+    for (void* p : {(void*)sc.colInfo, (void*)sc.erodeWork, (void*)sc.erodeState, (void*)sc.fillQueue})
+        if (p && (e = hipFree(p)) != hipSuccess) return (int)e;
+    return 0;
+}
+
+int mmgen_release_all()
+{
+    std::map<std::pair<int, void*>, Scratch> all;
+    { std::lock_guard<std::mutex> lk(g_mu); all.swap(g_scratch); }
+    hipError_t e = hipDeviceSynchronize();
+    if (e != hipSuccess) return (int)e;
+    for (auto& kv : all)
+        for (void* p : {(void*)kv.second.colInfo, (void*)kv.second.erodeWork, (void*)kv.second.erodeState, (void*)kv.second.fillQueue})
+            if (p && (e = hipFree(p)) != hipSuccess) return (int)e;
+    return 0;
+}
 
 int mmgen_reserve(int max_chunks_per_call, void* stream)
 {

@@ -241,8 +241,9 @@ k_ring_need(const float* __restrict__ bw, const int2* __restrict__ chunkPos, con
         need = dist <= maxCave;
         const float* cbw = bw + (size_t)MMGEN_BIOME_WEIGHTS_SIZE * chunk + t;
         for (int b = 0; b < MMGEN_NUM_BIOMES && !need; ++b) {
-            // random_biome can return a biome only if its weight is positive - or biome 0 when the draw is exactly 0
-            if (b != 0 && !(cbw[256 * b] > 0.f)) continue;
+            // random_biome can return a biome only if its weight is positive - or biome 0 when the draw is exactly 0, or PLAINS when the
+            // draw outlasts every weight (a draw that rounds to 1 over weights that sum to less)
+            if (b != 0 && b != MMBIO_PLAINS && !(cbw[256 * b] > 0.f)) continue;
             for (int g = 0; g < kSurfGenCount[b] && !need; ++g) {
                 const SurfGen& gen = kSurfGens[b][g];
                 if (dist <= kFeatureReach[gen.feature] && is_feature_pos(wx, wz, gen.cell, gen.pad, (int)gen.feature * 518721)) need = 1;
@@ -259,7 +260,7 @@ k_feature_placements(const float* __restrict__ hf, const float* __restrict__ bw,
                      const int* __restrict__ chunkList, const uint8_t* __restrict__ colNeed /*nullable: [chunk][256], 0 = column skipped (lazy ring)*/)
 {
     noise_tables_init();
-    __shared__ int s_ns[256], s_nc[256];
+    __shared__ int s_ns[4];
     const int chunk = chunkList ? chunkList[blockIdx.x] : blockIdx.x, t = threadIdx.x;
     const int2 cp = chunkPos[chunk];
     const int wx = cp.x + (t & 15), wz = cp.y + (t >> 4);
@@ -271,11 +272,22 @@ k_feature_placements(const float* __restrict__ hf, const float* __restrict__ bw,
     int ns = 0, nc = 0;
     const bool need = !colNeed || colNeed[(size_t)256 * chunk + t];
     if (need) column_placements<false>(wx, wz, height, cbw, cl, ccl, ns, nc, nullptr, nullptr, 0);
-    s_ns[t] = ns; s_nc[t] = nc;
+    // exclusive prefix of the two per-column counts in column order: a shuffle scan inside each wave (both counts in one word: a chunk
+    // holds far fewer than 65 536 of either), then the four wave totals through LDS
+    const unsigned both = (unsigned)ns | ((unsigned)nc << 16);
+    unsigned scan = both;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const unsigned up = (unsigned)__shfl_up((int)scan, d, 64);
+        if ((t & 63) >= d) scan += up;
+    }
+    if ((t & 63) == 63) s_ns[t >> 6] = (int)scan;
     __syncthreads();
-    int offS = 0, offC = 0;
-    for (int i = 0; i < t; ++i) { offS += s_ns[i]; offC += s_nc[i]; }
-    if (t == 255) { counts[2 * chunk] = offS + ns; counts[2 * chunk + 1] = offC + nc; }
+    unsigned base = 0, total = 0;
+    for (int w = 0; w < 4; ++w) { const unsigned v = (unsigned)s_ns[w]; if (w < (t >> 6)) base += v; total += v; }
+    const unsigned excl = base + scan - both;
+    const int offS = (int)(excl & 0xffffu), offC = (int)(excl >> 16);
+    if (t == 255) { counts[2 * chunk] = (int)(total & 0xffffu); counts[2 * chunk + 1] = (int)(total >> 16); }
     if (ns + nc == 0) return;
     mmgen_feature_placement* so = fpOut + (size_t)MMGEN_FP_CAP * chunk + offS;
     mmgen_cave_feature_placement* co = cfpOut + (size_t)MMGEN_CFP_CAP * chunk + offC;

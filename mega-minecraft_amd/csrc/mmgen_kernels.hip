@@ -204,10 +204,12 @@ k_cave_columns(const float* __restrict__ bw, const int2* __restrict__ chunkPos, 
 MM_DEV float cave_huge(float x, float y, float z, float b3 /* MM_SIMPLEX3_BOUND inside the pruning domain, FLT_MAX outside: no early exit */)
 {
     float acc = 0.f, amp = 1.f;
+    // the gradients' table-domain test once for the four octaves (mm_noise.cuh fbm3): the argument is 0.00035 x the block position
+    const bool tables = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(x), __builtin_fabsf(y)), __builtin_fabsf(z)) < (float)(1 << 18);
 #pragma unroll 1
     for (int i = 0; i < 4; ++i) {
         amp *= 0.5f;
-        acc += amp * simplex3_inl(x, y, z);
+        acc += amp * (__builtin_expect(tables, 1) ? simplex3_inl<true>(x, y, z) : simplex3(x, y, z));
         x *= 2.f; y *= 2.f; z *= 2.f;
 #if MM_CAVE_HUGE_PRUNE
         const float rest = amp * b3;
@@ -839,7 +841,7 @@ __global__ void __launch_bounds__(256) k_probe(int fn, const float* __restrict__
     case MMGEN_PROBE_SIMPLEX3_SPLIT: {
         const Sx3Cell c = simplex3_part1(in[3 * i], in[3 * i + 1], in[3 * i + 2]);
         float q[12];
-        simplex3_gradients(c.ix, c.iy, c.iz, c.gx, c.gy, c.gz, q);
+        simplex3_gradients(c, q);
         out[i] = simplex3_part3(c, q);
         break; }
     default: break;

@@ -1,6 +1,7 @@
 // Per-kernel HIP-event timing + roctx stage ranges (see mmgen_prof.h).  Host code only.
 #include "mmgen_prof.h"
 #include <rocprofiler-sdk-roctx/roctx.h>
+#include <atomic>
 #include <mutex>
 #include <vector>
 
@@ -9,7 +10,7 @@ namespace mmk {
 namespace {
 struct ProfRec { int id; hipEvent_t a, b; };
 std::mutex g_mu;
-bool g_prof = false;
+std::atomic<bool> g_prof{false};      // read on every launch by any thread, written under g_mu
 std::vector<ProfRec> g_recs;
 std::vector<hipEvent_t> g_pool;
 thread_local ProfRec t_open;
@@ -30,8 +31,8 @@ hipEvent_t get_event()
 }
 }  // namespace
 
-void profile_enable(bool on) { std::lock_guard<std::mutex> lk(g_mu); g_prof = on; }
-bool profile_enabled() { return g_prof; }
+void profile_enable(bool on) { std::lock_guard<std::mutex> lk(g_mu); g_prof.store(on, std::memory_order_relaxed); }
+bool profile_enabled() { return g_prof.load(std::memory_order_relaxed); }
 int profile_num_kernels() { return KID_COUNT; }
 const char* profile_kernel_name(int id) { return (id >= 0 && id < KID_COUNT) ? kKernelNames[id] : ""; }
 

@@ -16,6 +16,7 @@
 #include <vector>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include "../../include/mmgen.h"
 #include "mmgen_kernels.h"
 #include "mmgen_erosion.h"
@@ -59,6 +60,21 @@ k_copy_placements(const mmgen_feature_placement* __restrict__ sfp, const mmgen_c
     uint4* e = (uint4*)(dcfp + (size_t)MMGEN_CFP_CAP * d);
     for (int i = t; i < nC; i += 256) e[i] = c[i];
     if (t < 2) dcnt[2 * d + t] = scnt[2 * s + t];
+}
+
+// largest cave list length of the cells -> a word in host-visible (pinned, mapped) memory; only a list beyond the capacity writes
+__global__ void __launch_bounds__(256) k_caps_check(const int32_t* __restrict__ counts, int n, int* __restrict__ hostMax)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int c = counts[2 * i + 1];
+    if (c > MMGEN_CFP_CAP) __hip_atomic_fetch_max(hostMax, c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+__global__ void __launch_bounds__(256) k_caps_max(const int32_t* __restrict__ counts, int n, int* __restrict__ devMax)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) atomicMax(devMax, counts[2 * i + 1]);
 }
 
 __global__ void __launch_bounds__(256) k_select(const float* __restrict__ src, const int* __restrict__ idx, float* __restrict__ dst, int floatsPerChunk)
@@ -154,8 +170,51 @@ struct mmgen_region {
     std::vector<uint8_t> kMask;
     bool filled = false;          // mmgen_region_fill already ran for the current begin
     uint8_t* filledInto = nullptr;
+    // ---- stage DAG.  The caller's stream carries K1 / K2, the caves and the placement stages; the erosion branch
+    // runs beside the caves on sErode; the base fill runs on sFill in z slices, the rasterisers / decorators of slice i follow on sApply
+    // beside the fill of slice i + 1.  serial = everything on the caller's stream in the reference's stage order (per-kernel
+    // attribution for the roofline; MMGEN_REGION_SERIAL=1 or mmgen_region_set_serial).
+    int* hostMax = nullptr;       // pinned + mapped: largest cave list length beyond MMGEN_CFP_CAP seen by a finish (0 = none)
+    int* hostMaxDev = nullptr;    // its device address
+    DevBuf devMax;                // largest cave list length of the finishes since the last query (whatever its size)
+    bool serial = false;
+    int wantSlices = 0;           // 0 = automatic
+    hipStream_t sErode = nullptr, sFill = nullptr, sApply = nullptr;
+    static constexpr int kMaxSlices = 16;
+    hipEvent_t evK2 = nullptr, evErosion = nullptr, evGather = nullptr, evTail = nullptr, evFill[kMaxSlices] = {}, evEntry = nullptr;
+    int nSlices = 1;
+    int sliceRow[kMaxSlices + 1] = {};        // rows of R per slice: [sliceRow[i], sliceRow[i + 1])
+    int init_streams()
+    {
+        if (sErode) return 0;
+        hipError_t e;
+        // the erosion branch is a chain of ~25 short dependent launches: on an equal-priority queue its workgroups only get the slots
+        // the cave kernel's own queue leaves over (every pass then lasts as long as a whole cave launch, profiles/README.md r03); at the
+        // highest priority they take the next free slot and the chain hides under the caves
+        int prLeast = 0, prGreatest = 0;
+        if ((e = hipDeviceGetStreamPriorityRange(&prLeast, &prGreatest)) != hipSuccess) return (int)e;
+        const char* pe = getenv("MMGEN_REGION_EROSION_PRIORITY");
+        const int pr = (pe && *pe == '0') ? prLeast : prGreatest;
+        if ((e = hipStreamCreateWithPriority(&sErode, hipStreamNonBlocking, pr)) != hipSuccess) return (int)e;
+        if ((e = hipStreamCreateWithFlags(&sFill, hipStreamNonBlocking)) != hipSuccess) return (int)e;
+        if ((e = hipStreamCreateWithFlags(&sApply, hipStreamNonBlocking)) != hipSuccess) return (int)e;
+        hipEvent_t* ev[] = {&evK2, &evErosion, &evGather, &evTail, &evEntry};
+        for (hipEvent_t* x : ev) if ((e = hipEventCreateWithFlags(x, hipEventDisableTiming)) != hipSuccess) return (int)e;
+        for (int i = 0; i < kMaxSlices; ++i)
+            if ((e = hipEventCreateWithFlags(&evFill[i], hipEventDisableTiming)) != hipSuccess) return (int)e;
+        return 0;
+    }
     ~mmgen_region()
     {
+        if (hostMax) (void)hipHostFree(hostMax);
+        devMax.release();
+        if (sErode) {
+            (void)hipStreamSynchronize(sErode); (void)hipStreamSynchronize(sFill); (void)hipStreamSynchronize(sApply);
+            (void)hipStreamDestroy(sErode); (void)hipStreamDestroy(sFill); (void)hipStreamDestroy(sApply);
+            hipEvent_t ev[] = {evK2, evErosion, evGather, evTail, evEntry};
+            for (hipEvent_t x : ev) if (x) (void)hipEventDestroy(x);
+            for (int i = 0; i < kMaxSlices; ++i) if (evFill[i]) (void)hipEventDestroy(evFill[i]);
+        }
         DevBuf* all[] = {&posA, &hfA, &bwA, &gathA, &layersA, &posP, &hfP, &bwP, &layersP, &caveP, &colInfo, &fp, &cfp, &counts, &selAP, &zoneIdx,
                          &zoneIdxOut, &gathered, &erodeWork, &erodeState, &computeList, &targets, &gfp, &gcfp, &bounds, &fillQueue, &cellLazy, &colNeed};
         for (DevBuf* b : all) b->release();
@@ -170,6 +229,27 @@ int mmgen_region_create(mmgen_region** out)
 {
     if (!out) return (int)hipErrorInvalidValue;
     *out = new mmgen_region();
+    {
+        mmgen_region* r = *out;
+        hipError_t he = hipHostMalloc((void**)&r->hostMax, sizeof(int), hipHostMallocMapped);
+        if (he == hipSuccess) { *r->hostMax = 0; he = hipHostGetDevicePointer((void**)&r->hostMaxDev, r->hostMax, 0); }
+        if (he == hipSuccess && r->devMax.ensure(sizeof(int)) == 0) he = hipMemset(r->devMax.p, 0, sizeof(int));
+        else if (he == hipSuccess) he = hipErrorOutOfMemory;
+        if (he != hipSuccess) { delete r; *out = nullptr; return (int)he; }
+    }
+    const char* e = getenv("MMGEN_REGION_SERIAL");
+    (*out)->serial = e && *e && *e != '0';
+    const char* sl = getenv("MMGEN_REGION_SLICES");
+    (*out)->wantSlices = sl ? atoi(sl) : 0;
+    return 0;
+}
+
+int mmgen_region_set_serial(mmgen_region* r, int serial, int slices)
+{
+    if (!r || slices < 0 || slices > mmgen_region::kMaxSlices) return (int)hipErrorInvalidValue;
+    r->serial = serial != 0;
+    r->wantSlices = slices;
+    r->layoutValid = false;
     return 0;
 }
 
@@ -219,6 +299,16 @@ static int region_layout(mmgen_region* r, int cx0, int cz0, int nx, int nz, unsi
     r->nLazy = 0;
     for (uint8_t l : lazy) r->nLazy += l;
     for (int z = 0; z < nz; ++z) for (int x = 0; x < nx; ++x) targets[x + nx * z] = (x + ring) + r->pnx * (z + ring);
+    // z slices of the rectangle for the fill / rasteriser pipeline
+    {
+        // measured (profiles/README.md r03): the fill and the rasterisers each fill the register file of every CU, so slice i's rasterisers
+        // gain nothing from running beside slice i + 1's fill - one slice unless asked otherwise
+        int S = r->serial ? 1 : (r->wantSlices > 0 ? r->wantSlices : 1);
+        if (S > nz) S = nz;
+        if (S > mmgen_region::kMaxSlices) S = mmgen_region::kMaxSlices;
+        r->nSlices = S;
+        for (int i = 0; i <= S; ++i) r->sliceRow[i] = (int)((long long)nz * i / S);
+    }
     std::vector<int> zi((size_t)Z * 576), zo((size_t)Z * 144);
     for (int z = 0; z < Z; ++z) {
         for (int cz = 0; cz < 24; ++cz) for (int cx = 0; cx < 24; ++cx)
@@ -260,14 +350,35 @@ static int region_layout(mmgen_region* r, int cx0, int cz0, int nx, int nz, unsi
 #define MMGEN_EROSION_ZONE_BATCH 96      // zones relaxed per launch sequence (16 MB of planes each; 288 GB of HBM)
 #endif
 
+int mmgen_region_max_cave_placements(mmgen_region* r, int* out_max, void* stream)
+{
+    if (!r || !out_max) return (int)hipErrorInvalidValue;
+    hipStream_t s = (hipStream_t)stream;
+    int m = 0;
+    CK(hipMemcpyAsync(&m, r->devMax.p, sizeof(int), hipMemcpyDeviceToHost, s));
+    CK(hipMemsetAsync(r->devMax.p, 0, sizeof(int), s));
+    CK(hipStreamSynchronize(s));
+    const int h = __atomic_exchange_n(r->hostMax, 0, __ATOMIC_RELAXED);
+    *out_max = m > h ? m : h;
+    return 0;
+}
+
 int mmgen_region_begin(mmgen_region* r, int cx0, int cz0, int nx, int nz, unsigned flags, const uint8_t* h_local_mask, void* stream)
 {
     if (!r || nx <= 0 || nz <= 0) return (int)hipErrorInvalidValue;
+    if (__atomic_load_n(r->hostMax, __ATOMIC_RELAXED) > MMGEN_CFP_CAP) return MMGEN_ERROR_PLACEMENT_OVERFLOW;
     hipStream_t s = (hipStream_t)stream;
     const bool erosion = flags & MMGEN_REGION_EROSION, features = flags & MMGEN_REGION_FEATURES;
+    const bool par = !r->serial;
+    if (par) {
+        CK(r->init_streams());
+        // a begin -> fill without a finish leaves the fill stream unjoined: order it before this begin's writes
+        if (r->filled) CK(hipStreamWaitEvent(s, r->evFill[r->nSlices - 1], 0));
+    }
     r->began = false; r->filled = false; r->filledInto = nullptr;
     CK(region_layout(r, cx0, cz0, nx, nz, flags, h_local_mask, s));
     const int np = r->np, na = r->na;
+    hipStream_t sE = par ? r->sErode : s;
 
     CK(r->hfA.ensure(sizeof(float) * 256 * (size_t)na));
     CK(r->bwA.ensure(sizeof(float) * MMGEN_BIOME_WEIGHTS_SIZE * (size_t)na));
@@ -275,6 +386,11 @@ int mmgen_region_begin(mmgen_region* r, int cx0, int cz0, int nx, int nz, unsign
     CK(r->layersA.ensure(sizeof(float) * MMGEN_LAYERS_SIZE * (size_t)na));
     CK(r->caveP.ensure(sizeof(mmgen_cave_layer) * MMGEN_CAVE_LAYERS_SIZE * (size_t)np));
     CK(r->colInfo.ensure(sizeof(float) * 2 * 256 * (size_t)np));
+    if (features) {
+        CK(r->fp.ensure(sizeof(mmgen_feature_placement) * MMGEN_FP_CAP * (size_t)np));
+        CK(r->cfp.ensure(sizeof(mmgen_cave_feature_placement) * MMGEN_CFP_CAP * (size_t)np));
+        CK(r->counts.ensure(sizeof(int) * 2 * np));
+    }
 
     // ---- K1 + K2 on the raw area A
     {
@@ -286,19 +402,41 @@ int mmgen_region_begin(mmgen_region* r, int cx0, int cz0, int nx, int nz, unsign
     float *hfP, *bwP, *layersP;
     int32_t* posP;
     if (erosion) {
-        mmk::StageRange sr("mmgen:erosion");
-        // P-grid copies (eroded planes are scattered into layersP; layersA stays raw for the other zones' padding)
+        // P-grid copies (eroded planes are scattered into layersP; layersA stays raw for the other zones' padding).  The caves read only
+        // positions, heights and biome weights: those copies stay on the caller's stream, the layers go with the erosion branch.
         CK(r->posP.ensure(sizeof(int32_t) * 2 * np));
         CK(r->hfP.ensure(sizeof(float) * 256 * (size_t)np));
         CK(r->bwP.ensure(sizeof(float) * MMGEN_BIOME_WEIGHTS_SIZE * (size_t)np));
         CK(r->layersP.ensure(sizeof(float) * MMGEN_LAYERS_SIZE * (size_t)np));
         hfP = r->hfP.as<float>(); bwP = r->bwP.as<float>(); layersP = r->layersP.as<float>(); posP = r->posP.as<int32_t>();
         const int* sel = r->selAP.as<int>();
+        if (par) { CK(hipEventRecord(r->evK2, s)); CK(hipStreamWaitEvent(sE, r->evK2, 0)); }
         MMK_LAUNCH(mmk::KID_SELECT, k_select, dim3(np, 1), dim3(256), s, (const float*)r->posA.p, sel, (float*)posP, 2);
         MMK_LAUNCH(mmk::KID_SELECT, k_select, dim3(np, 1), dim3(256), s, r->hfA.as<float>(), sel, hfP, 256);
         MMK_LAUNCH(mmk::KID_SELECT, k_select, dim3(np, MMGEN_BIOME_WEIGHTS_SIZE / 256), dim3(256), s, r->bwA.as<float>(), sel, bwP, MMGEN_BIOME_WEIGHTS_SIZE);
-        MMK_LAUNCH(mmk::KID_SELECT, k_select, dim3(np, MMGEN_LAYERS_SIZE / 256), dim3(256), s, r->layersA.as<float>(), sel, layersP, MMGEN_LAYERS_SIZE);
+    } else {
+        hfP = r->hfA.as<float>(); bwP = r->bwA.as<float>(); layersP = r->layersA.as<float>(); posP = r->posA.as<int32_t>();
+        CK(mmk::launch_fix_backward(layersP, np, s));
+    }
 
+    // ---- K4 caves on the caller's stream (enqueued BEFORE the erosion loop below blocks the host on its own stream)
+    const int* list = r->computeList.as<int>();
+    const uint8_t* colNeed = nullptr;
+    if (r->nLazy && features) {
+        // lazy ring cells: only the columns that can produce a placement reaching the rectangle get caves and placements
+        CK(mmk::launch_ring_need(bwP, posP, list, r->nCompute, r->cellLazy.as<uint8_t>(), 16 * cx0, 16 * cz0, 16 * (cx0 + nx) - 1, 16 * (cz0 + nz) - 1,
+                                 r->colNeed.as<uint8_t>(), s));
+        colNeed = r->colNeed.as<uint8_t>();
+    }
+    auto caves = [&]() -> int {
+        mmk::StageRange sr("mmgen:caves");
+        return mmk::launch_caves(hfP, bwP, posP, r->nCompute, r->caveP.as<mmgen_cave_layer>(), r->colInfo.as<float>(), list, colNeed, s);
+    };
+    if (par) CK(caves());
+
+    if (erosion) {
+        mmk::StageRange sr("mmgen:erosion");
+        MMK_LAUNCH(mmk::KID_SELECT, k_select, dim3(np, MMGEN_LAYERS_SIZE / 256), dim3(256), sE, r->layersA.as<float>(), r->selAP.as<int>(), layersP, MMGEN_LAYERS_SIZE);
         // ---- E1 / K3 / E3 per zone batch
         const int Z = r->nZones;
         const int batch = Z < MMGEN_EROSION_ZONE_BATCH ? Z : MMGEN_EROSION_ZONE_BATCH;
@@ -309,36 +447,22 @@ int mmgen_region_begin(mmgen_region* r, int cx0, int cz0, int nx, int nz, unsign
         for (int z0 = 0; z0 < Z; z0 += batch) {
             const int nb = (Z - z0) < batch ? (Z - z0) : batch;
             CK(mmk::erosion_gather(r->layersA.as<float>(), r->hfA.as<float>(), r->zoneIdx.as<int>() + (size_t)z0 * 576, nb, r->gathered.as<float>(),
-                                   (size_t)MMGEN_GATHERED_LAYERS_SIZE, s));
+                                   (size_t)MMGEN_GATHERED_LAYERS_SIZE, sE));
             int mp = 0;
             CK(mmk::erode_zones(r->gathered.as<float>(), (size_t)MMGEN_GATHERED_LAYERS_SIZE, nb, r->erodeWork.as<float>(),
-                                r->erodeState.as<mm::ErosionState>(), nullptr, 0, s, &mp));
+                                r->erodeState.as<mm::ErosionState>(), nullptr, 0, sE, &mp));
             if (mp > r->lastMaxPasses) r->lastMaxPasses = mp;
-            CK(mmk::erosion_scatter(r->gathered.as<float>(), (size_t)MMGEN_GATHERED_LAYERS_SIZE, r->zoneIdxOut.as<int>() + (size_t)z0 * 144, nb, layersP, s));
+            CK(mmk::erosion_scatter(r->gathered.as<float>(), (size_t)MMGEN_GATHERED_LAYERS_SIZE, r->zoneIdxOut.as<int>() + (size_t)z0 * 144, nb, layersP, sE));
         }
-    } else {
-        hfP = r->hfA.as<float>(); bwP = r->bwA.as<float>(); layersP = r->layersA.as<float>(); posP = r->posA.as<int32_t>();
+        // ---- E3 fix-up
+        CK(mmk::launch_fix_backward(layersP, np, sE));
+        if (par) { CK(hipEventRecord(r->evErosion, sE)); CK(hipStreamWaitEvent(s, r->evErosion, 0)); }
     }
+    if (!par) CK(caves());
 
-    // ---- E3 fix-up, K4 caves, F1 placements
-    CK(mmk::launch_fix_backward(layersP, np, s));
-    const int* list = r->computeList.as<int>();
-    const uint8_t* colNeed = nullptr;
-    if (r->nLazy && features) {
-        // lazy ring cells: only the columns that can produce a placement reaching the rectangle get caves and placements
-        CK(mmk::launch_ring_need(bwP, posP, list, r->nCompute, r->cellLazy.as<uint8_t>(), 16 * cx0, 16 * cz0, 16 * (cx0 + nx) - 1, 16 * (cz0 + nz) - 1,
-                                 r->colNeed.as<uint8_t>(), s));
-        colNeed = r->colNeed.as<uint8_t>();
-    }
-    {
-        mmk::StageRange sr("mmgen:caves");
-        CK(mmk::launch_caves(hfP, bwP, posP, r->nCompute, r->caveP.as<mmgen_cave_layer>(), r->colInfo.as<float>(), list, colNeed, s));
-    }
+    // ---- F1 placements (eroded layers + cave layers of every computed cell)
     if (features) {
         mmk::StageRange sr("mmgen:feature_placements");
-        CK(r->fp.ensure(sizeof(mmgen_feature_placement) * MMGEN_FP_CAP * (size_t)np));
-        CK(r->cfp.ensure(sizeof(mmgen_cave_feature_placement) * MMGEN_CFP_CAP * (size_t)np));
-        CK(r->counts.ensure(sizeof(int) * 2 * np));
         CK(hipMemsetAsync(r->counts.p, 0, sizeof(int) * 2 * np, s));
         CK(mmk::launch_feature_placements(hfP, bwP, layersP, r->caveP.as<mmgen_cave_layer>(), posP, r->nCompute, r->fp.as<mmgen_feature_placement>(),
                                           r->cfp.as<mmgen_cave_feature_placement>(), r->counts.as<int>(), list, colNeed, s));
@@ -370,19 +494,40 @@ static bool region_in_prune_domain(const mmgen_region* r)
     return 16LL * r->cx0 > -lim && 16LL * (r->cx0 + r->nx) - 1 < lim && 16LL * r->cz0 > -lim && 16LL * (r->cz0 + r->nz) - 1 < lim;
 }
 
+static size_t slice_queue_bytes(const mmgen_region* r)
+{
+    int rows = 0;
+    for (int i = 0; i < r->nSlices; ++i) rows = (r->sliceRow[i + 1] - r->sliceRow[i]) > rows ? (r->sliceRow[i + 1] - r->sliceRow[i]) : rows;
+    return (mmk::fill_queue_bytes(rows * r->nx) + 255) / 256 * 256;
+}
+
 int mmgen_region_fill(mmgen_region* r, uint8_t* d_blocks, void* stream)
 {
     if (!r || !r->began || !d_blocks) return (int)hipErrorInvalidValue;
     hipStream_t s = (hipStream_t)stream;
     const bool erosion = r->flags & MMGEN_REGION_EROSION;
+    const bool par = !r->serial;
     float* hfP = erosion ? r->hfP.as<float>() : r->hfA.as<float>();
     float* bwP = erosion ? r->bwP.as<float>() : r->bwA.as<float>();
     float* layersP = erosion ? r->layersP.as<float>() : r->layersA.as<float>();
     int32_t* posP = erosion ? r->posP.as<int32_t>() : r->posA.as<int32_t>();
     mmk::StageRange sr("mmgen:fill");
-    CK(r->fillQueue.ensure(mmk::fill_queue_bytes(r->nx * r->nz)));
-    CK(mmk::launch_fill(hfP, bwP, layersP, r->caveP.as<mmgen_cave_layer>(), posP, r->nx * r->nz, d_blocks, r->targets.as<int>(),
-                        r->fillQueue.as<unsigned>(), mmk::fill_queue_bytes(r->nx * r->nz), region_in_prune_domain(r), s));
+    const size_t qb = slice_queue_bytes(r);
+    CK(r->fillQueue.ensure(qb * r->nSlices));
+    hipStream_t sF = par ? r->sFill : s;
+    if (par) {
+        // d_blocks is the caller's: whatever its stream holds at this point (a consumer of the buffer's previous contents, e.g. a copy of
+        // the last tile out of memory that the caller's allocator has just handed back) comes before the first write.  That also orders
+        // the fill behind this region's caves and erosion (both joined into the caller's stream by begin).
+        CK(hipEventRecord(r->evEntry, s));
+        CK(hipStreamWaitEvent(sF, r->evEntry, 0));
+    }
+    for (int i = 0; i < r->nSlices; ++i) {
+        const int c0 = r->sliceRow[i] * r->nx, n = (r->sliceRow[i + 1] - r->sliceRow[i]) * r->nx;
+        CK(mmk::launch_fill(hfP, bwP, layersP, r->caveP.as<mmgen_cave_layer>(), posP, n, d_blocks + (size_t)MMGEN_BLOCKS_PER_CHUNK * c0, r->targets.as<int>() + c0,
+                            (unsigned*)((char*)r->fillQueue.p + qb * i), qb, region_in_prune_domain(r), sF));
+        if (par) CK(hipEventRecord(r->evFill[i], sF));
+    }
     r->filled = true; r->filledInto = d_blocks;
     return 0;
 }
@@ -392,6 +537,7 @@ int mmgen_region_finish(mmgen_region* r, uint8_t* d_blocks, float* d_heightfield
     if (!r || !r->began || !d_blocks) return (int)hipErrorInvalidValue;
     hipStream_t s = (hipStream_t)stream;
     const bool erosion = r->flags & MMGEN_REGION_EROSION, features = r->flags & MMGEN_REGION_FEATURES, decor = r->flags & MMGEN_REGION_DECORATORS;
+    const bool par = !r->serial;
     const int nr = r->nx * r->nz;
     float* hfP = erosion ? r->hfP.as<float>() : r->hfA.as<float>();
     float* bwP = erosion ? r->bwP.as<float>() : r->bwA.as<float>();
@@ -399,22 +545,39 @@ int mmgen_region_finish(mmgen_region* r, uint8_t* d_blocks, float* d_heightfield
     int32_t* posP = erosion ? r->posP.as<int32_t>() : r->posA.as<int32_t>();
     const int* tgt = r->targets.as<int>();
 
+    if (__atomic_load_n(r->hostMax, __ATOMIC_RELAXED) > MMGEN_CFP_CAP) return MMGEN_ERROR_PLACEMENT_OVERFLOW;
     if (!r->filled || r->filledInto != d_blocks) CK(mmgen_region_fill(r, d_blocks, stream));
+    hipStream_t sA = par ? r->sApply : s;
     if (features) {
         mmk::StageRange sr("mmgen:features");
+        // every list length the gather is about to use, local or received (include/mmgen.h: MMGEN_ERROR_PLACEMENT_OVERFLOW)
+        MMK_LAUNCH(mmk::KID_SELECT, k_caps_check, dim3((r->np + 255) / 256), dim3(256), s, r->counts.as<int32_t>(), r->np, r->hostMaxDev);
+        MMK_LAUNCH(mmk::KID_SELECT, k_caps_max, dim3((r->np + 255) / 256), dim3(256), s, r->counts.as<int32_t>(), r->np, r->devMax.as<int>());
         CK(r->gfp.ensure(sizeof(mmgen_feature_placement) * MMGEN_MAX_GATHERED_FEATURES_PER_CHUNK * (size_t)nr));
         CK(r->gcfp.ensure(sizeof(mmgen_cave_feature_placement) * MMGEN_MAX_GATHERED_CAVE_FEATURES_PER_CHUNK * (size_t)nr));
         CK(r->bounds.ensure(sizeof(int) * 4 * nr));
         CK(mmk::launch_gather_placements(r->fp.as<mmgen_feature_placement>(), r->cfp.as<mmgen_cave_feature_placement>(), r->counts.as<int>(), tgt, nr,
                                          r->pnx, r->pnz, r->gfp.as<mmgen_feature_placement>(), r->gcfp.as<mmgen_cave_feature_placement>(),
                                          r->bounds.as<int>(), posP, s));
-        CK(mmk::launch_apply_features(d_blocks, posP, nr, r->gfp.as<mmgen_feature_placement>(), r->gcfp.as<mmgen_cave_feature_placement>(),
-                                      r->bounds.as<int>(), tgt, s));
     }
-    if (decor) {
-        mmk::StageRange sr("mmgen:decorators");
-        CK(mmk::launch_decorators(d_blocks, hfP, bwP, r->caveP.as<mmgen_cave_layer>(), posP, nr, tgt, s));
+    if (par) { CK(hipEventRecord(r->evGather, s)); CK(hipStreamWaitEvent(sA, r->evGather, 0)); }
+    // rasterisers + decorators slice by slice behind that slice's base fill
+    for (int i = 0; i < r->nSlices; ++i) {
+        const int c0 = r->sliceRow[i] * r->nx, n = (r->sliceRow[i + 1] - r->sliceRow[i]) * r->nx;
+        uint8_t* blk = d_blocks + (size_t)MMGEN_BLOCKS_PER_CHUNK * c0;
+        if (par) CK(hipStreamWaitEvent(sA, r->evFill[i], 0));
+        if (features) {
+            mmk::StageRange sr("mmgen:features");
+            CK(mmk::launch_apply_features(blk, posP, n, r->gfp.as<mmgen_feature_placement>() + (size_t)MMGEN_MAX_GATHERED_FEATURES_PER_CHUNK * c0,
+                                          r->gcfp.as<mmgen_cave_feature_placement>() + (size_t)MMGEN_MAX_GATHERED_CAVE_FEATURES_PER_CHUNK * c0,
+                                          r->bounds.as<int>() + 4 * c0, tgt + c0, sA));
+        }
+        if (decor) {
+            mmk::StageRange sr("mmgen:decorators");
+            CK(mmk::launch_decorators(blk, hfP, bwP, r->caveP.as<mmgen_cave_layer>(), posP, n, tgt + c0, sA));
+        }
     }
+    if (par) { CK(hipEventRecord(r->evTail, sA)); CK(hipStreamWaitEvent(s, r->evTail, 0)); }      // the caller's stream sees the finished blocks
 
     if (d_heightfields) MMK_LAUNCH(mmk::KID_SELECT, k_select, dim3(nr, 1), dim3(256), s, hfP, tgt, d_heightfields, 256);
     if (d_layers) MMK_LAUNCH(mmk::KID_SELECT, k_select, dim3(nr, MMGEN_LAYERS_SIZE / 256), dim3(256), s, layersP, tgt, d_layers, MMGEN_LAYERS_SIZE);

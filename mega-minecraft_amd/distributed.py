@@ -108,14 +108,26 @@ class TileContext:
     """Everything about one rank's tile that does not change from step to step: region rectangle, local mask, the exchange plan as
     device index tensors.  Built once; generate_tile() then does no host-side planning per step."""
 
-    def __init__(self, layout, rank, torch, device):
+    def __init__(self, layout, rank, torch, device, loopback=False):
         self.layout, self.rank = layout, rank
         self.region = layout.region(rank)
         self.multi = layout.world_size > 1
+        self.loopback = bool(loopback)
         mask = layout.local_mask(rank)
+        plan = layout.exchange_plan(rank) if self.multi else {}
+        if loopback:
+            # One-rank rehearsal of the transport (a box with a single GPU): every ring cell is computed here IN FULL (mask 1) and is
+            # also shipped rank -> rank through the real two-phase exchange - header, pack, grouped send / recv to self over the
+            # communicator, unpack - after its copy in the placement grid has been wiped (generate_tile).  The tile must come out equal
+            # to the plain region: what the rasterisers read travelled over RCCL.
+            if self.multi:
+                raise ValueError("loopback is a single-tile mode")
+            ring = [cell for cell, _, _, _ in layout._ring_only(rank)]
+            mask = [1] * len(mask)
+            plan = {rank: (ring, ring)}
+            self.multi = True
         self.mask_list = mask
         self.mask = (ctypes.c_uint8 * len(mask))(*mask)
-        plan = layout.exchange_plan(rank) if self.multi else {}
         self.peers = sorted(plan)
         send, recv, self.send_seg, self.recv_seg = [], [], [0], [0]
         for p in self.peers:
@@ -182,7 +194,12 @@ def generate_tile(backend, layout, rank, flags, dist=None, torch=None, want=(), 
     halo_bytes = 0
     if exchange:
         bufs = backend.region_placement_buffers()
-        halo_bytes = exchange_placements(backend, ctx, bufs, dist, torch, overlap=lambda: backend.region_fill(nx, nz))
+
+        def overlap():
+            backend.region_fill(nx, nz)
+            if ctx.loopback:                  # the packed payload is on its way: wipe the local copies, only the wire can restore them
+                bufs["counts"][ctx.recv_cells.long()] = 0
+        halo_bytes = exchange_placements(backend, ctx, bufs, dist, torch, overlap=overlap)
     out = backend.region_finish(nx, nz, want)
     out["halo_bytes_received"] = halo_bytes
     return out

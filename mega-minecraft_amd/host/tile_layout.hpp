@@ -65,8 +65,16 @@ struct ExchangePlan {
     std::vector<int32_t> sendCells, recvCells;        // concatenated over peers
     std::vector<int> sendSeg, recvSeg;                // [peers + 1] boundaries into the two lists
 
-    ExchangePlan(const TileLayout& lay, int rank)
+    // loopback: one-rank rehearsal of the transport - the only peer is the rank itself, every ring cell is both sent and received
+    // (distributed.py TileContext(loopback=True) is the same plan)
+    ExchangePlan(const TileLayout& lay, int rank, bool loopback = false)
     {
+        if (loopback) {
+            peers.push_back(rank);
+            lay.forRing(rank, [&](int cell, int, int, int) { sendCells.push_back(cell); recvCells.push_back(cell); });
+            sendSeg = {0, (int)sendCells.size()}; recvSeg = {0, (int)recvCells.size()};
+            return;
+        }
         struct Key { int cz, cx, cell; bool operator<(const Key& o) const { return cz != o.cz ? cz < o.cz : cx < o.cx; } };
         std::map<int, std::pair<std::vector<Key>, std::vector<Key>>> plan;        // peer -> (recv, send)
         lay.forRing(rank, [&](int cell, int cx, int cz, int own) { if (own >= 0 && own != rank) plan[own].first.push_back({cz, cx, cell}); });

@@ -8,33 +8,42 @@ namespace mmhost {
 #define TW_MM(expr) do { int e_ = (expr); if (e_) return e_; } while (0)
 #define TW_NCCL(expr) do { ncclResult_t r_ = (expr); if (r_ != ncclSuccess) { std::fprintf(stderr, "RCCL: %s\n", ncclGetErrorString(r_)); return 1000 + (int)r_; } } while (0)
 
-TiledWorld::TiledWorld(const TileLayout& lay, int rk, ncclComm_t c) : layout(lay), rank(rk), comm(c), plan(lay, rk), mask(lay.localMask(rk))
+TiledWorld::TiledWorld(const TileLayout& lay, int rk, ncclComm_t c, bool loop)
+    : layout(lay), rank(rk), comm(c), plan(lay, rk, loop), mask(loop ? std::vector<uint8_t>((size_t)lay.gridW() * lay.gridH(), 1) : lay.localMask(rk)), loopback(loop)
 {
-    (void)mmgen_region_create(&region);
-    (void)hipStreamCreateWithFlags(&sMain, hipStreamNonBlocking);
-    (void)hipStreamCreateWithFlags(&sComm, hipStreamNonBlocking);
-    (void)hipEventCreateWithFlags(&evPacked, hipEventDisableTiming);
-    (void)hipEventCreateWithFlags(&evArrived, hipEventDisableTiming);
+    initStatus = (loop && lay.worldSize() != 1) ? (int)hipErrorInvalidValue : init();
+}
+
+int TiledWorld::init()
+{
+    TW_MM(mmgen_region_create(&region));
+    TW_HIP(hipStreamCreateWithFlags(&sMain, hipStreamNonBlocking));
+    TW_HIP(hipStreamCreateWithFlags(&sComm, hipStreamNonBlocking));
+    TW_HIP(hipEventCreateWithFlags(&evPacked, hipEventDisableTiming));
+    TW_HIP(hipEventCreateWithFlags(&evArrived, hipEventDisableTiming));
     const size_t ns = plan.sendCells.size(), nr = plan.recvCells.size();
     if (ns) {
-        (void)hipMalloc((void**)&d_sendCells, 4 * ns); (void)hipMalloc((void**)&d_hdrS, 8 * ns); (void)hipMalloc((void**)&d_offS, 4 * (ns + 1));
-        (void)hipMemcpy(d_sendCells, plan.sendCells.data(), 4 * ns, hipMemcpyHostToDevice);
+        TW_HIP(hipMalloc((void**)&d_sendCells, 4 * ns)); TW_HIP(hipMalloc((void**)&d_hdrS, 8 * ns)); TW_HIP(hipMalloc((void**)&d_offS, 4 * (ns + 1)));
+        TW_HIP(hipMemcpy(d_sendCells, plan.sendCells.data(), 4 * ns, hipMemcpyHostToDevice));
     }
     if (nr) {
-        (void)hipMalloc((void**)&d_recvCells, 4 * nr); (void)hipMalloc((void**)&d_hdrR, 8 * nr); (void)hipMalloc((void**)&d_offR, 4 * (nr + 1));
-        (void)hipMemcpy(d_recvCells, plan.recvCells.data(), 4 * nr, hipMemcpyHostToDevice);
+        TW_HIP(hipMalloc((void**)&d_recvCells, 4 * nr)); TW_HIP(hipMalloc((void**)&d_hdrR, 8 * nr)); TW_HIP(hipMalloc((void**)&d_offR, 4 * (nr + 1)));
+        TW_HIP(hipMemcpy(d_recvCells, plan.recvCells.data(), 4 * nr, hipMemcpyHostToDevice));
     }
+    return 0;
 }
 
 TiledWorld::~TiledWorld()
 {
+    if (sMain) (void)hipStreamSynchronize(sMain);
+    if (sComm) (void)hipStreamSynchronize(sComm);
     for (void* p : {(void*)d_sendCells, (void*)d_recvCells, (void*)d_hdrS, (void*)d_hdrR, (void*)d_offS, (void*)d_offR, (void*)d_payS, (void*)d_payR})
         if (p) (void)hipFree(p);
     if (evPacked) (void)hipEventDestroy(evPacked);
     if (evArrived) (void)hipEventDestroy(evArrived);
     if (sComm) (void)hipStreamDestroy(sComm);
     if (sMain) (void)hipStreamDestroy(sMain);
-    mmgen_region_destroy(region);
+    if (region) mmgen_region_destroy(region);
 }
 
 // Two grouped point-to-point phases with every peer at once (<= 8 peers): list lengths, then the entries that exist.
@@ -62,6 +71,15 @@ int TiledWorld::exchange(uint8_t* d_blocks)
     if (totS > payCapS) { if (d_payS) TW_HIP(hipFree(d_payS)); payCapS = totS + totS / 4 + 1024; TW_HIP(hipMalloc((void**)&d_payS, 4 * payCapS)); }
     if (totR > payCapR) { if (d_payR) TW_HIP(hipFree(d_payR)); payCapR = totR + totR / 4 + 1024; TW_HIP(hipMalloc((void**)&d_payR, 4 * payCapR)); }
     if (totS) TW_MM(mmgen_ring_pack(fp, cfp, d_sendCells, d_hdrS, d_offS, ns, d_payS, sMain));
+    if (loopback) {
+        // the packed payload is on its way: wipe the ring's list lengths in the placement grid (top / bottom 3 rows, left / right 3
+        // columns of the rows between), only the wire can restore them
+        const int w = layout.gridW(), h = layout.gridH(), R = TileLayout::RING;
+        TW_HIP(hipMemsetAsync(counts, 0, 8 * (size_t)w * R, sMain));
+        TW_HIP(hipMemsetAsync(counts + 2 * (size_t)w * (h - R), 0, 8 * (size_t)w * R, sMain));
+        TW_HIP(hipMemset2DAsync(counts + 2 * (size_t)w * R, 8 * (size_t)w, 0, 8 * (size_t)R, (size_t)(h - 2 * R), sMain));
+        TW_HIP(hipMemset2DAsync(counts + 2 * ((size_t)w * R + (w - R)), 8 * (size_t)w, 0, 8 * (size_t)R, (size_t)(h - 2 * R), sMain));
+    }
     TW_HIP(hipEventRecord(evPacked, sMain));
     TW_HIP(hipStreamWaitEvent(sComm, evPacked, 0));
     TW_NCCL(ncclGroupStart());
@@ -84,7 +102,8 @@ int TiledWorld::exchange(uint8_t* d_blocks)
 int TiledWorld::generate(unsigned flags, uint8_t* d_blocks, float* d_heightfields)
 {
     const auto r = layout.region(rank);
-    const bool exch = (flags & MMGEN_REGION_FEATURES) && layout.worldSize() > 1 && !plan.peers.empty();
+    if (initStatus) return initStatus;
+    const bool exch = (flags & MMGEN_REGION_FEATURES) && (layout.worldSize() > 1 || loopback) && !plan.peers.empty();
     haloBytes = 0;
     TW_MM(mmgen_region_begin(region, r[0], r[1], r[2], r[3], flags, (flags & MMGEN_REGION_FEATURES) ? mask.data() : nullptr, sMain));
     if (exch) {

@@ -19,7 +19,12 @@ namespace mmhost {
 class TiledWorld {
 public:
     // comm may be null when layout.worldSize() == 1.  The communicator and the device are the caller's (one rank = one GPU).
-    TiledWorld(const TileLayout& layout, int rank, ncclComm_t comm);
+    // loopback (single tile, a communicator of one rank): every ring cell is computed here in full AND shipped rank -> rank through the
+    // real exchange (pack, grouped ncclSend / ncclRecv to self on the two streams, unpack) after its local copy has been wiped - the
+    // rehearsal of the transport on a box with one GPU; the tile must equal mmgen_region_generate's.
+    TiledWorld(const TileLayout& layout, int rank, ncclComm_t comm, bool loopback = false);
+    // 0, or the first error of the constructor (allocation, stream / event / region creation): check before generate()
+    int status() const { return initStatus; }
     ~TiledWorld();
     TiledWorld(const TiledWorld&) = delete;
     TiledWorld& operator=(const TiledWorld&) = delete;
@@ -41,6 +46,9 @@ private:
     int32_t *d_sendCells = nullptr, *d_recvCells = nullptr, *d_hdrS = nullptr, *d_hdrR = nullptr, *d_offS = nullptr, *d_offR = nullptr;
     int32_t *d_payS = nullptr, *d_payR = nullptr;
     size_t payCapS = 0, payCapR = 0, haloBytes = 0;
+    bool loopback = false;
+    int initStatus = 0;
+    int init();
     int exchange(uint8_t* d_blocks);
 };
 

@@ -257,6 +257,19 @@ class MMGen:
             self.lib.mmgen_region_last_erosion_passes.argtypes = [vp]
         return self._region_handle
 
+    def region_set_serial(self, serial, slices=0):
+        """serial=True: every kernel of the region path on one stream (per-kernel attribution); False: the stage DAG (include/mmgen.h)."""
+        self.lib.mmgen_region_set_serial.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+        self._check(self.lib.mmgen_region_set_serial(self._region(), int(bool(serial)), int(slices)), "mmgen_region_set_serial")
+
+    def region_max_cave_placements(self):
+        """Largest cave placement list length seen by region_finish since the last call (synchronises); > CFP_CAP (1024) means entries were
+        dropped (include/mmgen.h MMGEN_ERROR_PLACEMENT_OVERFLOW).  Clears the record."""
+        m = ctypes.c_int(0)
+        self.lib.mmgen_region_max_cave_placements.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int), ctypes.c_void_p]
+        self._check(self.lib.mmgen_region_max_cave_placements(self._region(), ctypes.byref(m), self._stream()), "mmgen_region_max_cave_placements")
+        return m.value
+
     def region_begin(self, cx0, cz0, nx, nz, flags, local_mask=None):
         mask = None
         if local_mask is not None:

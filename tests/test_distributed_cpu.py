@@ -148,3 +148,53 @@ def test_cpp_exchange_plan_equals_python_plan(layout_args, tmp_path):
             i_send = tok.index("send")
             assert [int(t) for t in tok[3:i_send]] == ctx.recv_cells[ctx.recv_seg[k]:ctx.recv_seg[k + 1]].tolist()
             assert [int(t) for t in tok[i_send + 1:]] == ctx.send_cells[ctx.send_seg[k]:ctx.send_seg[k + 1]].tolist()
+
+
+class _SelfLoop:
+    """in-process stand-in for a one-rank communicator: a send to self is matched with the next receive from self, in order"""
+    isend, irecv = "isend", "irecv"
+
+    class _Req:
+        def wait(self):
+            pass
+
+    def P2POp(self, op, tensor, peer):
+        return (op, tensor, peer)
+
+    def batch_isend_irecv(self, ops):
+        sends = [t for op, t, _ in ops if op == self.isend]
+        recvs = [t for op, t, _ in ops if op == self.irecv]
+        assert len(sends) == len(recvs)
+        for s, r in zip(sends, recvs):
+            r.copy_(s.clone())
+        return [self._Req() for _ in ops]
+
+
+def test_loopback_exchange_restores_the_wiped_ring(oracle):
+    """TileContext(loopback=True): the one-rank rehearsal of the transport.  Every ring cell is computed in full, packed, its list lengths
+    wiped in the placement grid, and restored from the payload that went rank -> rank; the tile equals the plain region, and a transport
+    that drops the payload is noticed (the ring's features are missing)."""
+    import torch
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    d = importlib.import_module("mega-minecraft_amd.distributed")
+    from oracle_binding import OracleBackend
+    lay = d.TileLayout(1487, -1111, 1, 1, 2, 2)
+    ref = oracle.generate_region(1487, -1111, 2, 2, erosion=True, features=True, decorators=True)
+    ob = OracleBackend(nthreads=oracle.nthreads)
+    ctx = d.TileContext(lay, 0, torch, "cpu", loopback=True)
+    assert ctx.peers == [0] and ctx.send_cells.tolist() == ctx.recv_cells.tolist() and len(ctx.send_cells) == 8 * 8 - 2 * 2
+    assert set(ctx.mask_list) == {1}
+    out = d.generate_tile(ob, lay, 0, 7, dist=_SelfLoop(), torch=torch, ctx=ctx)
+    assert np.array_equal(out["blocks"], ref["blocks"]) and out["halo_bytes_received"] > 0
+
+    class _Lossy(_SelfLoop):
+        def batch_isend_irecv(self, ops):
+            reqs = super().batch_isend_irecv(ops)
+            for op, t, _ in ops:
+                if op == self.irecv and t.numel() > 2 * len(ctx.recv_cells):       # the payload (the headers are 2 words per cell)
+                    t.zero_()
+            return reqs
+    bad = d.generate_tile(ob, lay, 0, 7, dist=_Lossy(), torch=torch, ctx=ctx)
+    assert not np.array_equal(bad["blocks"], ref["blocks"]), "a payload of zeros went unnoticed: the loopback does not test the wire"
+    with pytest.raises(ValueError):
+        d.TileContext(d.TileLayout(0, 0, 2, 1, 2, 2), 0, torch, "cpu", loopback=True)

@@ -452,6 +452,7 @@ def test_ring_wire_format_on_the_device(gen):
         assert torch.equal(dst["counts"][c].cpu(), bufs_cpu["counts"][c])
     assert int(dst["counts"].cpu().sum()) == int(bufs_cpu["counts"][cells.long()].sum())
     gen.region_finish(2, 2)
+    assert gen.region_max_cave_placements() == 1500          # the over-the-cap cell was noticed by finish; acknowledged here
 
 
 @pytest.mark.parametrize("is_cave", [False, True])
@@ -562,3 +563,135 @@ def test_bench_n2_rehearsal_on_one_gpu():
     assert line["halo_bytes_received_per_step_all_ranks"] > 0
     assert line["parity_spot_check"] == "bit-exact"
     assert "roofline" in line and "cpu_baseline" in line and line["scaling"] == "weak"
+
+
+# ------------------------------------------------------------------------------------------------ stage DAG == serial schedule
+@pytest.mark.gpu
+@pytest.mark.parametrize("slices", [0, 2, 5])
+def test_stage_dag_equals_serial_schedule(gen, slices):
+    """The region's stage DAG (erosion beside the caves, z slices pipelined over four streams, include/mmgen.h mmgen_region_set_serial) and
+    the one-stream schedule give identical blocks / heights / layers / cave layers, step after step (back-to-back steps of different
+    rectangles exercise the cross-step ordering of the internal streams), with and without the optional middle fill call."""
+    import torch
+    regs = [(-20, 7, 24, 40), (100, -300, 16, 24), (-20, 7, 24, 40)]
+    want = ("layers", "cave")
+    try:
+        gen.region_set_serial(True)
+        ref = [gen.generate_region(*r, want=want) for r in regs]
+        torch.cuda.synchronize()
+        gen.region_set_serial(False, slices)
+        got = [gen.generate_region(*r, want=want) for r in regs]          # enqueued back to back, no synchronisation in between
+        torch.cuda.synchronize()
+        for r, a, b in zip(regs, ref, got):
+            for k in ("blocks", "hf", "layers", "cave"):
+                assert torch.equal(a[k], b[k]), f"{k} of region {r} differs between the serial schedule and the DAG with {slices} slices"
+        # begin -> fill -> finish (the tiling caller's order), and a begin -> fill whose finish never comes followed by a new begin
+        cx0, cz0, nx, nz = regs[0]
+        mask = [2] * ((nx + 6) * (nz + 6))
+        gen.region_begin(cx0, cz0, nx, nz, 7, mask)
+        gen.region_fill(nx, nz)
+        gen.region_begin(cx0, cz0, nx, nz, 7, mask)
+        gen.region_fill(nx, nz)
+        out = gen.region_finish(nx, nz)
+        torch.cuda.synchronize()
+        assert torch.equal(out["blocks"], ref[0]["blocks"])
+    finally:
+        gen.region_set_serial(False, 0)
+
+
+# ------------------------------------------------------------------------------------------------ RCCL on the one GPU there is
+def _rccl_loopback_worker(port, outdir):
+    import importlib as il
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    pkg = il.import_module("mega-minecraft_amd")
+    d = il.import_module("mega-minecraft_amd.distributed")
+    gen = pkg.MMGen(0)
+    lay = d.TileLayout(1480, -1120, 1, 1, 12, 10)
+    ctx = d.TileContext(lay, 0, torch, gen.device, loopback=True)
+    outs = [d.generate_tile(gen, lay, 0, 7, dist=dist, torch=torch, ctx=ctx) for _ in range(2)]          # twice: buffers re-used
+    ref = gen.generate_region(1480, -1120, 12, 10)
+    torch.cuda.synchronize()
+    res = dict(equal=[bool(torch.equal(o["blocks"], ref["blocks"])) for o in outs], halo=[int(o["halo_bytes_received"]) for o in outs],
+               backend=dist.get_backend())
+    import json
+    json.dump(res, open(os.path.join(outdir, "loopback.json"), "w"))
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_rccl_loopback_ships_the_ring_through_the_real_transport(tmp_path):
+    """RCCL itself, on the one GPU a box has: a communicator of ONE rank (backend nccl = RCCL), the product's generate_tile /
+    exchange_placements with TileContext(loopback=True): the whole 3-chunk ring is packed on the device, sent rank 0 -> rank 0 by
+    torch.distributed.batch_isend_irecv (ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd on device buffers), its local copy wiped
+    while the payload is in flight, unpacked; the tile must equal the plain region.  Runs in a child process (its own process group)."""
+    import json
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    p = ctx.Process(target=_rccl_loopback_worker, args=(port, str(tmp_path)))
+    p.start(); p.join(600)
+    assert p.exitcode == 0, f"RCCL loopback worker exit code {p.exitcode}"
+    res = json.load(open(tmp_path / "loopback.json"))
+    assert res["backend"] == "nccl" and res["equal"] == [True, True] and all(h > 10000 for h in res["halo"]), res
+
+
+@pytest.mark.gpu
+def test_cpp_tiled_world_rccl_loopback(mmgen_pkg):
+    """The C++ host over RCCL (host/tiled_world.cpp: ncclGroupStart / ncclSend / ncclRecv on sMain and sComm, the event hand-over between
+    them, the base fill while the payload travels) with a one-rank communicator in loopback mode: tile == mmgen_region_generate."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(mmgen_pkg.LIB_PATH), "mmgen_tiled_demo")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([exe, "--loopback", "--tile", "20", "12", "--steps", "2"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "ring shipped rank 0 -> rank 0 over RCCL" in r.stdout and "ok" in r.stdout, r.stdout
+
+
+@pytest.mark.gpu
+def test_cave_placement_cap_overflow_is_loud(mmgen_pkg):
+    """The reference's cave placement lists are unbounded (chunk.cu:1028-1038); the library keeps MMGEN_CFP_CAP = 1 024 per chunk.  A list
+    beyond the cap (forced here by raising a cell's count between begin and finish, the way a received ring header could) is recorded by
+    finish, every later begin / finish fails with MMGEN_ERROR_PLACEMENT_OVERFLOW until mmgen_region_max_cave_placements acknowledges it,
+    and a normal world stays far below the cap."""
+    import torch
+    gen = mmgen_pkg.MMGen(0)                     # its own region handle: the sticky error must not leak into other tests
+    cx0, cz0, nx, nz = 1488, -1110, 3, 3
+    gen.region_begin(cx0, cz0, nx, nz, 7)
+    gen.region_finish(nx, nz)
+    normal = gen.region_max_cave_placements()
+    assert 0 < normal < 512, normal
+    gen.region_begin(cx0, cz0, nx, nz, 7)
+    bufs = gen.region_placement_buffers()
+    bufs["counts"][4, 1] = 1500                  # a ring cell claims 1 500 cave placements
+    gen.region_finish(nx, nz)
+    torch.cuda.synchronize()
+    with pytest.raises(RuntimeError, match="MMGEN_CFP_CAP"):
+        gen.region_begin(cx0, cz0, nx, nz, 7)
+    assert gen.region_max_cave_placements() == 1500
+    out = gen.generate_region(cx0, cz0, nx, nz)  # acknowledged: works again
+    assert gen.region_max_cave_placements() == normal and out["blocks"].shape[0] == nx * nz
+
+
+@pytest.mark.gpu
+def test_release_frees_the_stream_scratch(gen):
+    """mmgen_release(stream): the per-(device, stream) scratch of the per-stage calls does not outlive its stream"""
+    import ctypes
+    import torch
+    s = torch.cuda.Stream()
+    pos = gen.positions([(3, 4), (5, 6)])
+    with torch.cuda.stream(s):
+        hf, bw, _ = gen.generate_heightfields(pos, gathered=True)
+        a = gen.generate_caves(hf, bw, pos)
+        gen.lib.mmgen_release.argtypes = [ctypes.c_void_p]
+        assert gen.lib.mmgen_release(ctypes.c_void_p(s.cuda_stream)) == 0
+        assert gen.lib.mmgen_release(ctypes.c_void_p(s.cuda_stream)) == 0        # nothing left: a no-op
+        b = gen.generate_caves(hf, bw, pos)                                        # scratch comes back on demand
+    s.synchronize()
+    assert torch.equal(a, b)

@@ -129,7 +129,7 @@ def test_noise_table_domains():
     with the same fp32 operations (csrc/mm_noise.cuh).  Exactness needs only that every lookup index is inside the tables:
       * mod289 (x - floor(x * (1/289)) * 289, fp32) of an integer-valued |x| < 2^24 lies in [-1, 289]   (the guard the device checks),
       * glm::mod(x, 289) (x - 289 * floor(x / 289)) of the same lies in [0, 288]                           (simplex2),
-      * permute of every integer in [-16, 700) is an integer in [0, 288]: so chained indices stay in [-1, 578] within perm4[-8, 600)
+      * permute of every integer in [-16, 700) is an integer in [0, 288]: so chained indices stay in [-1, 578] within perm16[-8, 600)
         and gradient indices in [0, 288] within grad[296]."""
     f = np.float32
     xs = np.arange(-2 ** 24 + 1, 2 ** 24, dtype=np.int64).astype(f)

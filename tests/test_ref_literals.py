@@ -99,7 +99,7 @@ DEVICE_MAP = {
     "featurePlacement.hpp::deCasteljau": ([CS + "mm_features.cuh"], [r"void\s+de_casteljau\s*\([^)]*\)\s*\{"], None),
     "rng.hpp::saturate": ([CS + "mm_features.cuh"], [r"bool\s+saturated\s*\([^)]*\)\s*\{"], None),
     "rng.hpp::isSaturated": ([CS + "mm_features.cuh"], [r"bool\s+saturated\s*\([^)]*\)\s*\{"], None),
-    "rng.hpp::fbm": ([CS + "mm_noise.cuh"], [r"float\s+fbm2\s*\([^)]*\)\s*\{", r"float\s+fbm3\s*\([^)]*\)\s*\{"], None),
+    "rng.hpp::fbm": ([CS + "mm_noise.cuh"], [r"float\s+fbm2_loop\s*\([^)]*\)\s*\{", r"float\s+fbm3_loop\s*\([^)]*\)\s*\{"], None),
     "rng.hpp::worley2": ([CS + "mm_noise.cuh"], [r"Worley2\s+worley2\s*\([^)]*\)\s*\{"], None),
     "rng.hpp::worley3": ([CS + "mm_noise.cuh"], [r"Worley3\s+worley3\s*\([^)]*\)\s*\{"], None),
     "chunk.cu::chunkFillPlaceBlock": ([CS + "mmgen_kernels.hip"], [r"BaseBlock\s+place_block_base\s*\([^)]*\)\s*\{", r"void\s+fill_body\s*\([^{]*\)\s*\{"], None),
@@ -134,7 +134,8 @@ DEVICE_EXTRA = {
     "biomeFuncs.hpp::getBiomeNoise": (float(np.float32(0.32)),),         # overallBiomeScale, a file-level constant in the reference (biomeFuncs.hpp:105)
     # cave_huge: slack of its exact pruning; k_cave_voxels: kCaveFaMax = 0.9375 * MM_SIMPLEX3_BOUND (the octave amplitudes of fbm3<4> sum to
     # 0.9375), 1e30 = "no bound" outside the pruning domain (the bounds themselves are macros of mm_noise.cuh)
-    "chunk.cu::shouldGenerateCaveAtBlock": (float(np.float32(0.001)), 0.9375, float(np.float32(1e30))),
+    # ... and 18: cave_huge tests the gradient tables' domain (|argument| < 2^18) once for its four octaves
+    "chunk.cu::shouldGenerateCaveAtBlock": (float(np.float32(0.001)), 0.9375, float(np.float32(1e30)), 18.0),
     # cave_biome: fbm3From3's component offsets (rng.hpp:188-191, rolled into the loop) and 0.875 = the octave amplitudes of fbm2<3>
     "biomeFuncs.hpp::getCaveBiomeNoise": tuple(float(np.float32(v)) for v in (0.875, 5923.45, 4129.42, 5790.48, 1765.68, 4704.36, 5692.12)),
 }

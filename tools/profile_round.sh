@@ -7,7 +7,7 @@
 # usage: tools/profile_round.sh <tag> [stats|pmc|all] [extra bench args]
 tag=${1:-r02a}
 what=${2:-all}
-shift 2
+shift $(( $# < 2 ? $# : 2 ))
 root=${GRAFT_REPO_ROOT:-$PWD}
 out=$root/gpurun_out
 mkdir -p $out
