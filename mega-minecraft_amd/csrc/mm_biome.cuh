@@ -321,9 +321,9 @@ MM_DEV int cave_biome_t(int wx, int wy, int wz, float maxHeight, int seed, bool 
         float bandVal = 0.f;
         if (band >= 0) {
             const bool b0 = band == 0;
-            const float f1 = b0 ? fbm2<3>(qx, qz) : fbm2<3>(qx + -4921.34f, qz + 8402.13f);
+            const float f1 = b0 ? fbm2<3, true>(qx, qz) : fbm2<3, true>(qx + -4921.34f, qz + 8402.13f);
             const float edge1 = (b0 ? (top - 19.f) : (top - 72.f)) + (b0 ? 23.f : 18.f) * f1;
-            const float f2 = fbm2<3>(qx + (b0 ? 3821.34f : 9411.32f), qz + (b0 ? 4920.32f : -3921.34f));
+            const float f2 = fbm2<3, true>(qx + (b0 ? 3821.34f : 9411.32f), qz + (b0 ? 4920.32f : -3921.34f));
             const float edge0 = (edge1 - (b0 ? 5.f : 10.f)) + (b0 ? 3.f : 7.f) * f2;
             bandVal = smoothstep(edge0, edge1, py);
         }
@@ -332,13 +332,13 @@ MM_DEV int cave_biome_t(int wx, int wy, int wz, float maxHeight, int seed, bool 
         if (rand <= 0.f) return MMCB_NONE;
         shallow = band == 1 ? bandVal : (shallowZero ? 0.f : 1.f);
     } else {
-        const float n2sStart = (top - 19.f) + 23.f * fbm2<3>(qx, qz);
-        const float n2sEnd = (n2sStart - 5.f) + 3.f * fbm2<3>(qx + 3821.34f, qz + 4920.32f);
+        const float n2sStart = (top - 19.f) + 23.f * fbm2<3, true>(qx, qz);
+        const float n2sEnd = (n2sStart - 5.f) + 3.f * fbm2<3, true>(qx + 3821.34f, qz + 4920.32f);
         none = smoothstep(n2sEnd, n2sStart, py);
         rand -= none;                                   // NONE
         if (rand <= 0.f) return MMCB_NONE;
-        const float s2dStart = (top - 72.f) + 18.f * fbm2<3>(qx + -4921.34f, qz + 8402.13f);
-        const float s2dEnd = (s2dStart - 10.f) + 7.f * fbm2<3>(qx + 9411.32f, qz + -3921.34f);
+        const float s2dStart = (top - 72.f) + 18.f * fbm2<3, true>(qx + -4921.34f, qz + 8402.13f);
+        const float s2dEnd = (s2dStart - 10.f) + 7.f * fbm2<3, true>(qx + 9411.32f, qz + -3921.34f);
         shallow = smoothstep(s2dEnd, s2dStart, py);
     }
 

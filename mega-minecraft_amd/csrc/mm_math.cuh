@@ -168,9 +168,12 @@ MM_DEV float clampf(float x, float lo, float hi) { return gmin(gmax(x, lo), hi);
 MM_DEV float fract(float x) { return x - __builtin_floorf(x); }
 MM_DEV float gmod(float a, float b) { return a - b * __builtin_floorf(a / b); }
 MM_DEV float mixf(float x, float y, float a) { return x * (1.f - a) + y * a; }
+// glm::clamp = min(max(x, 0), 1) with compare-and-select; the hardware max / min differ from it only for x = -0 (they return +0) and
+// for NaN.  t = -0 and t = +0 give the same product t * t * (3 - 2 t) = +0, and no call site can produce a NaN (finite positions,
+// e1 != e0 everywhere: the edges are constants or differ by 5 - 3 |f|, 10 - 7 |f| with |f| < 1.02): two instructions instead of four
 MM_DEV float smoothstep(float e0, float e1, float x)
 {
-    const float t = clampf((x - e0) / (e1 - e0), 0.f, 1.f);
+    const float t = __builtin_fminf(__builtin_fmaxf((x - e0) / (e1 - e0), 0.f), 1.f);
     return t * t * (3.f - 2.f * t);
 }
 

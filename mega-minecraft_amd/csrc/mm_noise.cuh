@@ -371,9 +371,12 @@ MM_DEV float fbm2_loop(float x, float y)
 }
 
 // domain test once per stack (see fbm3 below): |floor(v + (vx + vy) * 0.366)| < 2 max|v| + 1, the last octave evaluates at 2^(OCT - 1) v
-template <int OCT>
+// HOIST is opt-in: it pays in the cave-biome bands (k_fill -1.2 %), and it costs k_heightfield 50 % of its time (its two dozen inlined
+// stacks sit in one divergent switch; measured, profiles/README.md r03), so the surface functions keep the per-octave test
+template <int OCT, bool HOIST = false>
 MM_DEV float fbm2(float x, float y)
 {
+    if (!HOIST) return fbm2_loop<OCT, false>(x, y);
     const float m = __builtin_fmaxf(__builtin_fabsf(x), __builtin_fabsf(y));
     if (__builtin_expect(m < (float)(1 << (22 - OCT)), 1)) return fbm2_loop<OCT, true>(x, y);
     // beyond the table domain (block coordinates of hundreds of millions): the shared out-of-line simplex2 with its per-call test, so that
@@ -541,10 +544,11 @@ MM_DEV float special_cave_noise(float px, float py, float pz, const Cells& cells
                 const f3 pt = row[z + 1];
                 const float dx = ((float)x + pt.x) - fx, dy = ((float)y + pt.y) - fy, dz = ((float)z + pt.z) - fz;
                 const float d2 = (dx * dx + dy * dy) + dz * dz;
-                // keep the three smallest: s1 <= s2 <= s3
-                const float a = gmin(s1, d2), b = gmax(s1, d2);
-                const float c = gmin(s2, b), d = gmax(s2, b);
-                s1 = a; s2 = c; s3 = gmin(s3, d);
+                // keep the three smallest: s1 <= s2 <= s3.  Squared distances are sums of squares: never NaN for a finite position, never -0,
+                // so the hardware min / max (one instruction each) return what glm's compare-and-select would
+                const float a = __builtin_fminf(s1, d2), b = __builtin_fmaxf(s1, d2);
+                const float c = __builtin_fminf(s2, b), d = __builtin_fmaxf(s2, b);
+                s1 = a; s2 = c; s3 = __builtin_fminf(s3, d);
             }
         }
     }

@@ -676,7 +676,8 @@ def test_cave_placement_cap_overflow_is_loud(mmgen_pkg):
         gen.region_begin(cx0, cz0, nx, nz, 7)
     assert gen.region_max_cave_placements() == 1500
     out = gen.generate_region(cx0, cz0, nx, nz)  # acknowledged: works again
-    assert gen.region_max_cave_placements() == normal and out["blocks"].shape[0] == nx * nz
+    # (generate_region builds the ring lazily: its lists are subsets of the full ones)
+    assert 0 < gen.region_max_cave_placements() <= normal and out["blocks"].shape[0] == nx * nz
 
 
 @pytest.mark.gpu
