@@ -224,13 +224,12 @@ MM_DEV float cave_huge(float x, float y, float z, float b3 /* MM_SIMPLEX3_BOUND 
 #define CELL_NY 8
 #define CELL_NZ 7
 #define CELL_N (CELL_NX * CELL_NY * CELL_NZ)
-#ifndef CAVE_COLS
-#define CAVE_COLS 4        // columns per batch (same z row of the chunk); 16 / CAVE_COLS batches per workgroup
-#endif
-#define CAVE_YEVAL 144     // voxels y < 144 may need the noise (threshold is 0 once y + 50*obw >= 142); 144 = 2.25 waves
-#define CAVE_VOXELS (CAVE_COLS * CAVE_YEVAL)      // 576 = 9 full waves: no partially filled wave
+#define CAVE_YEVAL 144     // voxels y < 144 may need the noise (threshold is 0 once y + 50*obw >= 142)
+#define CAVE_ROW 16        // one workgroup = one 16-column row of a chunk
+#define CAVE_VOXELS (CAVE_ROW * CAVE_YEVAL)       // 2 304 evaluated voxels per row
+#define CAVE_L2_CAP (CAVE_VOXELS / 2)             // list 2 (typically 40 - 45 % of list 1); a full list resolves the surplus in place
 #ifndef CAVE_THREADS
-#define CAVE_THREADS 192                          // 3 waves x 3 passes
+#define CAVE_THREADS 256                          // 4 waves: six workgroups (26.4 KB of LDS each) fill a CU's 24 wave slots
 #endif
 
 struct CellTile {
@@ -260,11 +259,12 @@ struct CellTile {
     }
 };
 
-// One workgroup = 4 neighbouring columns = 4 x 144 evaluated voxels (e -> column e / 144, y = e % 144), walked by CAVE_THREADS
-// lanes in CAVE_VOXELS / CAVE_THREADS passes of FULL waves (a 384-lane-per-column mapping pays 3 waves for 142 useful lanes).
-// Small workgroups (3 waves) pack the CU's wave slots tightly whatever SIMD the dispatcher starts a workgroup on.
-// Voxels y >= 144 never need noise: solid iff y <= min(max((int)h, 128), ravine cut), so their bits are built analytically.
-// The air/solid bits of all 4 x 384 voxels go to LDS as 64-bit words; runs are extracted with popcount prefixes over those words.
+// One workgroup = one 16-column row of a chunk = 16 x 144 evaluated voxels.  Voxels y >= 144 never need noise: solid iff
+// y <= min(max((int)h, 128), ravine cut), so their bits are built analytically.  The air / solid bits of all 16 x 384 voxels go to LDS as
+// 64-bit words; runs are extracted with popcount prefixes over those words.
+// The noise runs in dense phases over LDS-compacted voxel lists of the WHOLE row (order inside a list is irrelevant: voxels are
+// independent): a phase loses at most one partial wave at the end of its list, and a row-long list makes that 2 % of a phase where the
+// four-column batches of the previous layout lost 9 % (cave noise) to 22 % (threshold) - and paid four times the barriers.
 #ifndef MM_CAVE_WAVES
 #define MM_CAVE_WAVES 6
 #endif
@@ -274,17 +274,18 @@ k_cave_voxels(const float* __restrict__ hf, const float2* __restrict__ colInfo, 
               mmgen_cave_layer* __restrict__ caveLayers, const int* __restrict__ chunkList, const uint8_t* __restrict__ colNeed /*nullable, lazy ring*/)
 {
     __shared__ float s_cells[3 * CELL_N];
-    __shared__ unsigned long long s_solid[CAVE_COLS][6];      // solid bit of voxel y at word y / 64, bit y % 64
-    __shared__ int s_layers[CAVE_COLS][3 * MMGEN_MAX_CAVE_LAYERS_PER_COLUMN];
-    __shared__ unsigned short s_list1[CAVE_VOXELS], s_list2[CAVE_VOXELS];
-    __shared__ float s_thr[CAVE_VOXELS];
+    __shared__ unsigned long long s_solid[CAVE_ROW][6];       // solid bit of voxel y at word y / 64, bit y % 64
+    __shared__ int s_layers[4][3 * MMGEN_MAX_CAVE_LAYERS_PER_COLUMN];      // run extraction, four columns at a time
+    __shared__ unsigned short s_list1[CAVE_VOXELS], s_list2[CAVE_L2_CAP];
+    __shared__ float s_thr[CAVE_L2_CAP];
     __shared__ int s_count[2];
 
     const int t = threadIdx.x;
     const int bid = xcd_block(blockIdx.x, gridDim.x);
     const int chunk = chunkList ? chunkList[bid >> 4] : (bid >> 4);
-    const int row = bid & 15;                                  // one workgroup = one 16-column row of a chunk (z = row), in 4 batches of 4 columns
+    const int row = bid & 15;                                  // z = row
     const int2 cp = chunkPos[chunk];
+    const int colBase = 16 * row;                              // column c of the row: x = c, z = row
     // lazy ring: columns that cannot produce a placement reaching the rectangle get no cave noise: no solid bit is ever set for them,
     // so no flip is found and their 32 layers stay at the default {384, 384, NONE, NONE}
     unsigned rowNeed = 0xffffu;
@@ -300,8 +301,8 @@ k_cave_voxels(const float* __restrict__ hf, const float2* __restrict__ colInfo, 
         return;
     }
 
-    // cell tile, shared by the row's 4 batches: sample position = noisePos * (1, 1.6, 1) + offset with |offset| < 1.8; origin from the
-    // row's first column (16 columns are 0.08 cells wide: at most one cell boundary inside the row, like inside 4 columns)
+    // cell tile of the row: sample position = noisePos * (1, 1.6, 1) + offset with |offset| < 1.8; origin from the row's first column
+    // (16 columns are 0.08 cells wide: at most one cell boundary inside the row)
     CellTile tile;
     tile.pts = s_cells;
     tile.ox = (int)__builtin_floorf(((float)cp.x * 0.0050f) * 1.f) - 3;
@@ -312,28 +313,19 @@ k_cave_voxels(const float* __restrict__ hf, const float2* __restrict__ colInfo, 
         const f3 p = rand3from3((float)(tile.ox + ix), (float)(tile.oy + iy), (float)(tile.oz + iz));
         s_cells[3 * i] = p.x; s_cells[3 * i + 1] = p.y; s_cells[3 * i + 2] = p.z;
     }
+    for (int i = t; i < CAVE_ROW * 6; i += CAVE_THREADS) s_solid[i / 6][i % 6] = 0ull;
+    if (t < 2) s_count[t] = 0;
     noise_tables_init<false>();                                // no simplex2 in this kernel; ends with the workgroup barrier
 
-  for (int sub = 0; sub < 16 / CAVE_COLS; ++sub) {
-    const int colBase = 16 * row + CAVE_COLS * sub;            // first column of the batch: x = CAVE_COLS * sub + c, z = row
-    const unsigned needMask = (rowNeed >> (CAVE_COLS * sub)) & ((1u << CAVE_COLS) - 1u);
-    for (int i = t; i < CAVE_COLS * 6; i += CAVE_THREADS) s_solid[i / 6][i % 6] = 0ull;
-    if (t < 2) s_count[t] = 0;
-    for (int i = t; i < CAVE_COLS * 3 * MMGEN_MAX_CAVE_LAYERS_PER_COLUMN; i += CAVE_THREADS)
-        (&s_layers[0][0])[i] = ((i % 3) == 2) ? 0 : 384;       // {384, 384, biomes = 0}
-    __syncthreads();
-
-    // Three dense phases over LDS-compacted voxel lists (order inside a list is irrelevant: voxels are independent).  Ocean columns
-    // need the noise only below y ~ 92 and most voxels that pass the first test pass the second, so without compaction 4 - 40 %
-    // of the lanes idle through the 23 simplex evaluations.
+    // Ocean columns need the noise only below y ~ 92 and most voxels that pass the first test pass the second, so without compaction
+    // 4 - 40 % of the lanes idle through the 23 simplex evaluations.
     //   A  every voxel: everything that needs no noise; solid bit set as if the noise said "no cave"; voxels that need it -> list 1
     //   B  list 1: position warp (fbm3from3<5>) + Worley = the cave noise; voxels whose noise is below the largest threshold the voxel can
     //      have -> list 2 with their noise
     //   C  list 2: the threshold (huge, then fbm3<4> only if the noise is still below the bound); "cave" clears the solid bit again
     for (int u = t; u < CAVE_VOXELS; u += CAVE_THREADS) {
-        const int c = u % CAVE_COLS, y = u / CAVE_COLS;              // y-major: the lists come out ordered by depth
-        const int e = c * CAVE_YEVAL + y;
-        if (!((needMask >> c) & 1u)) continue;
+        const int c = u % CAVE_ROW, y = u / CAVE_ROW;               // y-major: the lists come out ordered by depth
+        if (!((rowNeed >> c) & 1u)) continue;
         const int col = chunk * 256 + colBase + c;
         const float maxHeight = hf[col];
         const float2 ci = colInfo[col];
@@ -342,13 +334,13 @@ k_cave_voxels(const float* __restrict__ hf, const float2* __restrict__ colInfo, 
         const float fy = (float)y;
         const bool inBand = (y != 0) && (y <= topSolid);
         const float topRatio = smoothstep(142.f, 95.f, fy + obw * 50.f);
-        const bool needThr = inBand && topRatio > 0.f;      // threshold is a product with topRatio: 0 → "threshold > 0.04" is false
+        const bool needThr = inBand && topRatio > 0.f;      // threshold is a product with topRatio: 0 -> "threshold > 0.04" is false
         // final cave = noise cave || (y != 0 && !inBand) || (inBand && fy > ravineY)   (y == 0 solid, y > topSolid air, ravine cut)
         const bool cave0 = ((y != 0) && !inBand) || (inBand && fy > ravineY);
-        // the wave's 64 lanes may straddle two columns / two 64-bit words: OR each lane's bit into its word
+        // the wave's 64 lanes cover four consecutive y of the 16 columns: OR each lane's bit into its word
         if (!cave0) {
             atomicOr(&s_solid[c][y >> 6], 1ull << (y & 63));
-            if (needThr) s_list1[atomicAdd(&s_count[0], 1)] = (unsigned short)e;      // a voxel that is a cave anyway needs no noise
+            if (needThr) s_list1[atomicAdd(&s_count[0], 1)] = (unsigned short)(c * CAVE_YEVAL + y);      // a voxel that is a cave anyway needs no noise
         }
     }
     __syncthreads();
@@ -360,6 +352,27 @@ k_cave_voxels(const float* __restrict__ hf, const float2* __restrict__ colInfo, 
     const bool prune = prune_domain(cp.x, cp.y + row);          // the row's 16 columns: x in [cp.x, cp.x + 15] (cp.x a multiple of 16), z = cp.y + row
     const float b3 = prune ? MM_SIMPLEX3_BOUND : 3.402823466e+38f;
     const float kCaveFaMax = prune ? 0.9375f * MM_SIMPLEX3_BOUND : 1e30f;      // outside the domain: a bound no noise reaches
+    // phase C for one voxel: its noise n is below the largest threshold it can have
+    auto resolve = [&](int e, float n) {
+        const int c = e / CAVE_YEVAL, y = e - c * CAVE_YEVAL;
+        const int idx2d = colBase + c;
+        const float obw = colInfo[chunk * 256 + idx2d].x;
+        const int wx = cp.x + (idx2d & 15), wz = cp.y + (idx2d >> 4);
+        const float npx = (float)wx * 0.0050f, npz = (float)wz * 0.0050f;
+        const float fy = (float)y;
+        const float npy = fy * 0.0050f;
+        const float topRatio = smoothstep(142.f, 95.f, fy + obw * 50.f);
+        const float bottomRatio = smoothstep(5.f, 20.f, fy);
+        const float huge = cave_huge(npx * 0.0700f, npy * 0.0700f, npz * 0.0700f, b3);
+        float bound = 0.24f + 0.12f * kCaveFaMax;
+        bound *= (1.f + 1.4f * huge);
+        bound *= topRatio * (0.3f + 0.7f * bottomRatio);
+        if (!(n < bound)) return;                              // (a further compaction of the survivors into a fourth phase measured 0 %)
+        float thr = 0.24f + 0.12f * fbm3<4>(npx * 4.f, npy * 4.f, npz * 4.f);
+        thr *= (1.f + 1.4f * huge);
+        thr *= topRatio * (0.3f + 0.7f * bottomRatio);
+        if (thr > 0.04f && n < thr) atomicAnd(&s_solid[c][y >> 6], ~(1ull << (y & 63)));
+    };
     const int count1 = s_count[0];
     for (int i = t; i < count1; i += CAVE_THREADS) {
         const int e = s_list1[i];
@@ -380,39 +393,18 @@ k_cave_voxels(const float* __restrict__ hf, const float2* __restrict__ colInfo, 
         const float n = special_cave_noise(npx * 1.f + o.x * 1.8f, npy * 1.6f + o.y * 1.8f, npz * 1.f + o.z * 1.8f, tile);
         if (n < bound) {
             const int k = atomicAdd(&s_count[1], 1);
-            s_list2[k] = (unsigned short)e;
-            s_thr[k] = n;
+            if (k < CAVE_L2_CAP) { s_list2[k] = (unsigned short)e; s_thr[k] = n; }
+            else resolve(e, n);                                // list 2 is full (more than half of the row's voxels got here): in place
         }
     }
     __syncthreads();
-    const int count2 = s_count[1];
-    for (int i = t; i < count2; i += CAVE_THREADS) {
-        const int e = s_list2[i];
-        const float n = s_thr[i];
-        const int c = e / CAVE_YEVAL, y = e - c * CAVE_YEVAL;
-        const int idx2d = colBase + c;
-        const float obw = colInfo[chunk * 256 + idx2d].x;
-        const int wx = cp.x + (idx2d & 15), wz = cp.y + (idx2d >> 4);
-        const float npx = (float)wx * 0.0050f, npz = (float)wz * 0.0050f;
-        const float fy = (float)y;
-        const float npy = fy * 0.0050f;
-        const float topRatio = smoothstep(142.f, 95.f, fy + obw * 50.f);
-        const float bottomRatio = smoothstep(5.f, 20.f, fy);
-        const float huge = cave_huge(npx * 0.0700f, npy * 0.0700f, npz * 0.0700f, b3);
-        float bound = 0.24f + 0.12f * kCaveFaMax;
-        bound *= (1.f + 1.4f * huge);
-        bound *= topRatio * (0.3f + 0.7f * bottomRatio);
-        if (!(n < bound)) continue;                            // (a further compaction of the survivors into a fourth phase measured 0 %)
-        float thr = 0.24f + 0.12f * fbm3<4>(npx * 4.f, npy * 4.f, npz * 4.f);
-        thr *= (1.f + 1.4f * huge);
-        thr *= topRatio * (0.3f + 0.7f * bottomRatio);
-        if (thr > 0.04f && n < thr) atomicAnd(&s_solid[c][y >> 6], ~(1ull << (y & 63)));
-    }
+    const int count2 = imin(s_count[1], CAVE_L2_CAP);
+    for (int i = t; i < count2; i += CAVE_THREADS) resolve(s_list2[i], s_thr[i]);
     // analytic part, y in [144, 384): solid iff y <= topSolid and not (y > ravineY)   (topRatio == 0 there)
-    if (t < CAVE_COLS * 4) {   // 4 lanes per column fill words 2..5 (word 2 holds y 128..191: bits >= 16 only)
+    if (t < CAVE_ROW * 4) {    // 4 lanes per column fill words 2..5 (word 2 holds y 128..191: bits >= 16 only)
         const int c = t >> 2, w = 2 + (t & 3);
         const int col = chunk * 256 + colBase + c;
-        const int topSolid = ((needMask >> c) & 1u) ? imax((int)hf[col], MMGEN_SEA_LEVEL) : -1;
+        const int topSolid = ((rowNeed >> c) & 1u) ? imax((int)hf[col], MMGEN_SEA_LEVEL) : -1;
         const float ravineY = colInfo[col].y;
         unsigned long long m = 0ull;
         for (int b = 0; b < 64; ++b) {
@@ -423,16 +415,21 @@ k_cave_voxels(const float* __restrict__ hf, const float2* __restrict__ colInfo, 
     }
     __syncthreads();
 
-    // flips: solid(y) != solid(y+1), y = 383 compares with "not solid"; rank by popcount prefix over the 4 x 384 voxels
-    for (int v = t; v < CAVE_COLS * 384; v += CAVE_THREADS) {
+    // flips: solid(y) != solid(y+1), y = 383 compares with "not solid"; rank by popcount prefix over the column's 384 voxels; four columns
+    // at a time through the LDS layer slots
+  for (int sub = 0; sub < CAVE_ROW / 4; ++sub) {
+    for (int i = t; i < 4 * 3 * MMGEN_MAX_CAVE_LAYERS_PER_COLUMN; i += CAVE_THREADS)
+        (&s_layers[0][0])[i] = ((i % 3) == 2) ? 0 : 384;       // {384, 384, biomes = 0}
+    __syncthreads();
+    for (int v = t; v < 4 * 384; v += CAVE_THREADS) {
         const int cc = v / 384, yy = v - cc * 384;
         const int w = yy >> 6, b = yy & 63;
         int before = 0;
         unsigned long long mine = 0ull;
 #pragma unroll
         for (int k = 0; k < 6; ++k) {
-            const unsigned long long m = s_solid[cc][k];
-            const unsigned long long nl = (k < 5) ? (s_solid[cc][k + 1] & 1ull) : 0ull;
+            const unsigned long long m = s_solid[4 * sub + cc][k];
+            const unsigned long long nl = (k < 5) ? (s_solid[4 * sub + cc][k + 1] & 1ull) : 0ull;
             const unsigned long long f = m ^ ((m >> 1) | (nl << 63));
             if (k < w) before += __popcll(f);
             if (k == w) mine = f;
@@ -444,11 +441,11 @@ k_cave_voxels(const float* __restrict__ hf, const float2* __restrict__ colInfo, 
         }
     }
     __syncthreads();
-    for (int i = t; i < CAVE_COLS * 3 * MMGEN_MAX_CAVE_LAYERS_PER_COLUMN; i += CAVE_THREADS) {
+    for (int i = t; i < 4 * 3 * MMGEN_MAX_CAVE_LAYERS_PER_COLUMN; i += CAVE_THREADS) {
         const int cc = i / (3 * MMGEN_MAX_CAVE_LAYERS_PER_COLUMN), k = i % (3 * MMGEN_MAX_CAVE_LAYERS_PER_COLUMN);
-        ((int*)(caveLayers + (size_t)MMGEN_MAX_CAVE_LAYERS_PER_COLUMN * (chunk * 256 + colBase + cc)))[k] = s_layers[cc][k];
+        ((int*)(caveLayers + (size_t)MMGEN_MAX_CAVE_LAYERS_PER_COLUMN * (chunk * 256 + colBase + 4 * sub + cc)))[k] = s_layers[cc][k];
     }
-    __syncthreads();                                           // the bit words, lists and layer slots are re-used by the next batch
+    __syncthreads();                                           // the layer slots are re-used by the next four columns
   }
 }
 
