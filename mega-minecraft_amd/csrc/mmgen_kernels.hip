@@ -584,15 +584,14 @@ MM_DEV BaseBlock place_block_base(const ColumnBiomes& cbi, const float* s_lh, co
 #ifndef MM_FILL_EXP
 #define MM_FILL_EXP 0      // timing experiments only (tools/build_variant.sh): 1 = no cave-biome phase, 2 = no cave-biome block rules
 #endif
-#ifndef FILL_COLS
-#define FILL_COLS 4          // columns per batch
-#endif
-#define FILL_VBITS (FILL_COLS == 4 ? 11 : (FILL_COLS == 8 ? 12 : 13))      // bits of a voxel's position in the batch (FILL_COLS * 384 voxels)
-#define FILL_VMASK ((1 << FILL_VBITS) - 1)
 #define FILL_ROW 16          // columns per workgroup: one row of the chunk, staged with whole-line loads
-#define FILL_L3_CAP 256      // deferred lush voxels per batch (typically 0 - 30)
+#define FILL_VOX (FILL_ROW * 384)     // 6 144 voxels per row
+#define FILL_VBITS 13        // bits of a voxel's position in the row
+#define FILL_VMASK ((1 << FILL_VBITS) - 1)
+#define FILL_L2_CAP 2048     // voxels of a row whose cave biome has a noise rule (typically a few hundred); a full list evaluates the surplus in place
+#define FILL_L3_CAP 512      // deferred lush voxels per row (typically 0 - 100)
 #ifndef FILL_THREADS
-#define FILL_THREADS 256      // phase 2 walks ~450 compacted voxels: 2 passes at 88 % lane use (768 lanes: 1 pass at 59 %)
+#define FILL_THREADS 512     // 8 waves: three workgroups (50 KB of LDS each) fill a CU's 24 wave slots
 #endif
 #ifndef MM_FILL_WAVES
 #define MM_FILL_WAVES 6
@@ -600,6 +599,10 @@ MM_DEV BaseBlock place_block_base(const ColumnBiomes& cbi, const float* s_lh, co
 
 // NEAR = the rows inside the pruning domain (mm_noise.cuh), evaluated with the exact prunings; k_fill_far takes the rows beyond it the
 // plain way.  Two kernels rather than a flag: the pruned path sits exactly at its register budget, and a row belongs to one of them.
+//
+// One workgroup = one 16-column row of a chunk, its voxel lists row-long (like k_cave_voxels): a dense phase loses at most one partial
+// wave at the end of its list - with the 4-column batches of the previous layout that was 12 % of the cave-biome phase, with a row's
+// ~1 800 stone voxels it is 2 % - and the row pays 5 workgroup barriers instead of 20.
 template <bool NEAR>
 MM_DEV void fill_body(const float* __restrict__ hf, const float* __restrict__ bw, const float* __restrict__ layers,
                       const mmgen_cave_layer* __restrict__ caveLayers, const int2* __restrict__ chunkPos, uint8_t* __restrict__ blocks,
@@ -613,9 +616,9 @@ MM_DEV void fill_body(const float* __restrict__ hf, const float* __restrict__ bw
     noise_tables_init();
     __shared__ float s_bw[FILL_ROW][MMGEN_NUM_BIOMES];
     __shared__ float s_lh[FILL_ROW][MMGEN_NUM_MATERIALS + 1];
-    __shared__ mmgen_cave_layer s_cl[FILL_COLS][MMGEN_MAX_CAVE_LAYERS_PER_COLUMN];
-    __shared__ unsigned int s_list[FILL_COLS * 384];          // voxel (FILL_VBITS) | block (8) | bottomDepth code (6) | topDepth code (6), from the low bits up
-    __shared__ unsigned short s_list2[FILL_COLS * 384];       // index into s_list (FILL_VBITS) | isLush << FILL_VBITS: voxels whose cave biome has a noise rule
+    __shared__ mmgen_cave_layer s_cl[FILL_ROW][MMGEN_MAX_CAVE_LAYERS_PER_COLUMN];
+    __shared__ unsigned int s_list[FILL_VOX];                 // voxel (FILL_VBITS) | block (8) | bottomDepth code (5) | topDepth code (5), from the low bits up
+    __shared__ unsigned short s_list2[FILL_L2_CAP];           // index into s_list (FILL_VBITS) | isLush << FILL_VBITS: voxels whose cave biome has a noise rule
     __shared__ unsigned short s_list3[FILL_L3_CAP];           // index into s_list: lush voxels close enough to a cave surface for clay / moss
     __shared__ int s_count[3];
     __shared__ unsigned s_qbase;
@@ -624,20 +627,23 @@ MM_DEV void fill_body(const float* __restrict__ hf, const float* __restrict__ bw
 
     const int t = threadIdx.x;
     const int bid = xcd_block(blockIdx.x, gridDim.x);
-    const int outChunk = bid >> 4, row = bid & 15;                 // one workgroup = one 16-column row of a chunk (z = row), in 4 batches of 4 columns
+    const int outChunk = bid >> 4, row = bid & 15;                 // one workgroup = one 16-column row of a chunk (z = row)
     const int chunk = srcIdx ? srcIdx[outChunk] : outChunk;        // inputs are read at `chunk`, blocks are written densely at outChunk
     const int2 cp = chunkPos[chunk];
+    const int idxBase = FILL_ROW * row;
 
     // the row's plane attributes, once: 24 weights + 20 layer starts + height per column.  A row of a plane is one 64-byte line, read whole
-    // (4-column workgroups fetched every line four times, from four workgroups that rarely share an L2: 2.3 x the algorithmic bytes)
     for (int i = t; i < FILL_ROW * 45; i += FILL_THREADS) {
         const int k = i / FILL_ROW, c = i % FILL_ROW;               // consecutive lanes = consecutive columns of one plane
-        const int idx2d = FILL_ROW * row + c;
+        const int idx2d = idxBase + c;
         if (k < MMGEN_NUM_BIOMES) s_bw[c][k] = bw[(size_t)MMGEN_BIOME_WEIGHTS_SIZE * chunk + 256 * k + idx2d];
         else if (k < MMGEN_NUM_BIOMES + MMGEN_NUM_MATERIALS) s_lh[c][k - MMGEN_NUM_BIOMES] = layers[(size_t)MMGEN_LAYERS_SIZE * chunk + 256 * (k - MMGEN_NUM_BIOMES) + idx2d];
         else s_lh[c][MMGEN_NUM_MATERIALS] = hf[chunk * 256 + idx2d];
     }
-
+    // the row's cave layers: 16 columns x 32 layers x 12 bytes, contiguous
+    for (int i = t; i < FILL_ROW * 96; i += FILL_THREADS)
+        ((int*)s_cl)[i] = ((const int*)(caveLayers + (size_t)MMGEN_MAX_CAVE_LAYERS_PER_COLUMN * (chunk * 256 + idxBase)))[i];
+    if (t < 3) s_count[t] = 0;
     __syncthreads();
     if (t < FILL_ROW) {
         int n = 0;
@@ -649,44 +655,55 @@ MM_DEV void fill_body(const float* __restrict__ hf, const float* __restrict__ bw
         }
         s_nzN[t] = (uint8_t)n; s_ocean[t] = ocean ? 1 : 0;
     }
-
-  for (int sub = 0; sub < FILL_ROW / FILL_COLS; ++sub) {
-    const int idxBase = FILL_ROW * row + FILL_COLS * sub;
-    const int cRow = FILL_COLS * sub;                              // first column of the batch inside the staged row
-    // the batch's cave layers: 4 columns x 32 layers x 12 bytes, contiguous
-    for (int i = t; i < FILL_COLS * 96; i += FILL_THREADS)
-        ((int*)s_cl)[i] = ((const int*)(caveLayers + (size_t)MMGEN_MAX_CAVE_LAYERS_PER_COLUMN * (chunk * 256 + idxBase)))[i];
-    if (t < 3) s_count[t] = 0;
     __syncthreads();
 
-    uint8_t* outBase = blocks + (size_t)MMGEN_BLOCKS_PER_CHUNK * outChunk + 384 * idxBase;     // the 4 columns are contiguous: 1536 bytes
+    uint8_t* outBase = blocks + (size_t)MMGEN_BLOCKS_PER_CHUNK * outChunk + 384 * idxBase;     // the 16 columns are contiguous: 6 144 bytes
 
     // phase 1: base blocks.  The two cave-surface distances only matter as "== 0" and "0 .. threshold" with threshold = 1.5 + 4.5 * simplex3
-    // (|simplex3| < 3.5 by the crudest bound: 42 * 4 corners * max((0.6 - r^2)^4 r) = 3.5), so they travel as 6-bit codes:
-    // negative -> 63, 62 and beyond -> 62.
-    // y-major walk (lane -> column t % 4, y = t / 4): a wave covers 16 consecutive y of all four columns, so the list that phase 2 walks
-    // is ordered by depth, and its exits - which go by depth zone - retire whole waves instead of idling lanes
-    for (int u = t; u < FILL_COLS * 384; u += FILL_THREADS) {
-        const int c = u % FILL_COLS, y = u / FILL_COLS;
-        const int v = 384 * c + y;                                  // position in the batch's 1 536 output bytes
-        const int idx2d = idxBase + c;
-        const int wx = cp.x + (idx2d & 15);
-        int wz = cp.y + (idx2d >> 4);
+    // (|simplex3| < 3.5 by the crudest bound: 42 * 4 corners * max((0.6 - r^2)^4 r) = 3.5, threshold < 17.25), so they travel as 5-bit
+    // codes: negative -> 31, 30 and beyond -> 30.
+    // Walk: a wave = 16 consecutive y of four neighbouring columns (16-byte pieces per column in a wave's store), the four column groups
+    // of a 16-y block in four consecutive waves: the list that phase 2 walks comes out ordered by depth, and the exits of the cave-biome
+    // evaluation - which go by depth zone - retire whole waves instead of idling lanes
+    for (int u = t; u < FILL_VOX; u += FILL_THREADS) {
+        const int c = 4 * ((u >> 6) & 3) + (u & 3), y = 16 * (u >> 8) + ((u >> 2) & 15);
+        const int v = 384 * c + y;                                  // position in the row's 6 144 output bytes
+        const int wx = cp.x + c;
+        int wz = cp.y + row;
         // wz is the same for the whole workgroup (one row of a chunk): left visible, the compiler hoists (float)wz * scale for each of the six
         // block-rule noises out of the loop into six VGPRs it then has to spill (the kernel sits at its register budget)
         asm volatile("" : "+v"(wz));
-        const ColumnBiomes cbi = {s_nzN[cRow + c], s_ocean[cRow + c] != 0, s_nzIdx[cRow + c], s_nzW[cRow + c], s_bw[cRow + c]};
-        const BaseBlock r = place_block_base(cbi, s_lh[cRow + c], s_cl[c], y, s_lh[cRow + c][MMGEN_NUM_MATERIALS], wx, wz);
+        const ColumnBiomes cbi = {s_nzN[c], s_ocean[c] != 0, s_nzIdx[c], s_nzW[c], s_bw[c]};
+        const BaseBlock r = place_block_base(cbi, s_lh[c], s_cl[c], y, s_lh[c][MMGEN_NUM_MATERIALS], wx, wz);
         if (r.needCave) {
             const int slot = atomicAdd(&s_count[0], 1);
-            const unsigned bdc = r.bottomDepth < 0 ? 63u : (unsigned)imin(r.bottomDepth, 62);
-            const unsigned tdc = r.topDepth < 0 ? 63u : (unsigned)imin(r.topDepth, 62);
-            s_list[slot] = (unsigned)v | ((unsigned)r.block << FILL_VBITS) | (bdc << (FILL_VBITS + 8)) | (tdc << (FILL_VBITS + 14));
+            const unsigned bdc = r.bottomDepth < 0 ? 31u : (unsigned)imin(r.bottomDepth, 30);
+            const unsigned tdc = r.topDepth < 0 ? 31u : (unsigned)imin(r.topDepth, 30);
+            s_list[slot] = (unsigned)v | ((unsigned)r.block << FILL_VBITS) | (bdc << (FILL_VBITS + 8)) | (tdc << (FILL_VBITS + 13));
         } else {
             outBase[v] = r.block;
         }
     }
     __syncthreads();
+
+    // phase 3 body: the one simplex3 both noise rules start with; lush voxels within reach of a cave surface go to list 3
+    auto noise_rule = [&](int i, int cb) {
+        const unsigned e = s_list[i];
+        const int v = e & FILL_VMASK;
+        uint8_t block = (uint8_t)((e >> FILL_VBITS) & 255);
+        const int bdc = (e >> (FILL_VBITS + 8)) & 31, tdc = (e >> (FILL_VBITS + 13)) & 31;
+        const int c = v / 384, y = v - 384 * c;
+        const int wx = cp.x + c, wz = cp.y + row;
+        float ax, ay, az;
+        cave_post_noise_pos(cb, wx, y, wz, ax, ay, az);
+        const float n = simplex3_inl(ax, ay, az);
+        if (cave_post_apply(block, cb, n, wx, y, wz, bdc == 31 ? -1 : bdc, tdc == 31 ? -1 : tdc)) {
+            const int slot = atomicAdd(&s_count[2], 1);
+            if (slot < FILL_L3_CAP) { s_list3[slot] = (unsigned short)i; return; }
+            block = lush_clay_or_moss(wx, y, wz, CellDirect());       // more than FILL_L3_CAP in one row: in place
+        }
+        outBase[v] = block;
+    };
 
     // phase 2: cave biome of the compacted stone voxels (9 simplex3 + 6 .. 12 simplex2 + 0 .. 2 simplex3 each).  NONE / WARPED / AMBER are
     // final here; CRYSTAL and LUSH voxels go to list 2
@@ -695,21 +712,22 @@ MM_DEV void fill_body(const float* __restrict__ hf, const float* __restrict__ bw
         const unsigned e = s_list[i];
         const int v = e & FILL_VMASK;
         uint8_t block = (uint8_t)((e >> FILL_VBITS) & 255);
-        const int bdc = (e >> (FILL_VBITS + 8)) & 63;
+        const int bdc = (e >> (FILL_VBITS + 8)) & 31;
         const int c = v / 384, y = v - 384 * c;
-        const int idx2d = idxBase + c;
-        const int wx = cp.x + (idx2d & 15), wz = cp.y + (idx2d >> 4);
+        const int wx = cp.x + c, wz = cp.y + row;
 #if MM_FILL_EXP != 1
         // WARPED / AMBER only act on the top DEEPSLATE / BLACKSTONE block of a cave floor (caveBottomDepth == 0)
         const bool wantDeep = bdc == 0 && (block == MMB_DEEPSLATE || block == MMB_BLACKSTONE);
         // LUSH_CAVES only converts within 1.5 + 4.5 simplex3 <= 1.5 + 4.5 * 1.37 = 7.67 blocks of a cave surface: further away only CRYSTAL_CAVES
-        // can change the block (depth codes: 63 = no such surface; MM_SIMPLEX3_BOUND holds inside the pruning domain)
-        const int tdc = (e >> (FILL_VBITS + 14)) & 63;
+        // can change the block (depth codes: 31 = no such surface; MM_SIMPLEX3_BOUND holds inside the pruning domain)
+        const int tdc = (e >> (FILL_VBITS + 13)) & 31;
         static_assert(1.5f + 4.5f * MM_SIMPLEX3_BOUND < 8.f, "depth beyond which LUSH_CAVES cannot convert");
         const bool crystalOnly = NEAR && !wantDeep && bdc > 7 && tdc > 7;
-        const int cb = cave_biome_t<NEAR>(wx, y, wz, s_lh[cRow + c][MMGEN_NUM_MATERIALS], 190249401, wantDeep, crystalOnly);
+        const int cb = cave_biome_t<NEAR>(wx, y, wz, s_lh[c][MMGEN_NUM_MATERIALS], 190249401, wantDeep, crystalOnly);
         if (MM_FILL_EXP != 2 && (cb == MMCB_CRYSTAL_CAVES || cb == MMCB_LUSH_CAVES)) {
-            s_list2[atomicAdd(&s_count[1], 1)] = (unsigned short)(i | (cb == MMCB_LUSH_CAVES ? (1 << FILL_VBITS) : 0));
+            const int k = atomicAdd(&s_count[1], 1);
+            if (k < FILL_L2_CAP) s_list2[k] = (unsigned short)(i | (cb == MMCB_LUSH_CAVES ? (1 << FILL_VBITS) : 0));
+            else noise_rule(i, cb);                                   // list 2 is full: in place
             continue;
         }
         if (wantDeep && cb != MMCB_NONE) cave_biome_block_post(block, cb, wx, y, wz, 0, -1);      // WARPED / AMBER re-skin, no noise
@@ -718,32 +736,16 @@ MM_DEV void fill_body(const float* __restrict__ hf, const float* __restrict__ bw
     }
     __syncthreads();
 
-    // phase 3: the one simplex3 both noise rules start with, densely; lush voxels within reach of a cave surface go to list 3
-    const int count2 = s_count[1];
+    // phase 3, densely over list 2
+    const int count2 = imin(s_count[1], FILL_L2_CAP);
     for (int k = t; k < count2; k += FILL_THREADS) {
         const int item = s_list2[k];
-        const int i = item & FILL_VMASK, cb = (item & (1 << FILL_VBITS)) ? MMCB_LUSH_CAVES : MMCB_CRYSTAL_CAVES;
-        const unsigned e = s_list[i];
-        const int v = e & FILL_VMASK;
-        uint8_t block = (uint8_t)((e >> FILL_VBITS) & 255);
-        const int bdc = (e >> (FILL_VBITS + 8)) & 63, tdc = (e >> (FILL_VBITS + 14)) & 63;
-        const int c = v / 384, y = v - 384 * c;
-        const int idx2d = idxBase + c;
-        const int wx = cp.x + (idx2d & 15), wz = cp.y + (idx2d >> 4);
-        float ax, ay, az;
-        cave_post_noise_pos(cb, wx, y, wz, ax, ay, az);
-        const float n = simplex3_inl(ax, ay, az);
-        if (cave_post_apply(block, cb, n, wx, y, wz, bdc == 63 ? -1 : bdc, tdc == 63 ? -1 : tdc)) {
-            const int slot = atomicAdd(&s_count[2], 1);
-            if (slot < FILL_L3_CAP) { s_list3[slot] = (unsigned short)i; continue; }
-            block = lush_clay_or_moss(wx, y, wz, CellDirect());       // more than FILL_L3_CAP in one batch: in place
-        }
-        outBase[v] = block;
+        noise_rule(item & FILL_VMASK, (item & (1 << FILL_VBITS)) ? MMCB_LUSH_CAVES : MMCB_CRYSTAL_CAVES);
     }
     __syncthreads();
 
     // phase 4: clay or moss (fbm3from3<3> + a 27-cell Worley search with 81 sin hashes = ~5 600 instructions) for the few lush voxels that
-    // got here: typically 0 - 30 per workgroup, which would leave most lanes of the workgroup idle through the longest code path of the
+    // got here: typically 0 - 100 per row, which would leave most lanes of the workgroup idle through the longest code path of the
     // kernel.  They are appended to a device-wide queue instead and k_fill_lush evaluates them 64 to a wave; only when the queue is
     // full (or absent) are they evaluated here.
     const int count3 = imin(s_count[2], FILL_L3_CAP);
@@ -759,10 +761,8 @@ MM_DEV void fill_body(const float* __restrict__ hf, const float* __restrict__ bw
         if (queued) { lushQueue[1 + qbase + k] = ((unsigned)outChunk << 17) | ((unsigned)idx2d << 9) | (unsigned)y; continue; }
         // a reservation that straddles the capacity marks its in-range slots as holes (they hold the previous launch's entries)
         if (lushQueue && qbase < lushCap && (unsigned)k < lushCap - qbase) lushQueue[1 + qbase + k] = 0xffffffffu;
-        outBase[v] = MM_FILL_EXP == 3 ? (uint8_t)MMB_MOSS : lush_clay_or_moss(cp.x + (idx2d & 15), y, cp.y + (idx2d >> 4), CellDirect());
+        outBase[v] = MM_FILL_EXP == 3 ? (uint8_t)MMB_MOSS : lush_clay_or_moss(cp.x + c, y, cp.y + row, CellDirect());
     }
-    __syncthreads();                                               // the lists and s_cl are re-used by the next batch
-  }
 }
 
 __attribute__((amdgpu_waves_per_eu(MM_FILL_WAVES, MM_FILL_WAVES)))

@@ -128,9 +128,9 @@ DEVICE_MAP = {
 DEVICE_BENIGN = {0.0, 0.5, 1.0, 2.0, 3.0, 4.0, 5.0, 6.0, 9.0, 16.0, 63.0, 64.0, 255.0, 256.0, 384.0, 65535.0, 2147483648.0, 48271.0,
                  float(np.float32(3.402823466e+38))}
 DEVICE_EXTRA = {
-    # fill_body: lane / batch geometry of the row workgroup (4 columns x 96 y per batch, 16-byte store pieces, 2^32 list keys) and the
+    # fill_body: lane / batch geometry of the row workgroup (16 columns x 384 y per row, 13-bit positions, 5-bit depth codes 30 / 31, 2^32 queue keys) and the
     # "further than 7 blocks from every cave surface" test of the CRYSTAL-only evaluations (LUSH_CAVES converts within 1.5 + 4.5 |simplex3|)
-    "chunk.cu::chunkFillPlaceBlock": (1.5, 4.5, 7.0, 8.0, 14.0, 15.0, 17.0, 45.0, 62.0, 96.0, 4294967296.0),
+    "chunk.cu::chunkFillPlaceBlock": (1.5, 4.5, 7.0, 8.0, 13.0, 15.0, 17.0, 30.0, 31.0, 45.0, 96.0, 4294967296.0),
     "biomeFuncs.hpp::getBiomeNoise": (float(np.float32(0.32)),),         # overallBiomeScale, a file-level constant in the reference (biomeFuncs.hpp:105)
     # cave_huge: slack of its exact pruning; k_cave_voxels: kCaveFaMax = 0.9375 * MM_SIMPLEX3_BOUND (the octave amplitudes of fbm3<4> sum to
     # 0.9375), 1e30 = "no bound" outside the pruning domain (the bounds themselves are macros of mm_noise.cuh)
