@@ -230,6 +230,9 @@ def test_config5_world_8_tiles_equals_single_region(mmgen_pkg):
     g = mmgen_pkg.MMGen(0)
     single = g.generate_region(wx0, wz0, W, H)["blocks"]
     assert torch.equal(world, single)
+    # the product-only capacity (MMGEN_CFP_CAP = 1 024 cave placements per chunk) over the whole 65 536-chunk world: far away
+    longest = g.region_max_cave_placements()
+    assert 0 < longest < 512, longest
     # not a trivially empty world: bedrock floor everywhere, and a healthy mix of block ids
     assert bool((single.view(-1, 384)[:, 0] == 56).all())
     assert int(torch.unique(single[::97]).numel()) > 40
