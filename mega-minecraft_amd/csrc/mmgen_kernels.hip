@@ -228,6 +228,7 @@ MM_DEV float cave_huge(float x, float y, float z, float b3 /* MM_SIMPLEX3_BOUND 
 #define CAVE_ROW 16        // one workgroup = one 16-column row of a chunk
 #define CAVE_VOXELS (CAVE_ROW * CAVE_YEVAL)       // 2 304 evaluated voxels per row
 #define CAVE_L2_CAP (CAVE_VOXELS / 2)             // list 2 (typically 40 - 45 % of list 1); a full list resolves the surplus in place
+#define CAVE_L3_CAP (CAVE_VOXELS / 3)             // list 3 (typically a third of list 2)
 #ifndef CAVE_THREADS
 #define CAVE_THREADS 256                          // 4 waves: six workgroups (26.4 KB of LDS each) fill a CU's 24 wave slots
 #endif
@@ -276,9 +277,14 @@ k_cave_voxels(const float* __restrict__ hf, const float2* __restrict__ colInfo, 
     __shared__ float s_cells[3 * CELL_N];
     __shared__ unsigned long long s_solid[CAVE_ROW][6];       // solid bit of voxel y at word y / 64, bit y % 64
     __shared__ int s_layers[4][3 * MMGEN_MAX_CAVE_LAYERS_PER_COLUMN];      // run extraction, four columns at a time
-    __shared__ unsigned short s_list1[CAVE_VOXELS], s_list2[CAVE_L2_CAP];
+    __shared__ __attribute__((aligned(16))) unsigned short s_list1[CAVE_VOXELS];
+    __shared__ unsigned short s_list2[CAVE_L2_CAP];
     __shared__ float s_thr[CAVE_L2_CAP];
-    __shared__ int s_count[2];
+    __shared__ int s_count[3];
+    // list 3 lives in list 1's memory once phase B is over: index into list 2 + the voxel's `huge`
+    static_assert(CAVE_L3_CAP * (sizeof(unsigned short) + sizeof(float)) <= sizeof(unsigned short) * CAVE_VOXELS, "list 3 fits in list 1");
+    unsigned short* s_list3 = s_list1;
+    float* s_huge = (float*)(s_list1 + CAVE_L3_CAP);
 
     const int t = threadIdx.x;
     const int bid = xcd_block(blockIdx.x, gridDim.x);
@@ -314,7 +320,7 @@ k_cave_voxels(const float* __restrict__ hf, const float2* __restrict__ colInfo, 
         s_cells[3 * i] = p.x; s_cells[3 * i + 1] = p.y; s_cells[3 * i + 2] = p.z;
     }
     for (int i = t; i < CAVE_ROW * 6; i += CAVE_THREADS) s_solid[i / 6][i % 6] = 0ull;
-    if (t < 2) s_count[t] = 0;
+    if (t < 3) s_count[t] = 0;
     noise_tables_init<false>();                                // no simplex2 in this kernel; ends with the workgroup barrier
 
     // Ocean columns need the noise only below y ~ 92 and most voxels that pass the first test pass the second, so without compaction
@@ -322,7 +328,9 @@ k_cave_voxels(const float* __restrict__ hf, const float2* __restrict__ colInfo, 
     //   A  every voxel: everything that needs no noise; solid bit set as if the noise said "no cave"; voxels that need it -> list 1
     //   B  list 1: position warp (fbm3from3<5>) + Worley = the cave noise; voxels whose noise is below the largest threshold the voxel can
     //      have -> list 2 with their noise
-    //   C  list 2: the threshold (huge, then fbm3<4> only if the noise is still below the bound); "cave" clears the solid bit again
+    //   C  list 2: `huge` (<= 4 octaves) and the bound it implies; voxels whose noise is still below it -> list 3 with their huge
+    //   D  list 3: the threshold itself (fbm3<4>); "cave" clears the solid bit again.  (With four-column batches this fourth phase measured
+    //      0 %: its partial wave cost what it saved.  With row-long lists a third of phase C's lanes no longer idle through four octaves.)
     for (int u = t; u < CAVE_VOXELS; u += CAVE_THREADS) {
         const int c = u % CAVE_ROW, y = u / CAVE_ROW;               // y-major: the lists come out ordered by depth
         if (!((rowNeed >> c) & 1u)) continue;
@@ -352,26 +360,40 @@ k_cave_voxels(const float* __restrict__ hf, const float2* __restrict__ colInfo, 
     const bool prune = prune_domain(cp.x, cp.y + row);          // the row's 16 columns: x in [cp.x, cp.x + 15] (cp.x a multiple of 16), z = cp.y + row
     const float b3 = prune ? MM_SIMPLEX3_BOUND : 3.402823466e+38f;
     const float kCaveFaMax = prune ? 0.9375f * MM_SIMPLEX3_BOUND : 1e30f;      // outside the domain: a bound no noise reaches
-    // phase C for one voxel: its noise n is below the largest threshold it can have
-    auto resolve = [&](int e, float n) {
-        const int c = e / CAVE_YEVAL, y = e - c * CAVE_YEVAL;
-        const int idx2d = colBase + c;
+    struct VoxelTerms { int c, y; float npx, npy, npz, T; };      // T = topRatio (0.3 + 0.7 bottomRatio)
+    auto terms = [&](int e) {
+        VoxelTerms v;
+        v.c = e / CAVE_YEVAL; v.y = e - v.c * CAVE_YEVAL;
+        const int idx2d = colBase + v.c;
         const float obw = colInfo[chunk * 256 + idx2d].x;
         const int wx = cp.x + (idx2d & 15), wz = cp.y + (idx2d >> 4);
-        const float npx = (float)wx * 0.0050f, npz = (float)wz * 0.0050f;
-        const float fy = (float)y;
-        const float npy = fy * 0.0050f;
+        v.npx = (float)wx * 0.0050f; v.npz = (float)wz * 0.0050f;
+        const float fy = (float)v.y;
+        v.npy = fy * 0.0050f;
         const float topRatio = smoothstep(142.f, 95.f, fy + obw * 50.f);
         const float bottomRatio = smoothstep(5.f, 20.f, fy);
-        const float huge = cave_huge(npx * 0.0700f, npy * 0.0700f, npz * 0.0700f, b3);
+        v.T = topRatio * (0.3f + 0.7f * bottomRatio);
+        return v;
+    };
+    // phase C for one voxel (its noise n is below the largest threshold it can have): false = solid whatever fbm3<4> is
+    auto below_huge_bound = [&](const VoxelTerms& v, float n, float& huge) {
+        huge = cave_huge(v.npx * 0.0700f, v.npy * 0.0700f, v.npz * 0.0700f, b3);
         float bound = 0.24f + 0.12f * kCaveFaMax;
         bound *= (1.f + 1.4f * huge);
-        bound *= topRatio * (0.3f + 0.7f * bottomRatio);
-        if (!(n < bound)) return;                              // (a further compaction of the survivors into a fourth phase measured 0 %)
-        float thr = 0.24f + 0.12f * fbm3<4>(npx * 4.f, npy * 4.f, npz * 4.f);
+        bound *= v.T;
+        return n < bound;
+    };
+    // phase D for one voxel
+    auto carve = [&](const VoxelTerms& v, float n, float huge) {
+        float thr = 0.24f + 0.12f * fbm3<4>(v.npx * 4.f, v.npy * 4.f, v.npz * 4.f);
         thr *= (1.f + 1.4f * huge);
-        thr *= topRatio * (0.3f + 0.7f * bottomRatio);
-        if (thr > 0.04f && n < thr) atomicAnd(&s_solid[c][y >> 6], ~(1ull << (y & 63)));
+        thr *= v.T;
+        if (thr > 0.04f && n < thr) atomicAnd(&s_solid[v.c][v.y >> 6], ~(1ull << (v.y & 63)));
+    };
+    auto resolve = [&](int e, float n) {                       // C + D in place (a list was full)
+        const VoxelTerms v = terms(e);
+        float huge;
+        if (below_huge_bound(v, n, huge)) carve(v, n, huge);
     };
     const int count1 = s_count[0];
     for (int i = t; i < count1; i += CAVE_THREADS) {
@@ -399,7 +421,20 @@ k_cave_voxels(const float* __restrict__ hf, const float2* __restrict__ colInfo, 
     }
     __syncthreads();
     const int count2 = imin(s_count[1], CAVE_L2_CAP);
-    for (int i = t; i < count2; i += CAVE_THREADS) resolve(s_list2[i], s_thr[i]);
+    for (int i = t; i < count2; i += CAVE_THREADS) {
+        const VoxelTerms v = terms(s_list2[i]);
+        float huge;
+        if (!below_huge_bound(v, s_thr[i], huge)) continue;
+        const int k = atomicAdd(&s_count[2], 1);
+        if (k < CAVE_L3_CAP) { s_list3[k] = (unsigned short)i; s_huge[k] = huge; }
+        else carve(v, s_thr[i], huge);
+    }
+    __syncthreads();
+    const int count3 = imin(s_count[2], CAVE_L3_CAP);
+    for (int k = t; k < count3; k += CAVE_THREADS) {
+        const int i = s_list3[k];
+        carve(terms(s_list2[i]), s_thr[i], s_huge[k]);
+    }
     // analytic part, y in [144, 384): solid iff y <= topSolid and not (y > ravineY)   (topRatio == 0 there)
     if (t < CAVE_ROW * 4) {    // 4 lanes per column fill words 2..5 (word 2 holds y 128..191: bits >= 16 only)
         const int c = t >> 2, w = 2 + (t & 3);
