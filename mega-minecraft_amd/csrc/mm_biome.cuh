@@ -262,31 +262,15 @@ MM_DEV float column_height(int wxi, int wzi, float* w24 /* nullable */)
 #endif
 // PRUNE = the column lies inside the pruning domain (prune_domain(wx, wz), mm_noise.cuh): a compile-time switch, so that the pruned path
 // carries no trace of the plain one (k_fill sits exactly at its register budget); kernels pick the instantiation per workgroup or per lane.
+// The part of getCaveBiome after the position warp: rocky, one depth band, the draw (biomeFuncs.hpp:135-220).  ox, oz = the warp's x and z
+// components, py = the warped height.
 template <bool PRUNE>
-MM_DEV int cave_biome_t(int wx, int wy, int wz, float maxHeight, int seed, bool wantDeep, bool crystalOnly)
+MM_DEV int cave_biome_draw(int wx, int wy, int wz, float maxHeight, int seed, bool wantDeep, bool crystalOnly, const float ox, const float py, const float oz)
 {
-    const float fx = (float)wx, fy = (float)wy, fz = (float)wz;
+    const float fx = (float)wx, fz = (float)wz;
     const float top = (float)MMGEN_SEA_LEVEL + 0.15f * (maxHeight - (float)MMGEN_SEA_LEVEL);
-    const float sx = fx * 0.0470f, sy = fy * 0.0470f, sz = fz * 0.0470f;
-    constexpr float kA = 0.875f * MM_SIMPLEX2_BOUND;            // >= |fbm2<3>| inside the pruning domain (mm_noise.cuh)
+    constexpr float kA = 0.875f * MM_SIMPLEX2_BOUND;
     constexpr bool prune = PRUNE && MM_CAVE_BIOME_PRUNE;
-    // fbm3From3<3> component by component (rng.hpp:180-186), y first; one rolled loop = one inlined simplex body (code size)
-    float o[3], py = 0.f;
-#pragma unroll 1
-    for (int it = 0; it < 3; ++it) {
-        const int k = it == 0 ? 1 : (it == 1 ? 0 : 2);
-        const float ax = k == 0 ? 0.f : (k == 1 ? 5923.45f : 1765.68f), ay = k == 0 ? 0.f : (k == 1 ? 4129.42f : 4704.36f),
-                    az = k == 0 ? 0.f : (k == 1 ? 5790.48f : 5692.12f);
-        o[k] = k == 0 ? fbm3<3>(sx, sy, sz) : fbm3<3>(sx + ax, sy + ay, sz + az);
-        if (it == 0) {
-            py = (fy + o[1] * 24.f) * 1.f;
-            if constexpr (prune) {
-                if (py >= (top - 19.f) + 23.f * kA + 0.05f) return MMCB_NONE;
-                if (!wantDeep && py <= ((top - 72.f) - 18.f * kA - 10.f) - 7.f * kA - 0.05f) return MMCB_NONE;
-            }
-        }
-    }
-    const float ox = o[0], oz = o[2];
     const float px = (fx + ox * 30.f) * 1.f, pz = (fz + oz * 30.f) * 1.f;
     const float qx = px * 0.2000f, qz = pz * 0.2000f;
 
@@ -362,6 +346,70 @@ MM_DEV int cave_biome_t(int wx, int wy, int wz, float maxHeight, int seed, bool 
         if (rand <= 0.f) return MMCB_AMBER_FOREST;
     }
     return MMCB_NONE;
+}
+
+template <bool PRUNE>
+MM_DEV int cave_biome_t(int wx, int wy, int wz, float maxHeight, int seed, bool wantDeep, bool crystalOnly)
+{
+    const float fx = (float)wx, fy = (float)wy, fz = (float)wz;
+    const float top = (float)MMGEN_SEA_LEVEL + 0.15f * (maxHeight - (float)MMGEN_SEA_LEVEL);
+    const float sx = fx * 0.0470f, sy = fy * 0.0470f, sz = fz * 0.0470f;
+    constexpr float kA = 0.875f * MM_SIMPLEX2_BOUND;            // >= |fbm2<3>| inside the pruning domain (mm_noise.cuh)
+    constexpr bool prune = PRUNE && MM_CAVE_BIOME_PRUNE;
+    // fbm3From3<3> component by component (rng.hpp:180-186), y first; one rolled loop = one inlined simplex body (code size)
+    float o[3], py = 0.f;
+#pragma unroll 1
+    for (int it = 0; it < 3; ++it) {
+        const int k = it == 0 ? 1 : (it == 1 ? 0 : 2);
+        const float ax = k == 0 ? 0.f : (k == 1 ? 5923.45f : 1765.68f), ay = k == 0 ? 0.f : (k == 1 ? 4129.42f : 4704.36f),
+                    az = k == 0 ? 0.f : (k == 1 ? 5790.48f : 5692.12f);
+        o[k] = k == 0 ? fbm3<3>(sx, sy, sz) : fbm3<3>(sx + ax, sy + ay, sz + az);
+        if (it == 0) {
+            py = (fy + o[1] * 24.f) * 1.f;
+            if constexpr (prune) {
+                if (py >= (top - 19.f) + 23.f * kA + 0.05f) return MMCB_NONE;
+                if (!wantDeep && py <= ((top - 72.f) - 18.f * kA - 10.f) - 7.f * kA - 0.05f) return MMCB_NONE;
+            }
+        }
+    }
+    return cave_biome_draw<PRUNE>(wx, wy, wz, maxHeight, seed, wantDeep, crystalOnly, o[0], py, o[2]);
+}
+
+// Split at the warped height py: cave_biome_py evaluates the y component of the warp (3 of the 9 simplex3) and decides what py alone
+// decides; cave_biome_rest takes py and does the rest.  cave_biome_t = both in one go (k_fill); k_cave_biomes runs the two halves as
+// separate dense phases (every lane of the first does the same three evaluations; only the survivors, compacted again, pay for the rest).
+template <bool PRUNE>
+MM_DEV bool cave_biome_py(int wx, int wy, int wz, float maxHeight, bool wantDeep, float& py)      // true: the result is NONE
+{
+    const float fx = (float)wx, fy = (float)wy, fz = (float)wz;
+    const float top = (float)MMGEN_SEA_LEVEL + 0.15f * (maxHeight - (float)MMGEN_SEA_LEVEL);
+    const float sx = fx * 0.0470f, sy = fy * 0.0470f, sz = fz * 0.0470f;
+    constexpr float kA = 0.875f * MM_SIMPLEX2_BOUND;            // >= |fbm2<3>| inside the pruning domain (mm_noise.cuh)
+    constexpr bool prune = PRUNE && MM_CAVE_BIOME_PRUNE;
+    // fbm3From3<3> component by component (rng.hpp:180-186), y first
+    const float oy = fbm3<3>(sx + 5923.45f, sy + 4129.42f, sz + 5790.48f);
+    py = (fy + oy * 24.f) * 1.f;
+    if constexpr (prune) {
+        if (py >= (top - 19.f) + 23.f * kA + 0.05f) return true;
+        if (!wantDeep && py <= ((top - 72.f) - 18.f * kA - 10.f) - 7.f * kA - 0.05f) return true;
+    }
+    return false;
+}
+
+template <bool PRUNE>
+MM_DEV int cave_biome_rest(int wx, int wy, int wz, float maxHeight, int seed, bool wantDeep, bool crystalOnly, const float py)
+{
+    const float fx = (float)wx, fy = (float)wy, fz = (float)wz;
+    const float sx = fx * 0.0470f, sy = fy * 0.0470f, sz = fz * 0.0470f;
+    // the x and z components of the warp; one rolled loop = one inlined simplex body (code size)
+    float o[3];
+#pragma unroll 1
+    for (int it = 0; it < 2; ++it) {
+        const int k = it == 0 ? 0 : 2;
+        const float ax = k == 0 ? 0.f : 1765.68f, ay = k == 0 ? 0.f : 4704.36f, az = k == 0 ? 0.f : 5692.12f;
+        o[k] = k == 0 ? fbm3<3>(sx, sy, sz) : fbm3<3>(sx + ax, sy + ay, sz + az);
+    }
+    return cave_biome_draw<PRUNE>(wx, wy, wz, maxHeight, seed, wantDeep, crystalOnly, o[0], py, o[2]);
 }
 
 MM_DEV int cave_biome(int wx, int wy, int wz, float maxHeight, int seed)

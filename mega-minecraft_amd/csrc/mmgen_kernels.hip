@@ -493,18 +493,21 @@ k_cave_voxels(const float* __restrict__ hf, const float2* __restrict__ colInfo, 
 #ifndef CB_THREADS
 #define CB_THREADS 256
 #endif
+#define CB_SURV_CAP 1024   // items of a group that outlive the warped-height stage (typically a few hundred of ~ 800); the surplus is finished in place
 __global__ void __launch_bounds__(CB_THREADS)
 k_cave_biomes(const float* __restrict__ hf, const int2* __restrict__ chunkPos, mmgen_cave_layer* __restrict__ caveLayers,
               const int* __restrict__ chunkList)
 {
     __shared__ unsigned short s_items[CB_COLS * MMGEN_MAX_CAVE_LAYERS_PER_COLUMN * 2];    // (column * 32 + slot) << 1 | top
-    __shared__ int s_count;
+    __shared__ unsigned short s_surv[CB_SURV_CAP];                                        // items whose warped height decides nothing ...
+    __shared__ float s_py[CB_SURV_CAP];                                                   // ... with that height
+    __shared__ int s_count[2];
     constexpr int groupsPerChunk = 256 / CB_COLS;
     const int chunk = chunkList ? chunkList[blockIdx.x / groupsPerChunk] : (int)(blockIdx.x / groupsPerChunk);
     const int col0 = (blockIdx.x % groupsPerChunk) * CB_COLS;
     const int t = threadIdx.x;
     mmgen_cave_layer* L0 = caveLayers + ((size_t)256 * chunk + col0) * MMGEN_MAX_CAVE_LAYERS_PER_COLUMN;
-    if (t == 0) s_count = 0;
+    if (t < 2) s_count[t] = 0;
     noise_tables_init();                                       // ends with the workgroup barrier
     // slot-major walk (lane -> column u % CB_COLS, slot u / CB_COLS): the item list comes out ordered by depth (slot 0 = the lowest layer of
     // every column first), and cave_biome's exits go by depth zone
@@ -513,22 +516,46 @@ k_cave_biomes(const float* __restrict__ hf, const int2* __restrict__ chunkPos, m
         const int start = L0[i].start, end = L0[i].end;
         if (start == 384) continue;                            // unused slot: biomes stay NONE (0)
         const int n = (end == 384) ? 1 : 2;                    // a layer open to the sky has no top block: top biome NONE
-        const int at = atomicAdd(&s_count, n);
+        const int at = atomicAdd(&s_count[0], n);
         s_items[at] = (unsigned short)(i << 1);
         if (n == 2) s_items[at + 1] = (unsigned short)((i << 1) | 1);
         else L0[i].top_biome = (uint8_t)MMCB_NONE;
     }
     __syncthreads();
-    const int count = s_count;
+    const int count = s_count[0];
     const int2 cp = chunkPos[chunk];
-    for (int k = t; k < count; k += CB_THREADS) {
-        const int item = s_items[k];
+    const bool near = prune_domain(cp.x, cp.y + (col0 >> 4)) && prune_domain(cp.x + 15, cp.y + ((col0 + CB_COLS - 1) >> 4));      // the group's columns
+    auto item_of = [&](int item, int& wx, int& wy, int& wz, float& maxHeight, int& seed) {
         const int i = item >> 1, top = item & 1;
         const int col = col0 + i / MMGEN_MAX_CAVE_LAYERS_PER_COLUMN;
-        const int wx = cp.x + (col & 15), wz = cp.y + (col >> 4);
-        const float maxHeight = hf[(size_t)256 * chunk + col];
-        if (top) L0[i].top_biome = (uint8_t)cave_biome(wx, L0[i].end + 1, wz, maxHeight, 4982921);
-        else L0[i].bottom_biome = (uint8_t)cave_biome(wx, L0[i].start, wz, maxHeight, 329271348);
+        wx = cp.x + (col & 15); wz = cp.y + (col >> 4);
+        maxHeight = hf[(size_t)256 * chunk + col];
+        wy = top ? L0[i].end + 1 : L0[i].start;
+        seed = top ? 4982921 : 329271348;
+    };
+    auto store = [&](int item, int biome) {
+        if (item & 1) L0[item >> 1].top_biome = (uint8_t)biome; else L0[item >> 1].bottom_biome = (uint8_t)biome;
+    };
+    // phase 1: the warped height of every item (3 simplex3, the same work in every lane); far above the depth bands the biome is NONE
+    // (inside the pruning domain).  The others are compacted again with their height ...
+    for (int k = t; k < count; k += CB_THREADS) {
+        const int item = s_items[k];
+        int wx, wy, wz, seed; float maxHeight, py;
+        item_of(item, wx, wy, wz, maxHeight, seed);
+        const bool none = near ? cave_biome_py<true>(wx, wy, wz, maxHeight, true, py) : cave_biome_py<false>(wx, wy, wz, maxHeight, true, py);
+        if (none) { store(item, MMCB_NONE); continue; }
+        const int at = atomicAdd(&s_count[1], 1);
+        if (at < CB_SURV_CAP) { s_surv[at] = (unsigned short)item; s_py[at] = py; }
+        else store(item, near ? cave_biome_rest<true>(wx, wy, wz, maxHeight, seed, true, false, py) : cave_biome_rest<false>(wx, wy, wz, maxHeight, seed, true, false, py));
+    }
+    __syncthreads();
+    // ... phase 2: the rest of the evaluation, densely over the survivors
+    const int nSurv = imin(s_count[1], CB_SURV_CAP);
+    for (int k = t; k < nSurv; k += CB_THREADS) {
+        const int item = s_surv[k];
+        int wx, wy, wz, seed; float maxHeight;
+        item_of(item, wx, wy, wz, maxHeight, seed);
+        store(item, near ? cave_biome_rest<true>(wx, wy, wz, maxHeight, seed, true, false, s_py[k]) : cave_biome_rest<false>(wx, wy, wz, maxHeight, seed, true, false, s_py[k]));
     }
 }
 

@@ -430,21 +430,10 @@ int mmgen_region_begin(mmgen_region* r, int cx0, int cz0, int nx, int nz, unsign
     }
     auto caves = [&]() -> int {
         mmk::StageRange sr("mmgen:caves");
-        // MMGEN_REGION_CAVE_SLICES = n > 1 (experiment): the cave work as n launches alternating between the caller's stream and
-        // the fill stream (free at this point), so that no single launch keeps the dispatcher for the whole 15 ms and the erosion branch's
-        // short launches get their turn between them, while each slice's tail runs under the next slice's head
-        const char* cs = getenv("MMGEN_REGION_CAVE_SLICES");
-        const int n = (par && cs) ? atoi(cs) : 1;
-        if (n <= 1) return mmk::launch_caves(hfP, bwP, posP, r->nCompute, r->caveP.as<mmgen_cave_layer>(), r->colInfo.as<float>(), list, colNeed, s);
-        CK(hipEventRecord(r->evGather, s));                       // (event re-used: the inputs of the caves are ready on the caller's stream)
-        CK(hipStreamWaitEvent(r->sFill, r->evGather, 0));
-        for (int i = 0; i < n; ++i) {
-            const int k0 = (int)((long long)r->nCompute * i / n), k1 = (int)((long long)r->nCompute * (i + 1) / n);
-            CK(mmk::launch_caves(hfP, bwP, posP, k1 - k0, r->caveP.as<mmgen_cave_layer>(), r->colInfo.as<float>(), list + k0, colNeed, (i & 1) ? r->sFill : s));
-        }
-        CK(hipEventRecord(r->evTail, r->sFill));
-        CK(hipStreamWaitEvent(s, r->evTail, 0));
-        return 0;
+        // (the cave work as 8 - 64 launches alternating between two streams, so that the erosion branch's short launches get their turn
+        // between them: measured, profiles/README.md r03 - an erosion launch still only completes when the cave launches in flight beside it
+        // do; no gain at 8 - 32 slices, -4 % at 64)
+        return mmk::launch_caves(hfP, bwP, posP, r->nCompute, r->caveP.as<mmgen_cave_layer>(), r->colInfo.as<float>(), list, colNeed, s);
     };
     if (par) CK(caves());
 
