@@ -98,13 +98,17 @@ MM_DEV double exp_(double x)
     return __longlong_as_double((long long)bits);
 }
 
+// one shared body per translation unit: inlined at every call site its two dozen fp64 constants are hoisted to the top of the kernel,
+// where they are the registers the rasterisers run out of
+static __device__ __attribute__((noinline)) float powf_general(float x, float y) { return (float)exp_((double)y * log_((double)x)); }
+
 MM_DEV float powf_(float x, float y)
 {
     if (y == 2.f) return x * x;
     if (x == 0.f) return (y > 0.f) ? 0.f : 1.f;
     if (x == 1.f || y == 0.f) return 1.f;
     if (x < 0.f) return __builtin_nanf("");
-    return (float)exp_((double)y * log_((double)x));
+    return powf_general(x, y);
 }
 
 MM_DEV double atan_(double x)

@@ -208,7 +208,7 @@ int mmgen_fill(const float* d_hf, const float* d_bw, const float* d_layers, cons
     if (e) return e;
     e = mmk::launch_fill(d_hf, d_bw, d_layers, d_cl, d_pos, n, d_blocks, nullptr, sc->fillQueue, mmk::fill_queue_bytes(n), false /* positions live on the device */, (hipStream_t)stream);
     if (e || !(d_fp || d_cfp)) return e;
-    return mmk::launch_apply_features(d_blocks, d_pos, n, d_fp, d_cfp, d_bounds, nullptr, (hipStream_t)stream);
+    return mmk::launch_apply_features(d_blocks, d_pos, n, d_fp, d_cfp, d_bounds, nullptr, sc->fillQueue /* k_fill_lush is done with it */, (hipStream_t)stream);
 }
 
 int mmgen_generate_feature_placements(const float* d_hf, const float* d_bw, const float* d_layers, const mmgen_cave_layer* d_cl, const int32_t* d_pos,

@@ -427,10 +427,17 @@ k_gather_placements(const mmgen_feature_placement* __restrict__ fp, const mmgen_
 // scan a handful of candidates instead of hundreds of entries.  Entries skipped by the filter would have returned false.
 // ---------------------------------------------------------------------------------------------------------
 #ifndef CAND_CAP
-#define CAND_CAP 256
+#define CAND_CAP 256                      // (placement, column) candidates of one column, surface + cave
 #endif
-#define APPLY_COLS 4                      // columns per workgroup: one wave each
+#define APPLY_COLS 4                      // waves per workgroup
 #define APPLY_THREADS (64 * APPLY_COLS)
+#ifndef APPLY_UNIT_W
+#define APPLY_UNIT_W 16                   // one wave = one UNIT at a time: W x H columns of a chunk
+#define APPLY_UNIT_H 1
+#endif
+#define APPLY_UNITS_PER_CHUNK ((16 / APPLY_UNIT_W) * (16 / APPLY_UNIT_H))
+#define APPLY_COUNTERS 8                  // work counters per launch, 64 B apart
+#define APPLY_UNIT_CAP 256                // placements that can reach one unit, surface + cave
 
 // LDS hand-off inside one wave: its LDS operations execute in issue order, only the compiler must not reorder across the hand-off
 MM_DEV void wave_lds_sync()
@@ -669,61 +676,52 @@ MM_DEV bool cave_extent(int feat, int lh, int dx, int dz, uint32_t fstate, bool 
     return true;
 }
 
-// Stable WAVE-wide compaction of the list entries that can reach column (wx, wz), as packed copies
-//   .x = (fx - wx + 128) | (fz - wz + 128) << 8 | fy << 16 | feature << 25 | canReplace << 30,
-//   .y = the vertical extent this placement can claim in this column, relative to fy: (dlo + 128) | dhi << 8 (surface entries),
-//        layerHeight | (dlo + 128) << 9 | dhi << 17 (cave entries)
-// so that the voxel loop never goes back to global memory: 64 entries per round, ballot + popcount prefix, no workgroup barrier.
-// Returns the number of candidates, or -1 when they do not fit CAND_CAP (caller falls back to the full scan).
-template <class Entry, int LIST_CAP, bool CAVE>
-MM_DEV int filter_column(const Entry* __restrict__ list, int wx, int wz, int2* s_cand, uint32_t* s_seed, unsigned& featureMask)
+// Stable WAVE-wide compaction of the list entries that can reach ANY column of the unit (wx0 .. wx0 + APPLY_UNIT_W - 1, wz0 .. wz0 + APPLY_UNIT_H - 1)
+// into records
+//   .x = fx, .y = fz, .z = fy | feature << 9 | canReplace << 14 | layerHeight << 15 | reach << 24, .w = the placement's stream right after seeding
+// appended at s_unit[base ..], list order kept: 64 entries per round, ballot + popcount prefix, no workgroup barrier.  The chunk's list is
+// read from global memory ONCE per unit (round 2 read it once per column: eight dependent memory round trips per column at 3 waves
+// per SIMD were a quarter of the kernel), the placements are seeded once per unit.  Returns base + the number of records (the caller
+// compares it with APPLY_UNIT_CAP).
+// kFeatureReach / kCaveFeatureReach as immediates (8 bits per feature): a table lookup indexed per lane is one more dependent memory
+// round trip in a chain that is nothing but round trips
+template <bool CAVE>
+MM_DEV int reach_of(int feat)
 {
+    constexpr int N = CAVE ? MMGEN_NUM_CAVE_FEATURES : MMGEN_NUM_FEATURES;
+    static_assert(N <= 32, "four 64-bit words");
+    unsigned long long w[4] = {0ull, 0ull, 0ull, 0ull};
+#pragma unroll
+    for (int f = 0; f < N; ++f) w[f >> 3] |= (unsigned long long)(CAVE ? kCaveFeatureReach[f] : kFeatureReach[f]) << (8 * (f & 7));
+    const unsigned long long v = feat < 16 ? (feat < 8 ? w[0] : w[1]) : (feat < 24 ? w[2] : w[3]);
+    return (int)((v >> (8 * (feat & 7))) & 255ull);
+}
+
+template <class Entry, int LIST_CAP, bool CAVE>
+MM_DEV int filter_unit(const Entry* __restrict__ list, int wx0, int wz0, int4* s_unit, int base)
+{
+    static_assert(LIST_CAP % 64 == 0, "whole rounds");
     const int lane = threadIdx.x & 63;
-    const bool noiseBounds = prune_domain(wx, wz);                  // the two extents that use a simplex bound (coral ellipsoids, glowstone)
-    int base = 0;
-    for (int r0 = 0; r0 < LIST_CAP; r0 += 64) {
-        const int i = r0 + lane;
-        // the whole entry in one round trip (this kernel runs at 3 waves per SIMD: every dependent global load is ~1 us nobody hides)
-        int feat = 0, fx = 0, fz = 0, fyRaw = 0, lhRaw = 0, canReplace = 0;
-        if (i < LIST_CAP) {
-            const Entry en = list[i];
-            feat = en.feature; fx = en.pos[0]; fyRaw = en.pos[1]; fz = en.pos[2]; canReplace = en.can_replace_blocks != 0;
-            if constexpr (CAVE) lhRaw = en.layer_height;
-        }
-        const unsigned long long noneMask = __ballot(feat == 0);
+    for (int r0 = 0;;) {
+        const Entry en = list[r0 + lane];
+        const int feat = en.feature, fx = en.pos[0], fy = en.pos[1], fz = en.pos[2], canReplace = en.can_replace_blocks != 0;
+        int lh = 0;
+        if constexpr (CAVE) lh = en.layer_height;
+        const unsigned long long noneMask = __ballot(feat == 0);                // the lists end at the first NONE
         const int firstNone = noneMask ? (int)__builtin_ctzll(noneMask) : 64;
-        const int reach = CAVE ? kCaveFeatureReach[feat] : kFeatureReach[feat];
-        bool cand = lane < firstNone && iabs(wx - fx) <= reach && iabs(wz - fz) <= reach;
-        int fy = 0, lh = 0;
-        uint32_t fstate = 0u;
-        if (cand) {
-            fy = fyRaw;
-            // the placement's own random stream, seeded once per (column, candidate) instead of once per voxel
-            fstate = CAVE ? cave_feature_stream(fx, fy, fz) : surface_feature_stream(fx, fy, fz);
-            int dlo, dhi;
-            if constexpr (CAVE) {
-                const int layerHeight = lhRaw;
-                cand = cave_extent(feat, layerHeight, wx - fx, wz - fz, fstate, noiseBounds, dlo, dhi);
-                lh = layerHeight | ((dlo + 128) << 9) | (dhi << 17);
-            } else {
-                cand = surface_extent(feat, fy, wx - fx, wz - fz, fstate, noiseBounds, dlo, dhi);
-                lh = (dlo + 128) | (dhi << 8);
-            }
-        }
+        const int reach = reach_of<CAVE>(feat);
+        const bool cand = lane < firstNone && wx0 - fx <= reach && fx - (wx0 + APPLY_UNIT_W - 1) <= reach && wz0 - fz <= reach && fz - (wz0 + APPLY_UNIT_H - 1) <= reach;
         const unsigned long long cm = __ballot(cand);
         if (cand) {
-            featureMask |= 1u << feat;
-            const int w = (fx - wx + 128) | ((fz - wz + 128) << 8) | ((fy & 511) << 16) | (feat << 25) | (canReplace << 30);
             const int slot = base + __popcll(cm & ((1ull << lane) - 1ull));
-            if (slot < CAND_CAP) {
-                s_cand[slot] = make_int2(w, lh);
-                s_seed[slot] = fstate;
-            }
+            if (slot < APPLY_UNIT_CAP) s_unit[slot] = make_int4(fx, fz, (fy & 511) | (feat << 9) | (canReplace << 14) | (lh << 15) | (reach << 24),
+                                                                (int)(CAVE ? cave_feature_stream(fx, fy, fz) : surface_feature_stream(fx, fy, fz)));
         }
         base += __popcll(cm);
-        if (firstNone < 64) break;
+        r0 += 64;
+        if (firstNone < 64 || r0 >= LIST_CAP) break;
     }
-    return base > CAND_CAP ? -1 : base;
+    return base;
 }
 
 #ifndef MM_APPLY_EXP
@@ -732,52 +730,113 @@ MM_DEV int filter_column(const Entry* __restrict__ list, int wx, int wz, int2* s
 #ifndef MM_APPLY_WAVES
 #define MM_APPLY_WAVES 3        // 168 VGPRs: the union of the 31 rasterisers
 #endif
-// One workgroup = 4 neighbouring columns of a chunk, one WAVE per column, no workgroup barrier after the noise tables are in LDS (a
-// column with nothing to rasterise retires at once).  The wave
-//   1. filters the chunk's (already chunk-prefiltered) lists for its column with ballots (filter_column), list order kept;
-//   2. turns the candidates into ITEMS: candidate k owns the voxels of its own vertical extent, an exclusive scan over the extents
-//      gives every (candidate, y) pair an item number;
-//   3. walks the items 64 at a time: every lane evaluates ONE (voxel, candidate) pair, whatever the extents look like - a lane-per-y
+// Persistent workgroups of four independent WAVES; a wave takes one UNIT (APPLY_UNIT_W x APPLY_UNIT_H columns of a chunk) at a time:
+//   0. filter_unit: the chunk's (already chunk-prefiltered) lists -> the placements that can reach the unit, in LDS, list order kept;
+//   then per column
+//   1. the unit's placements that reach the column get the vertical extent they can claim in it (surface_extent / cave_extent, clipped
+//      to the chunk's bounds); the non-empty ones are the column's candidates, compacted with ballots in list order;
+//   2. candidate k owns the voxels of its own vertical extent: an exclusive scan over the extents gives every (candidate, y) pair an
+//      item number;
+//   3. the items are walked 64 at a time: every lane evaluates ONE (voxel, candidate) pair, whatever the extents look like - a lane-per-y
 //      walk over the union of the extents leaves 2/3 of the lanes without work (measured: 18.8 of 64 lanes active).  "First match in
 //      list order wins" (chunk.cu:1438-1509) becomes an LDS atomicMin of (candidate index << 8 | block) per voxel;
-//   4. writes the claimed voxels.
+//   4. the claimed voxels are written back.
+// No workgroup barrier after the noise tables are in LDS.
 __attribute__((amdgpu_waves_per_eu(MM_APPLY_WAVES, MM_APPLY_WAVES)))
 __global__ void __launch_bounds__(APPLY_THREADS)
 k_apply_features(uint8_t* __restrict__ blocks, const int2* __restrict__ chunkPos, const mmgen_feature_placement* __restrict__ gfp,
-                 const mmgen_cave_feature_placement* __restrict__ gcfp, const int* __restrict__ bounds, const int* __restrict__ srcIdx, int nGroups)
+                 const mmgen_cave_feature_placement* __restrict__ gcfp, const int* __restrict__ bounds, const int* __restrict__ srcIdx, int nUnits,
+                 unsigned* __restrict__ nextUnit)
 {
-    __shared__ int2 s_cand[APPLY_COLS][2 * CAND_CAP];      // per wave: surface candidates, then cave candidates
-    __shared__ int s_pref[APPLY_COLS][2 * CAND_CAP + 1];   // exclusive prefix of the candidates' voxel counts
-    __shared__ uint32_t s_seed[APPLY_COLS][2 * CAND_CAP];  // the candidates' random streams right after seeding
+    __shared__ int4 s_unit[APPLY_COLS][APPLY_UNIT_CAP];    // per wave: the unit's placements, surface then cave
+    __shared__ unsigned s_cand[APPLY_COLS][CAND_CAP];      // per wave: the column's candidates: unit index | lowest y << 8 | (voxels - 1) << 17
+    __shared__ int s_pref[APPLY_COLS][CAND_CAP + 1];       // exclusive prefix of the candidates' voxel counts
     __shared__ unsigned s_claim[APPLY_COLS][384];          // per voxel: smallest (candidate << 8 | block) that claimed it
-    __shared__ uint8_t s_blk[APPLY_COLS][384];             // the column's base blocks
+    __shared__ __attribute__((aligned(16))) uint8_t s_blk[APPLY_COLS][384];      // the column's base blocks
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;      // wave index in an SGPR: so are chunk and column
-    // Persistent workgroups: the simplex tables (12 KB) are staged ONCE per workgroup, not once per four columns (most four-column groups
-    // of a generated world have a coral, a fungus or a redwood in reach: 6 GB of L2 -> LDS copies per launch).  After that barrier every
-    // wave walks its own columns (group g -> column 4 g + wave, groups strided over the grid); no workgroup barrier inside the loop.
+    // the simplex tables (12 KB) are staged ONCE per workgroup (most units of a generated world have a coral, a fungus or a redwood in reach)
     noise_tables_init();
-  for (int group = blockIdx.x; group < nGroups; group += gridDim.x) {
-    const int col = APPLY_COLS * group + wave;
-    const int chunk = col >> 8, idx2d = col & 255;      // dense output / list index; positions are read at srcIdx[chunk]; 256 % APPLY_COLS == 0
+    int4* unit = s_unit[wave];
+    unsigned* cand = s_cand[wave];
+    int* pref = s_pref[wave];
+    // Units cost anything between nothing (ocean) and ~100 us (jungle) and a wave only gets a few dozen: a fixed assignment leaves most
+    // waves idle while the unluckiest finishes (measured: 5.2 ms instead of 3.0).  The waves draw their units from counters instead;
+    // the next draw is in flight while the current unit is worked on.  ONE counter serialises at ~11 ns per draw in L2 (measured: 1.5 ms
+    // for the 131 072 units of the bench tile, whatever else the kernel did): APPLY_COUNTERS of them, a cache line apart, counter p
+    // hands out the units u = p (mod APPLY_COUNTERS); a wave moves on to the next counter when its own has run dry.
+    int part = (APPLY_COLS * blockIdx.x + wave) % APPLY_COUNTERS, dry = 0;
+    unsigned drawn = 0u;
+    if (lane == 0) drawn = atomicAdd(&nextUnit[16 * part], 1u);
+  for (;;) {
+    const int u = __builtin_amdgcn_readfirstlane((int)drawn) * APPLY_COUNTERS + part;
+    if (u >= nUnits) {
+        if (++dry == APPLY_COUNTERS) break;
+        part = (part + 1) % APPLY_COUNTERS;
+    }
+    if (lane == 0) drawn = atomicAdd(&nextUnit[16 * part], 1u);
+    if (u >= nUnits) continue;
+    const int chunk = u / APPLY_UNITS_PER_CHUNK, uu = u % APPLY_UNITS_PER_CHUNK;      // dense output / list index; positions are read at srcIdx[chunk]
+    const int x0 = APPLY_UNIT_W * (uu % (16 / APPLY_UNIT_W)), z0 = APPLY_UNIT_H * (uu / (16 / APPLY_UNIT_W));
+    const mmgen_feature_placement* listS = gfp + (size_t)MMGEN_MAX_GATHERED_FEATURES_PER_CHUNK * chunk;
+    const mmgen_cave_feature_placement* listC = gcfp + (size_t)MMGEN_MAX_GATHERED_CAVE_FEATURES_PER_CHUNK * chunk;
+    const int2 cp = chunkPos[srcIdx ? srcIdx[chunk] : chunk];
     const int b0 = bounds[4 * chunk], b1 = bounds[4 * chunk + 1], b2 = bounds[4 * chunk + 2], b3 = bounds[4 * chunk + 3];
     const bool doS = gfp && b0 <= b1, doC = gcfp && b2 <= b3;
     if (!doS && !doC) continue;
-
-    const int2 cp = chunkPos[srcIdx ? srcIdx[chunk] : chunk];
-    const int wx = cp.x + (idx2d & 15), wz = cp.y + (idx2d >> 4);
-    const mmgen_feature_placement* listS = gfp + (size_t)MMGEN_MAX_GATHERED_FEATURES_PER_CHUNK * chunk;
-    const mmgen_cave_feature_placement* listC = gcfp + (size_t)MMGEN_MAX_GATHERED_CAVE_FEATURES_PER_CHUNK * chunk;
-    int2* cand = s_cand[wave];
-    int nS = 0, nC = 0;
-    unsigned maskS = 0u, maskC = 0u;
-    if (doS) nS = filter_column<mmgen_feature_placement, MMGEN_MAX_GATHERED_FEATURES_PER_CHUNK, false>(listS, wx, wz, cand, s_seed[wave], maskS);
-    if (doC) nC = filter_column<mmgen_cave_feature_placement, MMGEN_MAX_GATHERED_CAVE_FEATURES_PER_CHUNK, true>(listC, wx, wz, cand + imax(nS, 0), s_seed[wave] + imax(nS, 0), maskC);
-    if (nS == 0 && nC == 0) continue;
-    uint8_t* colBlocks = blocks + (size_t)MMGEN_BLOCKS_PER_CHUNK * chunk + 384 * idx2d;
+    const int wx0 = cp.x + x0, wz0 = cp.y + z0;
     const int sLo = imax(b0, 0), sHi = imin(b1, 383), cLo = imax(b2, 0), cHi = imin(b3, 383);   // the chunk's height bounds (chunk.cu:1555-1570)
+    int nUS = 0, nU = 0;
+    if (doS) nUS = nU = filter_unit<mmgen_feature_placement, MMGEN_MAX_GATHERED_FEATURES_PER_CHUNK, false>(listS, wx0, wz0, unit, 0);
+    if (doC) nU = filter_unit<mmgen_cave_feature_placement, MMGEN_MAX_GATHERED_CAVE_FEATURES_PER_CHUNK, true>(listC, wx0, wz0, unit, nUS);
+    if (nU == 0) continue;
+    wave_lds_sync();
+    const bool unitFits = nU <= APPLY_UNIT_CAP;
+#if MM_APPLY_EXP == 6
+    if (nU != 0x7fffffff) continue;                                     // timing experiment: the per-unit work only
+#endif
 
-    if (nS < 0 || nC < 0) {
-        // more reachable entries than CAND_CAP (never seen on generated terrain): lane = y, scan the gathered lists themselves
+   for (int c = 0; c < APPLY_UNIT_W * APPLY_UNIT_H; ++c) {
+    const int cx = c % APPLY_UNIT_W, cz = c / APPLY_UNIT_W, idx2d = 16 * (z0 + cz) + x0 + cx, wx = wx0 + cx, wz = wz0 + cz;
+    uint8_t* colBlocks = blocks + (size_t)MMGEN_BLOCKS_PER_CHUNK * chunk + 384 * idx2d;
+
+    // candidates + items: exclusive scan of the candidates' vertical extents (clipped to the column and to the chunk's bounds)
+    int nCand = 0, total = 0;
+    if (unitFits) {
+        const bool noiseBounds = prune_domain(wx, wz);              // the two extents that use a simplex bound (coral ellipsoids, glowstone)
+        for (int k0 = 0; k0 < nU; k0 += 64) {
+            const int k = k0 + lane;
+            int n = 0, lo = 0;
+            if (k < nU) {
+                const int4 rc = unit[k];
+                const int fx = rc.x, fz = rc.y, fy = rc.z & 511, feat = (rc.z >> 9) & 31, reach = rc.z >> 24;
+                if (iabs(wx - fx) <= reach && iabs(wz - fz) <= reach) {
+                    const bool cave = k >= nUS;
+                    int dlo, dhi;
+                    const bool any = cave ? cave_extent(feat, (rc.z >> 15) & 511, wx - fx, wz - fz, (uint32_t)rc.w, noiseBounds, dlo, dhi)
+                                          : surface_extent(feat, fy, wx - fx, wz - fz, (uint32_t)rc.w, noiseBounds, dlo, dhi);
+                    if (any) {
+                        lo = imax(fy + dlo, cave ? cLo : sLo);
+                        n = imax(imin(fy + dhi, cave ? cHi : sHi) - lo + 1, 0);
+                    }
+                }
+            }
+            const unsigned long long vm = __ballot(n > 0);
+            if (vm == 0ull) continue;
+            int incl = n;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o); if (lane >= o) incl += v; }
+            if (n > 0) {
+                const int slot = nCand + __popcll(vm & ((1ull << lane) - 1ull));
+                if (slot < CAND_CAP) { cand[slot] = (unsigned)k | (lo << 8) | ((n - 1) << 17); pref[slot] = total + incl - n; }
+            }
+            nCand += __popcll(vm);
+            total += __builtin_amdgcn_readfirstlane(__shfl(incl, 63));
+        }
+        if (total == 0) continue;
+    }
+
+    if (!unitFits || nCand > CAND_CAP) {
+        // more reachable entries than the LDS lists hold (never seen on generated terrain): lane = y, scan the gathered lists themselves
         for (int y = lane; y < 384; y += 64) {
             const uint8_t block = colBlocks[y];
             uint8_t fb = 0;
@@ -807,33 +866,12 @@ k_apply_features(uint8_t* __restrict__ blocks, const int2* __restrict__ chunkPos
         continue;
     }
 
-    // items: exclusive scan of the candidates' vertical extents (clipped to the column and to the chunk's bounds)
-    const int nTot = nS + nC;
-    int* pref = s_pref[wave];
-    int total = 0;
-    int yLo = 384, yHi = -1;                               // union of the candidates' extents: the only voxels staged and written back
-    for (int k0 = 0; k0 < nTot; k0 += 64) {
-        const int k = k0 + lane;
-        int n = 0;
-        if (k < nTot) {
-            const int2 e = cand[k];
-            const int fy = (e.x >> 16) & 511;
-            int lo, hi;
-            if (k < nS) { lo = imax(fy + (e.y & 255) - 128, sLo); hi = imin(fy + (e.y >> 8), sHi); }
-            else { lo = imax(fy + ((e.y >> 9) & 255) - 128, cLo); hi = imin(fy + (e.y >> 17), cHi); }
-            n = imax(hi - lo + 1, 0);
-            if (n > 0) { yLo = imin(yLo, lo); yHi = imax(yHi, hi); }
-        }
-        int incl = n;
+    // stage the column, clear the claims
+    if (lane == 0) pref[nCand] = total;
+    ((uint32_t*)s_blk[wave])[lane] = ((const uint32_t*)colBlocks)[lane];
+    if (lane < 32) ((uint32_t*)s_blk[wave])[64 + lane] = ((const uint32_t*)colBlocks)[64 + lane];
 #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o); if (lane >= o) incl += v; }
-        if (k < nTot) pref[k] = total + incl - n;
-        total += __shfl(incl, 63);
-    }
-    if (lane == 0) pref[nTot] = total;
-    if (total == 0) continue;
-    yLo = wave_min(yLo); yHi = wave_max(yHi);
-    for (int y = yLo + lane; y <= yHi; y += 64) { s_blk[wave][y] = colBlocks[y]; s_claim[wave][y] = 0xffffffffu; }
+    for (int i = 0; i < 6; ++i) s_claim[wave][64 * i + lane] = 0xffffffffu;
     wave_lds_sync();
 
 #if MM_APPLY_EXP == 1
@@ -842,29 +880,30 @@ k_apply_features(uint8_t* __restrict__ blocks, const int2* __restrict__ chunkPos
     for (int j0 = 0; j0 < total; j0 += 64) {
         const int j = j0 + lane;
         if (j >= total) break;
-        int k = 0, kh = nTot;                               // pref[k] <= j < pref[kh]
+        int k = 0, kh = nCand;                              // pref[k] <= j < pref[kh]
         while (kh - k > 1) { const int mid = (k + kh) >> 1; if (pref[mid] <= j) k = mid; else kh = mid; }
-        const int2 e = cand[k];
-        const int fx = wx + (e.x & 255) - 128, fz = wz + ((e.x >> 8) & 255) - 128, fy = (e.x >> 16) & 511, feature = (e.x >> 25) & 31;
-        const bool cave = k >= nS;
-        const int lo = cave ? imax(fy + ((e.y >> 9) & 255) - 128, cLo) : imax(fy + (e.y & 255) - 128, sLo);
-        const int y = lo + (j - pref[k]);
-        if (s_blk[wave][y] != MMB_AIR && !((e.x >> 30) & 1)) continue;
+        const unsigned e = cand[k];
+        const int ku = e & 255, y = (int)((e >> 8) & 511) + (j - pref[k]);
+        const int4 rc = unit[ku];
+        if (s_blk[wave][y] != MMB_AIR && !((rc.z >> 14) & 1)) continue;
+        const int fy = rc.z & 511, feature = (rc.z >> 9) & 31;
         uint8_t fb = 0;
 #if MM_APPLY_EXP == 2
-        const bool placed = (fx + fy + fz + y) == 0x7fffffff;          // timing experiment: no rasteriser
+        const bool placed = (rc.x + fy + rc.y + y) == 0x7fffffff;      // timing experiment: no rasteriser
 #else
-        const uint32_t fstate = s_seed[wave][k];
-        const bool placed = cave ? place_cave_feature(feature, fx, fy, fz, e.y & 511, wx, y, wz, fstate, fb) : place_feature(feature, fx, fy, fz, wx, y, wz, fstate, fb);
+        const bool placed = ku >= nUS ? place_cave_feature(feature, rc.x, fy, rc.y, (rc.z >> 15) & 511, wx, y, wz, (uint32_t)rc.w, fb)
+                                      : place_feature(feature, rc.x, fy, rc.y, wx, y, wz, (uint32_t)rc.w, fb);
 #endif
         if (placed) atomicMin(&s_claim[wave][y], ((unsigned)k << 8) | fb);
     }
     wave_lds_sync();
-    for (int y = yLo + lane; y <= yHi; y += 64) {
-        const unsigned c = s_claim[wave][y];
-        if (c != 0xffffffffu) colBlocks[y] = (uint8_t)(c & 255u);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const unsigned cl = s_claim[wave][64 * i + lane];
+        if (cl != 0xffffffffu) colBlocks[64 * i + lane] = (uint8_t)(cl & 255u);
     }
     wave_lds_sync();                                       // the wave's LDS rows are re-used by its next column
+   }
   }
 }
 
@@ -1060,10 +1099,13 @@ int launch_gather_placements(const mmgen_feature_placement* fp, const mmgen_cave
     return 0;
 }
 
+size_t apply_work_bytes() { return 64 * APPLY_COUNTERS; }
+
 int launch_apply_features(uint8_t* blocks, const int32_t* pos, int n, const mmgen_feature_placement* gfp, const mmgen_cave_feature_placement* gcfp,
-                          const int* bounds, const int* srcIdx, hipStream_t s)
+                          const int* bounds, const int* srcIdx, unsigned* workCounter, hipStream_t s)
 {
     if (n <= 0) return 0;
+    if (!workCounter) return (int)hipErrorInvalidValue;
     static int cus = 0;
     if (!cus) {
         int dev = 0;
@@ -1071,11 +1113,13 @@ int launch_apply_features(uint8_t* blocks, const int32_t* pos, int n, const mmge
         if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return (int)hipErrorInvalidDevice;
         cus = prop.multiProcessorCount;
     }
-    // persistent: MM_APPLY_WAVES waves per SIMD = that many 4-wave workgroups per CU
-    const long long groups = (long long)n * (256 / APPLY_COLS), fit = (long long)cus * MM_APPLY_WAVES;
-    if (groups > 0x7fffffffLL) return (int)hipErrorInvalidValue;
+    // persistent: MM_APPLY_WAVES waves per SIMD = that many 4-wave workgroups per CU; every wave walks its own units
+    const long long units = (long long)n * APPLY_UNITS_PER_CHUNK, groups = (units + APPLY_COLS - 1) / APPLY_COLS, fit = (long long)cus * MM_APPLY_WAVES;
+    if (units > 0x7fffffffLL) return (int)hipErrorInvalidValue;
+    const hipError_t e = hipMemsetAsync(workCounter, 0, apply_work_bytes(), s);
+    if (e != hipSuccess) return (int)e;
     LAUNCH(KID_APPLY_FEATURES, mm::k_apply_features, dim3((unsigned)(groups < fit ? groups : fit)), dim3(APPLY_THREADS), s, blocks, (const int2*)pos, gfp, gcfp,
-           bounds, srcIdx, (int)groups);
+           bounds, srcIdx, (int)units, workCounter);
     return 0;
 }
 

@@ -158,7 +158,7 @@ struct mmgen_region {
     bool began = false;
     DevBuf posA, hfA, bwA, gathA, layersA;
     DevBuf posP, hfP, bwP, layersP, caveP, colInfo, fp, cfp, counts;
-    DevBuf selAP, zoneIdx, zoneIdxOut, gathered, erodeWork, erodeState, computeList, targets, gfp, gcfp, bounds, fillQueue, cellLazy, colNeed;
+    DevBuf selAP, zoneIdx, zoneIdxOut, gathered, erodeWork, erodeState, computeList, targets, gfp, gcfp, bounds, fillQueue, cellLazy, colNeed, applyWork;
     int lastMaxPasses = 0;
     // layout cache: the host-built index tables (positions, A->P selection, compute list, zone gather / scatter lists, fill targets)
     // depend only on (rectangle, flags, mask); a caller that regenerates the same layout (bench loop, fixed tiles) re-uses the
@@ -216,7 +216,7 @@ struct mmgen_region {
             for (int i = 0; i < kMaxSlices; ++i) if (evFill[i]) (void)hipEventDestroy(evFill[i]);
         }
         DevBuf* all[] = {&posA, &hfA, &bwA, &gathA, &layersA, &posP, &hfP, &bwP, &layersP, &caveP, &colInfo, &fp, &cfp, &counts, &selAP, &zoneIdx,
-                         &zoneIdxOut, &gathered, &erodeWork, &erodeState, &computeList, &targets, &gfp, &gcfp, &bounds, &fillQueue, &cellLazy, &colNeed};
+                         &zoneIdxOut, &gathered, &erodeWork, &erodeState, &computeList, &targets, &gfp, &gcfp, &bounds, &fillQueue, &cellLazy, &colNeed, &applyWork};
         for (DevBuf* b : all) b->release();
     }
 };
@@ -559,6 +559,7 @@ int mmgen_region_finish(mmgen_region* r, uint8_t* d_blocks, float* d_heightfield
         CK(r->gfp.ensure(sizeof(mmgen_feature_placement) * MMGEN_MAX_GATHERED_FEATURES_PER_CHUNK * (size_t)nr));
         CK(r->gcfp.ensure(sizeof(mmgen_cave_feature_placement) * MMGEN_MAX_GATHERED_CAVE_FEATURES_PER_CHUNK * (size_t)nr));
         CK(r->bounds.ensure(sizeof(int) * 4 * nr));
+        CK(r->applyWork.ensure(mmk::apply_work_bytes() * r->kMaxSlices));      // k_apply_features' work counters, one set per slice
         CK(mmk::launch_gather_placements(r->fp.as<mmgen_feature_placement>(), r->cfp.as<mmgen_cave_feature_placement>(), r->counts.as<int>(), tgt, nr,
                                          r->pnx, r->pnz, r->gfp.as<mmgen_feature_placement>(), r->gcfp.as<mmgen_cave_feature_placement>(),
                                          r->bounds.as<int>(), posP, s));
@@ -573,7 +574,7 @@ int mmgen_region_finish(mmgen_region* r, uint8_t* d_blocks, float* d_heightfield
             mmk::StageRange sr("mmgen:features");
             CK(mmk::launch_apply_features(blk, posP, n, r->gfp.as<mmgen_feature_placement>() + (size_t)MMGEN_MAX_GATHERED_FEATURES_PER_CHUNK * c0,
                                           r->gcfp.as<mmgen_cave_feature_placement>() + (size_t)MMGEN_MAX_GATHERED_CAVE_FEATURES_PER_CHUNK * c0,
-                                          r->bounds.as<int>() + 4 * c0, tgt + c0, sA));
+                                          r->bounds.as<int>() + 4 * c0, tgt + c0, (unsigned*)((char*)r->applyWork.p + mmk::apply_work_bytes() * i), sA));
         }
         if (decor) {
             mmk::StageRange sr("mmgen:decorators");
