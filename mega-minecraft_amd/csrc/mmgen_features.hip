@@ -426,18 +426,19 @@ k_gather_placements(const mmgen_feature_placement* __restrict__ fp, const mmgen_
 // into LDS in list order (wave ballots + popcount prefix: a stable compaction, first match still wins) and the voxels then
 // scan a handful of candidates instead of hundreds of entries.  Entries skipped by the filter would have returned false.
 // ---------------------------------------------------------------------------------------------------------
-#ifndef CAND_CAP
-#define CAND_CAP 256                      // (placement, column) candidates of one column, surface + cave
-#endif
 #define APPLY_COLS 4                      // waves per workgroup
 #define APPLY_THREADS (64 * APPLY_COLS)
 #ifndef APPLY_UNIT_W
-#define APPLY_UNIT_W 16                   // one wave = one UNIT at a time: W x H columns of a chunk
+#define APPLY_UNIT_W 8                    // one wave = one UNIT at a time: W x H columns of a chunk
 #define APPLY_UNIT_H 1
 #endif
+#define APPLY_UNIT_NCOL (APPLY_UNIT_W * APPLY_UNIT_H)
 #define APPLY_UNITS_PER_CHUNK ((16 / APPLY_UNIT_W) * (16 / APPLY_UNIT_H))
 #define APPLY_COUNTERS 8                  // work counters per launch, 64 B apart
-#define APPLY_UNIT_CAP 256                // placements that can reach one unit, surface + cave
+#define APPLY_UNIT_CAP 128                // placements that can reach one unit, surface + cave
+#define APPLY_ENT_CAP 256                 // (placement, column) pairs of one unit with a non-empty vertical extent
+#define APPLY_ITEM_CAP 65535              // (placement, voxel) pairs of one unit: item offsets are kept as 16-bit numbers
+static_assert(APPLY_UNIT_NCOL <= 16 && APPLY_UNIT_CAP <= 128, "s_ent packing");
 
 // LDS hand-off inside one wave: its LDS operations execute in issue order, only the compiler must not reorder across the hand-off
 MM_DEV void wave_lds_sync()
@@ -732,16 +733,18 @@ MM_DEV int filter_unit(const Entry* __restrict__ list, int wx0, int wz0, int4* s
 #endif
 // Persistent workgroups of four independent WAVES; a wave takes one UNIT (APPLY_UNIT_W x APPLY_UNIT_H columns of a chunk) at a time:
 //   0. filter_unit: the chunk's (already chunk-prefiltered) lists -> the placements that can reach the unit, in LDS, list order kept;
-//   then per column
-//   1. the unit's placements that reach the column get the vertical extent they can claim in it (surface_extent / cave_extent, clipped
-//      to the chunk's bounds); the non-empty ones are the column's candidates, compacted with ballots in list order;
-//   2. candidate k owns the voxels of its own vertical extent: an exclusive scan over the extents gives every (candidate, y) pair an
-//      item number;
-//   3. the items are walked 64 at a time: every lane evaluates ONE (voxel, candidate) pair, whatever the extents look like - a lane-per-y
-//      walk over the union of the extents leaves 2/3 of the lanes without work (measured: 18.8 of 64 lanes active).  "First match in
-//      list order wins" (chunk.cu:1438-1509) becomes an LDS atomicMin of (candidate index << 8 | block) per voxel;
+//   1. every (placement, column) pair gets the vertical extent the placement can claim in that column (surface_extent / cave_extent,
+//      clipped to the chunk's bounds); the non-empty ones are compacted PLACEMENT-MAJOR with an exclusive scan over their voxel counts,
+//      which gives every (placement, column, y) triple an item number;
+//   2. the items are walked 64 at a time: every lane evaluates ONE (voxel, placement) pair.  Placement-major order over several columns
+//      keeps most of a batch on one placement - one rasteriser, one geometry; per column (round 2, and the first version of this one)
+//      a batch was the ~20 items of one column from three or four different rasterisers, executed one after the other;
+//   3. "first match in list order wins" (chunk.cu:1438-1509): the items ascend in list order, so do the batches; inside a batch the
+//      placements that hit something write their voxels one placement after the other, each only where nothing was written before.
+//      One byte per voxel, no atomics;
 //   4. the claimed voxels are written back.
-// No workgroup barrier after the noise tables are in LDS.
+// No workgroup barrier after the noise tables are in LDS.  Units with more placements / pairs / items than the LDS lists hold (never
+// seen on generated terrain) scan the gathered lists directly.
 __attribute__((amdgpu_waves_per_eu(MM_APPLY_WAVES, MM_APPLY_WAVES)))
 __global__ void __launch_bounds__(APPLY_THREADS)
 k_apply_features(uint8_t* __restrict__ blocks, const int2* __restrict__ chunkPos, const mmgen_feature_placement* __restrict__ gfp,
@@ -749,16 +752,18 @@ k_apply_features(uint8_t* __restrict__ blocks, const int2* __restrict__ chunkPos
                  unsigned* __restrict__ nextUnit)
 {
     __shared__ int4 s_unit[APPLY_COLS][APPLY_UNIT_CAP];    // per wave: the unit's placements, surface then cave
-    __shared__ unsigned s_cand[APPLY_COLS][CAND_CAP];      // per wave: the column's candidates: unit index | lowest y << 8 | (voxels - 1) << 17
-    __shared__ int s_pref[APPLY_COLS][CAND_CAP + 1];       // exclusive prefix of the candidates' voxel counts
-    __shared__ unsigned s_claim[APPLY_COLS][384];          // per voxel: smallest (candidate << 8 | block) that claimed it
-    __shared__ __attribute__((aligned(16))) uint8_t s_blk[APPLY_COLS][384];      // the column's base blocks
+    __shared__ unsigned s_ent[APPLY_COLS][APPLY_ENT_CAP];  // per wave: placement | column << 7 | lowest y << 11 | (voxels - 1) << 20
+    __shared__ unsigned short s_pref[APPLY_COLS][APPLY_ENT_CAP + 2];      // exclusive prefix of the pairs' voxel counts (+ the total)
+    __shared__ __attribute__((aligned(16))) uint8_t s_claim[APPLY_COLS][APPLY_UNIT_NCOL * 384];      // per voxel: the block of the first placement that claimed it, or 255
+    __shared__ __attribute__((aligned(16))) uint8_t s_blk[APPLY_COLS][APPLY_UNIT_NCOL * 384];        // the unit's base blocks
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;      // wave index in an SGPR: so are chunk and column
     // the simplex tables (12 KB) are staged ONCE per workgroup (most units of a generated world have a coral, a fungus or a redwood in reach)
     noise_tables_init();
     int4* unit = s_unit[wave];
-    unsigned* cand = s_cand[wave];
-    int* pref = s_pref[wave];
+    unsigned* ent = s_ent[wave];
+    unsigned short* pref = s_pref[wave];
+    uint8_t* claim = s_claim[wave];
+    uint8_t* blk = s_blk[wave];
     // Units cost anything between nothing (ocean) and ~100 us (jungle) and a wave only gets a few dozen: a fixed assignment leaves most
     // waves idle while the unluckiest finishes (measured: 5.2 ms instead of 3.0).  The waves draw their units from counters instead;
     // the next draw is in flight while the current unit is worked on.  ONE counter serialises at ~11 ns per draw in L2 (measured: 1.5 ms
@@ -790,27 +795,26 @@ k_apply_features(uint8_t* __restrict__ blocks, const int2* __restrict__ chunkPos
     if (doC) nU = filter_unit<mmgen_cave_feature_placement, MMGEN_MAX_GATHERED_CAVE_FEATURES_PER_CHUNK, true>(listC, wx0, wz0, unit, nUS);
     if (nU == 0) continue;
     wave_lds_sync();
-    const bool unitFits = nU <= APPLY_UNIT_CAP;
+    uint8_t* unitBlocks = blocks + (size_t)MMGEN_BLOCKS_PER_CHUNK * chunk + 384 * (16 * z0 + x0);      // row cz of the unit: + 384 * 16 * cz
+    bool fits = nU <= APPLY_UNIT_CAP;
 #if MM_APPLY_EXP == 6
     if (nU != 0x7fffffff) continue;                                     // timing experiment: the per-unit work only
 #endif
 
-   for (int c = 0; c < APPLY_UNIT_W * APPLY_UNIT_H; ++c) {
-    const int cx = c % APPLY_UNIT_W, cz = c / APPLY_UNIT_W, idx2d = 16 * (z0 + cz) + x0 + cx, wx = wx0 + cx, wz = wz0 + cz;
-    uint8_t* colBlocks = blocks + (size_t)MMGEN_BLOCKS_PER_CHUNK * chunk + 384 * idx2d;
-
-    // candidates + items: exclusive scan of the candidates' vertical extents (clipped to the column and to the chunk's bounds)
-    int nCand = 0, total = 0;
-    if (unitFits) {
-        const bool noiseBounds = prune_domain(wx, wz);              // the two extents that use a simplex bound (coral ellipsoids, glowstone)
-        for (int k0 = 0; k0 < nU; k0 += 64) {
-            const int k = k0 + lane;
+    // (placement, column) pairs, placement-major: exclusive scan of their vertical extents (clipped to the column and to the chunk's bounds)
+    int nEnt = 0, total = 0;
+    if (fits) {
+        const int nPairs = nU * APPLY_UNIT_NCOL;
+        for (int p0 = 0; p0 < nPairs; p0 += 64) {
+            const int p = p0 + lane, k = p / APPLY_UNIT_NCOL, c = p % APPLY_UNIT_NCOL;
             int n = 0, lo = 0;
-            if (k < nU) {
+            if (p < nPairs) {
                 const int4 rc = unit[k];
                 const int fx = rc.x, fz = rc.y, fy = rc.z & 511, feat = (rc.z >> 9) & 31, reach = rc.z >> 24;
+                const int wx = wx0 + c % APPLY_UNIT_W, wz = wz0 + c / APPLY_UNIT_W;
                 if (iabs(wx - fx) <= reach && iabs(wz - fz) <= reach) {
                     const bool cave = k >= nUS;
+                    const bool noiseBounds = prune_domain(wx, wz);      // the two extents that use a simplex bound (coral ellipsoids, glowstone)
                     int dlo, dhi;
                     const bool any = cave ? cave_extent(feat, (rc.z >> 15) & 511, wx - fx, wz - fz, (uint32_t)rc.w, noiseBounds, dlo, dhi)
                                           : surface_extent(feat, fy, wx - fx, wz - fz, (uint32_t)rc.w, noiseBounds, dlo, dhi);
@@ -826,84 +830,113 @@ k_apply_features(uint8_t* __restrict__ blocks, const int2* __restrict__ chunkPos
 #pragma unroll
             for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o); if (lane >= o) incl += v; }
             if (n > 0) {
-                const int slot = nCand + __popcll(vm & ((1ull << lane) - 1ull));
-                if (slot < CAND_CAP) { cand[slot] = (unsigned)k | (lo << 8) | ((n - 1) << 17); pref[slot] = total + incl - n; }
+                const int slot = nEnt + __popcll(vm & ((1ull << lane) - 1ull));
+                if (slot < APPLY_ENT_CAP) { ent[slot] = (unsigned)k | (c << 7) | (lo << 11) | ((n - 1) << 20); pref[slot] = (unsigned short)(total + incl - n); }
             }
-            nCand += __popcll(vm);
+            nEnt += __popcll(vm);
             total += __builtin_amdgcn_readfirstlane(__shfl(incl, 63));
+            if (total > APPLY_ITEM_CAP) break;
         }
         if (total == 0) continue;
+        fits = nEnt <= APPLY_ENT_CAP && total <= APPLY_ITEM_CAP;
     }
 
-    if (!unitFits || nCand > CAND_CAP) {
-        // more reachable entries than the LDS lists hold (never seen on generated terrain): lane = y, scan the gathered lists themselves
-        for (int y = lane; y < 384; y += 64) {
-            const uint8_t block = colBlocks[y];
-            uint8_t fb = 0;
-            bool placed = false;
-            if (doS && y >= sLo && y <= sHi) {
-                for (int i = 0; i < MMGEN_MAX_GATHERED_FEATURES_PER_CHUNK; ++i) {
-                    const int feature = listS[i].feature;
-                    if (feature == MMF_NONE) break;
-                    if (block != MMB_AIR && !listS[i].can_replace_blocks) continue;
-                    const int fy = listS[i].pos[1];
-                    if (y < fy + kFeatureBounds[feature][0] || y > fy + kFeatureBounds[feature][1]) continue;
-                    if (place_feature(feature, listS[i].pos[0], fy, listS[i].pos[2], wx, y, wz, surface_feature_stream(listS[i].pos[0], fy, listS[i].pos[2]), fb)) { placed = true; break; }
+    if (!fits) {
+        // lane = y, column by column, scan the gathered lists themselves
+        for (int c = 0; c < APPLY_UNIT_NCOL; ++c) {
+            uint8_t* colBlocks = unitBlocks + 384 * (16 * (c / APPLY_UNIT_W) + c % APPLY_UNIT_W);
+            const int wx = wx0 + c % APPLY_UNIT_W, wz = wz0 + c / APPLY_UNIT_W;
+            for (int y = lane; y < 384; y += 64) {
+                const uint8_t block = colBlocks[y];
+                uint8_t fb = 0;
+                bool placed = false;
+                if (doS && y >= sLo && y <= sHi) {
+                    for (int i = 0; i < MMGEN_MAX_GATHERED_FEATURES_PER_CHUNK; ++i) {
+                        const int feature = listS[i].feature;
+                        if (feature == MMF_NONE) break;
+                        if (block != MMB_AIR && !listS[i].can_replace_blocks) continue;
+                        const int fy = listS[i].pos[1];
+                        if (y < fy + kFeatureBounds[feature][0] || y > fy + kFeatureBounds[feature][1]) continue;
+                        if (place_feature(feature, listS[i].pos[0], fy, listS[i].pos[2], wx, y, wz, surface_feature_stream(listS[i].pos[0], fy, listS[i].pos[2]), fb)) { placed = true; break; }
+                    }
                 }
-            }
-            if (doC && !placed && y >= cLo && y <= cHi) {
-                for (int i = 0; i < MMGEN_MAX_GATHERED_CAVE_FEATURES_PER_CHUNK; ++i) {
-                    const int feature = listC[i].feature;
-                    if (feature == MMCF_NONE) break;
-                    if (block != MMB_AIR && !listC[i].can_replace_blocks) continue;
-                    const int fy = listC[i].pos[1], lh = listC[i].layer_height;
-                    if (y < fy + kCaveFeatureBounds[feature][0] || y > fy + lh + kCaveFeatureBounds[feature][1]) continue;
-                    if (place_cave_feature(feature, listC[i].pos[0], fy, listC[i].pos[2], lh, wx, y, wz, cave_feature_stream(listC[i].pos[0], fy, listC[i].pos[2]), fb)) { placed = true; break; }
+                if (doC && !placed && y >= cLo && y <= cHi) {
+                    for (int i = 0; i < MMGEN_MAX_GATHERED_CAVE_FEATURES_PER_CHUNK; ++i) {
+                        const int feature = listC[i].feature;
+                        if (feature == MMCF_NONE) break;
+                        if (block != MMB_AIR && !listC[i].can_replace_blocks) continue;
+                        const int fy = listC[i].pos[1], lh = listC[i].layer_height;
+                        if (y < fy + kCaveFeatureBounds[feature][0] || y > fy + lh + kCaveFeatureBounds[feature][1]) continue;
+                        if (place_cave_feature(feature, listC[i].pos[0], fy, listC[i].pos[2], lh, wx, y, wz, cave_feature_stream(listC[i].pos[0], fy, listC[i].pos[2]), fb)) { placed = true; break; }
+                    }
                 }
+                if (placed) colBlocks[y] = fb;
             }
-            if (placed) colBlocks[y] = fb;
         }
         continue;
     }
 
-    // stage the column, clear the claims
-    if (lane == 0) pref[nCand] = total;
-    ((uint32_t*)s_blk[wave])[lane] = ((const uint32_t*)colBlocks)[lane];
-    if (lane < 32) ((uint32_t*)s_blk[wave])[64 + lane] = ((const uint32_t*)colBlocks)[64 + lane];
+    // stage the unit's blocks (APPLY_UNIT_W x 384 contiguous bytes per row), clear the claims
+    if (lane == 0) pref[nEnt] = (unsigned short)total;
+    constexpr int ROW_WORDS = APPLY_UNIT_W * 384 / 4;
 #pragma unroll
-    for (int i = 0; i < 6; ++i) s_claim[wave][64 * i + lane] = 0xffffffffu;
+    for (int cz = 0; cz < APPLY_UNIT_H; ++cz)
+        for (int i = lane; i < ROW_WORDS; i += 64) {
+            ((uint32_t*)blk)[ROW_WORDS * cz + i] = ((const uint32_t*)(unitBlocks + 384 * 16 * cz))[i];
+            ((uint32_t*)claim)[ROW_WORDS * cz + i] = 0xffffffffu;
+        }
     wave_lds_sync();
 
 #if MM_APPLY_EXP == 1
-    total = 0;                                                          // timing experiment: fixed per-column work only
+    total = 0;                                                          // timing experiment: fixed per-unit work only
 #endif
     for (int j0 = 0; j0 < total; j0 += 64) {
         const int j = j0 + lane;
-        if (j >= total) break;
-        int k = 0, kh = nCand;                              // pref[k] <= j < pref[kh]
-        while (kh - k > 1) { const int mid = (k + kh) >> 1; if (pref[mid] <= j) k = mid; else kh = mid; }
-        const unsigned e = cand[k];
-        const int ku = e & 255, y = (int)((e >> 8) & 511) + (j - pref[k]);
-        const int4 rc = unit[ku];
-        if (s_blk[wave][y] != MMB_AIR && !((rc.z >> 14) & 1)) continue;
-        const int fy = rc.z & 511, feature = (rc.z >> 9) & 31;
+        bool placed = false;
+        int k = 0, v = 0;
         uint8_t fb = 0;
+        if (j < total) {
+            int e = 0, eh = nEnt;                           // pref[e] <= j < pref[eh]
+            while (eh - e > 1) { const int mid = (e + eh) >> 1; if ((int)pref[mid] <= j) e = mid; else eh = mid; }
+            const unsigned en = ent[e];
+            k = en & 127;
+            const int c = (en >> 7) & 15, y = (int)((en >> 11) & 511) + (j - (int)pref[e]);
+            v = 384 * c + y;
+            const int4 rc = unit[k];
+            if (blk[v] == MMB_AIR || ((rc.z >> 14) & 1)) {
+                const int fy = rc.z & 511, feature = (rc.z >> 9) & 31, wx = wx0 + c % APPLY_UNIT_W, wz = wz0 + c / APPLY_UNIT_W;
 #if MM_APPLY_EXP == 2
-        const bool placed = (rc.x + fy + rc.y + y) == 0x7fffffff;      // timing experiment: no rasteriser
+                placed = (rc.x + fy + rc.y + y) == 0x7fffffff;        // timing experiment: no rasteriser
 #else
-        const bool placed = ku >= nUS ? place_cave_feature(feature, rc.x, fy, rc.y, (rc.z >> 15) & 511, wx, y, wz, (uint32_t)rc.w, fb)
-                                      : place_feature(feature, rc.x, fy, rc.y, wx, y, wz, (uint32_t)rc.w, fb);
+                placed = k >= nUS ? place_cave_feature(feature, rc.x, fy, rc.y, (rc.z >> 15) & 511, wx, y, wz, (uint32_t)rc.w, fb)
+                                  : place_feature(feature, rc.x, fy, rc.y, wx, y, wz, (uint32_t)rc.w, fb);
 #endif
-        if (placed) atomicMin(&s_claim[wave][y], ((unsigned)k << 8) | fb);
+            }
+        }
+        // first match in list order wins: the batch's placements in ascending order, one masked write each (a placement has one item per voxel)
+        unsigned long long todo = __ballot(placed);
+        while (todo) {
+            const int kk = __shfl(k, (int)__builtin_ctzll(todo));
+            const bool mine = placed && k == kk;
+            if (mine && claim[v] == 255) claim[v] = fb;
+            todo &= ~__ballot(mine);
+            wave_lds_sync();
+        }
     }
     wave_lds_sync();
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
-        const unsigned cl = s_claim[wave][64 * i + lane];
-        if (cl != 0xffffffffu) colBlocks[64 * i + lane] = (uint8_t)(cl & 255u);
-    }
-    wave_lds_sync();                                       // the wave's LDS rows are re-used by its next column
-   }
+    for (int cz = 0; cz < APPLY_UNIT_H; ++cz)
+        for (int i = lane; i < ROW_WORDS; i += 64) {
+            const uint32_t cl = ((const uint32_t*)claim)[ROW_WORDS * cz + i];
+            if (cl != 0xffffffffu) {
+                const uint32_t old = ((const uint32_t*)blk)[ROW_WORDS * cz + i];
+                uint32_t out = 0u;
+#pragma unroll
+                for (int b = 0; b < 4; ++b) { const uint32_t cb = (cl >> (8 * b)) & 255u; out |= (cb != 255u ? cb : (old >> (8 * b)) & 255u) << (8 * b); }
+                ((uint32_t*)(unitBlocks + 384 * 16 * cz))[i] = out;
+            }
+        }
+    wave_lds_sync();                                       // the wave's LDS lists are re-used by its next unit
   }
 }
 
