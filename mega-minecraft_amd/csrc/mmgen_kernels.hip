@@ -573,7 +573,25 @@ struct BaseBlock { uint8_t block; bool needCave; int bottomDepth, topDepth; };
 // exactly 0 whatever its weight) plus the biomes of positive weight, ascending.  Subtracting a zero weight changes nothing and cannot
 // trigger the "<= 0" exit of a positive remainder, so the walk returns exactly what the 24-entry walk returns - in 2 - 4 steps, not 10 - 23.
 #define FILL_NZ_CAP 8
-struct ColumnBiomes { int n; bool isOcean; const uint8_t* idx; const float* w; const float* all; };
+// drawMinY / drawWater: where the biome drawn for a voxel can matter at all.  Besides the grass block of the top voxel, the drawn biome only
+// enters through biomeBlockPreProcess / biomeBlockPostProcess (biomeFuncs.hpp:385-600), and those act for nine biomes only, each from a
+// fixed height up (or on water): in a column where none of them has weight, or below the lowest of their thresholds, every biome
+// gives the same block and the draw (a hash + a walk over the weights per voxel, ~85 % of the voxels of a generated world) is skipped.
+struct ColumnBiomes { int n; bool isOcean; const uint8_t* idx; const float* w; const float* all; int drawMinY; bool drawWater; };
+
+// lowest y at which biome b changes a block in biome_block_pre / biome_block_post other than through isTop or WATER (384 = never)
+MM_DEV int biome_rule_min_y(int b, float height)
+{
+    switch (b) {
+    case MMBIO_ARCHIPELAGO: return MMGEN_SEA_LEVEL;           // wy < SEA_LEVEL returns
+    case MMBIO_MESA: return 90;                               // fy < 90 returns
+    case MMBIO_SHREKS_SWAMP: return 100;
+    case MMBIO_TIANZI_MOUNTAINS: return 90;
+    case MMBIO_MOUNTAINS: return 190;
+    case MMBIO_CRYSTALS: return height > 176.f ? 0 : 384;     // quartz above a noisy start height (biome_block_pre); its post rule is isTop only
+    default: return 384;                                      // TROPICAL_BEACH, BEACH: isTop only; FROZEN_WASTELAND: WATER only; the rest: none
+    }
+}
 MM_DEV int random_biome(const ColumnBiomes& cb, float rand)
 {
     if (cb.n > FILL_NZ_CAP) return random_biome(cb.all, 1, rand);          // more than 8 biomes meet in this column: the plain walk
@@ -593,18 +611,25 @@ MM_DEV BaseBlock place_block_base(const ColumnBiomes& cbi, const float* s_lh, co
 
     const bool isOcean = cbi.isOcean;
 
-    MinStd rng = rng3(wx, y, wz);
-    const int randBiome = random_biome(cbi, rng.u01());
     const bool isTop = fy >= height - 1.f;
+    const bool isWater = fy > height && y <= MMGEN_SEA_LEVEL;
+    int randBiome = MMBIO_PLAINS;                             // a biome without rules
+    if (isTop || y >= cbi.drawMinY || (isWater && cbi.drawWater)) {
+        MinStd rng = rng3(wx, y, wz);
+        randBiome = random_biome(cbi, rng.u01());
+    }
 
     uint8_t block = MMB_AIR;
-    if (fy > height && y <= MMGEN_SEA_LEVEL) {
+    if (isWater) {
         block = MMB_WATER;
         biome_block_post(block, randBiome, wx, y, wz, isTop);
         if (isOcean) { r.block = block; return r; }
     }
 
     int bottomDepth = -384, topDepth = -384;
+#ifdef MM_FILL_BASE_EXP
+    if (!(MM_FILL_BASE_EXP & 1))
+#endif
     for (int k = 0; k < MMGEN_MAX_CAVE_LAYERS_PER_COLUMN; ++k) {
         const int start = s_cl[k].start, end = s_cl[k].end;
         if (start == 384) { bottomDepth = -384; break; }
@@ -629,6 +654,9 @@ MM_DEV BaseBlock place_block_base(const ColumnBiomes& cbi, const float* s_lh, co
 
     const int l0 = (fy >= s_lh[MMGEN_NUM_FORWARD_MATERIALS]) ? MMGEN_NUM_FORWARD_MATERIALS : 0;
     int layer = -1;
+#ifdef MM_FILL_BASE_EXP
+    if (!(MM_FILL_BASE_EXP & 2))
+#endif
     for (int l = l0; l < MMGEN_NUM_MATERIALS; ++l) {
         if (s_lh[l] <= fy && fy < s_lh[l + 1]) { layer = l; break; }
     }
@@ -685,7 +713,8 @@ MM_DEV void fill_body(const float* __restrict__ hf, const float* __restrict__ bw
     __shared__ int s_count[3];
     __shared__ unsigned s_qbase;
     __shared__ float s_nzW[FILL_ROW][FILL_NZ_CAP];
-    __shared__ uint8_t s_nzIdx[FILL_ROW][FILL_NZ_CAP], s_nzN[FILL_ROW], s_ocean[FILL_ROW];
+    __shared__ uint8_t s_nzIdx[FILL_ROW][FILL_NZ_CAP], s_nzN[FILL_ROW], s_ocean[FILL_ROW], s_drawWater[FILL_ROW];
+    __shared__ short s_drawMinY[FILL_ROW];
 
     const int t = threadIdx.x;
     const int bid = xcd_block(blockIdx.x, gridDim.x);
@@ -708,14 +737,16 @@ MM_DEV void fill_body(const float* __restrict__ hf, const float* __restrict__ bw
     if (t < 3) s_count[t] = 0;
     __syncthreads();
     if (t < FILL_ROW) {
-        int n = 0;
-        bool ocean = false;
+        int n = 0, minY = 384;
+        bool ocean = false, water = false;
         for (int b = 0; b < MMGEN_NUM_BIOMES; ++b) {
             const float w = s_bw[t][b];
             if (b < MMGEN_NUM_OCEAN_BIOMES) ocean = ocean || (w > 0.f);
             if (b == 0 || w > 0.f) { if (n < FILL_NZ_CAP) { s_nzIdx[t][n] = (uint8_t)b; s_nzW[t][n] = w; } ++n; }
+            // (biome 0 can be drawn at weight 0 and PLAINS is the walk's fall-through: neither has a rule)
+            if (w > 0.f) { minY = imin(minY, biome_rule_min_y(b, s_lh[t][MMGEN_NUM_MATERIALS])); water = water || b == MMBIO_FROZEN_WASTELAND; }
         }
-        s_nzN[t] = (uint8_t)n; s_ocean[t] = ocean ? 1 : 0;
+        s_nzN[t] = (uint8_t)n; s_ocean[t] = ocean ? 1 : 0; s_drawMinY[t] = (short)minY; s_drawWater[t] = water ? 1 : 0;
     }
     __syncthreads();
 
@@ -735,7 +766,7 @@ MM_DEV void fill_body(const float* __restrict__ hf, const float* __restrict__ bw
         // wz is the same for the whole workgroup (one row of a chunk): left visible, the compiler hoists (float)wz * scale for each of the six
         // block-rule noises out of the loop into six VGPRs it then has to spill (the kernel sits at its register budget)
         asm volatile("" : "+v"(wz));
-        const ColumnBiomes cbi = {s_nzN[c], s_ocean[c] != 0, s_nzIdx[c], s_nzW[c], s_bw[c]};
+        const ColumnBiomes cbi = {s_nzN[c], s_ocean[c] != 0, s_nzIdx[c], s_nzW[c], s_bw[c], s_drawMinY[c], s_drawWater[c] != 0};
         const BaseBlock r = place_block_base(cbi, s_lh[c], s_cl[c], y, s_lh[c][MMGEN_NUM_MATERIALS], wx, wz);
         if (r.needCave) {
             const int slot = atomicAdd(&s_count[0], 1);
