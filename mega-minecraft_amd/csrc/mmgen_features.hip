@@ -728,6 +728,12 @@ MM_DEV int filter_unit(const Entry* __restrict__ list, int wx0, int wz0, int4* s
 #ifndef MM_APPLY_EXP
 #define MM_APPLY_EXP 0       // timing experiments only (tools/build_variant.sh)
 #endif
+#ifndef MM_APPLY_STATS
+#define MM_APPLY_STATS 0     // debugging aid: work census of every launch on stderr (units with items, placements, pairs, items)
+#endif
+#if MM_APPLY_STATS
+__device__ unsigned long long g_applyStats[8];
+#endif
 #ifndef MM_APPLY_WAVES
 #define MM_APPLY_WAVES 3        // 168 VGPRs: the union of the 31 rasterisers
 #endif
@@ -876,6 +882,12 @@ k_apply_features(uint8_t* __restrict__ blocks, const int2* __restrict__ chunkPos
         continue;
     }
 
+#if MM_APPLY_STATS
+    if (lane == 0) {
+        atomicAdd(&g_applyStats[0], 1ull); atomicAdd(&g_applyStats[1], (unsigned long long)nUS); atomicAdd(&g_applyStats[2], (unsigned long long)(nU - nUS));
+        atomicAdd(&g_applyStats[3], (unsigned long long)nEnt); atomicAdd(&g_applyStats[4], (unsigned long long)total);
+    }
+#endif
     // stage the unit's blocks (APPLY_UNIT_W x 384 contiguous bytes per row), clear the claims
     if (lane == 0) pref[nEnt] = (unsigned short)total;
     constexpr int ROW_WORDS = APPLY_UNIT_W * 384 / 4;
@@ -1153,6 +1165,13 @@ int launch_apply_features(uint8_t* blocks, const int32_t* pos, int n, const mmge
     if (e != hipSuccess) return (int)e;
     LAUNCH(KID_APPLY_FEATURES, mm::k_apply_features, dim3((unsigned)(groups < fit ? groups : fit)), dim3(APPLY_THREADS), s, blocks, (const int2*)pos, gfp, gcfp,
            bounds, srcIdx, (int)units, workCounter);
+#if MM_APPLY_STATS
+    {
+        unsigned long long h[8];
+        (void)hipStreamSynchronize(s); (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(mm::g_applyStats), sizeof h);
+        fprintf(stderr, "apply census (cumulative): chunks %d units-with-items %llu surface placements %llu cave placements %llu pairs %llu items %llu\n", n, h[0], h[1], h[2], h[3], h[4]);
+    }
+#endif
     return 0;
 }
 
