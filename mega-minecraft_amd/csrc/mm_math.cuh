@@ -227,4 +227,13 @@ MM_DEV MinStd rng4(int x, int y, int z, int w)
     return r;
 }
 
+// LDS hand-off inside one wave: its LDS operations execute in issue order, only the compiler must not reorder across the hand-off
+MM_DEV void wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+
 }  // namespace mm

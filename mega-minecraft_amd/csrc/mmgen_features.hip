@@ -440,14 +440,6 @@ k_gather_placements(const mmgen_feature_placement* __restrict__ fp, const mmgen_
 #define APPLY_ITEM_CAP 65535              // (placement, voxel) pairs of one unit: item offsets are kept as 16-bit numbers
 static_assert(APPLY_UNIT_NCOL <= 16 && APPLY_UNIT_CAP <= 128, "s_ent packing");
 
-// LDS hand-off inside one wave: its LDS operations execute in issue order, only the compiler must not reorder across the hand-off
-MM_DEV void wave_lds_sync()
-{
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
 MM_DEV int wave_min(int v) { for (int o = 32; o > 0; o >>= 1) v = imin(v, __shfl_xor(v, o)); return v; }
 MM_DEV int wave_max(int v) { for (int o = 32; o > 0; o >>= 1) v = imax(v, __shfl_xor(v, o)); return v; }
 

@@ -13,7 +13,7 @@ int launch_caves(const float* hf, const float* bw, const int32_t* pos, int n, mm
 int launch_fill(const float* hf, const float* bw, const float* layers, const mmgen_cave_layer* caveLayers, const int32_t* pos, int n,
                 uint8_t* blocks, const int* srcIdx /*nullable: input chunk of each output chunk*/,
                 unsigned* lushQueue /*nullable device scratch: deferred clay / moss voxels*/, size_t lushQueueBytes, bool allInPruneDomain /* every chunk within MM_PRUNE_DOMAIN blocks of the origin: k_fill_far is not launched */, hipStream_t s);
-inline size_t fill_queue_bytes(int n) { return 4 * ((size_t)n * 2048 + 1); }      // 2 048 deferred voxels per chunk on average; overflow is evaluated in place
+size_t fill_queue_bytes(int n);      // launch_fill's scratch for n chunks: lush queue (2 048 deferred voxels per chunk on average; overflow is evaluated in place) + row lists (393 KB per chunk, at most 8 192 chunks' worth) + work counters
 int launch_probe(int fn, const float* in, int n, float* out, hipStream_t s);
 int prepare_kernels();      // builds this translation unit's noise-table image on the current device (called from mmgen_init)
 }  // namespace mmk

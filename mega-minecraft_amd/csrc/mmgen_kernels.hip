@@ -577,7 +577,7 @@ struct BaseBlock { uint8_t block; bool needCave; int bottomDepth, topDepth; };
 // enters through biomeBlockPreProcess / biomeBlockPostProcess (biomeFuncs.hpp:385-600), and those act for nine biomes only, each from a
 // fixed height up (or on water): in a column where none of them has weight, or below the lowest of their thresholds, every biome
 // gives the same block and the draw (a hash + a walk over the weights per voxel, ~85 % of the voxels of a generated world) is skipped.
-struct ColumnBiomes { int n; bool isOcean; const uint8_t* idx; const float* w; const float* all; int drawMinY; bool drawWater; };
+struct ColumnBiomes { int n; bool isOcean; const uint8_t* idx; const float* w; const float* all; int drawMinY; bool drawWater; bool layersSorted; };
 
 // lowest y at which biome b changes a block in biome_block_pre / biome_block_post other than through isTop or WATER (384 = never)
 MM_DEV int biome_rule_min_y(int b, float height)
@@ -600,6 +600,17 @@ MM_DEV int random_biome(const ColumnBiomes& cb, float rand)
         if (rand <= 0.f) return cb.idx[k];
     }
     return MMBIO_PLAINS;
+}
+
+// kMaterialBlock[layer] as immediates (8 bits per material): indexed per lane the table is a dependent memory round trip per voxel
+MM_DEV uint8_t material_block(int layer)
+{
+    static_assert(MMGEN_NUM_MATERIALS <= 24, "three 64-bit words");
+    unsigned long long w[3] = {0ull, 0ull, 0ull};
+#pragma unroll
+    for (int m = 0; m < MMGEN_NUM_MATERIALS; ++m) w[m >> 3] |= (unsigned long long)kMaterialBlock[m] << (8 * (m & 7));
+    const unsigned long long v = layer < 8 ? w[0] : (layer < 16 ? w[1] : w[2]);
+    return (uint8_t)((v >> (8 * (layer & 7))) & 255ull);
 }
 
 MM_DEV BaseBlock place_block_base(const ColumnBiomes& cbi, const float* s_lh, const mmgen_cave_layer* s_cl, int y, float height, int wx, int wz)
@@ -657,10 +668,21 @@ MM_DEV BaseBlock place_block_base(const ColumnBiomes& cbi, const float* s_lh, co
 #ifdef MM_FILL_BASE_EXP
     if (!(MM_FILL_BASE_EXP & 2))
 #endif
+    if (cbi.layersSorted) {
+        // Both runs of layer starts - forward 0 .. 9, backward + eroded 10 .. 20 (the last entry is the height) - are non-decreasing in
+        // nearly every column.  Then the first l >= l0 with s_lh[l] <= fy < s_lh[l + 1] is the last layer of fy's run that starts at or
+        // below fy (earlier ones end at or below fy, later ones start above it, and for l0 = 0 the second run starts above fy altogether):
+        // nine independent compares instead of a data-dependent walk of up to twenty
+        int cnt = 0;
+#pragma unroll
+        for (int i = 1; i < MMGEN_NUM_FORWARD_MATERIALS; ++i) cnt += (s_lh[l0 + i] <= fy) ? 1 : 0;
+        const int l = l0 + cnt;
+        if (s_lh[l0] <= fy && fy < s_lh[l + 1]) layer = l;
+    } else
     for (int l = l0; l < MMGEN_NUM_MATERIALS; ++l) {
         if (s_lh[l] <= fy && fy < s_lh[l + 1]) { layer = l; break; }
     }
-    block = (layer < 0) ? (uint8_t)MMB_STONE : kMaterialBlock[layer];   // canonical: no layer (y == height exactly) → STONE
+    block = (layer < 0) ? (uint8_t)MMB_STONE : material_block(layer);   // canonical: no layer (y == height exactly) → STONE
     if (isTop && block == MMB_DIRT) block = kGrassBlock[randBiome];
 
     biome_block_post(block, randBiome, wx, y, wz, isTop);
@@ -746,7 +768,10 @@ MM_DEV void fill_body(const float* __restrict__ hf, const float* __restrict__ bw
             // (biome 0 can be drawn at weight 0 and PLAINS is the walk's fall-through: neither has a rule)
             if (w > 0.f) { minY = imin(minY, biome_rule_min_y(b, s_lh[t][MMGEN_NUM_MATERIALS])); water = water || b == MMBIO_FROZEN_WASTELAND; }
         }
-        s_nzN[t] = (uint8_t)n; s_ocean[t] = ocean ? 1 : 0; s_drawMinY[t] = (short)minY; s_drawWater[t] = water ? 1 : 0;
+        bool sorted = true;
+        for (int l = 0; l < MMGEN_NUM_MATERIALS; ++l)
+            if (l != MMGEN_NUM_FORWARD_MATERIALS - 1) sorted = sorted && s_lh[t][l] <= s_lh[t][l + 1];
+        s_nzN[t] = (uint8_t)n; s_ocean[t] = ocean ? 1 : 0; s_drawMinY[t] = (short)minY; s_drawWater[t] = (water ? 1 : 0) | (sorted ? 2 : 0);
     }
     __syncthreads();
 
@@ -766,7 +791,7 @@ MM_DEV void fill_body(const float* __restrict__ hf, const float* __restrict__ bw
         // wz is the same for the whole workgroup (one row of a chunk): left visible, the compiler hoists (float)wz * scale for each of the six
         // block-rule noises out of the loop into six VGPRs it then has to spill (the kernel sits at its register budget)
         asm volatile("" : "+v"(wz));
-        const ColumnBiomes cbi = {s_nzN[c], s_ocean[c] != 0, s_nzIdx[c], s_nzW[c], s_bw[c], s_drawMinY[c], s_drawWater[c] != 0};
+        const ColumnBiomes cbi = {s_nzN[c], s_ocean[c] != 0, s_nzIdx[c], s_nzW[c], s_bw[c], s_drawMinY[c], (s_drawWater[c] & 1) != 0, (s_drawWater[c] & 2) != 0};
         const BaseBlock r = place_block_base(cbi, s_lh[c], s_cl[c], y, s_lh[c][MMGEN_NUM_MATERIALS], wx, wz);
         if (r.needCave) {
             const int slot = atomicAdd(&s_count[0], 1);
@@ -858,12 +883,290 @@ MM_DEV void fill_body(const float* __restrict__ hf, const float* __restrict__ bw
     }
 }
 
-__attribute__((amdgpu_waves_per_eu(MM_FILL_WAVES, MM_FILL_WAVES)))
-__global__ void __launch_bounds__(FILL_THREADS)
-k_fill(const float* __restrict__ hf, const float* __restrict__ bw, const float* __restrict__ layers, const mmgen_cave_layer* __restrict__ caveLayers,
-       const int2* __restrict__ chunkPos, uint8_t* __restrict__ blocks, const int* __restrict__ srcIdx, unsigned* __restrict__ lushQueue, unsigned lushCap)
+// ---------------------------------------------------------------------------------------------------------
+// K6 for the rows INSIDE the pruning domain (all of them, for any world within 32 768 blocks of the origin): three kernels.
+//   k_fill_base  one workgroup = one row: every voxel's base block, written; the stone voxels a cave biome could still alter are appended
+//                to the row's list in global memory (4 bytes each).  No noise tables unless a biome with a noise rule has weight in the
+//                row, 9 KB of LDS: seven workgroups per CU hide the staging latency that three 50 KB workgroups of the fused kernel could not.
+//   k_fill_scan  exclusive prefix of the rows' 64-voxel batch counts + the row each range of FILL_RANGE batches starts in.
+//   k_fill_cave  persistent waves, no workgroup barrier after the tables are staged: a wave draws ranges of batches from work counters
+//                (k_apply_features' scheme) and evaluates the cave biome of 64 listed voxels at a time, every lane busy whatever row the
+//                voxels come from.  CRYSTAL / LUSH voxels (their rules start with one more simplex3) are set aside in a per-wave LDS
+//                buffer and evaluated 64 at a time as soon as 64 have gathered; lush voxels close to a cave surface go from a second
+//                per-wave buffer to the device-wide queue of k_fill_lush, 64 per reservation.
+// k_fill_far (fill_body<false>) keeps the rows beyond the domain, the fused way.
+// ---------------------------------------------------------------------------------------------------------
+#define FILL_RANGE 8             // batches per draw: ~60 us of work, the longest a wave can still be busy after the others ran dry
+#define FILL_COUNTERS 16         // work counters, 64 B apart (one serialises at ~11 ns per draw in L2)
+#define FILLB_THREADS 256
+#define FILLC_THREADS 256
+#define FILLC_DEF_CAP 128        // per wave: CRYSTAL / LUSH voxels waiting for their noise rule
+#define FILLC_LUSH_CAP 128       // per wave: lush voxels waiting for a queue reservation
+
+__global__ void __launch_bounds__(FILLB_THREADS)
+k_fill_base(const float* __restrict__ hf, const float* __restrict__ bw, const float* __restrict__ layers, const mmgen_cave_layer* __restrict__ caveLayers,
+            const int2* __restrict__ chunkPos, uint8_t* __restrict__ blocks, const int* __restrict__ srcIdx, int row0,
+            unsigned* __restrict__ rowLists /*[rows][FILL_VOX]*/, int* __restrict__ rowCounts)
 {
-    fill_body<true>(hf, bw, layers, caveLayers, chunkPos, blocks, srcIdx, lushQueue, lushCap);
+    __shared__ float s_bw[FILL_ROW][MMGEN_NUM_BIOMES];
+    __shared__ float s_lh[FILL_ROW][MMGEN_NUM_MATERIALS + 1];
+    __shared__ mmgen_cave_layer s_cl[FILL_ROW][MMGEN_MAX_CAVE_LAYERS_PER_COLUMN];
+    __shared__ int s_count, s_needTables;
+    __shared__ float s_nzW[FILL_ROW][FILL_NZ_CAP];
+    __shared__ uint8_t s_nzIdx[FILL_ROW][FILL_NZ_CAP], s_nzN[FILL_ROW], s_ocean[FILL_ROW], s_drawWater[FILL_ROW];
+    __shared__ short s_drawMinY[FILL_ROW];
+
+    const int t = threadIdx.x;
+    const int lrow = xcd_block(blockIdx.x, gridDim.x), bid = row0 + lrow;      // row of this launch / of the batch the pointers belong to
+    const int outChunk = bid >> 4, row = bid & 15;                 // one workgroup = one 16-column row of a chunk (z = row)
+    const int chunk = srcIdx ? srcIdx[outChunk] : outChunk;        // inputs are read at `chunk`, blocks are written densely at outChunk
+    const int2 cp = chunkPos[chunk];
+    if (!prune_domain(cp.x, cp.y + row)) {                         // k_fill_far's row (the row's x range is [cp.x, cp.x + 15], cp.x a multiple of 16)
+        if (t == 0) rowCounts[lrow] = 0;
+        return;
+    }
+    const int idxBase = FILL_ROW * row;
+
+    // the row's plane attributes, once: 24 weights + 20 layer starts + height per column.  A row of a plane is one 64-byte line, read whole
+    for (int i = t; i < FILL_ROW * 45; i += FILLB_THREADS) {
+        const int k = i / FILL_ROW, c = i % FILL_ROW;               // consecutive lanes = consecutive columns of one plane
+        const int idx2d = idxBase + c;
+        if (k < MMGEN_NUM_BIOMES) s_bw[c][k] = bw[(size_t)MMGEN_BIOME_WEIGHTS_SIZE * chunk + 256 * k + idx2d];
+        else if (k < MMGEN_NUM_BIOMES + MMGEN_NUM_MATERIALS) s_lh[c][k - MMGEN_NUM_BIOMES] = layers[(size_t)MMGEN_LAYERS_SIZE * chunk + 256 * (k - MMGEN_NUM_BIOMES) + idx2d];
+        else s_lh[c][MMGEN_NUM_MATERIALS] = hf[chunk * 256 + idx2d];
+    }
+    // the row's cave layers: 16 columns x 32 layers x 12 bytes, contiguous
+    for (int i = t; i < FILL_ROW * 96; i += FILLB_THREADS)
+        ((int*)s_cl)[i] = ((const int*)(caveLayers + (size_t)MMGEN_MAX_CAVE_LAYERS_PER_COLUMN * (chunk * 256 + idxBase)))[i];
+    if (t == 0) { s_count = 0; s_needTables = 0; }
+    __syncthreads();
+    if (t < FILL_ROW) {
+        int n = 0, minY = 384;
+        bool ocean = false, water = false;
+        for (int b = 0; b < MMGEN_NUM_BIOMES; ++b) {
+            const float w = s_bw[t][b];
+            if (b < MMGEN_NUM_OCEAN_BIOMES) ocean = ocean || (w > 0.f);
+            if (b == 0 || w > 0.f) { if (n < FILL_NZ_CAP) { s_nzIdx[t][n] = (uint8_t)b; s_nzW[t][n] = w; } ++n; }
+            // (biome 0 can be drawn at weight 0 and PLAINS is the walk's fall-through: neither has a rule)
+            if (w > 0.f) { minY = imin(minY, biome_rule_min_y(b, s_lh[t][MMGEN_NUM_MATERIALS])); water = water || b == MMBIO_FROZEN_WASTELAND; }
+        }
+        bool sorted = true;
+        for (int l = 0; l < MMGEN_NUM_MATERIALS; ++l)
+            if (l != MMGEN_NUM_FORWARD_MATERIALS - 1) sorted = sorted && s_lh[t][l] <= s_lh[t][l + 1];
+        s_nzN[t] = (uint8_t)n; s_ocean[t] = ocean ? 1 : 0; s_drawMinY[t] = (short)minY; s_drawWater[t] = (water ? 1 : 0) | (sorted ? 2 : 0);
+        if (minY < 384) s_needTables = 1;                           // every rule with a height threshold is a noise rule (biome_rule_min_y)
+    }
+    __syncthreads();
+    // simplex tables only for the rows in which a biome with a noise rule has weight (a biome is only drawn at positive weight)
+    if (s_needTables) noise_tables_init();
+
+    uint8_t* outBase = blocks + (size_t)MMGEN_BLOCKS_PER_CHUNK * outChunk + 384 * idxBase;     // the 16 columns are contiguous: 6 144 bytes
+    unsigned* list = rowLists + (size_t)FILL_VOX * lrow;
+
+    // The two cave-surface distances only matter as "== 0" and "0 .. threshold" with threshold = 1.5 + 4.5 * simplex3 (|simplex3| < 3.5 by
+    // the crudest bound: 42 * 4 corners * max((0.6 - r^2)^4 r) = 3.5, threshold < 17.25), so they travel as 5-bit codes: negative -> 31,
+    // 30 and beyond -> 30.
+    // Walk: a wave = 16 consecutive y of four neighbouring columns (16-byte pieces per column in a wave's store), the four column groups
+    // of a 16-y block in four consecutive waves: the list comes out ordered by depth, and the exits of the cave-biome evaluation - which
+    // go by depth zone - retire whole waves of k_fill_cave instead of idling lanes
+    for (int u = t; u < FILL_VOX; u += FILLB_THREADS) {
+        const int c = 4 * ((u >> 6) & 3) + (u & 3), y = 16 * (u >> 8) + ((u >> 2) & 15);
+        const int v = 384 * c + y;                                  // position in the row's 6 144 output bytes
+        const int wx = cp.x + c;
+        int wz = cp.y + row;
+        // wz is the same for the whole workgroup (one row of a chunk): left visible, the compiler hoists (float)wz * scale for each of the six
+        // block-rule noises out of the loop into six VGPRs
+        asm volatile("" : "+v"(wz));
+        const ColumnBiomes cbi = {s_nzN[c], s_ocean[c] != 0, s_nzIdx[c], s_nzW[c], s_bw[c], s_drawMinY[c], (s_drawWater[c] & 1) != 0, (s_drawWater[c] & 2) != 0};
+        const BaseBlock r = place_block_base(cbi, s_lh[c], s_cl[c], y, s_lh[c][MMGEN_NUM_MATERIALS], wx, wz);
+        outBase[v] = r.block;                                       // k_fill_cave only writes the voxels it changes
+        if (r.needCave) {
+            const int slot = atomicAdd(&s_count, 1);
+            const unsigned bdc = r.bottomDepth < 0 ? 31u : (unsigned)imin(r.bottomDepth, 30);
+            const unsigned tdc = r.topDepth < 0 ? 31u : (unsigned)imin(r.topDepth, 30);
+            list[slot] = (unsigned)v | ((unsigned)r.block << FILL_VBITS) | (bdc << (FILL_VBITS + 8)) | (tdc << (FILL_VBITS + 13));
+        }
+    }
+    __syncthreads();
+    if (t == 0) rowCounts[lrow] = s_count;
+}
+
+// batchStart[r] = number of 64-voxel batches in the lists of the rows before r (batchStart[nRows] = all of them); rangeRow[g] = the row
+// batch FILL_RANGE * g lies in.  One workgroup per 1 024 rows; each sums the counts before its rows itself (a few hundred KB out of L2).
+__global__ void __launch_bounds__(1024)
+k_fill_scan(const int* __restrict__ rowCounts, int nRows, int* __restrict__ batchStart, int* __restrict__ rangeRow)
+{
+    __shared__ int s_w[16], s_offset;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    auto wave_sum = [&](int v) { for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o); return v; };
+    int part = 0;
+    for (int i = t; i < 1024 * (int)blockIdx.x; i += 1024) part += (rowCounts[i] + 63) >> 6;
+    part = wave_sum(part);
+    if (lane == 0) s_w[wave] = part;
+    __syncthreads();
+    if (t == 0) { int o = 0; for (int w = 0; w < 16; ++w) o += s_w[w]; s_offset = o; }
+    __syncthreads();
+    const int offset = s_offset;
+    const int row = 1024 * blockIdx.x + t;
+    const int nb = row < nRows ? (rowCounts[row] + 63) >> 6 : 0;
+    int incl = nb;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o); if (lane >= o) incl += v; }
+    __syncthreads();                                               // s_w is re-used
+    if (lane == 63) s_w[wave] = incl;
+    __syncthreads();
+    int before = 0;
+    for (int w = 0; w < wave; ++w) before += s_w[w];
+    const int a = offset + before + incl - nb, b = a + nb;
+    if (row < nRows) {
+        batchStart[row] = a;
+        if (row == nRows - 1) batchStart[nRows] = b;
+        for (int g = (a + FILL_RANGE - 1) / FILL_RANGE; g * FILL_RANGE < b; ++g) rangeRow[g] = row;
+    }
+}
+
+__attribute__((amdgpu_waves_per_eu(MM_FILL_WAVES, MM_FILL_WAVES)))
+__global__ void __launch_bounds__(FILLC_THREADS)
+k_fill_cave(const float* __restrict__ hf, const int2* __restrict__ chunkPos, uint8_t* __restrict__ blocks, const int* __restrict__ srcIdx, int row0,
+            const unsigned* __restrict__ rowLists, const int* __restrict__ rowCounts, const int* __restrict__ batchStart, const int* __restrict__ rangeRow,
+            int nRows, unsigned* __restrict__ lushQueue /*[0] = count, entries from [1]; nullable*/, unsigned lushCap, unsigned* __restrict__ work)
+{
+    __shared__ uint2 s_def[FILLC_THREADS / 64][FILLC_DEF_CAP];     // .x = list entry | isLush << 31, .y = row of this launch
+    __shared__ unsigned s_lushBuf[FILLC_THREADS / 64][FILLC_LUSH_CAP];      // k_fill_lush's entries: outChunk << 17 | column << 9 | y
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    noise_tables_init();                                           // once per (persistent) workgroup; no workgroup barrier after this one
+    uint2* def = s_def[wave];
+    unsigned* lushBuf = s_lushBuf[wave];
+    int nDef = 0, nLush = 0;                                       // wave-uniform
+    const unsigned long long below = (1ull << lane) - 1ull;
+
+    // the position of a listed voxel; the row's chunk position through L2 (a wave's voxels come from one or two rows)
+    struct Voxel { int outChunk, c, y, wx, wz; };
+    auto voxel_of = [&](int lrow, int v) {
+        Voxel x;
+        const int bid = row0 + lrow;
+        x.outChunk = bid >> 4;
+        const int2 cp = chunkPos[srcIdx ? srcIdx[x.outChunk] : x.outChunk];
+        x.c = v / 384; x.y = v - 384 * x.c;
+        x.wx = cp.x + x.c; x.wz = cp.y + (bid & 15);
+        return x;
+    };
+    auto block_ptr = [&](int lrow, int v) { const int bid = row0 + lrow; return blocks + (size_t)MMGEN_BLOCKS_PER_CHUNK * (bid >> 4) + 384 * FILL_ROW * (bid & 15) + v; };
+
+    const int total = batchStart[nRows], nRanges = (total + FILL_RANGE - 1) / FILL_RANGE;
+    int part = (int)((FILLC_THREADS / 64) * blockIdx.x + wave) % FILL_COUNTERS, dry = 0;
+    unsigned drawn = 0u;
+    if (lane == 0) drawn = atomicAdd(&work[16 * part], 1u);
+    bool more = true;                                              // ranges left to draw
+    int b = 0, b1 = 0, lrow = 0, rowA = 0, rowB = 0, cnt = 0;      // the range being worked on: next batch, end, and the row batch b lies in
+    // Per batch only the list entry comes from memory, and it is requested one batch ahead (a row has ~28 batches in a row); the row's
+    // 16 heights sit in the lanes of one register
+    unsigned ePre = 0u;
+    int preB = -1;
+
+    // One loop, three kinds of step (each heavy body exists once in the code): a full reservation of lush voxels, a full batch of deferred
+    // CRYSTAL / LUSH voxels, the next batch of listed voxels; when the ranges have run dry the two buffers are drained.
+    for (;;) {
+        if (nLush >= 64 || (!more && nDef == 0 && nLush > 0)) {
+            // lush voxels from the top of the wave's buffer to the device-wide queue; a reservation that does not fit is evaluated here
+            const int n = imin(nLush, 64);
+            wave_lds_sync();
+            unsigned qbase = 0xffffffffu;
+            if (lushQueue) { if (lane == 0) qbase = atomicAdd(lushQueue, (unsigned)n); qbase = (unsigned)__builtin_amdgcn_readfirstlane((int)qbase); }
+            const bool queued = lushQueue && qbase <= lushCap && (unsigned)n <= lushCap - qbase;
+            if (lane < n) {
+                const unsigned e = lushBuf[nLush - n + lane];
+                if (queued) lushQueue[1 + qbase + lane] = e;
+                else {
+                    // a reservation that straddles the capacity marks its in-range slots as holes (they hold the previous launch's entries)
+                    if (lushQueue && qbase < lushCap && (unsigned)lane < lushCap - qbase) lushQueue[1 + qbase + lane] = 0xffffffffu;
+                    const int outChunk = e >> 17, idx2d = (e >> 9) & 255, y = e & 511;
+                    const int2 cp = chunkPos[srcIdx ? srcIdx[outChunk] : outChunk];
+                    blocks[(size_t)MMGEN_BLOCKS_PER_CHUNK * outChunk + 384 * idx2d + y] = lush_clay_or_moss(cp.x + (idx2d & 15), y, cp.y + (idx2d >> 4), CellDirect());
+                }
+            }
+            nLush -= n;
+            continue;
+        }
+        if (nDef >= 64 || (!more && nDef > 0)) {
+            // CRYSTAL / LUSH voxels from the top of the wave's buffer: the one simplex3 both noise rules start with
+            const int n = imin(nDef, 64);
+            wave_lds_sync();
+            bool lush = false;
+            unsigned word = 0u;
+            if (lane < n) {
+                const uint2 d = def[nDef - n + lane];
+                const int dr = (int)d.y, v = d.x & FILL_VMASK;
+                const int cb = (d.x >> 31) ? MMCB_LUSH_CAVES : MMCB_CRYSTAL_CAVES;
+                const uint8_t base = (uint8_t)((d.x >> FILL_VBITS) & 255);
+                uint8_t block = base;
+                const int bdc = (d.x >> (FILL_VBITS + 8)) & 31, tdc = (d.x >> (FILL_VBITS + 13)) & 31;
+                const Voxel x = voxel_of(dr, v);
+                float ax, ay, az;
+                cave_post_noise_pos(cb, x.wx, x.y, x.wz, ax, ay, az);
+                const float nz = simplex3_inl(ax, ay, az);
+                lush = cave_post_apply(block, cb, nz, x.wx, x.y, x.wz, bdc == 31 ? -1 : bdc, tdc == 31 ? -1 : tdc);
+                if (lush) word = ((unsigned)x.outChunk << 17) | ((unsigned)(FILL_ROW * ((row0 + dr) & 15) + x.c) << 9) | (unsigned)x.y;
+                else if (block != base) *block_ptr(dr, v) = block;
+            }
+            nDef -= n;
+            const unsigned long long lm = __ballot(lush);
+            if (lush) lushBuf[nLush + __popcll(lm & below)] = word;
+            nLush += __popcll(lm);
+            continue;
+        }
+        if (!more) break;
+        if (b >= b1) {                                             // next range
+            const int g = __builtin_amdgcn_readfirstlane((int)drawn) * FILL_COUNTERS + part;
+            if (g >= nRanges) {
+                if (++dry == FILL_COUNTERS) { more = false; continue; }
+                part = (part + 1) % FILL_COUNTERS;
+            }
+            if (lane == 0) drawn = atomicAdd(&work[16 * part], 1u);        // the next draw is in flight while this range is worked on
+            if (g >= nRanges) continue;
+            b = FILL_RANGE * g; b1 = imin(b + FILL_RANGE, total);
+            lrow = rangeRow[g];
+            rowA = batchStart[lrow]; rowB = batchStart[lrow + 1]; cnt = rowCounts[lrow];
+        }
+        while (b >= rowB) { ++lrow; rowA = rowB; rowB = batchStart[lrow + 1]; cnt = rowCounts[lrow]; }      // rows without stone voxels have no batch
+        const int k = 64 * (b - rowA) + lane;
+        const unsigned* list = rowLists + (size_t)FILL_VOX * lrow;
+        unsigned e = ePre;
+        if (preB != b) e = k < cnt ? list[k] : 0u;
+        ++b;
+        if (b < b1 && b < rowB) { ePre = k + 64 < cnt ? list[k + 64] : 0u; preB = b; }      // same row, same range: the next step's entry
+        bool defer = false;
+        uint2 d = make_uint2(0u, (unsigned)lrow);
+        if (k < cnt) {
+            const int v = e & FILL_VMASK;
+            const uint8_t base = (uint8_t)((e >> FILL_VBITS) & 255);
+            const int bdc = (e >> (FILL_VBITS + 8)) & 31, tdc = (e >> (FILL_VBITS + 13)) & 31;
+            const Voxel x = voxel_of(lrow, v);
+            // WARPED / AMBER only act on the top DEEPSLATE / BLACKSTONE block of a cave floor (caveBottomDepth == 0)
+            const bool wantDeep = bdc == 0 && (base == MMB_DEEPSLATE || base == MMB_BLACKSTONE);
+            // LUSH_CAVES only converts within 1.5 + 4.5 simplex3 <= 1.5 + 4.5 * 1.37 = 7.67 blocks of a cave surface: further away only
+            // CRYSTAL_CAVES can change the block (depth codes: 31 = no such surface; MM_SIMPLEX3_BOUND holds inside the pruning domain)
+            static_assert(1.5f + 4.5f * MM_SIMPLEX3_BOUND < 8.f, "depth beyond which LUSH_CAVES cannot convert");
+            const bool crystalOnly = !wantDeep && bdc > 7 && tdc > 7;
+            const float maxHeight = hf[(srcIdx ? srcIdx[x.outChunk] : x.outChunk) * 256 + FILL_ROW * ((row0 + lrow) & 15) + x.c];
+#if MM_FILL_EXP == 4
+            const int cb = (x.wx + x.y + x.wz == 0x7fffffff && maxHeight == 1.f && crystalOnly) ? MMCB_LUSH_CAVES : MMCB_NONE;      // timing experiment: the machinery without the cave biome
+#else
+            const int cb = cave_biome_t<true>(x.wx, x.y, x.wz, maxHeight, 190249401, wantDeep, crystalOnly);
+#endif
+            if (cb == MMCB_CRYSTAL_CAVES || cb == MMCB_LUSH_CAVES) {
+                defer = true;
+                d.x = e | (cb == MMCB_LUSH_CAVES ? 0x80000000u : 0u);
+            } else if (wantDeep && cb != MMCB_NONE) {
+                uint8_t block = base;
+                cave_biome_block_post(block, cb, x.wx, x.y, x.wz, 0, -1);      // WARPED / AMBER re-skin, no noise
+                if (block != base) *block_ptr(lrow, v) = block;
+            }
+        }
+        const unsigned long long dm = __ballot(defer);
+        if (defer) def[nDef + __popcll(dm & below)] = d;
+        nDef += __popcll(dm);
+    }
 }
 
 __global__ void __launch_bounds__(FILL_THREADS)
@@ -990,33 +1293,71 @@ int launch_caves(const float* hf, const float* bw, const int32_t* pos, int n, mm
     return 0;
 }
 
+// Scratch of one launch_fill call (caller-owned, fill_scratch layout below): the lush queue, the work counters of k_fill_cave, and per
+// sub-batch of kFillSub chunks the row lists with their counts / batch prefix / range index.
+namespace {
+struct FillScratch { unsigned* lush; unsigned lushCap; unsigned* work; int* counts; int* batchStart; int* rangeRow; unsigned* lists; size_t bytes; };
+constexpr int kFillBatch = 1 << 14;           // queue entries carry the (batch-relative) chunk index in 15 bits
+constexpr int kFillSub = 1 << 13;             // chunks per k_fill_base / k_fill_cave launch: bounds the row lists (393 KB per chunk)
+inline size_t align256(size_t b) { return (b + 255) / 256 * 256; }
+FillScratch fill_scratch(char* base, int n)      // base may be null: only `bytes` is meaningful then
+{
+    const size_t nb = (size_t)(n < kFillBatch ? n : kFillBatch), rows = 16 * (size_t)(n < kFillSub ? n : kFillSub);
+    FillScratch f;
+    size_t o = 0;
+    f.lush = (unsigned*)(base + o); f.lushCap = (unsigned)(2048 * nb); o += align256(4 * (2048 * nb + 1));
+    f.work = (unsigned*)(base + o); o += align256(64 * FILL_COUNTERS);
+    f.counts = (int*)(base + o); o += align256(4 * rows);
+    f.batchStart = (int*)(base + o); o += align256(4 * (rows + 1));
+    f.rangeRow = (int*)(base + o); o += align256(4 * (rows * (FILL_VOX / 64 / FILL_RANGE) + 1));
+    f.lists = (unsigned*)(base + o); o += 4 * (size_t)FILL_VOX * rows;
+    f.bytes = o;
+    return f;
+}
+}  // namespace
+
+size_t fill_queue_bytes(int n) { return n <= 0 ? 0 : fill_scratch((char*)0x1000, n).bytes; }
+
 int launch_fill(const float* hf, const float* bw, const float* layers, const mmgen_cave_layer* caveLayers, const int32_t* pos, int n,
-                uint8_t* blocks, const int* srcIdx, unsigned* lushQueue, size_t lushQueueBytes, bool allInPruneDomain, hipStream_t s)
+                uint8_t* blocks, const int* srcIdx, unsigned* scratch, size_t scratchBytes, bool allInPruneDomain, hipStream_t s)
 {
     if (n <= 0) return 0;
-    const unsigned cap = lushQueue && lushQueueBytes >= 8 ? (unsigned)(lushQueueBytes / 4 - 1) : 0u;
-    if (!cap) lushQueue = nullptr;
-    constexpr int kBatch = 1 << 14;                // queue entries carry the (batch-relative) chunk index in 15 bits
-    for (int b0 = 0; b0 < n; b0 += kBatch) {
-        const int nb = n - b0 < kBatch ? n - b0 : kBatch;
+    if (!scratch || scratchBytes < fill_queue_bytes(n)) return (int)hipErrorInvalidValue;
+    const FillScratch f = fill_scratch((char*)scratch, n);
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return (int)hipErrorInvalidDevice;
+        cus = prop.multiProcessorCount;
+    }
+    for (int b0 = 0; b0 < n; b0 += kFillBatch) {
+        const int nb = n - b0 < kFillBatch ? n - b0 : kFillBatch;
         // without an index list inputs and outputs are both dense: shift every per-chunk pointer; with one only the list and the output move
         const size_t in0 = srcIdx ? 0 : (size_t)b0;
         const int* idx = srcIdx ? srcIdx + b0 : nullptr;
         uint8_t* out = blocks + (size_t)MMGEN_BLOCKS_PER_CHUNK * b0;
         const int2* p = (const int2*)pos + in0;
-        if (lushQueue) {
-            hipError_t e = hipMemsetAsync(lushQueue, 0, 4, s);                   // the counter; entries are (re)written by every launch
+        const float* hfB = hf + 256 * in0;
+        const float* bwB = bw + (size_t)MMGEN_BIOME_WEIGHTS_SIZE * in0;
+        const float* layB = layers + (size_t)MMGEN_LAYERS_SIZE * in0;
+        const mmgen_cave_layer* clB = caveLayers + (size_t)MMGEN_CAVE_LAYERS_SIZE * in0;
+        hipError_t e = hipMemsetAsync(f.lush, 0, 4, s);                          // the counter; entries are (re)written by every launch
+        if (e != hipSuccess) return (int)e;
+        for (int c0 = 0; c0 < nb; c0 += kFillSub) {
+            const int nc = nb - c0 < kFillSub ? nb - c0 : kFillSub, nRows = nc * (256 / FILL_ROW), row0 = c0 * (256 / FILL_ROW);
+            e = hipMemsetAsync(f.work, 0, 64 * FILL_COUNTERS, s);
             if (e != hipSuccess) return (int)e;
+            LAUNCH(KID_FILL_BASE, mm::k_fill_base, dim3(nRows), dim3(FILLB_THREADS), s, hfB, bwB, layB, clB, p, out, idx, row0, f.lists, f.counts);
+            LAUNCH(KID_FILL_SCAN, mm::k_fill_scan, dim3((nRows + 1023) / 1024), dim3(1024), s, (const int*)f.counts, nRows, f.batchStart, f.rangeRow);
+            // persistent: MM_FILL_WAVES waves per SIMD = that many 4-wave workgroups per CU
+            LAUNCH(KID_FILL, mm::k_fill_cave, dim3(cus * MM_FILL_WAVES), dim3(FILLC_THREADS), s, hfB, p, out, idx, row0, (const unsigned*)f.lists, (const int*)f.counts,
+                   (const int*)f.batchStart, (const int*)f.rangeRow, nRows, f.lush, f.lushCap, f.work);
         }
-        LAUNCH(KID_FILL, mm::k_fill, dim3(nb * (256 / FILL_ROW)), dim3(FILL_THREADS), s, hf + 256 * in0, bw + (size_t)MMGEN_BIOME_WEIGHTS_SIZE * in0,
-               layers + (size_t)MMGEN_LAYERS_SIZE * in0, caveLayers + (size_t)MMGEN_CAVE_LAYERS_SIZE * in0, p, out, idx, lushQueue, cap);
-        if (!allInPruneDomain)             // rows beyond the pruning domain (each kernel leaves the other's rows alone)
-            LAUNCH(KID_FILL_FAR, mm::k_fill_far, dim3(nb * (256 / FILL_ROW)), dim3(FILL_THREADS), s, hf + 256 * in0, bw + (size_t)MMGEN_BIOME_WEIGHTS_SIZE * in0,
-                   layers + (size_t)MMGEN_LAYERS_SIZE * in0, caveLayers + (size_t)MMGEN_CAVE_LAYERS_SIZE * in0, p, out, idx, lushQueue, cap);
-        if (lushQueue) {
-            const unsigned grid = (unsigned)nb * 4 < 2048u ? (unsigned)nb * 4 : 2048u;
-            LAUNCH(KID_FILL_LUSH, mm::k_fill_lush, dim3(grid), dim3(256), s, (const unsigned*)lushQueue, cap, p, idx, out);
-        }
+        if (!allInPruneDomain)             // rows beyond the pruning domain (k_fill_base leaves them alone)
+            LAUNCH(KID_FILL_FAR, mm::k_fill_far, dim3(nb * (256 / FILL_ROW)), dim3(FILL_THREADS), s, hfB, bwB, layB, clB, p, out, idx, f.lush, f.lushCap);
+        const unsigned grid = (unsigned)nb * 4 < 2048u ? (unsigned)nb * 4 : 2048u;
+        LAUNCH(KID_FILL_LUSH, mm::k_fill_lush, dim3(grid), dim3(256), s, (const unsigned*)f.lush, f.lushCap, p, idx, out);
     }
     return 0;
 }

@@ -9,7 +9,7 @@
 namespace mmk {
 
 enum KernelId {
-    KID_HEIGHTFIELD, KID_LAYERS, KID_FIX_BACKWARD, KID_CAVE_COLUMNS, KID_CAVE_VOXELS, KID_CAVE_BIOMES, KID_FILL, KID_FILL_FAR, KID_FILL_LUSH, KID_PROBE,
+    KID_HEIGHTFIELD, KID_LAYERS, KID_FIX_BACKWARD, KID_CAVE_COLUMNS, KID_CAVE_VOXELS, KID_CAVE_BIOMES, KID_FILL, KID_FILL_FAR, KID_FILL_LUSH, KID_FILL_BASE, KID_FILL_SCAN, KID_PROBE,
     KID_EROSION_GATHER, KID_ERODE_INIT, KID_ERODE_PASS, KID_ERODE_WRITEBACK, KID_EROSION_SCATTER,
     KID_FEATURE_PLACEMENTS, KID_GATHER_PLACEMENTS, KID_APPLY_FEATURES, KID_DECORATORS, KID_FEATURE_BOX,
     KID_SELECT, KID_RING_NEED, KID_COPY_PLACEMENTS, KID_RING_PACK, KID_RING_UNPACK,

@@ -16,7 +16,7 @@ std::vector<hipEvent_t> g_pool;
 thread_local ProfRec t_open;
 
 const char* const kKernelNames[KID_COUNT] = {
-    "k_heightfield", "k_layers", "k_fix_backward", "k_cave_columns", "k_cave_voxels", "k_cave_biomes", "k_fill", "k_fill_far", "k_fill_lush", "k_probe",
+    "k_heightfield", "k_layers", "k_fix_backward", "k_cave_columns", "k_cave_voxels", "k_cave_biomes", "k_fill_cave", "k_fill_far", "k_fill_lush", "k_fill_base", "k_fill_scan", "k_probe",
     "k_erosion_gather", "k_erode_init", "k_erode_pass", "k_erode_writeback", "k_erosion_scatter",
     "k_feature_placements", "k_gather_placements", "k_apply_features", "k_decorators", "k_feature_box",
     "k_select", "k_ring_need", "k_copy_placements", "k_ring_pack", "k_ring_unpack",
