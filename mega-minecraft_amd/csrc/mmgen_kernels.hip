@@ -979,7 +979,13 @@ k_fill_base(const float* __restrict__ hf, const float* __restrict__ bw, const fl
         asm volatile("" : "+v"(wz));
         const ColumnBiomes cbi = {s_nzN[c], s_ocean[c] != 0, s_nzIdx[c], s_nzW[c], s_bw[c], s_drawMinY[c], (s_drawWater[c] & 1) != 0, (s_drawWater[c] & 2) != 0};
         const BaseBlock r = place_block_base(cbi, s_lh[c], s_cl[c], y, s_lh[c][MMGEN_NUM_MATERIALS], wx, wz);
+#ifdef MM_FILL_BASE_EXP
+        if (!(MM_FILL_BASE_EXP & 4) || r.block == 255)
+#endif
         outBase[v] = r.block;                                       // k_fill_cave only writes the voxels it changes
+#ifdef MM_FILL_BASE_EXP
+        if (!(MM_FILL_BASE_EXP & 8) || r.block == 255)
+#endif
         if (r.needCave) {
             const int slot = atomicAdd(&s_count, 1);
             const unsigned bdc = r.bottomDepth < 0 ? 31u : (unsigned)imin(r.bottomDepth, 30);
@@ -1033,11 +1039,15 @@ k_fill_cave(const float* __restrict__ hf, const int2* __restrict__ chunkPos, uin
 {
     __shared__ uint2 s_def[FILLC_THREADS / 64][FILLC_DEF_CAP];     // .x = list entry | isLush << 31, .y = row of this launch
     __shared__ unsigned s_lushBuf[FILLC_THREADS / 64][FILLC_LUSH_CAP];      // k_fill_lush's entries: outChunk << 17 | column << 9 | y
+    __shared__ uint2 s_s2[FILLC_THREADS / 64][FILLC_DEF_CAP];      // voxels whose warped height decides nothing: list entry, row of this launch ...
+    __shared__ float s_s2py[FILLC_THREADS / 64][FILLC_DEF_CAP];    // ... and that height
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     noise_tables_init();                                           // once per (persistent) workgroup; no workgroup barrier after this one
     uint2* def = s_def[wave];
     unsigned* lushBuf = s_lushBuf[wave];
-    int nDef = 0, nLush = 0;                                       // wave-uniform
+    uint2* s2 = s_s2[wave];
+    float* s2py = s_s2py[wave];
+    int nDef = 0, nLush = 0, nS2 = 0;                              // wave-uniform
     const unsigned long long below = (1ull << lane) - 1ull;
 
     // the position of a listed voxel; the row's chunk position through L2 (a wave's voxels come from one or two rows)
@@ -1115,6 +1125,43 @@ k_fill_cave(const float* __restrict__ hf, const int2* __restrict__ chunkPos, uin
             nLush += __popcll(lm);
             continue;
         }
+        if (nS2 >= 64 || (!more && nS2 > 0)) {
+            // stage 2 of the cave biome (the x and z components of the warp, rocky, one depth band, the draw) for voxels whose warped
+            // height did not settle it
+            const int n = imin(nS2, 64);
+            wave_lds_sync();
+            bool defer = false;
+            uint2 d = make_uint2(0u, 0u);
+            if (lane < n) {
+                d = s2[nS2 - n + lane];
+                const float py = s2py[nS2 - n + lane];
+                const unsigned e = d.x;
+                const int dr = (int)d.y, v = e & FILL_VMASK;
+                const uint8_t base = (uint8_t)((e >> FILL_VBITS) & 255);
+                const int bdc = (e >> (FILL_VBITS + 8)) & 31, tdc = (e >> (FILL_VBITS + 13)) & 31;
+                const Voxel x = voxel_of(dr, v);
+                const bool wantDeep = bdc == 0 && (base == MMB_DEEPSLATE || base == MMB_BLACKSTONE);
+                // LUSH_CAVES only converts within 1.5 + 4.5 simplex3 <= 1.5 + 4.5 * 1.37 = 7.67 blocks of a cave surface: further away only
+                // CRYSTAL_CAVES can change the block (depth codes: 31 = no such surface; MM_SIMPLEX3_BOUND holds inside the pruning domain)
+                static_assert(1.5f + 4.5f * MM_SIMPLEX3_BOUND < 8.f, "depth beyond which LUSH_CAVES cannot convert");
+                const bool crystalOnly = !wantDeep && bdc > 7 && tdc > 7;
+                const float maxHeight = hf[(srcIdx ? srcIdx[x.outChunk] : x.outChunk) * 256 + FILL_ROW * ((row0 + dr) & 15) + x.c];
+                const int cb = cave_biome_rest<true>(x.wx, x.y, x.wz, maxHeight, 190249401, wantDeep, crystalOnly, py);
+                if (cb == MMCB_CRYSTAL_CAVES || cb == MMCB_LUSH_CAVES) {
+                    defer = true;
+                    d.x = e | (cb == MMCB_LUSH_CAVES ? 0x80000000u : 0u);
+                } else if (wantDeep && cb != MMCB_NONE) {
+                    uint8_t block = base;
+                    cave_biome_block_post(block, cb, x.wx, x.y, x.wz, 0, -1);      // WARPED / AMBER re-skin, no noise
+                    if (block != base) *block_ptr(dr, v) = block;
+                }
+            }
+            nS2 -= n;
+            const unsigned long long dm = __ballot(defer);
+            if (defer) def[nDef + __popcll(dm & below)] = d;
+            nDef += __popcll(dm);
+            continue;
+        }
         if (!more) break;
         if (b >= b1) {                                             // next range
             const int g = __builtin_amdgcn_readfirstlane((int)drawn) * FILL_COUNTERS + part;
@@ -1135,37 +1182,27 @@ k_fill_cave(const float* __restrict__ hf, const int2* __restrict__ chunkPos, uin
         if (preB != b) e = k < cnt ? list[k] : 0u;
         ++b;
         if (b < b1 && b < rowB) { ePre = k + 64 < cnt ? list[k + 64] : 0u; preB = b; }      // same row, same range: the next step's entry
-        bool defer = false;
-        uint2 d = make_uint2(0u, (unsigned)lrow);
+        // stage 1: the warped height (3 of the 9 simplex3 of the warp, the same work in every lane); above / below the depth bands it
+        // settles the biome (NONE), the other voxels go on to stage 2, 64 at a time
+        bool on = false;
+        float py = 0.f;
         if (k < cnt) {
             const int v = e & FILL_VMASK;
             const uint8_t base = (uint8_t)((e >> FILL_VBITS) & 255);
-            const int bdc = (e >> (FILL_VBITS + 8)) & 31, tdc = (e >> (FILL_VBITS + 13)) & 31;
+            const int bdc = (e >> (FILL_VBITS + 8)) & 31;
             const Voxel x = voxel_of(lrow, v);
             // WARPED / AMBER only act on the top DEEPSLATE / BLACKSTONE block of a cave floor (caveBottomDepth == 0)
             const bool wantDeep = bdc == 0 && (base == MMB_DEEPSLATE || base == MMB_BLACKSTONE);
-            // LUSH_CAVES only converts within 1.5 + 4.5 simplex3 <= 1.5 + 4.5 * 1.37 = 7.67 blocks of a cave surface: further away only
-            // CRYSTAL_CAVES can change the block (depth codes: 31 = no such surface; MM_SIMPLEX3_BOUND holds inside the pruning domain)
-            static_assert(1.5f + 4.5f * MM_SIMPLEX3_BOUND < 8.f, "depth beyond which LUSH_CAVES cannot convert");
-            const bool crystalOnly = !wantDeep && bdc > 7 && tdc > 7;
             const float maxHeight = hf[(srcIdx ? srcIdx[x.outChunk] : x.outChunk) * 256 + FILL_ROW * ((row0 + lrow) & 15) + x.c];
 #if MM_FILL_EXP == 4
-            const int cb = (x.wx + x.y + x.wz == 0x7fffffff && maxHeight == 1.f && crystalOnly) ? MMCB_LUSH_CAVES : MMCB_NONE;      // timing experiment: the machinery without the cave biome
+            on = (x.wx + x.y + x.wz == 0x7fffffff && maxHeight == 1.f && wantDeep);      // timing experiment: the machinery without the cave biome
 #else
-            const int cb = cave_biome_t<true>(x.wx, x.y, x.wz, maxHeight, 190249401, wantDeep, crystalOnly);
+            on = !cave_biome_py<true>(x.wx, x.y, x.wz, maxHeight, wantDeep, py);
 #endif
-            if (cb == MMCB_CRYSTAL_CAVES || cb == MMCB_LUSH_CAVES) {
-                defer = true;
-                d.x = e | (cb == MMCB_LUSH_CAVES ? 0x80000000u : 0u);
-            } else if (wantDeep && cb != MMCB_NONE) {
-                uint8_t block = base;
-                cave_biome_block_post(block, cb, x.wx, x.y, x.wz, 0, -1);      // WARPED / AMBER re-skin, no noise
-                if (block != base) *block_ptr(lrow, v) = block;
-            }
         }
-        const unsigned long long dm = __ballot(defer);
-        if (defer) def[nDef + __popcll(dm & below)] = d;
-        nDef += __popcll(dm);
+        const unsigned long long om = __ballot(on);
+        if (on) { const int at = nS2 + __popcll(om & below); s2[at] = make_uint2(e, (unsigned)lrow); s2py[at] = py; }
+        nS2 += __popcll(om);
     }
 }
 
@@ -1350,8 +1387,8 @@ int launch_fill(const float* hf, const float* bw, const float* layers, const mmg
             if (e != hipSuccess) return (int)e;
             LAUNCH(KID_FILL_BASE, mm::k_fill_base, dim3(nRows), dim3(FILLB_THREADS), s, hfB, bwB, layB, clB, p, out, idx, row0, f.lists, f.counts);
             LAUNCH(KID_FILL_SCAN, mm::k_fill_scan, dim3((nRows + 1023) / 1024), dim3(1024), s, (const int*)f.counts, nRows, f.batchStart, f.rangeRow);
-            // persistent: MM_FILL_WAVES waves per SIMD = that many 4-wave workgroups per CU
-            LAUNCH(KID_FILL, mm::k_fill_cave, dim3(cus * MM_FILL_WAVES), dim3(FILLC_THREADS), s, hfB, p, out, idx, row0, (const unsigned*)f.lists, (const int*)f.counts,
+            // persistent: MM_FILL_WAVES waves per SIMD
+            LAUNCH(KID_FILL, mm::k_fill_cave, dim3(cus * (4 * MM_FILL_WAVES / (FILLC_THREADS / 64))), dim3(FILLC_THREADS), s, hfB, p, out, idx, row0, (const unsigned*)f.lists, (const int*)f.counts,
                    (const int*)f.batchStart, (const int*)f.rangeRow, nRows, f.lush, f.lushCap, f.work);
         }
         if (!allInPruneDomain)             // rows beyond the pruning domain (k_fill_base leaves them alone)
