@@ -29,7 +29,7 @@ extern "C" {
  * single-threaded, terrain.cpp:587-960).  A mmgen_region owns its scratch. */
 int mmgen_init(int device);
 const char* mmgen_error_string(int code);
-/* pre-size the library-internal scratch of the per-stage calls on `stream` (per-column cave info, deferred-voxel queue) so that later
+/* pre-size the library-internal scratch of the per-stage calls on `stream` (per-column cave info, fill's voxel lists: 393 KB per chunk, at most 8 192 chunks' worth) so that later
  * calls on that stream allocate nothing (graph capture).  Scratch is keyed by (device, stream). */
 int mmgen_reserve(int max_chunks_per_call, void* stream);
 /* frees the library-internal scratch kept for `stream` on the current device (synchronises it first): call before destroying a stream,
