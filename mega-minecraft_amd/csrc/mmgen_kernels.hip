@@ -888,7 +888,7 @@ MM_DEV void fill_body(const float* __restrict__ hf, const float* __restrict__ bw
 //   k_fill_base  one workgroup = one row: every voxel's base block, written; the stone voxels a cave biome could still alter are appended
 //                to the row's list in global memory (4 bytes each).  No noise tables unless a biome with a noise rule has weight in the
 //                row, 9 KB of LDS: seven workgroups per CU hide the staging latency that three 50 KB workgroups of the fused kernel could not.
-//   k_fill_scan  exclusive prefix of the rows' 64-voxel batch counts + the row each range of FILL_RANGE batches starts in.
+//   k_fill_scan  exclusive prefix of the rows' 64-voxel batch counts + the row each range of `range` batches starts in.
 //   k_fill_cave  persistent waves, no workgroup barrier after the tables are staged: a wave draws ranges of batches from work counters
 //                (k_apply_features' scheme) and evaluates the cave biome of 64 listed voxels at a time, every lane busy whatever row the
 //                voxels come from.  CRYSTAL / LUSH voxels (their rules start with one more simplex3) are set aside in a per-wave LDS
@@ -896,7 +896,8 @@ MM_DEV void fill_body(const float* __restrict__ hf, const float* __restrict__ bw
 //                per-wave buffer to the device-wide queue of k_fill_lush, 64 per reservation.
 // k_fill_far (fill_body<false>) keeps the rows beyond the domain, the fused way.
 // ---------------------------------------------------------------------------------------------------------
-#define FILL_RANGE 8             // batches per draw: ~60 us of work, the longest a wave can still be busy after the others ran dry
+#define FILL_RANGE 8             // batches per draw at most: ~60 us of work, the longest a wave can still be busy after the others ran dry
+                                 // (small launches draw smaller ranges: launch_fill)
 #define FILL_COUNTERS 16         // work counters, 64 B apart (one serialises at ~11 ns per draw in L2)
 #define FILLB_THREADS 256
 #define FILLC_THREADS 256
@@ -998,9 +999,9 @@ k_fill_base(const float* __restrict__ hf, const float* __restrict__ bw, const fl
 }
 
 // batchStart[r] = number of 64-voxel batches in the lists of the rows before r (batchStart[nRows] = all of them); rangeRow[g] = the row
-// batch FILL_RANGE * g lies in.  One workgroup per 1 024 rows; each sums the counts before its rows itself (a few hundred KB out of L2).
+// batch range * g lies in.  One workgroup per 1 024 rows; each sums the counts before its rows itself (a few hundred KB out of L2).
 __global__ void __launch_bounds__(1024)
-k_fill_scan(const int* __restrict__ rowCounts, int nRows, int* __restrict__ batchStart, int* __restrict__ rangeRow)
+k_fill_scan(const int* __restrict__ rowCounts, int nRows, int range, int* __restrict__ batchStart, int* __restrict__ rangeRow)
 {
     __shared__ int s_w[16], s_offset;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -1027,7 +1028,7 @@ k_fill_scan(const int* __restrict__ rowCounts, int nRows, int* __restrict__ batc
     if (row < nRows) {
         batchStart[row] = a;
         if (row == nRows - 1) batchStart[nRows] = b;
-        for (int g = (a + FILL_RANGE - 1) / FILL_RANGE; g * FILL_RANGE < b; ++g) rangeRow[g] = row;
+        for (int g = (a + range - 1) / range; g * range < b; ++g) rangeRow[g] = row;
     }
 }
 
@@ -1035,7 +1036,7 @@ __attribute__((amdgpu_waves_per_eu(MM_FILL_WAVES, MM_FILL_WAVES)))
 __global__ void __launch_bounds__(FILLC_THREADS)
 k_fill_cave(const float* __restrict__ hf, const int2* __restrict__ chunkPos, uint8_t* __restrict__ blocks, const int* __restrict__ srcIdx, int row0,
             const unsigned* __restrict__ rowLists, const int* __restrict__ rowCounts, const int* __restrict__ batchStart, const int* __restrict__ rangeRow,
-            int nRows, unsigned* __restrict__ lushQueue /*[0] = count, entries from [1]; nullable*/, unsigned lushCap, unsigned* __restrict__ work)
+            int nRows, int range, unsigned* __restrict__ lushQueue /*[0] = count, entries from [1]; nullable*/, unsigned lushCap, unsigned* __restrict__ work)
 {
     __shared__ uint2 s_def[FILLC_THREADS / 64][FILLC_DEF_CAP];     // .x = list entry | isLush << 31, .y = row of this launch
     __shared__ unsigned s_lushBuf[FILLC_THREADS / 64][FILLC_LUSH_CAP];      // k_fill_lush's entries: outChunk << 17 | column << 9 | y
@@ -1063,7 +1064,7 @@ k_fill_cave(const float* __restrict__ hf, const int2* __restrict__ chunkPos, uin
     };
     auto block_ptr = [&](int lrow, int v) { const int bid = row0 + lrow; return blocks + (size_t)MMGEN_BLOCKS_PER_CHUNK * (bid >> 4) + 384 * FILL_ROW * (bid & 15) + v; };
 
-    const int total = batchStart[nRows], nRanges = (total + FILL_RANGE - 1) / FILL_RANGE;
+    const int total = batchStart[nRows], nRanges = (total + range - 1) / range;
     int part = (int)((FILLC_THREADS / 64) * blockIdx.x + wave) % FILL_COUNTERS, dry = 0;
     unsigned drawn = 0u;
     if (lane == 0) drawn = atomicAdd(&work[16 * part], 1u);
@@ -1171,7 +1172,7 @@ k_fill_cave(const float* __restrict__ hf, const int2* __restrict__ chunkPos, uin
             }
             if (lane == 0) drawn = atomicAdd(&work[16 * part], 1u);        // the next draw is in flight while this range is worked on
             if (g >= nRanges) continue;
-            b = FILL_RANGE * g; b1 = imin(b + FILL_RANGE, total);
+            b = range * g; b1 = imin(b + range, total);
             lrow = rangeRow[g];
             rowA = batchStart[lrow]; rowB = batchStart[lrow + 1]; cnt = rowCounts[lrow];
         }
@@ -1346,7 +1347,7 @@ FillScratch fill_scratch(char* base, int n)      // base may be null: only `byte
     f.work = (unsigned*)(base + o); o += align256(64 * FILL_COUNTERS);
     f.counts = (int*)(base + o); o += align256(4 * rows);
     f.batchStart = (int*)(base + o); o += align256(4 * (rows + 1));
-    f.rangeRow = (int*)(base + o); o += align256(4 * (rows * (FILL_VOX / 64 / FILL_RANGE) + 1));
+    f.rangeRow = (int*)(base + o); o += align256(4 * (rows * (FILL_VOX / 64) + 1));      // ranges of one batch, every voxel listed: the most there can be
     f.lists = (unsigned*)(base + o); o += 4 * (size_t)FILL_VOX * rows;
     f.bytes = o;
     return f;
@@ -1386,10 +1387,13 @@ int launch_fill(const float* hf, const float* bw, const float* layers, const mmg
             e = hipMemsetAsync(f.work, 0, 64 * FILL_COUNTERS, s);
             if (e != hipSuccess) return (int)e;
             LAUNCH(KID_FILL_BASE, mm::k_fill_base, dim3(nRows), dim3(FILLB_THREADS), s, hfB, bwB, layB, clB, p, out, idx, row0, f.lists, f.counts);
-            LAUNCH(KID_FILL_SCAN, mm::k_fill_scan, dim3((nRows + 1023) / 1024), dim3(1024), s, (const int*)f.counts, nRows, f.batchStart, f.rangeRow);
+            // a row lists ~28 batches; enough ranges for every wave to draw a few (a 256-chunk call would otherwise hand 2 ranges to each)
+            const long long perWave = 28LL * nRows / ((long long)cus * 4 * MM_FILL_WAVES * 6);
+            const int range = perWave < 1 ? 1 : (perWave > FILL_RANGE ? FILL_RANGE : (int)perWave);
+            LAUNCH(KID_FILL_SCAN, mm::k_fill_scan, dim3((nRows + 1023) / 1024), dim3(1024), s, (const int*)f.counts, nRows, range, f.batchStart, f.rangeRow);
             // persistent: MM_FILL_WAVES waves per SIMD
             LAUNCH(KID_FILL, mm::k_fill_cave, dim3(cus * (4 * MM_FILL_WAVES / (FILLC_THREADS / 64))), dim3(FILLC_THREADS), s, hfB, p, out, idx, row0, (const unsigned*)f.lists, (const int*)f.counts,
-                   (const int*)f.batchStart, (const int*)f.rangeRow, nRows, f.lush, f.lushCap, f.work);
+                   (const int*)f.batchStart, (const int*)f.rangeRow, nRows, range, f.lush, f.lushCap, f.work);
         }
         if (!allInPruneDomain)             // rows beyond the pruning domain (k_fill_base leaves them alone)
             LAUNCH(KID_FILL_FAR, mm::k_fill_far, dim3(nb * (256 / FILL_ROW)), dim3(FILL_THREADS), s, hfB, bwB, layB, clB, p, out, idx, f.lush, f.lushCap);
