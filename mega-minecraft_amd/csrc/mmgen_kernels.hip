@@ -970,9 +970,15 @@ k_fill_base(const float* __restrict__ hf, const float* __restrict__ bw, const fl
     // Walk: a wave = 16 consecutive y of four neighbouring columns (16-byte pieces per column in a wave's store), the four column groups
     // of a 16-y block in four consecutive waves: the list comes out ordered by depth, and the exits of the cave-biome evaluation - which
     // go by depth zone - retire whole waves of k_fill_cave instead of idling lanes
+    static_assert(FILLB_THREADS == 256, "the walk below: a thread keeps its column, y advances by 16 per iteration");
+    const int c = 4 * (t >> 6) + (t & 3);
+    // everything above the column's surface and the sea is air (place_block_base's first test): nothing else is evaluated there - two
+    // thirds of a generated world's voxels
+    const int yAir = imax((int)__builtin_floorf(s_lh[c][MMGEN_NUM_MATERIALS]), MMGEN_SEA_LEVEL);      // y > yAir  <=>  fy > height && y > SEA_LEVEL
     for (int u = t; u < FILL_VOX; u += FILLB_THREADS) {
-        const int c = 4 * ((u >> 6) & 3) + (u & 3), y = 16 * (u >> 8) + ((u >> 2) & 15);
+        const int y = 16 * (u >> 8) + ((u >> 2) & 15);
         const int v = 384 * c + y;                                  // position in the row's 6 144 output bytes
+        if (y > yAir) { outBase[v] = MMB_AIR; continue; }
         const int wx = cp.x + c;
         int wz = cp.y + row;
         // wz is the same for the whole workgroup (one row of a chunk): left visible, the compiler hoists (float)wz * scale for each of the six
