@@ -906,6 +906,10 @@ MM_DEV void fill_body(const float* __restrict__ hf, const float* __restrict__ bw
 #define FILLC_DEF_CAP 128        // per wave: CRYSTAL / LUSH voxels waiting for their noise rule
 #define FILLC_LUSH_CAP 128       // per wave: lush voxels waiting for a queue reservation
 
+#ifndef MM_FILLB_WAVES
+#define MM_FILLB_WAVES 7          // what 21.7 KB of LDS per workgroup allows
+#endif
+__attribute__((amdgpu_waves_per_eu(MM_FILLB_WAVES, MM_FILLB_WAVES)))
 __global__ void __launch_bounds__(FILLB_THREADS)
 k_fill_base(const float* __restrict__ hf, const float* __restrict__ bw, const float* __restrict__ layers, const mmgen_cave_layer* __restrict__ caveLayers,
             const int2* __restrict__ chunkPos, uint8_t* __restrict__ blocks, const int* __restrict__ srcIdx, int row0,
@@ -943,21 +947,34 @@ k_fill_base(const float* __restrict__ hf, const float* __restrict__ bw, const fl
         ((int*)s_cl)[i] = ((const int*)(caveLayers + (size_t)MMGEN_MAX_CAVE_LAYERS_PER_COLUMN * (chunk * 256 + idxBase)))[i];
     if (t == 0) { s_count = 0; s_needTables = 0; }
     __syncthreads();
-    if (t < FILL_ROW) {
-        int n = 0, minY = 384;
-        bool ocean = false, water = false;
-        for (int b = 0; b < MMGEN_NUM_BIOMES; ++b) {
-            const float w = s_bw[t][b];
-            if (b < MMGEN_NUM_OCEAN_BIOMES) ocean = ocean || (w > 0.f);
-            if (b == 0 || w > 0.f) { if (n < FILL_NZ_CAP) { s_nzIdx[t][n] = (uint8_t)b; s_nzW[t][n] = w; } ++n; }
-            // (biome 0 can be drawn at weight 0 and PLAINS is the walk's fall-through: neither has a rule)
-            if (w > 0.f) { minY = imin(minY, biome_rule_min_y(b, s_lh[t][MMGEN_NUM_MATERIALS])); water = water || b == MMBIO_FROZEN_WASTELAND; }
+    {
+        // per column: the biomes of positive weight (plus biome 0) in ascending order, and what the voxel loop needs to know about them -
+        // 16 lanes per column (lane g looks at biomes g and g + 16, at layer pairs g and g + 16), ordered by ballots
+        static_assert(FILLB_THREADS == 16 * FILL_ROW && MMGEN_NUM_BIOMES <= 32 && MMGEN_NUM_MATERIALS <= 32, "16 lanes per column");
+        const int c = t >> 4, g = t & 15, shift = 16 * ((t & 63) >> 4);
+        auto group = [&](bool p) { return (unsigned)(__ballot(p) >> shift) & 0xffffu; };      // the predicate over this column's 16 lanes
+        const float height = s_lh[c][MMGEN_NUM_MATERIALS];
+        const bool has1 = g + 16 < MMGEN_NUM_BIOMES;
+        const float w0 = s_bw[c][g], w1 = has1 ? s_bw[c][g + 16] : 0.f;
+        const bool k0 = g == 0 || w0 > 0.f, k1 = has1 && w1 > 0.f;
+        const unsigned m0 = group(k0), m1 = group(k1), lower = (1u << g) - 1u;
+        const int n0 = __popc(m0), pos0 = __popc(m0 & lower), pos1 = n0 + __popc(m1 & lower);
+        if (k0 && pos0 < FILL_NZ_CAP) { s_nzIdx[c][pos0] = (uint8_t)g; s_nzW[c][pos0] = w0; }
+        if (k1 && pos1 < FILL_NZ_CAP) { s_nzIdx[c][pos1] = (uint8_t)(g + 16); s_nzW[c][pos1] = w1; }
+        const bool ocean = group((g < MMGEN_NUM_OCEAN_BIOMES && w0 > 0.f) || (g + 16 < MMGEN_NUM_OCEAN_BIOMES && w1 > 0.f)) != 0u;
+        // (biome 0 can be drawn at weight 0 and PLAINS is the walk's fall-through: neither has a rule)
+        int minY = imin(w0 > 0.f ? biome_rule_min_y(g, height) : 384, w1 > 0.f ? biome_rule_min_y(g + 16, height) : 384);
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) minY = imin(minY, __shfl_xor(minY, o));
+        const bool water = group((g == MMBIO_FROZEN_WASTELAND && w0 > 0.f) || (g + 16 == MMBIO_FROZEN_WASTELAND && w1 > 0.f)) != 0u;
+        const int l1 = g + 16;
+        const bool ok0 = g == MMGEN_NUM_FORWARD_MATERIALS - 1 || s_lh[c][g] <= s_lh[c][g + 1];
+        const bool ok1 = l1 >= MMGEN_NUM_MATERIALS || l1 == MMGEN_NUM_FORWARD_MATERIALS - 1 || s_lh[c][l1] <= s_lh[c][l1 + 1];
+        const bool sorted = group(ok0 && ok1) == 0xffffu;
+        if (g == 0) {
+            s_nzN[c] = (uint8_t)(n0 + __popc(m1)); s_ocean[c] = ocean ? 1 : 0; s_drawMinY[c] = (short)minY; s_drawWater[c] = (water ? 1 : 0) | (sorted ? 2 : 0);
+            if (minY < 384) s_needTables = 1;                       // every rule with a height threshold is a noise rule (biome_rule_min_y)
         }
-        bool sorted = true;
-        for (int l = 0; l < MMGEN_NUM_MATERIALS; ++l)
-            if (l != MMGEN_NUM_FORWARD_MATERIALS - 1) sorted = sorted && s_lh[t][l] <= s_lh[t][l + 1];
-        s_nzN[t] = (uint8_t)n; s_ocean[t] = ocean ? 1 : 0; s_drawMinY[t] = (short)minY; s_drawWater[t] = (water ? 1 : 0) | (sorted ? 2 : 0);
-        if (minY < 384) s_needTables = 1;                           // every rule with a height threshold is a noise rule (biome_rule_min_y)
     }
     __syncthreads();
     // simplex tables only for the rows in which a biome with a noise rule has weight (a biome is only drawn at positive weight)
