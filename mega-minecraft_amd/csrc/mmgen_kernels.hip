@@ -28,7 +28,11 @@ MM_DEV int xcd_block(int b, int n) { return (!MM_XCD_SWIZZLE || (n & 511)) ? b :
 // K1 — heightfield + 24 biome weights.  GATHERED variant also produces the 18x18 ring the layer stage needs
 // (the ring heights are a pure function of position, so no neighbour chunk is read).
 // =========================================================================================================
+#ifndef MM_HF_WAVES
+#define MM_HF_WAVES 6           // latency bound (a lane = one column's chain of table lookups): 0.81 / 0.70 / 0.56 ms at 4 / 5 / 6 waves per SIMD
+#endif
 template <bool GATHERED>
+__attribute__((amdgpu_waves_per_eu(MM_HF_WAVES, MM_HF_WAVES)))
 __global__ void __launch_bounds__(GATHERED ? 384 : 256)
 k_heightfield(const int2* __restrict__ chunkPos, float* __restrict__ hf, float* __restrict__ bw, float* __restrict__ gathered)
 {
@@ -50,12 +54,27 @@ k_heightfield(const int2* __restrict__ chunkPos, float* __restrict__ hf, float* 
 
     const float wx = (float)(cp.x + x), wz = (float)(cp.y + z);
     const BiomeNoise bn = biome_noise(wx, wz);
-    float height = 0.f;
+    // The weights first, then the heights of the biomes that have one: the loop of the 24 height functions (the register peak of the
+    // kernel) keeps a mask of the positive weights instead of the biome noise, and reads each weight back from where it was just
+    // stored - its plane for the chunk's own columns, an LDS row for the 68 ring columns of the gathered variant.
+    __shared__ float s_ringW[GATHERED ? MMGEN_NUM_BIOMES * 68 : 1];
     float* wout = bw + (size_t)MMGEN_BIOME_WEIGHTS_SIZE * chunk + idx;
+    int stride = 256;
+    if (GATHERED && !interior) {
+        const int ord = z == -1 ? x + 1 : (z == 16 ? 19 + x : (x == -1 ? 36 + z : 52 + z));      // 18 + 18 + 16 + 16 ring columns
+        wout = s_ringW + ord;
+        stride = 68;
+    }
+    unsigned positive = 0u;
     for (int b = 0; b < MMGEN_NUM_BIOMES; ++b) {
         const float w = biome_weight(b, bn);
-        if (w > 0.f) height += w * biome_height(b, wx, wz);
-        if (interior) wout[256 * b] = w;
+        if (w > 0.f) positive |= 1u << b;
+        wout[stride * b] = w;
+    }
+    float height = 0.f;
+    for (int b = 0; b < MMGEN_NUM_BIOMES; ++b) {
+        if (!((positive >> b) & 1u)) continue;
+        height += wout[stride * b] * biome_height(b, wx, wz);
     }
     if (interior) hf[(size_t)256 * chunk + idx] = height;
     if (GATHERED) gathered[(size_t)MMGEN_GATHERED_HEIGHTFIELD_SIZE * chunk + t] = height;
@@ -496,6 +515,9 @@ k_cave_voxels(const float* __restrict__ hf, const float2* __restrict__ colInfo, 
 #define CB_THREADS 256
 #endif
 #define CB_SURV_CAP 1024   // items of a group that outlive the warped-height stage (typically a few hundred of ~ 800); the surplus is finished in place
+#ifdef MM_CB_WAVES
+__attribute__((amdgpu_waves_per_eu(MM_CB_WAVES, MM_CB_WAVES)))
+#endif
 __global__ void __launch_bounds__(CB_THREADS)
 k_cave_biomes(const float* __restrict__ hf, const int2* __restrict__ chunkPos, mmgen_cave_layer* __restrict__ caveLayers,
               const int* __restrict__ chunkList)
