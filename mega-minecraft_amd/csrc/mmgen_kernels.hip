@@ -509,7 +509,7 @@ k_cave_voxels(const float* __restrict__ hf, const float2* __restrict__ colInfo, 
 // 32 slots are occupied.  One workgroup = CB_COLS columns of a chunk: the (column, slot, bottom | top) evaluations that exist are
 // compacted into an LDS list and walked densely, so that every lane of every pass carries one.
 #ifndef CB_COLS
-#define CB_COLS 128        // measured (columns x threads): 32 x 128 1.35 ms, 64 x 128 1.31, 128 x 128 1.71, 128 x 256 1.17, 256 x 256 1.48
+#define CB_COLS 64         // measured (columns x threads), two-stage kernel: 32 x 128 0.84 ms, 64 x 128 0.77, 64 x 256 0.64, 128 x 256 0.69, 256 x 256 0.80
 #endif
 #ifndef CB_THREADS
 #define CB_THREADS 256
