@@ -506,80 +506,123 @@ k_cave_voxels(const float* __restrict__ hf, const float2* __restrict__ colInfo, 
 }
 
 // Cave biomes of the layers' end blocks: at most 2 getCaveBiome evaluations per occupied layer slot, and only a few of a column's
-// 32 slots are occupied.  One workgroup = CB_COLS columns of a chunk: the (column, slot, bottom | top) evaluations that exist are
-// compacted into an LDS list and walked densely, so that every lane of every pass carries one.
-#ifndef CB_COLS
-#define CB_COLS 64         // measured (columns x threads), two-stage kernel: 32 x 128 0.84 ms, 64 x 128 0.77, 64 x 256 0.64, 128 x 256 0.69, 256 x 256 0.80
-#endif
-#ifndef CB_THREADS
+// 32 slots are occupied.  Persistent waves, no workgroup barrier after the tables are staged (k_fill_cave's scheme): a wave draws UNITS
+// of 64 columns from work counters, walks their slots (lane = column, slot by slot until no column has one left), and streams the
+// (column, slot, bottom | top) evaluations that exist through two per-wave LDS buffers: stage 1 = the warped height of 64 items (far
+// above the depth bands it settles the biome: NONE), stage 2 = the rest of the evaluation for 64 survivors.  Every stage runs with full
+// waves whatever unit its items came from.
 #define CB_THREADS 256
+#define CB_UNIT_COLS 64
+#define CB_COUNTERS 16
+#define CB_S1_CAP 192      // < 64 waiting + at most 128 new ones per slot round
+#define CB_S2_CAP 128
+#ifndef MM_CB_WAVES
+#define MM_CB_WAVES 6
 #endif
-#define CB_SURV_CAP 1024   // items of a group that outlive the warped-height stage (typically a few hundred of ~ 800); the surplus is finished in place
-#ifdef MM_CB_WAVES
 __attribute__((amdgpu_waves_per_eu(MM_CB_WAVES, MM_CB_WAVES)))
-#endif
 __global__ void __launch_bounds__(CB_THREADS)
 k_cave_biomes(const float* __restrict__ hf, const int2* __restrict__ chunkPos, mmgen_cave_layer* __restrict__ caveLayers,
-              const int* __restrict__ chunkList)
+              const int* __restrict__ chunkList, int nUnits, unsigned* __restrict__ work)
 {
-    __shared__ unsigned short s_items[CB_COLS * MMGEN_MAX_CAVE_LAYERS_PER_COLUMN * 2];    // (column * 32 + slot) << 1 | top
-    __shared__ unsigned short s_surv[CB_SURV_CAP];                                        // items whose warped height decides nothing ...
-    __shared__ float s_py[CB_SURV_CAP];                                                   // ... with that height
-    __shared__ int s_count[2];
-    constexpr int groupsPerChunk = 256 / CB_COLS;
-    const int chunk = chunkList ? chunkList[blockIdx.x / groupsPerChunk] : (int)(blockIdx.x / groupsPerChunk);
-    const int col0 = (blockIdx.x % groupsPerChunk) * CB_COLS;
-    const int t = threadIdx.x;
-    mmgen_cave_layer* L0 = caveLayers + ((size_t)256 * chunk + col0) * MMGEN_MAX_CAVE_LAYERS_PER_COLUMN;
-    if (t < 2) s_count[t] = 0;
-    noise_tables_init();                                       // ends with the workgroup barrier
-    // slot-major walk (lane -> column u % CB_COLS, slot u / CB_COLS): the item list comes out ordered by depth (slot 0 = the lowest layer of
-    // every column first), and cave_biome's exits go by depth zone
-    for (int u = t; u < CB_COLS * MMGEN_MAX_CAVE_LAYERS_PER_COLUMN; u += CB_THREADS) {
-        const int i = (u % CB_COLS) * MMGEN_MAX_CAVE_LAYERS_PER_COLUMN + u / CB_COLS;
-        const int start = L0[i].start, end = L0[i].end;
-        if (start == 384) continue;                            // unused slot: biomes stay NONE (0)
-        const int n = (end == 384) ? 1 : 2;                    // a layer open to the sky has no top block: top biome NONE
-        const int at = atomicAdd(&s_count[0], n);
-        s_items[at] = (unsigned short)(i << 1);
-        if (n == 2) s_items[at + 1] = (unsigned short)((i << 1) | 1);
-        else L0[i].top_biome = (uint8_t)MMCB_NONE;
-    }
-    __syncthreads();
-    const int count = s_count[0];
-    const int2 cp = chunkPos[chunk];
-    const bool near = prune_domain(cp.x, cp.y + (col0 >> 4)) && prune_domain(cp.x + 15, cp.y + ((col0 + CB_COLS - 1) >> 4));      // the group's columns
-    auto item_of = [&](int item, int& wx, int& wy, int& wz, float& maxHeight, int& seed) {
-        const int i = item >> 1, top = item & 1;
-        const int col = col0 + i / MMGEN_MAX_CAVE_LAYERS_PER_COLUMN;
-        wx = cp.x + (col & 15); wz = cp.y + (col >> 4);
-        maxHeight = hf[(size_t)256 * chunk + col];
-        wy = top ? L0[i].end + 1 : L0[i].start;
-        seed = top ? 4982921 : 329271348;
+    __shared__ uint2 s_s1[CB_THREADS / 64][CB_S1_CAP];         // .x = list index << 14 | column << 6 | slot << 1 | top, .y = y of the block
+    __shared__ uint2 s_s2[CB_THREADS / 64][CB_S2_CAP];
+    __shared__ float s_py[CB_THREADS / 64][CB_S2_CAP];         // stage 2: the item's warped height
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    noise_tables_init();                                       // once per (persistent) workgroup; no workgroup barrier after this one
+    uint2* s1 = s_s1[wave];
+    uint2* s2 = s_s2[wave];
+    float* s2py = s_py[wave];
+    int n1 = 0, n2 = 0;                                        // wave-uniform
+    const unsigned long long below = (1ull << lane) - 1ull;
+
+    struct Item { int chunk, col, wx, wz, seed; float maxHeight; bool near; };
+    auto item_of = [&](unsigned id) {
+        Item it;
+        const int li = (int)(id >> 14);
+        it.chunk = chunkList ? chunkList[li] : li;
+        it.col = (id >> 6) & 255;
+        const int2 cp = chunkPos[it.chunk];
+        it.wx = cp.x + (it.col & 15); it.wz = cp.y + (it.col >> 4);
+        it.maxHeight = hf[(size_t)256 * it.chunk + it.col];
+        it.seed = (id & 1u) ? 4982921 : 329271348;
+        it.near = prune_domain(it.wx, it.wz);
+        return it;
     };
-    auto store = [&](int item, int biome) {
-        if (item & 1) L0[item >> 1].top_biome = (uint8_t)biome; else L0[item >> 1].bottom_biome = (uint8_t)biome;
+    auto store = [&](unsigned id, const Item& it, int biome) {
+        mmgen_cave_layer* l = caveLayers + ((size_t)256 * it.chunk + it.col) * MMGEN_MAX_CAVE_LAYERS_PER_COLUMN + ((id >> 1) & 31);
+        if (id & 1u) l->top_biome = (uint8_t)biome; else l->bottom_biome = (uint8_t)biome;
     };
-    // phase 1: the warped height of every item (3 simplex3, the same work in every lane); far above the depth bands the biome is NONE
-    // (inside the pruning domain).  The others are compacted again with their height ...
-    for (int k = t; k < count; k += CB_THREADS) {
-        const int item = s_items[k];
-        int wx, wy, wz, seed; float maxHeight, py;
-        item_of(item, wx, wy, wz, maxHeight, seed);
-        const bool none = near ? cave_biome_py<true>(wx, wy, wz, maxHeight, true, py) : cave_biome_py<false>(wx, wy, wz, maxHeight, true, py);
-        if (none) { store(item, MMCB_NONE); continue; }
-        const int at = atomicAdd(&s_count[1], 1);
-        if (at < CB_SURV_CAP) { s_surv[at] = (unsigned short)item; s_py[at] = py; }
-        else store(item, near ? cave_biome_rest<true>(wx, wy, wz, maxHeight, seed, true, false, py) : cave_biome_rest<false>(wx, wy, wz, maxHeight, seed, true, false, py));
-    }
-    __syncthreads();
-    // ... phase 2: the rest of the evaluation, densely over the survivors
-    const int nSurv = imin(s_count[1], CB_SURV_CAP);
-    for (int k = t; k < nSurv; k += CB_THREADS) {
-        const int item = s_surv[k];
-        int wx, wy, wz, seed; float maxHeight;
-        item_of(item, wx, wy, wz, maxHeight, seed);
-        store(item, near ? cave_biome_rest<true>(wx, wy, wz, maxHeight, seed, true, false, s_py[k]) : cave_biome_rest<false>(wx, wy, wz, maxHeight, seed, true, false, s_py[k]));
+
+    int part = (int)((CB_THREADS / 64) * blockIdx.x + wave) % CB_COUNTERS, dry = 0;
+    unsigned drawn = 0u;
+    if (lane == 0) drawn = atomicAdd(&work[16 * part], 1u);
+    bool more = true;                                          // units left to draw
+    int unit = -1, slot = MMGEN_MAX_CAVE_LAYERS_PER_COLUMN;    // the unit being walked and its next slot round (32 = done)
+    for (;;) {
+        if (n2 >= 64 || (!more && n1 == 0 && n2 > 0)) {
+            // stage 2: the rest of getCaveBiome for items whose warped height did not settle it
+            const int n = imin(n2, 64);
+            wave_lds_sync();
+            if (lane < n) {
+                const uint2 d = s2[n2 - n + lane];
+                const float py = s2py[n2 - n + lane];
+                const Item it = item_of(d.x);
+                store(d.x, it, it.near ? cave_biome_rest<true>(it.wx, (int)d.y, it.wz, it.maxHeight, it.seed, true, false, py)
+                                       : cave_biome_rest<false>(it.wx, (int)d.y, it.wz, it.maxHeight, it.seed, true, false, py));
+            }
+            n2 -= n;
+            continue;
+        }
+        if (n1 >= 64 || (!more && n1 > 0)) {
+            // stage 1: the warped height (3 simplex3, the same work in every lane)
+            const int n = imin(n1, 64);
+            wave_lds_sync();
+            bool on = false;
+            uint2 d = make_uint2(0u, 0u);
+            float py = 0.f;
+            if (lane < n) {
+                d = s1[n1 - n + lane];
+                const Item it = item_of(d.x);
+                const bool none = it.near ? cave_biome_py<true>(it.wx, (int)d.y, it.wz, it.maxHeight, true, py)
+                                          : cave_biome_py<false>(it.wx, (int)d.y, it.wz, it.maxHeight, true, py);
+                if (none) store(d.x, it, MMCB_NONE); else on = true;
+            }
+            n1 -= n;
+            const unsigned long long om = __ballot(on);
+            if (on) { const int at = n2 + __popcll(om & below); s2[at] = d; s2py[at] = py; }
+            n2 += __popcll(om);
+            continue;
+        }
+        if (!more) break;
+        if (slot >= MMGEN_MAX_CAVE_LAYERS_PER_COLUMN) {              // next unit
+            const int u = __builtin_amdgcn_readfirstlane((int)drawn) * CB_COUNTERS + part;
+            if (u >= nUnits) {
+                if (++dry == CB_COUNTERS) { more = false; continue; }
+                part = (part + 1) % CB_COUNTERS;
+            }
+            if (lane == 0) drawn = atomicAdd(&work[16 * part], 1u);  // the next draw is in flight while this unit is walked
+            if (u >= nUnits) continue;
+            unit = u; slot = 0;
+        }
+        // one slot of the unit's 64 columns (lane = column): a used slot has one item (its bottom block) or two (a layer open to the sky
+        // has no top block: top biome NONE); used slots come first in a column, the walk ends when no column has one left
+        constexpr int unitsPerChunk = 256 / CB_UNIT_COLS;
+        const int li = unit / unitsPerChunk, col = CB_UNIT_COLS * (unit % unitsPerChunk) + lane;
+        const int chunk = chunkList ? chunkList[li] : li;
+        mmgen_cave_layer* l = caveLayers + ((size_t)256 * chunk + col) * MMGEN_MAX_CAVE_LAYERS_PER_COLUMN + slot;
+        const int start = l->start, end = l->end;
+        const bool used = start != 384, two = used && end != 384;
+        const unsigned long long um = __ballot(used), tm = __ballot(two);
+        if (um == 0ull) { slot = MMGEN_MAX_CAVE_LAYERS_PER_COLUMN; continue; }
+        if (used) {
+            if (!two) l->top_biome = (uint8_t)MMCB_NONE;
+            const unsigned id = ((unsigned)li << 14) | ((unsigned)col << 6) | ((unsigned)slot << 1);
+            const int at = n1 + __popcll(um & below) + __popcll(tm & below);
+            s1[at] = make_uint2(id, (unsigned)start);
+            if (two) s1[at + 1] = make_uint2(id | 1u, (unsigned)(end + 1));
+        }
+        n1 += __popcll(um) + __popcll(tm);
+        ++slot;
     }
 }
 
@@ -1374,7 +1417,21 @@ int launch_caves(const float* hf, const float* bw, const int32_t* pos, int n, mm
     if (n <= 0) return 0;
     LAUNCH(KID_CAVE_COLUMNS, mm::k_cave_columns, dim3(n), dim3(256), s, bw, (const int2*)pos, (float2*)colInfoScratch, chunkList);
     LAUNCH(KID_CAVE_VOXELS, mm::k_cave_voxels, dim3(n * 16), dim3(CAVE_THREADS), s, hf, (const float2*)colInfoScratch, (const int2*)pos, caveLayers, chunkList, colNeed);
-    LAUNCH(KID_CAVE_BIOMES, mm::k_cave_biomes, dim3(n * (256 / CB_COLS)), dim3(CB_THREADS), s, hf, (const int2*)pos, caveLayers, chunkList);
+    // k_cave_voxels was the last reader of the per-column info: its first KB becomes k_cave_biomes' work counters
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return (int)hipErrorInvalidDevice;
+        cus = prop.multiProcessorCount;
+    }
+    static_assert(64 * CB_COUNTERS <= 256 * sizeof(float2), "the counters fit the per-column info of one chunk");
+    const hipError_t e = hipMemsetAsync(colInfoScratch, 0, 64 * CB_COUNTERS, s);
+    if (e != hipSuccess) return (int)e;
+    const long long units = (long long)n * (256 / CB_UNIT_COLS), fit = (long long)cus * MM_CB_WAVES;       // persistent: MM_CB_WAVES 4-wave workgroups per CU
+    if (units >= (1LL << 18) * (256 / CB_UNIT_COLS)) return (int)hipErrorInvalidValue;                  // item ids carry the list index in 18 bits
+    LAUNCH(KID_CAVE_BIOMES, mm::k_cave_biomes, dim3((unsigned)(units / 4 + 1 < fit ? units / 4 + 1 : fit)), dim3(CB_THREADS), s, hf, (const int2*)pos, caveLayers, chunkList,
+           (int)units, (unsigned*)colInfoScratch);
     return 0;
 }
 
