@@ -175,9 +175,9 @@ __global__ void __launch_bounds__(256) k_fix_backward(float* __restrict__ layers
 // K4 — caves.
 //   k_cave_columns : per column, everything of shouldGenerateCaveAtBlock that does not depend on y
 //                    (ocean+beach weight, the whole ravine branch → one y threshold)
-//   k_cave_voxels  : one workgroup (3 waves, 3 passes) per 4 columns, lane = voxel; Worley cell points of the columns' reachable
-//                    8x8x7 cell box staged in LDS; solid/air bits → LDS bit words → popcount ranks → (start,end) runs
-//   k_cave_biomes  : the occupied layer slots' (bottom, top) cave-biome evaluations, compacted per 128 columns and walked densely
+//   k_cave_voxels  : one workgroup (4 waves) per 16-column row, four dense phases over row-long voxel lists; Worley cell points of the row's
+//                    reachable 8x8x7 cell box staged in LDS; solid/air bits → LDS bit words → popcount ranks → (start,end) runs
+//   k_cave_biomes  : the occupied layer slots' (bottom, top) cave-biome evaluations, streamed by persistent waves 64 at a time
 // =========================================================================================================
 __global__ void __launch_bounds__(256)
 k_cave_columns(const float* __restrict__ bw, const int2* __restrict__ chunkPos, float2* __restrict__ colInfo, const int* __restrict__ chunkList)
@@ -627,7 +627,7 @@ k_cave_biomes(const float* __restrict__ hf, const int2* __restrict__ chunkPos, m
 }
 
 // =========================================================================================================
-// K6 — fill.  One workgroup (4 waves) = 4 neighbouring columns.  Two phases inside the workgroup:
+// K6 — fill (shared pieces; the kernels are further down).  Per voxel:
 //   1. every voxel gets its base block (bedrock / air / water / cave air / layer material + surface-biome rules): cheap, lane = y;
 //   2. the voxels whose block a cave biome could still alter (STONE / DEEPSLATE / BLACKSTONE below ground — the only blocks
 //      caveBiomeBlockPostProcess touches) are compacted into an LDS list and processed densely: the cave-biome evaluation
