@@ -188,6 +188,30 @@ def test_full_batch_properties(gen, oracle):
     assert_bit_equal(np_(a["cave"])[sel], oc, "cave layers sample")
 
 
+def test_fill_call_larger_than_its_sub_batches(gen, oracle):
+    """mmgen_fill cuts a call into sub-batches of 8 192 chunks for its row lists (and into batches of 16 384 for its queue): one call of
+    8 192 + 88 chunks must equal the same chunks filled in small calls, on both sides of the cut, and the oracle on a sample."""
+    import torch
+    rng = np.random.default_rng(5)
+    n = 8192 + 88
+    coords = [(int(x), int(z)) for x, z in rng.integers(-3000, 3000, (n, 2))]
+    pos = gen.positions(coords)
+    hf, bw, g = gen.generate_heightfields(pos, gathered=True)
+    layers = gen.fix_backward_layers(gen.generate_layers(g, bw, pos))
+    cave = gen.generate_caves(hf, bw, pos)
+    big = gen.fill(hf, bw, layers, cave, pos)
+    torch.cuda.synchronize()
+    for lo, hi in ((0, 40), (8192 - 40, 8192 + 40), (n - 24, n)):
+        part = gen.fill(hf[lo:hi].contiguous(), bw[lo:hi].contiguous(), layers[lo:hi].contiguous(), cave[lo:hi].contiguous(), pos[lo:hi].contiguous())
+        assert torch.equal(part, big[lo:hi]), (lo, hi)
+    sel = [0, 8191, 8192, 8193, n - 1]
+    opos = oracle.positions([coords[i] for i in sel])
+    ohf, obw = oracle.heightfields(opos)
+    ol = oracle.fix_backward(oracle.layers(opos, oracle.gather_heightfields(opos, ohf), obw))
+    oc = oracle.caves(opos, ohf, obw)
+    assert_bit_equal(np_(big)[sel], oracle.fill(opos, ohf, obw, ol, oc), "blocks on both sides of the sub-batch cut")
+
+
 # ------------------------------------------------------------------------------------------------ config 3: one erosion zone
 def _zone_planes_oracle(oracle, zone):
     coords = [(zone[0] - 6 + x, zone[1] - 6 + z) for z in range(24) for x in range(24)]
