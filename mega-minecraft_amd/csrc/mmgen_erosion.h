@@ -4,8 +4,9 @@
 #include <stddef.h>
 
 #ifndef EROSION_K
-#define EROSION_K 4         // relaxation passes per launch (temporal blocking; 40 x 40-cell LDS tiles).  Measured on 84 zones: K = 2 / 3 / 4 / 6 / 8 / 12
-                            // -> 3.1 / 3.1 / 2.3 / 2.6 / 3.3 / 3.4 ms (one pass per launch: 3.8 ms): larger K = fewer launches but more ring cells and LDS
+#define EROSION_K 6         // relaxation passes per launch (temporal blocking; 44 x 44-cell LDS tiles).  Larger K = fewer launches but more ring cells and
+                            // LDS.  Measured per step of the bench tile (72 zones), K x row groups per tile: 3 x 19 2.07 ms, 4 x 4 1.85, 4 x 10 1.66, 5 x 14 1.82,
+                            // 6 x 4 2.13, 6 x 11 1.54, 6 x 22 1.87, 8 x 12 3.23 (round 2, four row groups: K = 2 / 3 / 4 / 6 / 8 / 12 -> 3.1 / 3.1 / 2.3 / 2.6 / 3.3 / 3.4)
 #endif
 
 namespace mm {

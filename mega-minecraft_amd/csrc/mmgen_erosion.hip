@@ -36,7 +36,7 @@ namespace mm {
 #define EROSION_EXT (32 + 2 * EROSION_K)
 #define EROSION_CELLS_EXT (EROSION_EXT * EROSION_EXT)
 #ifndef EROSION_STRIPS
-#define EROSION_STRIPS 10                                  // row groups: one lane = one column of the extended tile x EROSION_ROWS rows (2 / 4 / 5 / 8 / 10 / 20 strips: 2.56 / 1.85 / 1.79 / 1.93 / 1.66 / 3.04 ms per step)
+#define EROSION_STRIPS 11                                  // row groups: one lane = one column of the extended tile x EROSION_ROWS rows (mmgen_erosion.h: K x row groups)
 #endif
 #define EROSION_ROWS (EROSION_EXT / EROSION_STRIPS)
 #define EROSION_THREADS (EROSION_EXT * EROSION_STRIPS)
