@@ -963,8 +963,10 @@ MM_DEV void fill_body(const float* __restrict__ hf, const float* __restrict__ bw
 //                per-wave buffer to the device-wide queue of k_fill_lush, 64 per reservation.
 // k_fill_far (fill_body<false>) keeps the rows beyond the domain, the fused way.
 // ---------------------------------------------------------------------------------------------------------
-#define FILL_RANGE 8             // batches per draw at most: ~60 us of work, the longest a wave can still be busy after the others ran dry
+#ifndef FILL_RANGE
+#define FILL_RANGE 4             // batches per draw at most: ~60 us of work, the longest a wave can still be busy after the others ran dry
                                  // (small launches draw smaller ranges: launch_fill)
+#endif
 #define FILL_COUNTERS 16         // work counters, 64 B apart (one serialises at ~11 ns per draw in L2)
 #define FILLB_THREADS 256
 #define FILLC_THREADS 256
