@@ -157,8 +157,8 @@ struct mmgen_region {
     int nCompute = 0, nZones = 0, nLazy = 0;
     bool began = false;
     DevBuf posA, hfA, bwA, gathA, layersA;
-    DevBuf posP, hfP, bwP, layersP, caveP, colInfo, fp, cfp, counts;
-    DevBuf selAP, zoneIdx, zoneIdxOut, gathered, erodeWork, erodeState, computeList, targets, gfp, gcfp, bounds, fillQueue, cellLazy, colNeed, applyWork;
+    DevBuf layersP, caveP, colInfo, fp, cfp, counts;
+    DevBuf zoneIdx, zoneIdxOut, gathered, erodeWork, erodeState, computeList, targets, gfp, gcfp, bounds, fillQueue, cellLazy, colNeed, applyWork;
     int lastMaxPasses = 0;
     // layout cache: the host-built index tables (positions, A->P selection, compute list, zone gather / scatter lists, fill targets)
     // depend only on (rectangle, flags, mask); a caller that regenerates the same layout (bench loop, fixed tiles) re-uses the
@@ -215,7 +215,7 @@ struct mmgen_region {
             for (hipEvent_t x : ev) if (x) (void)hipEventDestroy(x);
             for (int i = 0; i < kMaxSlices; ++i) if (evFill[i]) (void)hipEventDestroy(evFill[i]);
         }
-        DevBuf* all[] = {&posA, &hfA, &bwA, &gathA, &layersA, &posP, &hfP, &bwP, &layersP, &caveP, &colInfo, &fp, &cfp, &counts, &selAP, &zoneIdx,
+        DevBuf* all[] = {&posA, &hfA, &bwA, &gathA, &layersA, &layersP, &caveP, &colInfo, &fp, &cfp, &counts, &zoneIdx,
                          &zoneIdxOut, &gathered, &erodeWork, &erodeState, &computeList, &targets, &gfp, &gcfp, &bounds, &fillQueue, &cellLazy, &colNeed, &applyWork};
         for (DevBuf* b : all) b->release();
     }
@@ -285,10 +285,21 @@ static int region_layout(mmgen_region* r, int cx0, int cz0, int nx, int nz, unsi
     r->nZones = (int)zonesX.size();
     const int na = r->na, nr = nx * nz, Z = r->nZones;
 
-    std::vector<int32_t> posA(2 * (size_t)na), selAP(np), computeList, targets(nr);
+    // Order of the raw area A: the cells of the placement grid P first, in P's order, then the padding cells.  Every per-chunk array of
+    // A (positions, heights, biome weights) then starts with the array of P - no copies - and only the layers exist twice (raw in A for
+    // the zones' padding, eroded in P).
+    std::vector<int32_t> posA(2 * (size_t)na), aIndex((size_t)na), computeList, targets(nr);
     std::vector<uint8_t> lazy(np, 0);
-    for (int z = 0; z < r->anz; ++z) for (int x = 0; x < r->anx; ++x) { posA[2 * (x + r->anx * z)] = (r->ax0 + x) * 16; posA[2 * (x + r->anx * z) + 1] = (r->az0 + z) * 16; }
-    for (int z = 0; z < r->pnz; ++z) for (int x = 0; x < r->pnx; ++x) selAP[x + r->pnx * z] = (r->px0 + x - r->ax0) + r->anx * (r->pz0 + z - r->az0);
+    {
+        int next = np;
+        for (int z = 0; z < r->anz; ++z) for (int x = 0; x < r->anx; ++x) {
+            const int gx = r->ax0 + x - r->px0, gz = r->az0 + z - r->pz0;
+            const int a = (gx >= 0 && gx < r->pnx && gz >= 0 && gz < r->pnz) ? gx + r->pnx * gz : next++;
+            aIndex[x + (size_t)r->anx * z] = a;
+            posA[2 * (size_t)a] = (r->ax0 + x) * 16; posA[2 * (size_t)a + 1] = (r->az0 + z) * 16;
+        }
+        if (next != na) return (int)hipErrorUnknown;        // P lies inside A by construction
+    }
     for (int i = 0; i < np; ++i) {
         const int x = i % r->pnx - ring, z = i / r->pnx - ring;
         const bool inR = x >= 0 && x < nx && z >= 0 && z < nz;
@@ -312,7 +323,7 @@ static int region_layout(mmgen_region* r, int cx0, int cz0, int nx, int nz, unsi
     std::vector<int> zi((size_t)Z * 576), zo((size_t)Z * 144);
     for (int z = 0; z < Z; ++z) {
         for (int cz = 0; cz < 24; ++cz) for (int cx = 0; cx < 24; ++cx)
-            zi[(size_t)z * 576 + cx + 24 * cz] = (zonesX[z] - 6 + cx - r->ax0) + r->anx * (zonesZ[z] - 6 + cz - r->az0);
+            zi[(size_t)z * 576 + cx + 24 * cz] = aIndex[(zonesX[z] - 6 + cx - r->ax0) + (size_t)r->anx * (zonesZ[z] - 6 + cz - r->az0)];
         for (int cz = 0; cz < 12; ++cz) for (int cx = 0; cx < 12; ++cx) {
             const int gx = zonesX[z] + cx - r->px0, gz = zonesZ[z] + cz - r->pz0;
             zo[(size_t)z * 144 + cx + 12 * cz] = (gx >= 0 && gx < r->pnx && gz >= 0 && gz < r->pnz) ? gx + r->pnx * gz : -1;
@@ -320,11 +331,9 @@ static int region_layout(mmgen_region* r, int cx0, int cz0, int nx, int nz, unsi
     }
 
     CK(r->posA.ensure(sizeof(int32_t) * 2 * na));
-    CK(r->selAP.ensure(sizeof(int) * np));
     CK(r->computeList.ensure(sizeof(int) * np));
     CK(r->targets.ensure(sizeof(int) * nr));
     CK(hipMemcpyAsync(r->posA.p, posA.data(), sizeof(int32_t) * 2 * na, hipMemcpyHostToDevice, s));
-    CK(hipMemcpyAsync(r->selAP.p, selAP.data(), sizeof(int) * np, hipMemcpyHostToDevice, s));
     CK(hipMemcpyAsync(r->computeList.p, computeList.data(), sizeof(int) * r->nCompute, hipMemcpyHostToDevice, s));
     CK(hipMemcpyAsync(r->targets.p, targets.data(), sizeof(int) * nr, hipMemcpyHostToDevice, s));
     if (r->nLazy) {
@@ -402,18 +411,11 @@ int mmgen_region_begin(mmgen_region* r, int cx0, int cz0, int nx, int nz, unsign
     float *hfP, *bwP, *layersP;
     int32_t* posP;
     if (erosion) {
-        // P-grid copies (eroded planes are scattered into layersP; layersA stays raw for the other zones' padding).  The caves read only
-        // positions, heights and biome weights: those copies stay on the caller's stream, the layers go with the erosion branch.
-        CK(r->posP.ensure(sizeof(int32_t) * 2 * np));
-        CK(r->hfP.ensure(sizeof(float) * 256 * (size_t)np));
-        CK(r->bwP.ensure(sizeof(float) * MMGEN_BIOME_WEIGHTS_SIZE * (size_t)np));
+        // The P grid's arrays are the first np chunks of A's (region_layout orders A that way); only the layers exist twice: eroded planes
+        // are scattered into layersP, layersA stays raw for the other zones' padding (the copy goes with the erosion branch).
         CK(r->layersP.ensure(sizeof(float) * MMGEN_LAYERS_SIZE * (size_t)np));
-        hfP = r->hfP.as<float>(); bwP = r->bwP.as<float>(); layersP = r->layersP.as<float>(); posP = r->posP.as<int32_t>();
-        const int* sel = r->selAP.as<int>();
+        hfP = r->hfA.as<float>(); bwP = r->bwA.as<float>(); layersP = r->layersP.as<float>(); posP = r->posA.as<int32_t>();
         if (par) { CK(hipEventRecord(r->evK2, s)); CK(hipStreamWaitEvent(sE, r->evK2, 0)); }
-        MMK_LAUNCH(mmk::KID_SELECT, k_select, dim3(np, 1), dim3(256), s, (const float*)r->posA.p, sel, (float*)posP, 2);
-        MMK_LAUNCH(mmk::KID_SELECT, k_select, dim3(np, 1), dim3(256), s, r->hfA.as<float>(), sel, hfP, 256);
-        MMK_LAUNCH(mmk::KID_SELECT, k_select, dim3(np, MMGEN_BIOME_WEIGHTS_SIZE / 256), dim3(256), s, r->bwA.as<float>(), sel, bwP, MMGEN_BIOME_WEIGHTS_SIZE);
     } else {
         hfP = r->hfA.as<float>(); bwP = r->bwA.as<float>(); layersP = r->layersA.as<float>(); posP = r->posA.as<int32_t>();
         CK(mmk::launch_fix_backward(layersP, np, s));
@@ -439,7 +441,7 @@ int mmgen_region_begin(mmgen_region* r, int cx0, int cz0, int nx, int nz, unsign
 
     if (erosion) {
         mmk::StageRange sr("mmgen:erosion");
-        MMK_LAUNCH(mmk::KID_SELECT, k_select, dim3(np, MMGEN_LAYERS_SIZE / 256), dim3(256), sE, r->layersA.as<float>(), r->selAP.as<int>(), layersP, MMGEN_LAYERS_SIZE);
+        CK(hipMemcpyAsync(layersP, r->layersA.p, sizeof(float) * MMGEN_LAYERS_SIZE * (size_t)np, hipMemcpyDeviceToDevice, sE));
         // ---- E1 / K3 / E3 per zone batch
         const int Z = r->nZones;
         const int batch = Z < MMGEN_EROSION_ZONE_BATCH ? Z : MMGEN_EROSION_ZONE_BATCH;
@@ -510,10 +512,10 @@ int mmgen_region_fill(mmgen_region* r, uint8_t* d_blocks, void* stream)
     hipStream_t s = (hipStream_t)stream;
     const bool erosion = r->flags & MMGEN_REGION_EROSION;
     const bool par = !r->serial;
-    float* hfP = erosion ? r->hfP.as<float>() : r->hfA.as<float>();
-    float* bwP = erosion ? r->bwP.as<float>() : r->bwA.as<float>();
+    float* hfP = r->hfA.as<float>();        // the P grid's arrays are the first np chunks of A's
+    float* bwP = r->bwA.as<float>();
     float* layersP = erosion ? r->layersP.as<float>() : r->layersA.as<float>();
-    int32_t* posP = erosion ? r->posP.as<int32_t>() : r->posA.as<int32_t>();
+    int32_t* posP = r->posA.as<int32_t>();
     mmk::StageRange sr("mmgen:fill");
     const size_t qb = slice_queue_bytes(r);
     CK(r->fillQueue.ensure(qb * r->nSlices));
@@ -542,10 +544,10 @@ int mmgen_region_finish(mmgen_region* r, uint8_t* d_blocks, float* d_heightfield
     const bool erosion = r->flags & MMGEN_REGION_EROSION, features = r->flags & MMGEN_REGION_FEATURES, decor = r->flags & MMGEN_REGION_DECORATORS;
     const bool par = !r->serial;
     const int nr = r->nx * r->nz;
-    float* hfP = erosion ? r->hfP.as<float>() : r->hfA.as<float>();
-    float* bwP = erosion ? r->bwP.as<float>() : r->bwA.as<float>();
+    float* hfP = r->hfA.as<float>();        // the P grid's arrays are the first np chunks of A's
+    float* bwP = r->bwA.as<float>();
     float* layersP = erosion ? r->layersP.as<float>() : r->layersA.as<float>();
-    int32_t* posP = erosion ? r->posP.as<int32_t>() : r->posA.as<int32_t>();
+    int32_t* posP = r->posA.as<int32_t>();
     const int* tgt = r->targets.as<int>();
 
     if (__atomic_load_n(r->hostMax, __ATOMIC_RELAXED) > MMGEN_CFP_CAP) return MMGEN_ERROR_PLACEMENT_OVERFLOW;
