@@ -949,7 +949,14 @@ k_apply_features(uint8_t* __restrict__ blocks, const int2* __restrict__ chunkPos
 // 2 draws per column + 2 per used cave layer.  minstd has no increment, so x_{n+k} = a^k x_n mod m: every lane jumps the
 // stream to its column's first draw and all 256 columns run in parallel (decorators only touch their own column).
 // ---------------------------------------------------------------------------------------------------------
-MM_DEV uint32_t mulmod(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * b) % 2147483647ull); }
+// a * b mod 2^31 - 1 for a, b below the modulus: 2^31 = 1 (mod m), so the 62-bit product folds twice (no 64-bit division)
+MM_DEV uint32_t mulmod(uint32_t a, uint32_t b)
+{
+    const uint64_t p = (uint64_t)a * b;
+    uint64_t r = (p & 0x7fffffffull) + (p >> 31);             // < 2^32
+    r = (r & 0x7fffffffull) + (r >> 31);                      // <= 2^31
+    return (uint32_t)(r >= 0x7fffffffull ? r - 0x7fffffffull : r);
+}
 
 MM_DEV void try_place_decorator(uint8_t* col, int y, const DecoGen& g)     // tryPlaceSingleDecorator chunk.cu:1634-1677
 {
@@ -979,16 +986,27 @@ k_decorators(uint8_t* __restrict__ blocks, const float* __restrict__ hf, const f
              const mmgen_cave_layer* __restrict__ caveLayers, const int2* __restrict__ chunkPos, const int* __restrict__ srcIdx)
 {
     noise_tables_init();
-    __shared__ int s_draws[256];
+    __shared__ int s_draws[4];
     const int outChunk = blockIdx.x, t = threadIdx.x;
     const int chunk = srcIdx ? srcIdx[outChunk] : outChunk;
     const mmgen_cave_layer* ccl = caveLayers + ((size_t)256 * chunk + t) * MMGEN_MAX_CAVE_LAYERS_PER_COLUMN;
-    int used = 0;
-    while (used < MMGEN_MAX_CAVE_LAYERS_PER_COLUMN && ccl[used].start != 384) ++used;
-    s_draws[t] = 2 + 2 * used;
+    // the used slots (the first unused one starts at 384), four loads in flight per round trip instead of one
+    int used = MMGEN_MAX_CAVE_LAYERS_PER_COLUMN;
+#pragma unroll 1
+    for (int k0 = 0; k0 < MMGEN_MAX_CAVE_LAYERS_PER_COLUMN; k0 += 4) {
+        const int s0 = ccl[k0].start, s1 = ccl[k0 + 1].start, s2 = ccl[k0 + 2].start, s3 = ccl[k0 + 3].start;
+        const int first = s0 == 384 ? 0 : (s1 == 384 ? 1 : (s2 == 384 ? 2 : (s3 == 384 ? 3 : 4)));
+        if (first < 4) { used = k0 + first; break; }
+    }
+    // draws consumed by the columns before this one: a shuffle scan inside each wave, the four wave totals through LDS
+    const int mine = 2 + 2 * used;
+    int incl = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int up = __shfl_up(incl, d, 64); if ((t & 63) >= d) incl += up; }
+    if ((t & 63) == 63) s_draws[t >> 6] = incl;
     __syncthreads();
-    int skip = 0;
-    for (int i = 0; i < t; ++i) skip += s_draws[i];
+    int skip = incl - mine;
+    for (int w = 0; w < (t >> 6); ++w) skip += s_draws[w];
 
     const int2 cp = chunkPos[chunk];
     MinStd rng = rng4(cp.x, 0, cp.y, 7589341);
