@@ -259,7 +259,7 @@ k_feature_placements(const float* __restrict__ hf, const float* __restrict__ bw,
                      mmgen_feature_placement* __restrict__ fpOut, mmgen_cave_feature_placement* __restrict__ cfpOut, int* __restrict__ counts,
                      const int* __restrict__ chunkList, const uint8_t* __restrict__ colNeed /*nullable: [chunk][256], 0 = column skipped (lazy ring)*/)
 {
-    noise_tables_init();
+    // (no simplex noise in this kernel: the tables stay where they are)
     __shared__ int s_ns[4];
     const int chunk = chunkList ? chunkList[blockIdx.x] : blockIdx.x, t = threadIdx.x;
     const int2 cp = chunkPos[chunk];
@@ -985,7 +985,7 @@ __global__ void __launch_bounds__(256)
 k_decorators(uint8_t* __restrict__ blocks, const float* __restrict__ hf, const float* __restrict__ bw,
              const mmgen_cave_layer* __restrict__ caveLayers, const int2* __restrict__ chunkPos, const int* __restrict__ srcIdx)
 {
-    noise_tables_init();
+    // (no simplex noise in this kernel: the tables stay where they are)
     __shared__ int s_draws[4];
     const int outChunk = blockIdx.x, t = threadIdx.x;
     const int chunk = srcIdx ? srcIdx[outChunk] : outChunk;
