@@ -159,6 +159,10 @@ MM_DEV void column_placements(int wx, int wz, float height, const float* cbw /*s
     nSurf = 0; nCave = 0;
     const int ground = (int)height;
     MinStd rng = rng3(wx, wz, 329828101);
+    // the column's 24 weights in one round trip, under the cave-layer walk (random_biome below would read them one dependent load at a time)
+    float w24[MMGEN_NUM_BIOMES];
+#pragma unroll
+    for (int b = 0; b < MMGEN_NUM_BIOMES; ++b) w24[b] = cbw[256 * b];
 
     bool surfaceIsCave = false;
     for (int k = 0; k < MMGEN_MAX_CAVE_LAYERS_PER_COLUMN; ++k) {
@@ -192,7 +196,13 @@ MM_DEV void column_placements(int wx, int wz, float height, const float* cbw /*s
     }
 
     if (!surfaceIsCave) {
-        const int biome = random_biome(cbw, 256, rng.u01());
+        int biome = MMBIO_PLAINS;
+        {
+            float rand = rng.u01();
+            bool found = false;
+#pragma unroll
+            for (int b = 0; b < MMGEN_NUM_BIOMES; ++b) { rand -= w24[b]; if (!found && rand <= 0.f) { biome = b; found = true; } }      // random_biome (mm_biome.cuh), unrolled over registers
+        }
         for (int g = 0; g < kSurfGenCount[biome]; ++g) {
             const SurfGen& gen = kSurfGens[biome][g];
             if (rng.u01() >= gen.chance) continue;
@@ -1017,7 +1027,17 @@ k_decorators(uint8_t* __restrict__ blocks, const float* __restrict__ hf, const f
 
     uint8_t* col = blocks + (size_t)MMGEN_BLOCKS_PER_CHUNK * outChunk + 384 * t;
     const float* cbw = bw + (size_t)MMGEN_BIOME_WEIGHTS_SIZE * chunk + t;
-    const int biome = random_biome(cbw, 256, rng.u01());
+    int biome = MMBIO_PLAINS;
+    {
+        // the 24 weights in one round trip instead of one dependent load per step of random_biome's walk (mm_biome.cuh)
+        float w24[MMGEN_NUM_BIOMES];
+#pragma unroll
+        for (int b = 0; b < MMGEN_NUM_BIOMES; ++b) w24[b] = cbw[256 * b];
+        float r = rng.u01();
+        bool found = false;
+#pragma unroll
+        for (int b = 0; b < MMGEN_NUM_BIOMES; ++b) { r -= w24[b]; if (!found && r <= 0.f) { biome = b; found = true; } }
+    }
     float rand = rng.u01();
     for (int g = 0; g < kDecoCount[biome]; ++g) {
         const DecoGen& gen = kDecoGens[biome][g];
