@@ -150,11 +150,18 @@ MM_DEV bool is_feature_pos(int wx, int wz, int cell, int pad, int seed)      // 
     return wx == px && wz == pz;
 }
 
+#define F1_KEEP 4          // cave placements per column the counting pass of k_feature_placements keeps in registers (a column rarely has two)
+MM_DEV unsigned pack_found(int feature, int canReplace, int y, int layerHeight)      // y, layerHeight in 0 .. 511
+{
+    return (unsigned)feature | ((unsigned)(canReplace != 0) << 8) | ((unsigned)(y & 1023) << 9) | ((unsigned)layerHeight << 19);
+}
 // Walks one column exactly like generateColumnFeaturePlacements (chunk.cu:1041-1145).  WRITE=false only counts.
 template <bool WRITE>
 MM_DEV void column_placements(int wx, int wz, float height, const float* cbw /*stride 256*/, const float* clayers /*stride 256*/,
                               const mmgen_cave_layer* ccl, int& nSurf, int& nCave, mmgen_feature_placement* surfOut,
-                              mmgen_cave_feature_placement* caveOut, int caveCap)
+                              mmgen_cave_feature_placement* caveOut, int caveCap, unsigned (*found)[F1_KEEP + 1] = nullptr /* counting pass: the
+                              surface placement and the first F1_KEEP cave placements, packed (pack_found), so that the writing pass need not walk
+                              the column again */)
 {
     nSurf = 0; nCave = 0;
     const int ground = (int)height;
@@ -181,6 +188,7 @@ MM_DEV void column_placements(int wx, int wz, float height, const float* cbw /*s
                     || layerHeight < (int)gen.minLayerHeight)
                     continue;
                 if (is_feature_pos(wx, wz, gen.cell, gen.pad, seed)) {
+                    if (!WRITE && found && nCave < F1_KEEP) (*found)[1 + nCave] = pack_found(gen.feature, gen.canReplace, start + 1, layerHeight);
                     if (WRITE && nCave < caveCap) {
                         mmgen_cave_feature_placement p = {};
                         p.feature = gen.feature; p.pos[0] = wx; p.pos[1] = start + 1; p.pos[2] = wz; p.layer_height = layerHeight;
@@ -219,6 +227,7 @@ MM_DEV void column_placements(int wx, int wz, float height, const float* cbw /*s
                 if (!canPlace) continue;
             }
             if (is_feature_pos(wx, wz, gen.cell, gen.pad, (int)gen.feature * 518721)) {
+                if (!WRITE && found) (*found)[0] = pack_found(gen.feature, gen.canReplace, ground + 1, 0);
                 if (WRITE) {
                     mmgen_feature_placement p = {};
                     p.feature = gen.feature; p.pos[0] = wx; p.pos[1] = ground + 1; p.pos[2] = wz; p.can_replace_blocks = gen.canReplace;
@@ -280,8 +289,9 @@ k_feature_placements(const float* __restrict__ hf, const float* __restrict__ bw,
     const mmgen_cave_layer* ccl = caveLayers + ((size_t)256 * chunk + t) * MMGEN_MAX_CAVE_LAYERS_PER_COLUMN;
 
     int ns = 0, nc = 0;
+    unsigned found[F1_KEEP + 1] = {};
     const bool need = !colNeed || colNeed[(size_t)256 * chunk + t];
-    if (need) column_placements<false>(wx, wz, height, cbw, cl, ccl, ns, nc, nullptr, nullptr, 0);
+    if (need) column_placements<false>(wx, wz, height, cbw, cl, ccl, ns, nc, nullptr, nullptr, 0, &found);
     // exclusive prefix of the two per-column counts in column order: a shuffle scan inside each wave (both counts in one word: a chunk
     // holds far fewer than 65 536 of either), then the four wave totals through LDS
     const unsigned both = (unsigned)ns | ((unsigned)nc << 16);
@@ -302,7 +312,21 @@ k_feature_placements(const float* __restrict__ hf, const float* __restrict__ bw,
     mmgen_feature_placement* so = fpOut + (size_t)MMGEN_FP_CAP * chunk + offS;
     mmgen_cave_feature_placement* co = cfpOut + (size_t)MMGEN_CFP_CAP * chunk + offC;
     const int capLeft = imax(0, MMGEN_CFP_CAP - offC);
-    column_placements<true>(wx, wz, height, cbw, cl, ccl, ns, nc, so, co, capLeft);
+    if (nc > F1_KEEP) { column_placements<true>(wx, wz, height, cbw, cl, ccl, ns, nc, so, co, capLeft); return; }      // more than the registers kept: walk again
+    if (ns) {
+        mmgen_feature_placement p = {};
+        p.feature = (uint8_t)(found[0] & 255u); p.pos[0] = wx; p.pos[1] = (int)((found[0] >> 9) & 1023u); p.pos[2] = wz; p.can_replace_blocks = (uint8_t)((found[0] >> 8) & 1u);
+        so[0] = p;
+    }
+#pragma unroll
+    for (int i = 0; i < F1_KEEP; ++i) {
+        if (i < nc && i < capLeft) {
+            mmgen_cave_feature_placement p = {};
+            p.feature = (uint8_t)(found[1 + i] & 255u); p.pos[0] = wx; p.pos[1] = (int)((found[1 + i] >> 9) & 1023u); p.pos[2] = wz;
+            p.layer_height = (int)(found[1 + i] >> 19); p.can_replace_blocks = (uint8_t)((found[1 + i] >> 8) & 1u);
+            co[i] = p;
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------
