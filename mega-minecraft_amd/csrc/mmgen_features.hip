@@ -390,18 +390,23 @@ k_gather_placements(const mmgen_feature_placement* __restrict__ fp, const mmgen_
     const int o = blockIdx.x, t = threadIdx.x;
     const int c = targetChunk[o];
     const int cx = c % gridW, cz = c / gridW;
-    if (t == 0) {
-        int aS = 0, aC = 0;
-        for (int k = 0; k < 49; ++k) {
-            const int nx = cx + kGatherDX[k], nz = cz + kGatherDZ[k];
-            const bool ok = nx >= 0 && nx < gridW && nz >= 0 && nz < gridH;
-            const int n = ok ? nx + gridW * nz : -1;
-            s_src[k] = n;
-            s_offS[k] = aS; s_offC[k] = aC;
-            if (ok) { aS += counts[2 * n]; aC += imin(counts[2 * n + 1], MMGEN_CFP_CAP); }
+    // the 49 source cells in the reference's order: lane k of the first wave reads cell k's two counts, a shuffle scan gives the offsets
+    if (t < 64) {
+        int nS = 0, nC = 0, n = -1;
+        if (t < 49) {
+            const int nx = cx + kGatherDX[t], nz = cz + kGatherDZ[t];
+            if (nx >= 0 && nx < gridW && nz >= 0 && nz < gridH) { n = nx + gridW * nz; nS = counts[2 * n]; nC = imin(counts[2 * n + 1], MMGEN_CFP_CAP); }
+            s_src[t] = n;
         }
-        s_offS[49] = aS; s_offC[49] = aC;
-        s_b[0] = 384; s_b[1] = -1; s_b[2] = 384; s_b[3] = -1;
+        int inS = nS, inC = nC;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int uS = __shfl_up(inS, d, 64), uC = __shfl_up(inC, d, 64);
+            if (t >= d) { inS += uS; inC += uC; }
+        }
+        if (t < 49) { s_offS[t] = inS - nS; s_offC[t] = inC - nC; }
+        if (t == 48) { s_offS[49] = inS; s_offC[49] = inC; }
+        if (t == 0) { s_b[0] = 384; s_b[1] = -1; s_b[2] = 384; s_b[3] = -1; }
     }
     __syncthreads();
     const int totS = s_offS[49], totC = s_offC[49];
