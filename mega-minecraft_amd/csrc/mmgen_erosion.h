@@ -34,8 +34,10 @@ struct ErosionState {
 namespace mmk {
 size_t erosion_work_bytes(int zones);
 size_t erosion_state_bytes(int zones);
+// layersOut != null (region path): the kept 12 x 12 chunks of every zone (zoneChunkIdxOut, [zones][144], -1 = skip) go straight into the
+// chunk-major layers and `gathered` is left as it was; else the final planes are written back into `gathered` (Chunk::erodeZone's contract)
 int erode_zones(float* gathered, size_t strideFloats, int zones, float* work, mm::ErosionState* states, float* accOut, size_t accStride,
-                hipStream_t s, int* maxPasses);
+                hipStream_t s, int* maxPasses, const int* zoneChunkIdxOut = nullptr, float* layersOut = nullptr);
 int erosion_gather(const float* layers, const float* hf, const int* zoneChunkIdx, int zones, float* gathered, size_t strideFloats, hipStream_t s);
 int erosion_scatter(const float* gathered, size_t strideFloats, const int* zoneChunkIdxOut, int zones, float* layersOut, hipStream_t s);
 }  // namespace mmk

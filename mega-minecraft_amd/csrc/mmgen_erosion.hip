@@ -274,6 +274,23 @@ k_erosion_scatter(const float* __restrict__ gatheredBase, size_t gatheredStride,
         gatheredBase[gatheredStride * zone + (size_t)plane * ZN + gx + ZS * gz];
 }
 
+// Region path: the centre 12 x 12 chunks' eroded planes straight from the zones' work planes into the chunk-major layers (what
+// k_erode_writeback + k_erosion_scatter do through the gathered buffer, for the quarter of each zone that is kept).
+__global__ void __launch_bounds__(256)
+k_erode_finish(const float* __restrict__ workBase, const ErosionState* __restrict__ states, int lastT, const int* __restrict__ zoneChunkIdxOut /*[zones][144], -1 = skip*/,
+               float* __restrict__ layersOut)
+{
+    const int zone = blockIdx.z, plane = blockIdx.y, cc = blockIdx.x;
+    const int chunk = zoneChunkIdxOut[zone * 144 + cc];
+    if (chunk < 0) return;
+    const ErosionPhase* st = &states[zone].slot[lastT & 1];      // the phase the last launch ran with: done, all planes final
+    const int t = threadIdx.x;
+    const int cx = cc % 12 + 6, cz = cc / 12 + 6;
+    const int gx = cx * 16 + (t & 15), gz = cz * 16 + (t >> 4);
+    layersOut[(size_t)MMGEN_LAYERS_SIZE * chunk + 256 * (MMGEN_NUM_STRATIFIED_MATERIALS + plane) + t] =
+        workBase[ZONE_WORK_FLOATS * zone + ((size_t)plane * 3 + st->plane(plane)) * ZN + gx + ZS * gz];
+}
+
 }  // namespace mm
 
 namespace mmk {
@@ -284,7 +301,7 @@ size_t erosion_state_bytes(int zones) { return (size_t)zones * sizeof(mm::Erosio
 // Runs the relaxation to convergence for `zones` packed zone buffers (stride in floats).  Synchronises the stream (the
 // reference's erodeZone is synchronous too).  Returns 0 or a hipError_t; *maxPasses receives the largest pass count.
 int erode_zones(float* gathered, size_t strideFloats, int zones, float* work, mm::ErosionState* states, float* accOut, size_t accStride,
-                hipStream_t s, int* maxPasses)
+                hipStream_t s, int* maxPasses, const int* zoneChunkIdxOut, float* layersOut)
 {
     if (zones <= 0) return 0;
     MMK_LAUNCH(KID_ERODE_INIT, mm::k_erode_init, dim3((2 * ZN + 255) / 256, zones), dim3(256), s, states, work, zones);
@@ -314,6 +331,12 @@ int erode_zones(float* gathered, size_t strideFloats, int zones, float* work, mm
         if (launched > 100000) return (int)hipErrorLaunchFailure;
     }
     if (maxPasses) { int m = 0; for (auto& z : h) { const int ps = z.slot[(launched - 1) & 1].passes; m = ps > m ? ps : m; } *maxPasses = m; }
+    if (layersOut) {
+        // region path: no in-place contract to honour, the kept chunks' planes go straight to the layers
+        MMK_LAUNCH(KID_EROSION_SCATTER, mm::k_erode_finish, dim3(144, 8, zones), dim3(256), s, (const float*)work, (const mm::ErosionState*)states, launched - 1,
+                   zoneChunkIdxOut, layersOut);
+        return 0;
+    }
     MMK_LAUNCH(KID_ERODE_WRITEBACK, mm::k_erode_writeback, dim3(ZN / 256, 1, zones), dim3(256), s, gathered, strideFloats, work, states, accOut,
                accStride, launched - 1);
     return 0;

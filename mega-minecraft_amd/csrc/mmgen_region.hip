@@ -455,9 +455,8 @@ int mmgen_region_begin(mmgen_region* r, int cx0, int cz0, int nx, int nz, unsign
                                    (size_t)MMGEN_GATHERED_LAYERS_SIZE, sE));
             int mp = 0;
             CK(mmk::erode_zones(r->gathered.as<float>(), (size_t)MMGEN_GATHERED_LAYERS_SIZE, nb, r->erodeWork.as<float>(),
-                                r->erodeState.as<mm::ErosionState>(), nullptr, 0, sE, &mp));
+                                r->erodeState.as<mm::ErosionState>(), nullptr, 0, sE, &mp, r->zoneIdxOut.as<int>() + (size_t)z0 * 144, layersP));
             if (mp > r->lastMaxPasses) r->lastMaxPasses = mp;
-            CK(mmk::erosion_scatter(r->gathered.as<float>(), (size_t)MMGEN_GATHERED_LAYERS_SIZE, r->zoneIdxOut.as<int>() + (size_t)z0 * 144, nb, layersP, sE));
         }
         // ---- E3 fix-up
         CK(mmk::launch_fix_backward(layersP, np, sE));
