@@ -456,14 +456,14 @@ k_gather_placements(const mmgen_feature_placement* __restrict__ fp, const mmgen_
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// K6b — feature evaluation per voxel (second half of kernFill, chunk.cu:1438-1509).  One workgroup per column, lane = y.
+// K6b — feature evaluation per voxel (second half of kernFill, chunk.cu:1438-1509): k_apply_features, further down.
 //
-// The reference makes every voxel walk the whole gathered list (up to 2048 + 4096 entries).  Here the workgroup first
-// filters the list for ITS column: a placement can only claim voxels within a fixed horizontal reach of its position
-// (every rasteriser starts with, or implies, such a bound — table below, validated against the oracle in
-// tests/test_oracle_stages.py::test_feature_reach_table), so the six waves compact the indices of the reachable entries
-// into LDS in list order (wave ballots + popcount prefix: a stable compaction, first match still wins) and the voxels then
-// scan a handful of candidates instead of hundreds of entries.  Entries skipped by the filter would have returned false.
+// The reference makes every voxel walk the whole gathered list (up to 2048 + 4096 entries).  A placement can only claim voxels within a
+// fixed horizontal reach of its position (every rasteriser starts with, or implies, such a bound — table above, validated against the
+// oracle in tests/test_oracle_stages.py::test_feature_reach_table), and for most features the placement's own first draws bound its
+// claim per column far more tightly (surface_extent / cave_extent).  So the lists are filtered per UNIT of 8 columns in list order (wave
+// ballots + popcount prefix: a stable compaction, first match still wins), and only (voxel, placement) pairs inside those extents are
+// ever evaluated.  Entries skipped by the filters would have returned false.
 // ---------------------------------------------------------------------------------------------------------
 #define APPLY_COLS 4                      // waves per workgroup
 #define APPLY_THREADS (64 * APPLY_COLS)
