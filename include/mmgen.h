@@ -220,6 +220,9 @@ int mmgen_unpack_chunk_host(const uint8_t* packed, size_t packed_bytes, uint8_t*
 /* Test-only: evaluates device math function `fn` (MMGEN_PROBE_*) on n packed fp32 items (ints bit-cast); used by the parity
  * tests to pin the device math against golden vectors.  Not part of the reference's interface. */
 int mmgen_debug_probe(int fn, const float* d_in, int n, float* d_out, void* stream);
+/* Test-only: caps the queue of deferred clay / moss voxels of mmgen_fill / the region path at `entries` (0 = the library's own size, 2 048 per
+ * chunk), so that a test can drive the path that evaluates them in place when a reservation does not fit.  Process-wide. */
+int mmgen_debug_set_lush_queue_cap(int entries);
 /* Test-only: the library's constant rule tables (BiomeUtils::init, biomeFuncs.hpp:725-1256) as floats in the layout of
  * tools/extract_ref_tables.py, so that a test can hold them to the reference's literals.  d_out == NULL: returns the number of floats. */
 int mmgen_debug_tables(float* d_out, int capacity_floats, void* stream);

@@ -241,6 +241,8 @@ int mmgen_debug_feature_box(int is_cave, int feature, const int32_t* h_feature_p
     return mmk::launch_feature_box(is_cave, feature, h_feature_pos, layer_height, h_box_min, h_box_size, d_out, (hipStream_t)stream);
 }
 
+int mmgen_debug_set_lush_queue_cap(int entries) { mmk::debug_set_lush_queue_cap(entries); return 0; }
+
 int mmgen_debug_tables(float* d_out, int capacity_floats, void* stream)
 {
     if (!d_out) return mmk::table_dump_floats();                 // query: number of floats

@@ -14,6 +14,7 @@ int launch_fill(const float* hf, const float* bw, const float* layers, const mmg
                 uint8_t* blocks, const int* srcIdx /*nullable: input chunk of each output chunk*/,
                 unsigned* lushQueue /*nullable device scratch: deferred clay / moss voxels*/, size_t lushQueueBytes, bool allInPruneDomain /* every chunk within MM_PRUNE_DOMAIN blocks of the origin: k_fill_far is not launched */, hipStream_t s);
 size_t fill_queue_bytes(int n);      // launch_fill's scratch for n chunks: lush queue (2 048 deferred voxels per chunk on average; overflow is evaluated in place) + row lists (393 KB per chunk, at most 8 192 chunks' worth) + work counters
+void debug_set_lush_queue_cap(int entries);      // test-only (include/mmgen.h mmgen_debug_set_lush_queue_cap)
 int launch_probe(int fn, const float* in, int n, float* out, hipStream_t s);
 int prepare_kernels();      // builds this translation unit's noise-table image on the current device (called from mmgen_init)
 }  // namespace mmk

@@ -1444,6 +1444,7 @@ struct FillScratch { unsigned* lush; unsigned lushCap; unsigned* work; int* coun
 constexpr int kFillBatch = 1 << 14;           // queue entries carry the (batch-relative) chunk index in 15 bits
 constexpr int kFillSub = 1 << 13;             // chunks per k_fill_base / k_fill_cave launch: bounds the row lists (393 KB per chunk)
 inline size_t align256(size_t b) { return (b + 255) / 256 * 256; }
+std::atomic<unsigned> g_lushCapOverride{0u};        // mmgen_debug_set_lush_queue_cap
 FillScratch fill_scratch(char* base, int n)      // base may be null: only `bytes` is meaningful then
 {
     const size_t nb = (size_t)(n < kFillBatch ? n : kFillBatch), rows = 16 * (size_t)(n < kFillSub ? n : kFillSub);
@@ -1456,11 +1457,14 @@ FillScratch fill_scratch(char* base, int n)      // base may be null: only `byte
     f.rangeRow = (int*)(base + o); o += align256(4 * (rows * (FILL_VOX / 64) + 1));      // ranges of one batch, every voxel listed: the most there can be
     f.lists = (unsigned*)(base + o); o += 4 * (size_t)FILL_VOX * rows;
     f.bytes = o;
+    const unsigned cap = g_lushCapOverride.load(std::memory_order_relaxed);
+    if (cap && cap < f.lushCap) f.lushCap = cap;
     return f;
 }
 }  // namespace
 
 size_t fill_queue_bytes(int n) { return n <= 0 ? 0 : fill_scratch((char*)0x1000, n).bytes; }
+void debug_set_lush_queue_cap(int entries) { g_lushCapOverride.store(entries > 0 ? (unsigned)entries : 0u, std::memory_order_relaxed); }
 
 int launch_fill(const float* hf, const float* bw, const float* layers, const mmgen_cave_layer* caveLayers, const int32_t* pos, int n,
                 uint8_t* blocks, const int* srcIdx, unsigned* scratch, size_t scratchBytes, bool allInPruneDomain, hipStream_t s)

@@ -74,6 +74,28 @@ def test_full_pipeline_region_matches_oracle(gen, oracle, region):
         raise AssertionError(f"{len(bad)} block ids differ; first: chunk {c} column {i // 384} y {i % 384}: got {got[c, i]} want {ref['blocks'][c, i]}")
 
 
+def test_lush_voxels_are_evaluated_in_place_when_their_queue_is_full(gen, oracle):
+    """Clay / moss voxels of lush caves normally go through a device-wide queue to k_fill_lush; a reservation that does not fit is
+    evaluated by the wave that made it (and marks its in-range slots as holes).  With the queue capped at 96 entries most of a region's
+    reservations take that path: same blocks."""
+    MOSS = 125                                                   # MMB_MOSS: only lush caves make it
+    for cx0, cz0 in ((-37, 21), (10, -5), (60, 60), (-80, 33), (5, 90), (-120, -70)):
+        nx, nz = 4, 3
+        ref = oracle.generate_region(cx0, cz0, nx, nz, erosion=True, features=True, decorators=True)
+        if int((ref["blocks"] == MOSS).sum()) > 300:
+            break
+    else:
+        pytest.skip("none of the candidate regions has lush caves")
+    try:
+        assert gen.lib.mmgen_debug_set_lush_queue_cap(96) == 0
+        out = gen.generate_region(cx0, cz0, nx, nz)
+        assert_bit_equal(np_(out["blocks"]), ref["blocks"], "blocks with a 96-entry lush queue")
+    finally:
+        gen.lib.mmgen_debug_set_lush_queue_cap(0)
+    out = gen.generate_region(cx0, cz0, nx, nz)
+    assert_bit_equal(np_(out["blocks"]), ref["blocks"], "blocks with the full queue")
+
+
 @pytest.mark.parametrize("flags", [(False, False, False), (True, False, False), (False, True, False), (False, False, True), (True, True, False)])
 def test_region_flag_combinations(gen, oracle, flags):
     erosion, features, decorators = flags
