@@ -711,10 +711,9 @@ MM_DEV bool cave_extent(int feat, int lh, int dx, int dz, uint32_t fstate, bool 
 // Stable WAVE-wide compaction of the list entries that can reach ANY column of the unit (wx0 .. wx0 + APPLY_UNIT_W - 1, wz0 .. wz0 + APPLY_UNIT_H - 1)
 // into records
 //   .x = fx, .y = fz, .z = fy | feature << 9 | canReplace << 14 | layerHeight << 15 | reach << 24, .w = the placement's stream right after seeding
-// appended at s_unit[base ..], list order kept: 64 entries per round, ballot + popcount prefix, no workgroup barrier.  The chunk's list is
-// read from global memory ONCE per unit (round 2 read it once per column: eight dependent memory round trips per column at 3 waves
-// per SIMD were a quarter of the kernel), the placements are seeded once per unit.  Returns base + the number of records (the caller
-// compares it with APPLY_UNIT_CAP).
+// list order kept: 64 entries per round (filter_round), ballot + popcount prefix, no workgroup barrier.  The chunk's list is read from
+// global memory ONCE per unit (round 2 read it once per column: eight dependent memory round trips per column at 3 waves per SIMD
+// were a quarter of the kernel), the placements are seeded once per unit.
 // kFeatureReach / kCaveFeatureReach as immediates (8 bits per feature): a table lookup indexed per lane is one more dependent memory
 // round trip in a chain that is nothing but round trips
 template <bool CAVE>
@@ -729,31 +728,28 @@ MM_DEV int reach_of(int feat)
     return (int)((v >> (8 * (feat & 7))) & 255ull);
 }
 
+// One round of filter_unit's walk: entries r0 .. r0 + 63 of `list`; the placements that can reach the unit are appended at s_unit[base ..]
+// (the caller keeps 64 slots free).  Returns the number appended; ended = the list ends inside this round (first NONE, or its capacity).
 template <class Entry, int LIST_CAP, bool CAVE>
-MM_DEV int filter_unit(const Entry* __restrict__ list, int wx0, int wz0, int4* s_unit, int base)
+MM_DEV int filter_round(const Entry* __restrict__ list, int r0, int wx0, int wz0, int4* s_unit, int base, bool& ended)
 {
     static_assert(LIST_CAP % 64 == 0, "whole rounds");
     const int lane = threadIdx.x & 63;
-    for (int r0 = 0;;) {
-        const Entry en = list[r0 + lane];
-        const int feat = en.feature, fx = en.pos[0], fy = en.pos[1], fz = en.pos[2], canReplace = en.can_replace_blocks != 0;
-        int lh = 0;
-        if constexpr (CAVE) lh = en.layer_height;
-        const unsigned long long noneMask = __ballot(feat == 0);                // the lists end at the first NONE
-        const int firstNone = noneMask ? (int)__builtin_ctzll(noneMask) : 64;
-        const int reach = reach_of<CAVE>(feat);
-        const bool cand = lane < firstNone && wx0 - fx <= reach && fx - (wx0 + APPLY_UNIT_W - 1) <= reach && wz0 - fz <= reach && fz - (wz0 + APPLY_UNIT_H - 1) <= reach;
-        const unsigned long long cm = __ballot(cand);
-        if (cand) {
-            const int slot = base + __popcll(cm & ((1ull << lane) - 1ull));
-            if (slot < APPLY_UNIT_CAP) s_unit[slot] = make_int4(fx, fz, (fy & 511) | (feat << 9) | (canReplace << 14) | (lh << 15) | (reach << 24),
-                                                                (int)(CAVE ? cave_feature_stream(fx, fy, fz) : surface_feature_stream(fx, fy, fz)));
-        }
-        base += __popcll(cm);
-        r0 += 64;
-        if (firstNone < 64 || r0 >= LIST_CAP) break;
-    }
-    return base;
+    const Entry en = list[r0 + lane];
+    const int feat = en.feature, fx = en.pos[0], fy = en.pos[1], fz = en.pos[2], canReplace = en.can_replace_blocks != 0;
+    int lh = 0;
+    if constexpr (CAVE) lh = en.layer_height;
+    const unsigned long long noneMask = __ballot(feat == 0);                // the lists end at the first NONE
+    const int firstNone = noneMask ? (int)__builtin_ctzll(noneMask) : 64;
+    const int reach = reach_of<CAVE>(feat);
+    const bool cand = lane < firstNone && wx0 - fx <= reach && fx - (wx0 + APPLY_UNIT_W - 1) <= reach && wz0 - fz <= reach && fz - (wz0 + APPLY_UNIT_H - 1) <= reach;
+    const unsigned long long cm = __ballot(cand);
+    if (cand)
+        s_unit[base + __popcll(cm & ((1ull << lane) - 1ull))] =
+            make_int4(fx, fz, (fy & 511) | (feat << 9) | (canReplace << 14) | (lh << 15) | (reach << 24),
+                      (int)(CAVE ? cave_feature_stream(fx, fy, fz) : surface_feature_stream(fx, fy, fz)));
+    ended = firstNone < 64 || r0 + 64 >= LIST_CAP;
+    return __popcll(cm);
 }
 
 #ifndef MM_APPLY_EXP
@@ -768,31 +764,34 @@ __device__ unsigned long long g_applyStats[8];
 #ifndef MM_APPLY_WAVES
 #define MM_APPLY_WAVES 3        // 168 VGPRs: the union of the 31 rasterisers
 #endif
-// Persistent workgroups of four independent WAVES; a wave takes one UNIT (APPLY_UNIT_W x APPLY_UNIT_H columns of a chunk) at a time:
-//   0. filter_unit: the chunk's (already chunk-prefiltered) lists -> the placements that can reach the unit, in LDS, list order kept;
-//   1. every (placement, column) pair gets the vertical extent the placement can claim in that column (surface_extent / cave_extent,
-//      clipped to the chunk's bounds); the non-empty ones are compacted PLACEMENT-MAJOR with an exclusive scan over their voxel counts,
-//      which gives every (placement, column, y) triple an item number;
-//   2. the items are walked 64 at a time: every lane evaluates ONE (voxel, placement) pair.  Placement-major order over several columns
-//      keeps most of a batch on one placement - one rasteriser, one geometry; per column (round 2, and the first version of this one)
-//      a batch was the ~20 items of one column from three or four different rasterisers, executed one after the other;
-//   3. "first match in list order wins" (chunk.cu:1438-1509): the items ascend in list order, so do the batches; inside a batch the
-//      placements that hit something write their voxels one placement after the other, each only where nothing was written before.
-//      One byte per voxel, no atomics;
-//   4. the claimed voxels are written back.
-// No workgroup barrier after the noise tables are in LDS.  Units with more placements / pairs / items than the LDS lists hold (never
-// seen on generated terrain) scan the gathered lists directly.
+// Persistent workgroups of four independent WAVES; a wave takes one UNIT (APPLY_UNIT_W x APPLY_UNIT_H columns of a chunk) at a time and
+// STREAMS it through three bounded per-wave LDS buffers (one loop, every step's code exists once):
+//   A. placements: the chunk's (already chunk-prefiltered) lists are walked 64 entries at a time; the placements that can reach the unit
+//      gather in `unit` (list order, surface list first).  When another round might not fit, or the lists are at their end:
+//   B. pairs: every (placement, column) pair of the gathered placements gets the vertical extent the placement can claim in that column
+//      (surface_extent / cave_extent, clipped to the chunk's bounds); the non-empty ones are appended PLACEMENT-MAJOR to `ent` with an
+//      exclusive scan over their voxel counts, which gives every (placement, column, y) triple an item number.  When another round of
+//      64 pairs might not fit, or the pairs are at their end:
+//   C. items: walked 64 at a time, every lane evaluates ONE (voxel, placement) pair.  Placement-major order over several columns keeps
+//      most of a batch on one placement - one rasteriser, one geometry; per column (round 2) a batch was the ~20 items of one column from
+//      three or four different rasterisers, executed one after the other.  "First match in list order wins" (chunk.cu:1438-1509): the
+//      items ascend in list order - inside a batch, from batch to batch, and from one flush of the buffers to the next - so the
+//      placements of a batch that hit something write their voxels one placement after the other, each only where nothing was
+//      written before.  One byte per voxel, no atomics.
+//   D. the claimed voxels are written back.
+// On generated terrain a unit is one A, one B and one C step; lists of any length (the 2 048 / 4 096 entries of the reference) only mean
+// more flushes.  No workgroup barrier after the noise tables are in LDS.
 __attribute__((amdgpu_waves_per_eu(MM_APPLY_WAVES, MM_APPLY_WAVES)))
 __global__ void __launch_bounds__(APPLY_THREADS)
 k_apply_features(uint8_t* __restrict__ blocks, const int2* __restrict__ chunkPos, const mmgen_feature_placement* __restrict__ gfp,
                  const mmgen_cave_feature_placement* __restrict__ gcfp, const int* __restrict__ bounds, const int* __restrict__ srcIdx, int nUnits,
                  unsigned* __restrict__ nextUnit)
 {
-    __shared__ int4 s_unit[APPLY_COLS][APPLY_UNIT_CAP];    // per wave: the unit's placements, surface then cave
+    __shared__ int4 s_unit[APPLY_COLS][APPLY_UNIT_CAP];    // per wave: the gathered placements, surface then cave
     __shared__ unsigned s_ent[APPLY_COLS][APPLY_ENT_CAP];  // per wave: placement | column << 7 | lowest y << 11 | (voxels - 1) << 20
     __shared__ unsigned short s_pref[APPLY_COLS][APPLY_ENT_CAP + 2];      // exclusive prefix of the pairs' voxel counts (+ the total)
     __shared__ __attribute__((aligned(16))) uint8_t s_claim[APPLY_COLS][APPLY_UNIT_NCOL * 384];      // per voxel: the block of the first placement that claimed it, or 255
-    __shared__ __attribute__((aligned(16))) uint8_t s_blk[APPLY_COLS][APPLY_UNIT_NCOL * 384];        // the unit's base blocks
+    __shared__ unsigned s_air[APPLY_COLS][APPLY_UNIT_NCOL * 384 / 32];      // per voxel: the base block is AIR (all the item test needs of it)
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;      // wave index in an SGPR: so are chunk and column
     // the simplex tables (12 KB) are staged ONCE per workgroup (most units of a generated world have a coral, a fungus or a redwood in reach)
     noise_tables_init();
@@ -800,7 +799,9 @@ k_apply_features(uint8_t* __restrict__ blocks, const int2* __restrict__ chunkPos
     unsigned* ent = s_ent[wave];
     unsigned short* pref = s_pref[wave];
     uint8_t* claim = s_claim[wave];
-    uint8_t* blk = s_blk[wave];
+    unsigned* air = s_air[wave];
+    constexpr int ROW_WORDS = APPLY_UNIT_W * 384 / 4;
+    static_assert(64 <= APPLY_UNIT_CAP && 64 <= APPLY_ENT_CAP && 64 * 384 <= APPLY_ITEM_CAP && 64 % APPLY_UNIT_NCOL == 0, "a round of 64 always fits an empty buffer, and holds whole placements");
     // Units cost anything between nothing (ocean) and ~100 us (jungle) and a wave only gets a few dozen: a fixed assignment leaves most
     // waves idle while the unluckiest finishes (measured: 5.2 ms instead of 3.0).  The waves draw their units from counters instead;
     // the next draw is in flight while the current unit is worked on.  ONE counter serialises at ~11 ns per draw in L2 (measured: 1.5 ms
@@ -827,22 +828,114 @@ k_apply_features(uint8_t* __restrict__ blocks, const int2* __restrict__ chunkPos
     if (!doS && !doC) continue;
     const int wx0 = cp.x + x0, wz0 = cp.y + z0;
     const int sLo = imax(b0, 0), sHi = imin(b1, 383), cLo = imax(b2, 0), cHi = imin(b3, 383);   // the chunk's height bounds (chunk.cu:1555-1570)
-    int nUS = 0, nU = 0;
-    if (doS) nUS = nU = filter_unit<mmgen_feature_placement, MMGEN_MAX_GATHERED_FEATURES_PER_CHUNK, false>(listS, wx0, wz0, unit, 0);
-    if (doC) nU = filter_unit<mmgen_cave_feature_placement, MMGEN_MAX_GATHERED_CAVE_FEATURES_PER_CHUNK, true>(listC, wx0, wz0, unit, nUS);
-    if (nU == 0) continue;
-    wave_lds_sync();
     uint8_t* unitBlocks = blocks + (size_t)MMGEN_BLOCKS_PER_CHUNK * chunk + 384 * (16 * z0 + x0);      // row cz of the unit: + 384 * 16 * cz
-    bool fits = nU <= APPLY_UNIT_CAP;
+
+    int phase = doS ? 0 : 1, r0 = 0;                        // list being walked (0 surface, 1 cave, 2 = both at their end) and the next round
+    int nU = 0, nUS = 0;                                    // gathered placements, and how many of them are surface placements
+    bool staged = false;                                    // the unit's air bits are in LDS, the claims cleared
+#if MM_APPLY_STATS
+    unsigned long long stS = 0, stC = 0, stEnt = 0, stItems = 0;
+#endif
+    for (;;) {
+        // ---- A. gather placements until another round might not fit or the lists end
+        while (phase < 2 && nU + 64 <= APPLY_UNIT_CAP) {
+            bool ended;
+            if (phase == 0) {
+                const int n = filter_round<mmgen_feature_placement, MMGEN_MAX_GATHERED_FEATURES_PER_CHUNK, false>(listS, r0, wx0, wz0, unit, nU, ended);
+                nU += n; nUS += n;
+            } else {
+                nU += filter_round<mmgen_cave_feature_placement, MMGEN_MAX_GATHERED_CAVE_FEATURES_PER_CHUNK, true>(listC, r0, wx0, wz0, unit, nU, ended);
+            }
+            r0 += 64;
+            if (ended) { r0 = 0; phase = (phase == 0 && doC) ? 1 : 2; }
+        }
+        if (nU == 0) break;                                 // (only when the lists are at their end)
+        wave_lds_sync();
+#if MM_APPLY_STATS
+        stS += nUS; stC += nU - nUS;
+#endif
 #if MM_APPLY_EXP == 6
-    if (nU != 0x7fffffff) continue;                                     // timing experiment: the per-unit work only
+        nU = 0;                                             // timing experiment: the list walk only
 #endif
 
-    // (placement, column) pairs, placement-major: exclusive scan of their vertical extents (clipped to the column and to the chunk's bounds)
-    int nEnt = 0, total = 0;
-    if (fits) {
+        // ---- B + C. pairs of the gathered placements, items whenever the pair buffer fills up and at the end
         const int nPairs = nU * APPLY_UNIT_NCOL;
-        for (int p0 = 0; p0 < nPairs; p0 += 64) {
+        int nEnt = 0, total = 0;
+        for (int p0 = 0;;) {
+            const bool pairsDone = p0 >= nPairs;
+            if (pairsDone || nEnt + 64 > APPLY_ENT_CAP || total + 64 * 384 > APPLY_ITEM_CAP) {
+                if (total > 0) {
+                    if (!staged) {
+                        // the unit's air bits (APPLY_UNIT_W x 384 contiguous bytes per row; one mask word = 32 voxels = two 16-byte loads), claims cleared
+                        static_assert(MMB_AIR == 0, "zero-byte test below");
+#pragma unroll
+                        for (int cz = 0; cz < APPLY_UNIT_H; ++cz) {
+                            for (int m = lane; m < ROW_WORDS / 8; m += 64) {
+                                const uint4* src = (const uint4*)(unitBlocks + 384 * 16 * cz) + 2 * m;
+                                unsigned bits = 0u;
+#pragma unroll
+                                for (int h = 0; h < 2; ++h) {
+                                    const uint4 a = src[h];
+                                    const uint32_t w[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+                                    for (int q = 0; q < 4; ++q) {
+                                        const uint32_t z = ~(((w[q] & 0x7f7f7f7fu) + 0x7f7f7f7fu) | w[q] | 0x7f7f7f7fu);      // 0x80 in every byte that is 0
+                                        bits |= (((z >> 7) & 1u) | ((z >> 14) & 2u) | ((z >> 21) & 4u) | ((z >> 28) & 8u)) << (16 * h + 4 * q);
+                                    }
+                                }
+                                air[(ROW_WORDS / 8) * cz + m] = bits;
+                            }
+                            for (int i = lane; i < ROW_WORDS; i += 64) ((uint32_t*)claim)[ROW_WORDS * cz + i] = 0xffffffffu;
+                        }
+                        staged = true;
+                    }
+                    if (lane == 0) pref[nEnt] = (unsigned short)total;
+                    wave_lds_sync();
+#if MM_APPLY_STATS
+                    stEnt += nEnt; stItems += total;
+#endif
+#if MM_APPLY_EXP == 1
+                    total = 0;                                          // timing experiment: fixed per-unit work only
+#endif
+                    for (int j0 = 0; j0 < total; j0 += 64) {
+                        const int j = j0 + lane;
+                        bool placed = false;
+                        int k = 0, v = 0;
+                        uint8_t fb = 0;
+                        if (j < total) {
+                            int e = 0, eh = nEnt;                       // pref[e] <= j < pref[eh]
+                            while (eh - e > 1) { const int mid = (e + eh) >> 1; if ((int)pref[mid] <= j) e = mid; else eh = mid; }
+                            const unsigned en = ent[e];
+                            k = en & 127;
+                            const int c = (en >> 7) & 15, y = (int)((en >> 11) & 511) + (j - (int)pref[e]);
+                            v = 384 * c + y;
+                            const int4 rc = unit[k];
+                            if (((air[v >> 5] >> (v & 31)) & 1u) || ((rc.z >> 14) & 1)) {
+                                const int fy = rc.z & 511, feature = (rc.z >> 9) & 31, wx = wx0 + c % APPLY_UNIT_W, wz = wz0 + c / APPLY_UNIT_W;
+#if MM_APPLY_EXP == 2
+                                placed = (rc.x + fy + rc.y + y) == 0x7fffffff;        // timing experiment: no rasteriser
+#else
+                                placed = k >= nUS ? place_cave_feature(feature, rc.x, fy, rc.y, (rc.z >> 15) & 511, wx, y, wz, (uint32_t)rc.w, fb)
+                                                  : place_feature(feature, rc.x, fy, rc.y, wx, y, wz, (uint32_t)rc.w, fb);
+#endif
+                            }
+                        }
+                        // first match in list order wins: the batch's placements in ascending order, one masked write each (a placement has one item per voxel)
+                        unsigned long long todo = __ballot(placed);
+                        while (todo) {
+                            const int kk = __shfl(k, (int)__builtin_ctzll(todo));
+                            const bool mine = placed && k == kk;
+                            if (mine && claim[v] == 255) claim[v] = fb;
+                            todo &= ~__ballot(mine);
+                            wave_lds_sync();
+                        }
+                    }
+                    wave_lds_sync();                               // ent / pref are refilled
+                }
+                nEnt = 0; total = 0;
+                if (pairsDone) break;
+            }
+            // one round of 64 (placement, column) pairs = whole placements, placement-major
             const int p = p0 + lane, k = p / APPLY_UNIT_NCOL, c = p % APPLY_UNIT_NCOL;
             int n = 0, lo = 0;
             if (p < nPairs) {
@@ -861,118 +954,38 @@ k_apply_features(uint8_t* __restrict__ blocks, const int2* __restrict__ chunkPos
                     }
                 }
             }
+            p0 += 64;
             const unsigned long long vm = __ballot(n > 0);
             if (vm == 0ull) continue;
             int incl = n;
 #pragma unroll
-            for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o); if (lane >= o) incl += v; }
+            for (int o = 1; o < 64; o <<= 1) { const int up = __shfl_up(incl, o); if (lane >= o) incl += up; }
             if (n > 0) {
                 const int slot = nEnt + __popcll(vm & ((1ull << lane) - 1ull));
-                if (slot < APPLY_ENT_CAP) { ent[slot] = (unsigned)k | (c << 7) | (lo << 11) | ((n - 1) << 20); pref[slot] = (unsigned short)(total + incl - n); }
+                ent[slot] = (unsigned)k | (c << 7) | (lo << 11) | ((n - 1) << 20);
+                pref[slot] = (unsigned short)(total + incl - n);
             }
             nEnt += __popcll(vm);
             total += __builtin_amdgcn_readfirstlane(__shfl(incl, 63));
-            if (total > APPLY_ITEM_CAP) break;
         }
-        if (total == 0) continue;
-        fits = nEnt <= APPLY_ENT_CAP && total <= APPLY_ITEM_CAP;
+        nU = 0; nUS = 0;                                    // the placement buffer is free again
+        if (phase == 2) break;
     }
-
-    if (!fits) {
-        // lane = y, column by column, scan the gathered lists themselves
-        for (int c = 0; c < APPLY_UNIT_NCOL; ++c) {
-            uint8_t* colBlocks = unitBlocks + 384 * (16 * (c / APPLY_UNIT_W) + c % APPLY_UNIT_W);
-            const int wx = wx0 + c % APPLY_UNIT_W, wz = wz0 + c / APPLY_UNIT_W;
-            for (int y = lane; y < 384; y += 64) {
-                const uint8_t block = colBlocks[y];
-                uint8_t fb = 0;
-                bool placed = false;
-                if (doS && y >= sLo && y <= sHi) {
-                    for (int i = 0; i < MMGEN_MAX_GATHERED_FEATURES_PER_CHUNK; ++i) {
-                        const int feature = listS[i].feature;
-                        if (feature == MMF_NONE) break;
-                        if (block != MMB_AIR && !listS[i].can_replace_blocks) continue;
-                        const int fy = listS[i].pos[1];
-                        if (y < fy + kFeatureBounds[feature][0] || y > fy + kFeatureBounds[feature][1]) continue;
-                        if (place_feature(feature, listS[i].pos[0], fy, listS[i].pos[2], wx, y, wz, surface_feature_stream(listS[i].pos[0], fy, listS[i].pos[2]), fb)) { placed = true; break; }
-                    }
-                }
-                if (doC && !placed && y >= cLo && y <= cHi) {
-                    for (int i = 0; i < MMGEN_MAX_GATHERED_CAVE_FEATURES_PER_CHUNK; ++i) {
-                        const int feature = listC[i].feature;
-                        if (feature == MMCF_NONE) break;
-                        if (block != MMB_AIR && !listC[i].can_replace_blocks) continue;
-                        const int fy = listC[i].pos[1], lh = listC[i].layer_height;
-                        if (y < fy + kCaveFeatureBounds[feature][0] || y > fy + lh + kCaveFeatureBounds[feature][1]) continue;
-                        if (place_cave_feature(feature, listC[i].pos[0], fy, listC[i].pos[2], lh, wx, y, wz, cave_feature_stream(listC[i].pos[0], fy, listC[i].pos[2]), fb)) { placed = true; break; }
-                    }
-                }
-                if (placed) colBlocks[y] = fb;
-            }
-        }
-        continue;
-    }
-
 #if MM_APPLY_STATS
-    if (lane == 0) {
-        atomicAdd(&g_applyStats[0], 1ull); atomicAdd(&g_applyStats[1], (unsigned long long)nUS); atomicAdd(&g_applyStats[2], (unsigned long long)(nU - nUS));
-        atomicAdd(&g_applyStats[3], (unsigned long long)nEnt); atomicAdd(&g_applyStats[4], (unsigned long long)total);
+    if (lane == 0 && staged) {
+        atomicAdd(&g_applyStats[0], 1ull); atomicAdd(&g_applyStats[1], stS); atomicAdd(&g_applyStats[2], stC);
+        atomicAdd(&g_applyStats[3], stEnt); atomicAdd(&g_applyStats[4], stItems);
     }
 #endif
-    // stage the unit's blocks (APPLY_UNIT_W x 384 contiguous bytes per row), clear the claims
-    if (lane == 0) pref[nEnt] = (unsigned short)total;
-    constexpr int ROW_WORDS = APPLY_UNIT_W * 384 / 4;
-#pragma unroll
-    for (int cz = 0; cz < APPLY_UNIT_H; ++cz)
-        for (int i = lane; i < ROW_WORDS; i += 64) {
-            ((uint32_t*)blk)[ROW_WORDS * cz + i] = ((const uint32_t*)(unitBlocks + 384 * 16 * cz))[i];
-            ((uint32_t*)claim)[ROW_WORDS * cz + i] = 0xffffffffu;
-        }
-    wave_lds_sync();
-
-#if MM_APPLY_EXP == 1
-    total = 0;                                                          // timing experiment: fixed per-unit work only
-#endif
-    for (int j0 = 0; j0 < total; j0 += 64) {
-        const int j = j0 + lane;
-        bool placed = false;
-        int k = 0, v = 0;
-        uint8_t fb = 0;
-        if (j < total) {
-            int e = 0, eh = nEnt;                           // pref[e] <= j < pref[eh]
-            while (eh - e > 1) { const int mid = (e + eh) >> 1; if ((int)pref[mid] <= j) e = mid; else eh = mid; }
-            const unsigned en = ent[e];
-            k = en & 127;
-            const int c = (en >> 7) & 15, y = (int)((en >> 11) & 511) + (j - (int)pref[e]);
-            v = 384 * c + y;
-            const int4 rc = unit[k];
-            if (blk[v] == MMB_AIR || ((rc.z >> 14) & 1)) {
-                const int fy = rc.z & 511, feature = (rc.z >> 9) & 31, wx = wx0 + c % APPLY_UNIT_W, wz = wz0 + c / APPLY_UNIT_W;
-#if MM_APPLY_EXP == 2
-                placed = (rc.x + fy + rc.y + y) == 0x7fffffff;        // timing experiment: no rasteriser
-#else
-                placed = k >= nUS ? place_cave_feature(feature, rc.x, fy, rc.y, (rc.z >> 15) & 511, wx, y, wz, (uint32_t)rc.w, fb)
-                                  : place_feature(feature, rc.x, fy, rc.y, wx, y, wz, (uint32_t)rc.w, fb);
-#endif
-            }
-        }
-        // first match in list order wins: the batch's placements in ascending order, one masked write each (a placement has one item per voxel)
-        unsigned long long todo = __ballot(placed);
-        while (todo) {
-            const int kk = __shfl(k, (int)__builtin_ctzll(todo));
-            const bool mine = placed && k == kk;
-            if (mine && claim[v] == 255) claim[v] = fb;
-            todo &= ~__ballot(mine);
-            wave_lds_sync();
-        }
-    }
+    if (!staged) continue;
+    // ---- D. the claimed voxels back to the chunk
     wave_lds_sync();
 #pragma unroll
     for (int cz = 0; cz < APPLY_UNIT_H; ++cz)
         for (int i = lane; i < ROW_WORDS; i += 64) {
             const uint32_t cl = ((const uint32_t*)claim)[ROW_WORDS * cz + i];
             if (cl != 0xffffffffu) {
-                const uint32_t old = ((const uint32_t*)blk)[ROW_WORDS * cz + i];
+                const uint32_t old = ((const uint32_t*)(unitBlocks + 384 * 16 * cz))[i];
                 uint32_t out = 0u;
 #pragma unroll
                 for (int b = 0; b < 4; ++b) { const uint32_t cb = (cl >> (8 * b)) & 255u; out |= (cb != 255u ? cb : (old >> (8 * b)) & 255u) << (8 * b); }

@@ -518,7 +518,7 @@ def test_rasterisers_stay_inside_reach(gen, golden, is_cave):
 
 
 # (surface features, placements per chunk), (cave features, placements per chunk): densities keep a column's candidates below the
-# 256-entry caps of the unit / column lists (beyond them k_apply_features scans the lists directly and the extents are not exercised)
+# capacities of k_apply_features' buffers (128 placements, 256 pairs per flush): the dense cases below run through many flushes per unit
 TIGHT_CASES = [
     (([2] * 20 + [16] + [15] * 2, 70), ([8, 9], 200)),                  # CORAL, PURPLE / MEDIUM_PURPLE_MUSHROOM; WARPED / AMBER_FUNGUS
     (([6], 14), ([4, 7], 150)),                                        # REDWOOD_TREE; GLOWSTONE_CLUSTER, CRYSTAL_PILLAR
