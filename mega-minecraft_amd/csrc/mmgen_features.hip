@@ -468,8 +468,8 @@ k_gather_placements(const mmgen_feature_placement* __restrict__ fp, const mmgen_
 #define APPLY_COLS 4                      // waves per workgroup
 #define APPLY_THREADS (64 * APPLY_COLS)
 #ifndef APPLY_UNIT_W
-#define APPLY_UNIT_W 8                    // one wave = one UNIT at a time: W x H columns of a chunk
-#define APPLY_UNIT_H 1
+#define APPLY_UNIT_W 4                    // one wave = one UNIT at a time: W x H columns of a chunk (streaming kernel: 4 x 1 1.78 ms, 2 x 2 1.81,
+#define APPLY_UNIT_H 2                    // 4 x 2 1.35, 8 x 1 1.41, 2 x 4 1.44, 16 x 1 1.78, 8 x 2 1.72)
 #endif
 #define APPLY_UNIT_NCOL (APPLY_UNIT_W * APPLY_UNIT_H)
 #define APPLY_UNITS_PER_CHUNK ((16 / APPLY_UNIT_W) * (16 / APPLY_UNIT_H))
