@@ -290,6 +290,9 @@ struct CellTile {
 #ifndef MM_CAVE_WAVES
 #define MM_CAVE_WAVES 6
 #endif
+#ifndef MM_CAVE_EXP
+#define MM_CAVE_EXP 0        // timing experiments only (tools/build_variant.sh)
+#endif
 __attribute__((amdgpu_waves_per_eu(MM_CAVE_WAVES, MM_CAVE_WAVES)))
 __global__ void __launch_bounds__(CAVE_THREADS)
 k_cave_voxels(const float* __restrict__ hf, const float2* __restrict__ colInfo, const int2* __restrict__ chunkPos,
@@ -297,7 +300,6 @@ k_cave_voxels(const float* __restrict__ hf, const float2* __restrict__ colInfo, 
 {
     __shared__ float s_cells[3 * CELL_N];
     __shared__ unsigned long long s_solid[CAVE_ROW][6];       // solid bit of voxel y at word y / 64, bit y % 64
-    __shared__ int s_layers[4][3 * MMGEN_MAX_CAVE_LAYERS_PER_COLUMN];      // run extraction, four columns at a time
     __shared__ __attribute__((aligned(16))) unsigned short s_list1[CAVE_VOXELS];
     __shared__ unsigned short s_list2[CAVE_L2_CAP];
     __shared__ float s_thr[CAVE_L2_CAP];
@@ -352,14 +354,17 @@ k_cave_voxels(const float* __restrict__ hf, const float2* __restrict__ colInfo, 
     //   C  list 2: `huge` (<= 4 octaves) and the bound it implies; voxels whose noise is still below it -> list 3 with their huge
     //   D  list 3: the threshold itself (fbm3<4>); "cave" clears the solid bit again.  (With four-column batches this fourth phase measured
     //      0 %: its partial wave cost what it saved.  With row-long lists a third of phase C's lanes no longer idle through four octaves.)
+    static_assert(CAVE_THREADS % CAVE_ROW == 0, "a thread keeps its column through the walk below");
+    {
+    const int c = t % CAVE_ROW;                                 // y-major walk (the lists come out ordered by depth): column fixed per thread
+    const int col = chunk * 256 + colBase + c;
+    const float maxHeight = hf[col];
+    const float2 ci = colInfo[col];
+    const float obw = ci.x, ravineY = ci.y;
+    const int topSolid = imax((int)maxHeight, MMGEN_SEA_LEVEL);
+    if ((rowNeed >> c) & 1u)
     for (int u = t; u < CAVE_VOXELS; u += CAVE_THREADS) {
-        const int c = u % CAVE_ROW, y = u / CAVE_ROW;               // y-major: the lists come out ordered by depth
-        if (!((rowNeed >> c) & 1u)) continue;
-        const int col = chunk * 256 + colBase + c;
-        const float maxHeight = hf[col];
-        const float2 ci = colInfo[col];
-        const float obw = ci.x, ravineY = ci.y;
-        const int topSolid = imax((int)maxHeight, MMGEN_SEA_LEVEL);
+        const int y = u / CAVE_ROW;
         const float fy = (float)y;
         const bool inBand = (y != 0) && (y <= topSolid);
         const float topRatio = smoothstep(142.f, 95.f, fy + obw * 50.f);
@@ -371,6 +376,7 @@ k_cave_voxels(const float* __restrict__ hf, const float2* __restrict__ colInfo, 
             atomicOr(&s_solid[c][y >> 6], 1ull << (y & 63));
             if (needThr) s_list1[atomicAdd(&s_count[0], 1)] = (unsigned short)(c * CAVE_YEVAL + y);      // a voxel that is a cave anyway needs no noise
         }
+    }
     }
     __syncthreads();
     // The reference evaluates  cave = threshold > 0.04 && caveNoise < threshold  with threshold = ((0.24 + 0.12 fa) (1 + 1.4 huge)) T,
@@ -432,8 +438,15 @@ k_cave_voxels(const float* __restrict__ hf, const float2* __restrict__ colInfo, 
         bound *= (1.f + 1.4f * 1.f);
         bound *= topRatio * (0.3f + 0.7f * bottomRatio);
         if (!(bound > 0.04f)) continue;                        // threshold <= bound <= 0.04: no noise cave
+#if MM_CAVE_EXP == 1
+        const float n = bound + npx;                            // timing experiment: everything but the cave noise
+#elif MM_CAVE_EXP == 2
+        const f3 o = fbm3from3<5>(npx * 0.8000f, npy * 0.8000f, npz * 0.8000f);
+        const float n = bound + o.x + o.y + o.z;                // timing experiment: the warp without the Worley search
+#else
         const f3 o = fbm3from3<5>(npx * 0.8000f, npy * 0.8000f, npz * 0.8000f);
         const float n = special_cave_noise(npx * 1.f + o.x * 1.8f, npy * 1.6f + o.y * 1.8f, npz * 1.f + o.z * 1.8f, tile);
+#endif
         if (n < bound) {
             const int k = atomicAdd(&s_count[1], 1);
             if (k < CAVE_L2_CAP) { s_list2[k] = (unsigned short)e; s_thr[k] = n; }
@@ -471,38 +484,31 @@ k_cave_voxels(const float* __restrict__ hf, const float2* __restrict__ colInfo, 
     }
     __syncthreads();
 
-    // flips: solid(y) != solid(y+1), y = 383 compares with "not solid"; rank by popcount prefix over the column's 384 voxels; four columns
-    // at a time through the LDS layer slots
-  for (int sub = 0; sub < CAVE_ROW / 4; ++sub) {
-    for (int i = t; i < 4 * 3 * MMGEN_MAX_CAVE_LAYERS_PER_COLUMN; i += CAVE_THREADS)
-        (&s_layers[0][0])[i] = ((i % 3) == 2) ? 0 : 384;       // {384, 384, biomes = 0}
-    __syncthreads();
-    for (int v = t; v < 4 * 384; v += CAVE_THREADS) {
-        const int cc = v / 384, yy = v - cc * 384;
-        const int w = yy >> 6, b = yy & 63;
-        int before = 0;
-        unsigned long long mine = 0ull;
-#pragma unroll
-        for (int k = 0; k < 6; ++k) {
-            const unsigned long long m = s_solid[4 * sub + cc][k];
-            const unsigned long long nl = (k < 5) ? (s_solid[4 * sub + cc][k + 1] & 1ull) : 0ull;
-            const unsigned long long f = m ^ ((m >> 1) | (nl << 63));
-            if (k < w) before += __popcll(f);
-            if (k == w) mine = f;
-        }
-        if ((mine >> b) & 1ull) {
-            const int rank = before + __popcll(mine & ((1ull << b) - 1ull));
-            if (rank < 2 * MMGEN_MAX_CAVE_LAYERS_PER_COLUMN)       // canonical: runs beyond 32 layers are dropped
-                s_layers[cc][3 * (rank >> 1) + (rank & 1)] = yy;
+    // flips: solid(y) != solid(y+1), y = 383 compares with "not solid"; the r-th flip of a column (counted from below) is the start
+    // (r even) or the end (r odd) of layer r / 2; runs beyond 32 layers are dropped (canonical).  All 16 columns' slots get their default
+    // {384, 384, biomes 0} with whole-line stores, then one thread per (column, 64-voxel word) walks the set bits of its flip word and
+    // overwrites the slots its flips belong to (a column has a handful).
+    int* rowLayers = (int*)(caveLayers + (size_t)MMGEN_MAX_CAVE_LAYERS_PER_COLUMN * (chunk * 256 + colBase));
+    for (int i = t; i < CAVE_ROW * 3 * MMGEN_MAX_CAVE_LAYERS_PER_COLUMN; i += CAVE_THREADS) rowLayers[i] = ((i % 3) == 2) ? 0 : 384;
+    __syncthreads();                                           // (orders the defaults before the overwrites below)
+    if (t < CAVE_ROW * 6) {
+        const int c = t / 6, w = t % 6;
+        auto flips = [&](int k) {
+            const unsigned long long m = s_solid[c][k];
+            const unsigned long long nl = (k < 5) ? (s_solid[c][k + 1] & 1ull) : 0ull;
+            return m ^ ((m >> 1) | (nl << 63));
+        };
+        int rank = 0;
+        for (int k = 0; k < w; ++k) rank += __popcll(flips(k));
+        unsigned long long f = flips(w);
+        int* colLayers = rowLayers + 3 * MMGEN_MAX_CAVE_LAYERS_PER_COLUMN * c;
+        while (f && rank < 2 * MMGEN_MAX_CAVE_LAYERS_PER_COLUMN) {
+            const int b = (int)__builtin_ctzll(f);
+            f &= f - 1ull;
+            colLayers[3 * (rank >> 1) + (rank & 1)] = 64 * w + b;
+            ++rank;
         }
     }
-    __syncthreads();
-    for (int i = t; i < 4 * 3 * MMGEN_MAX_CAVE_LAYERS_PER_COLUMN; i += CAVE_THREADS) {
-        const int cc = i / (3 * MMGEN_MAX_CAVE_LAYERS_PER_COLUMN), k = i % (3 * MMGEN_MAX_CAVE_LAYERS_PER_COLUMN);
-        ((int*)(caveLayers + (size_t)MMGEN_MAX_CAVE_LAYERS_PER_COLUMN * (chunk * 256 + colBase + 4 * sub + cc)))[k] = s_layers[cc][k];
-    }
-    __syncthreads();                                           // the layer slots are re-used by the next four columns
-  }
 }
 
 // Cave biomes of the layers' end blocks: at most 2 getCaveBiome evaluations per occupied layer slot, and only a few of a column's
