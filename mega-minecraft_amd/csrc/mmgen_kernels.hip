@@ -299,7 +299,9 @@ k_cave_voxels(const float* __restrict__ hf, const float2* __restrict__ colInfo, 
               mmgen_cave_layer* __restrict__ caveLayers, const int* __restrict__ chunkList, const uint8_t* __restrict__ colNeed /*nullable, lazy ring*/)
 {
     __shared__ float s_cells[3 * CELL_N];
-    __shared__ unsigned long long s_solid[CAVE_ROW][6];       // solid bit of voxel y at word y / 64, bit y % 64
+    __shared__ unsigned long long s_solid[CAVE_ROW][6];       // solid bit of voxel y at word y / 64, bit y % 64 (set / cleared through its 32-bit halves)
+    __shared__ float s_obw[CAVE_ROW], s_ravine[CAVE_ROW];      // the row's per-column info (k_cave_columns)
+    __shared__ int s_top[CAVE_ROW];                            // max((int)height, SEA_LEVEL); -1 for a column the lazy ring skips
     __shared__ __attribute__((aligned(16))) unsigned short s_list1[CAVE_VOXELS];
     __shared__ unsigned short s_list2[CAVE_L2_CAP];
     __shared__ float s_thr[CAVE_L2_CAP];
@@ -343,6 +345,12 @@ k_cave_voxels(const float* __restrict__ hf, const float2* __restrict__ colInfo, 
         s_cells[3 * i] = p.x; s_cells[3 * i + 1] = p.y; s_cells[3 * i + 2] = p.z;
     }
     for (int i = t; i < CAVE_ROW * 6; i += CAVE_THREADS) s_solid[i / 6][i % 6] = 0ull;
+    if (t < CAVE_ROW) {
+        const int col = chunk * 256 + colBase + t;
+        const float2 ci = colInfo[col];
+        s_obw[t] = ci.x; s_ravine[t] = ci.y;
+        s_top[t] = ((rowNeed >> t) & 1u) ? imax((int)hf[col], MMGEN_SEA_LEVEL) : -1;
+    }
     if (t < 3) s_count[t] = 0;
     noise_tables_init<false>();                                // no simplex2 in this kernel; ends with the workgroup barrier
 
@@ -357,12 +365,9 @@ k_cave_voxels(const float* __restrict__ hf, const float2* __restrict__ colInfo, 
     static_assert(CAVE_THREADS % CAVE_ROW == 0, "a thread keeps its column through the walk below");
     {
     const int c = t % CAVE_ROW;                                 // y-major walk (the lists come out ordered by depth): column fixed per thread
-    const int col = chunk * 256 + colBase + c;
-    const float maxHeight = hf[col];
-    const float2 ci = colInfo[col];
-    const float obw = ci.x, ravineY = ci.y;
-    const int topSolid = imax((int)maxHeight, MMGEN_SEA_LEVEL);
-    if ((rowNeed >> c) & 1u)
+    const float obw = s_obw[c], ravineY = s_ravine[c];
+    const int topSolid = s_top[c];
+    if (topSolid >= 0)
     for (int u = t; u < CAVE_VOXELS; u += CAVE_THREADS) {
         const int y = u / CAVE_ROW;
         const float fy = (float)y;
@@ -373,7 +378,7 @@ k_cave_voxels(const float* __restrict__ hf, const float2* __restrict__ colInfo, 
         const bool cave0 = ((y != 0) && !inBand) || (inBand && fy > ravineY);
         // the wave's 64 lanes cover four consecutive y of the 16 columns: OR each lane's bit into its word
         if (!cave0) {
-            atomicOr(&s_solid[c][y >> 6], 1ull << (y & 63));
+            atomicOr((unsigned*)&s_solid[c][0] + (y >> 5), 1u << (y & 31));
             if (needThr) s_list1[atomicAdd(&s_count[0], 1)] = (unsigned short)(c * CAVE_YEVAL + y);      // a voxel that is a cave anyway needs no noise
         }
     }
@@ -392,7 +397,7 @@ k_cave_voxels(const float* __restrict__ hf, const float2* __restrict__ colInfo, 
         VoxelTerms v;
         v.c = e / CAVE_YEVAL; v.y = e - v.c * CAVE_YEVAL;
         const int idx2d = colBase + v.c;
-        const float obw = colInfo[chunk * 256 + idx2d].x;
+        const float obw = s_obw[v.c];
         const int wx = cp.x + (idx2d & 15), wz = cp.y + (idx2d >> 4);
         v.npx = (float)wx * 0.0050f; v.npz = (float)wz * 0.0050f;
         const float fy = (float)v.y;
@@ -415,7 +420,7 @@ k_cave_voxels(const float* __restrict__ hf, const float2* __restrict__ colInfo, 
         float thr = 0.24f + 0.12f * fbm3<4>(v.npx * 4.f, v.npy * 4.f, v.npz * 4.f);
         thr *= (1.f + 1.4f * huge);
         thr *= v.T;
-        if (thr > 0.04f && n < thr) atomicAnd(&s_solid[v.c][v.y >> 6], ~(1ull << (v.y & 63)));
+        if (thr > 0.04f && n < thr) atomicAnd((unsigned*)&s_solid[v.c][0] + (v.y >> 5), ~(1u << (v.y & 31)));
     };
     auto resolve = [&](int e, float n) {                       // C + D in place (a list was full)
         const VoxelTerms v = terms(e);
@@ -427,7 +432,7 @@ k_cave_voxels(const float* __restrict__ hf, const float2* __restrict__ colInfo, 
         const int e = s_list1[i];
         const int c = e / CAVE_YEVAL, y = e - c * CAVE_YEVAL;
         const int idx2d = colBase + c;
-        const float obw = colInfo[chunk * 256 + idx2d].x;
+        const float obw = s_obw[c];
         const int wx = cp.x + (idx2d & 15), wz = cp.y + (idx2d >> 4);
         const float npx = (float)wx * 0.0050f, npz = (float)wz * 0.0050f;
         const float fy = (float)y;
@@ -472,15 +477,11 @@ k_cave_voxels(const float* __restrict__ hf, const float2* __restrict__ colInfo, 
     // analytic part, y in [144, 384): solid iff y <= topSolid and not (y > ravineY)   (topRatio == 0 there)
     if (t < CAVE_ROW * 4) {    // 4 lanes per column fill words 2..5 (word 2 holds y 128..191: bits >= 16 only)
         const int c = t >> 2, w = 2 + (t & 3);
-        const int col = chunk * 256 + colBase + c;
-        const int topSolid = ((rowNeed >> c) & 1u) ? imax((int)hf[col], MMGEN_SEA_LEVEL) : -1;
-        const float ravineY = colInfo[col].y;
-        unsigned long long m = 0ull;
-        for (int b = 0; b < 64; ++b) {
-            const int yy = 64 * w + b;
-            if (yy >= CAVE_YEVAL && yy <= topSolid && !((float)yy > ravineY)) m |= 1ull << b;
-        }
-        if (m) atomicOr(&s_solid[c][w], m);
+        const float ravineY = s_ravine[c];
+        // (float)y > ravineY  <=>  y > floor(ravineY) for an integer y; no ravine = +inf
+        const int cut = ravineY >= 383.f ? 383 : (int)__builtin_floorf(ravineY);
+        const int lo = imax(CAVE_YEVAL, 64 * w) - 64 * w, hi = imin(imin(s_top[c], cut), 64 * w + 63) - 64 * w;      // bit range inside the word
+        if (hi >= lo) atomicOr(&s_solid[c][w], (~0ull >> (63 - hi)) & (~0ull << lo));
     }
     __syncthreads();
 
