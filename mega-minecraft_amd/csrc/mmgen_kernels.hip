@@ -339,6 +339,9 @@ k_cave_voxels(const float* __restrict__ hf, const float2* __restrict__ colInfo, 
     tile.ox = (int)__builtin_floorf(((float)cp.x * 0.0050f) * 1.f) - 3;
     tile.oy = -3;
     tile.oz = (int)__builtin_floorf(((float)(cp.y + row) * 0.0050f) * 1.f) - 3;
+#if MM_CAVE_EXP == 3 || MM_CAVE_EXP == 4 || MM_CAVE_EXP == 5
+    if (t == 12345)                                             // timing experiment: no tile staging (with the cave noise removed)
+#endif
     for (int i = t; i < CELL_N; i += CAVE_THREADS) {
         const int iz = i % CELL_NZ, iy = (i / CELL_NZ) % CELL_NY, ix = i / (CELL_NZ * CELL_NY);
         const f3 p = rand3from3((float)(tile.ox + ix), (float)(tile.oy + iy), (float)(tile.oz + iz));
@@ -362,26 +365,60 @@ k_cave_voxels(const float* __restrict__ hf, const float2* __restrict__ colInfo, 
     //   C  list 2: `huge` (<= 4 octaves) and the bound it implies; voxels whose noise is still below it -> list 3 with their huge
     //   D  list 3: the threshold itself (fbm3<4>); "cave" clears the solid bit again.  (With four-column batches this fourth phase measured
     //      0 %: its partial wave cost what it saved.  With row-long lists a third of phase C's lanes no longer idle through four octaves.)
-    static_assert(CAVE_THREADS % CAVE_ROW == 0, "a thread keeps its column through the walk below");
+    static_assert(CAVE_THREADS == 256 && CAVE_ROW == 16 && CAVE_YEVAL == 144, "the walk below: thread t = column t % 16, y = t / 16 + 16 i, i < 9");
     {
-    const int c = t % CAVE_ROW;                                 // y-major walk (the lists come out ordered by depth): column fixed per thread
+    // y-major walk (the lists come out ordered by depth): a thread keeps its column, a wave covers four consecutive y of the 16 columns
+    // per step.  Nothing touches LDS inside the walk: the solid bits gather in registers (y + 16 i lies in 32-bit word i / 2), the four
+    // lanes of a column OR theirs together and one of them writes the words; the list positions come from ballots, with ONE counter
+    // update per wave - per step that was 64 conflicting LDS atomics and a counter round trip.
+    const int c = t % CAVE_ROW, yb = t / CAVE_ROW, lane = t & 63;
     const float obw = s_obw[c], ravineY = s_ravine[c];
     const int topSolid = s_top[c];
-    if (topSolid >= 0)
-    for (int u = t; u < CAVE_VOXELS; u += CAVE_THREADS) {
-        const int y = u / CAVE_ROW;
-        const float fy = (float)y;
-        const bool inBand = (y != 0) && (y <= topSolid);
-        const float topRatio = smoothstep(142.f, 95.f, fy + obw * 50.f);
-        const bool needThr = inBand && topRatio > 0.f;      // threshold is a product with topRatio: 0 -> "threshold > 0.04" is false
-        // final cave = noise cave || (y != 0 && !inBand) || (inBand && fy > ravineY)   (y == 0 solid, y > topSolid air, ravine cut)
-        const bool cave0 = ((y != 0) && !inBand) || (inBand && fy > ravineY);
-        // the wave's 64 lanes cover four consecutive y of the 16 columns: OR each lane's bit into its word
-        if (!cave0) {
-            atomicOr((unsigned*)&s_solid[c][0] + (y >> 5), 1u << (y & 31));
-            if (needThr) s_list1[atomicAdd(&s_count[0], 1)] = (unsigned short)(c * CAVE_YEVAL + y);      // a voxel that is a cave anyway needs no noise
+    const unsigned long long below = (1ull << lane) - 1ull;
+    unsigned bitsW[5] = {0u, 0u, 0u, 0u, 0u};
+    unsigned listed = 0u;                                       // bit i: voxel y = yb + 16 i needs the noise
+    unsigned char posIn[9];                                     // ... and is the posIn[i]-th such voxel of the wave's step i
+    int nBefore = 0;                                            // wave-uniform: list entries of the wave's steps so far
+    int before[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        const int y = yb + 16 * i;
+        bool need = false;
+#if MM_CAVE_EXP != 4
+        if (topSolid >= 0) {
+            const float fy = (float)y;
+            const bool inBand = (y != 0) && (y <= topSolid);
+            const float topRatio = smoothstep(142.f, 95.f, fy + obw * 50.f);
+            const bool needThr = inBand && topRatio > 0.f;      // threshold is a product with topRatio: 0 -> "threshold > 0.04" is false
+            // final cave = noise cave || (y != 0 && !inBand) || (inBand && fy > ravineY)   (y == 0 solid, y > topSolid air, ravine cut)
+            const bool cave0 = ((y != 0) && !inBand) || (inBand && fy > ravineY);
+            if (!cave0) {
+                bitsW[i >> 1] |= 1u << (y & 31);
+                need = needThr;                                 // a voxel that is a cave anyway needs no noise
+            }
         }
+#endif
+        const unsigned long long m = __ballot(need);
+        if (need) listed |= 1u << i;
+        posIn[i] = (unsigned char)__popcll(m & below);
+        before[i] = nBefore;
+        nBefore += __popcll(m);
     }
+    // solid bits: the column's four lanes of this wave (lane, lane ^ 16, lane ^ 32, lane ^ 48) together, lanes 0 .. 15 write
+#pragma unroll
+    for (int w = 0; w < 5; ++w) {
+        unsigned b = bitsW[w];
+        b |= (unsigned)__shfl_xor((int)b, 16);
+        b |= (unsigned)__shfl_xor((int)b, 32);
+        if (lane < 16 && b) atomicOr((unsigned*)&s_solid[c][0] + w, b);
+    }
+    // list 1: one reservation per wave, entries in step order
+    int base = 0;
+    if (lane == 0 && nBefore) base = atomicAdd(&s_count[0], nBefore);
+    base = __shfl(base, 0);
+#pragma unroll
+    for (int i = 0; i < 9; ++i)
+        if ((listed >> i) & 1u) s_list1[base + before[i] + posIn[i]] = (unsigned short)(c * CAVE_YEVAL + yb + 16 * i);
     }
     __syncthreads();
     // The reference evaluates  cave = threshold > 0.04 && caveNoise < threshold  with threshold = ((0.24 + 0.12 fa) (1 + 1.4 huge)) T,
@@ -443,8 +480,8 @@ k_cave_voxels(const float* __restrict__ hf, const float2* __restrict__ colInfo, 
         bound *= (1.f + 1.4f * 1.f);
         bound *= topRatio * (0.3f + 0.7f * bottomRatio);
         if (!(bound > 0.04f)) continue;                        // threshold <= bound <= 0.04: no noise cave
-#if MM_CAVE_EXP == 1
-        const float n = bound + npx;                            // timing experiment: everything but the cave noise
+#if MM_CAVE_EXP == 1 || MM_CAVE_EXP >= 3
+        const float n = bound + __builtin_fabsf(npx) + 1.f;      // timing experiment: everything but the cave noise (never below the bound)
 #elif MM_CAVE_EXP == 2
         const f3 o = fbm3from3<5>(npx * 0.8000f, npy * 0.8000f, npz * 0.8000f);
         const float n = bound + o.x + o.y + o.z;                // timing experiment: the warp without the Worley search
@@ -490,6 +527,10 @@ k_cave_voxels(const float* __restrict__ hf, const float2* __restrict__ colInfo, 
     // {384, 384, biomes 0} with whole-line stores, then one thread per (column, 64-voxel word) walks the set bits of its flip word and
     // overwrites the slots its flips belong to (a column has a handful).
     int* rowLayers = (int*)(caveLayers + (size_t)MMGEN_MAX_CAVE_LAYERS_PER_COLUMN * (chunk * 256 + colBase));
+#if MM_CAVE_EXP == 5
+    if (t == 12345)                                             // timing experiment: no run extraction, no layer stores
+    {
+#endif
     for (int i = t; i < CAVE_ROW * 3 * MMGEN_MAX_CAVE_LAYERS_PER_COLUMN; i += CAVE_THREADS) rowLayers[i] = ((i % 3) == 2) ? 0 : 384;
     __syncthreads();                                           // (orders the defaults before the overwrites below)
     if (t < CAVE_ROW * 6) {
@@ -510,6 +551,9 @@ k_cave_voxels(const float* __restrict__ hf, const float2* __restrict__ colInfo, 
             ++rank;
         }
     }
+#if MM_CAVE_EXP == 5
+    }
+#endif
 }
 
 // Cave biomes of the layers' end blocks: at most 2 getCaveBiome evaluations per occupied layer slot, and only a few of a column's
