@@ -365,6 +365,22 @@ k_cave_voxels(const float* __restrict__ hf, const float2* __restrict__ colInfo, 
     //   C  list 2: `huge` (<= 4 octaves) and the bound it implies; voxels whose noise is still below it -> list 3 with their huge
     //   D  list 3: the threshold itself (fbm3<4>); "cave" clears the solid bit again.  (With four-column batches this fourth phase measured
     //      0 %: its partial wave cost what it saved.  With row-long lists a third of phase C's lanes no longer idle through four octaves.)
+    // every slot's default {384, 384, biomes 0}, whole lines, long before the runs overwrite a few of them (the barriers in between order the stores)
+    {
+        int* rowLayersEarly = (int*)(caveLayers + (size_t)MMGEN_MAX_CAVE_LAYERS_PER_COLUMN * (chunk * 256 + colBase));
+#if MM_CAVE_EXP != 5
+        for (int i = t; i < CAVE_ROW * 3 * MMGEN_MAX_CAVE_LAYERS_PER_COLUMN; i += CAVE_THREADS) rowLayersEarly[i] = ((i % 3) == 2) ? 0 : 384;
+#endif
+    }
+    // analytic part, y in [144, 384): solid iff y <= topSolid and not (y > ravineY)   (topRatio == 0 there)
+    if (t < CAVE_ROW * 4) {    // 4 lanes per column fill words 2..5 (word 2 holds y 128..191: bits >= 16 only)
+        const int c = t >> 2, w = 2 + (t & 3);
+        const float ravineY = s_ravine[c];
+        // (float)y > ravineY  <=>  y > floor(ravineY) for an integer y; no ravine = +inf
+        const int cut = ravineY >= 383.f ? 383 : (int)__builtin_floorf(ravineY);
+        const int lo = imax(CAVE_YEVAL, 64 * w) - 64 * w, hi = imin(imin(s_top[c], cut), 64 * w + 63) - 64 * w;      // bit range inside the word
+        if (hi >= lo) atomicOr(&s_solid[c][w], (~0ull >> (63 - hi)) & (~0ull << lo));
+    }
     static_assert(CAVE_THREADS == 256 && CAVE_ROW == 16 && CAVE_YEVAL == 144, "the walk below: thread t = column t % 16, y = t / 16 + 16 i, i < 9");
     {
     // y-major walk (the lists come out ordered by depth): a thread keeps its column, a wave covers four consecutive y of the 16 columns
@@ -511,28 +527,17 @@ k_cave_voxels(const float* __restrict__ hf, const float2* __restrict__ colInfo, 
         const int i = s_list3[k];
         carve(terms(s_list2[i]), s_thr[i], s_huge[k]);
     }
-    // analytic part, y in [144, 384): solid iff y <= topSolid and not (y > ravineY)   (topRatio == 0 there)
-    if (t < CAVE_ROW * 4) {    // 4 lanes per column fill words 2..5 (word 2 holds y 128..191: bits >= 16 only)
-        const int c = t >> 2, w = 2 + (t & 3);
-        const float ravineY = s_ravine[c];
-        // (float)y > ravineY  <=>  y > floor(ravineY) for an integer y; no ravine = +inf
-        const int cut = ravineY >= 383.f ? 383 : (int)__builtin_floorf(ravineY);
-        const int lo = imax(CAVE_YEVAL, 64 * w) - 64 * w, hi = imin(imin(s_top[c], cut), 64 * w + 63) - 64 * w;      // bit range inside the word
-        if (hi >= lo) atomicOr(&s_solid[c][w], (~0ull >> (63 - hi)) & (~0ull << lo));
-    }
     __syncthreads();
 
     // flips: solid(y) != solid(y+1), y = 383 compares with "not solid"; the r-th flip of a column (counted from below) is the start
     // (r even) or the end (r odd) of layer r / 2; runs beyond 32 layers are dropped (canonical).  All 16 columns' slots get their default
-    // {384, 384, biomes 0} with whole-line stores, then one thread per (column, 64-voxel word) walks the set bits of its flip word and
-    // overwrites the slots its flips belong to (a column has a handful).
+    // {384, 384, biomes 0} with whole-line stores at the start of the kernel (several barriers before this point); here one thread per
+    // (column, 64-voxel word) walks the set bits of its flip word and overwrites the slots its flips belong to (a column has a handful).
     int* rowLayers = (int*)(caveLayers + (size_t)MMGEN_MAX_CAVE_LAYERS_PER_COLUMN * (chunk * 256 + colBase));
 #if MM_CAVE_EXP == 5
     if (t == 12345)                                             // timing experiment: no run extraction, no layer stores
     {
 #endif
-    for (int i = t; i < CAVE_ROW * 3 * MMGEN_MAX_CAVE_LAYERS_PER_COLUMN; i += CAVE_THREADS) rowLayers[i] = ((i % 3) == 2) ? 0 : 384;
-    __syncthreads();                                           // (orders the defaults before the overwrites below)
     if (t < CAVE_ROW * 6) {
         const int c = t / 6, w = t % 6;
         auto flips = [&](int k) {
