@@ -290,9 +290,6 @@ struct CellTile {
 #ifndef MM_CAVE_WAVES
 #define MM_CAVE_WAVES 6
 #endif
-#ifndef MM_CAVE_EXP
-#define MM_CAVE_EXP 0        // timing experiments only (tools/build_variant.sh)
-#endif
 __attribute__((amdgpu_waves_per_eu(MM_CAVE_WAVES, MM_CAVE_WAVES)))
 __global__ void __launch_bounds__(CAVE_THREADS)
 k_cave_voxels(const float* __restrict__ hf, const float2* __restrict__ colInfo, const int2* __restrict__ chunkPos,
@@ -339,9 +336,6 @@ k_cave_voxels(const float* __restrict__ hf, const float2* __restrict__ colInfo, 
     tile.ox = (int)__builtin_floorf(((float)cp.x * 0.0050f) * 1.f) - 3;
     tile.oy = -3;
     tile.oz = (int)__builtin_floorf(((float)(cp.y + row) * 0.0050f) * 1.f) - 3;
-#if MM_CAVE_EXP == 3 || MM_CAVE_EXP == 4 || MM_CAVE_EXP == 5
-    if (t == 12345)                                             // timing experiment: no tile staging (with the cave noise removed)
-#endif
     for (int i = t; i < CELL_N; i += CAVE_THREADS) {
         const int iz = i % CELL_NZ, iy = (i / CELL_NZ) % CELL_NY, ix = i / (CELL_NZ * CELL_NY);
         const f3 p = rand3from3((float)(tile.ox + ix), (float)(tile.oy + iy), (float)(tile.oz + iz));
@@ -368,9 +362,7 @@ k_cave_voxels(const float* __restrict__ hf, const float2* __restrict__ colInfo, 
     // every slot's default {384, 384, biomes 0}, whole lines, long before the runs overwrite a few of them (the barriers in between order the stores)
     {
         int* rowLayersEarly = (int*)(caveLayers + (size_t)MMGEN_MAX_CAVE_LAYERS_PER_COLUMN * (chunk * 256 + colBase));
-#if MM_CAVE_EXP != 5
         for (int i = t; i < CAVE_ROW * 3 * MMGEN_MAX_CAVE_LAYERS_PER_COLUMN; i += CAVE_THREADS) rowLayersEarly[i] = ((i % 3) == 2) ? 0 : 384;
-#endif
     }
     // analytic part, y in [144, 384): solid iff y <= topSolid and not (y > ravineY)   (topRatio == 0 there)
     if (t < CAVE_ROW * 4) {    // 4 lanes per column fill words 2..5 (word 2 holds y 128..191: bits >= 16 only)
@@ -400,7 +392,6 @@ k_cave_voxels(const float* __restrict__ hf, const float2* __restrict__ colInfo, 
     for (int i = 0; i < 9; ++i) {
         const int y = yb + 16 * i;
         bool need = false;
-#if MM_CAVE_EXP != 4
         if (topSolid >= 0) {
             const float fy = (float)y;
             const bool inBand = (y != 0) && (y <= topSolid);
@@ -413,7 +404,6 @@ k_cave_voxels(const float* __restrict__ hf, const float2* __restrict__ colInfo, 
                 need = needThr;                                 // a voxel that is a cave anyway needs no noise
             }
         }
-#endif
         const unsigned long long m = __ballot(need);
         if (need) listed |= 1u << i;
         posIn[i] = (unsigned char)__popcll(m & below);
@@ -496,15 +486,8 @@ k_cave_voxels(const float* __restrict__ hf, const float2* __restrict__ colInfo, 
         bound *= (1.f + 1.4f * 1.f);
         bound *= topRatio * (0.3f + 0.7f * bottomRatio);
         if (!(bound > 0.04f)) continue;                        // threshold <= bound <= 0.04: no noise cave
-#if MM_CAVE_EXP == 1 || MM_CAVE_EXP >= 3
-        const float n = bound + __builtin_fabsf(npx) + 1.f;      // timing experiment: everything but the cave noise (never below the bound)
-#elif MM_CAVE_EXP == 2
-        const f3 o = fbm3from3<5>(npx * 0.8000f, npy * 0.8000f, npz * 0.8000f);
-        const float n = bound + o.x + o.y + o.z;                // timing experiment: the warp without the Worley search
-#else
         const f3 o = fbm3from3<5>(npx * 0.8000f, npy * 0.8000f, npz * 0.8000f);
         const float n = special_cave_noise(npx * 1.f + o.x * 1.8f, npy * 1.6f + o.y * 1.8f, npz * 1.f + o.z * 1.8f, tile);
-#endif
         if (n < bound) {
             const int k = atomicAdd(&s_count[1], 1);
             if (k < CAVE_L2_CAP) { s_list2[k] = (unsigned short)e; s_thr[k] = n; }
@@ -534,10 +517,6 @@ k_cave_voxels(const float* __restrict__ hf, const float2* __restrict__ colInfo, 
     // {384, 384, biomes 0} with whole-line stores at the start of the kernel (several barriers before this point); here one thread per
     // (column, 64-voxel word) walks the set bits of its flip word and overwrites the slots its flips belong to (a column has a handful).
     int* rowLayers = (int*)(caveLayers + (size_t)MMGEN_MAX_CAVE_LAYERS_PER_COLUMN * (chunk * 256 + colBase));
-#if MM_CAVE_EXP == 5
-    if (t == 12345)                                             // timing experiment: no run extraction, no layer stores
-    {
-#endif
     if (t < CAVE_ROW * 6) {
         const int c = t / 6, w = t % 6;
         auto flips = [&](int k) {
@@ -556,9 +535,6 @@ k_cave_voxels(const float* __restrict__ hf, const float2* __restrict__ colInfo, 
             ++rank;
         }
     }
-#if MM_CAVE_EXP == 5
-    }
-#endif
 }
 
 // Cave biomes of the layers' end blocks: at most 2 getCaveBiome evaluations per occupied layer slot, and only a few of a column's

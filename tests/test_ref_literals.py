@@ -135,7 +135,8 @@ DEVICE_EXTRA = {
     # cave_huge: slack of its exact pruning; k_cave_voxels: kCaveFaMax = 0.9375 * MM_SIMPLEX3_BOUND (the octave amplitudes of fbm3<4> sum to
     # 0.9375), 1e30 = "no bound" outside the pruning domain (the bounds themselves are macros of mm_noise.cuh)
     # ... and 18: cave_huge tests the gradient tables' domain (|argument| < 2^18) once for its four octaves
-    "chunk.cu::shouldGenerateCaveAtBlock": (float(np.float32(0.001)), 0.9375, float(np.float32(1e30)), 18.0),
+    "chunk.cu::shouldGenerateCaveAtBlock": (float(np.float32(0.001)), 0.9375, float(np.float32(1e30)), 18.0,
+                                            31.0, 32.0, 144.0, 383.0),      # bit positions in 32-bit words; the 144-voxel walk; the closed-form analytic bits
     # cave_biome: fbm3From3's component offsets (rng.hpp:188-191, rolled into the loop) and 0.875 = the octave amplitudes of fbm2<3>
     "biomeFuncs.hpp::getCaveBiomeNoise": tuple(float(np.float32(v)) for v in (0.875, 5923.45, 4129.42, 5790.48, 1765.68, 4704.36, 5692.12)),
 }
