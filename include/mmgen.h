@@ -63,7 +63,8 @@ int mmgen_fix_backward_layers(float* d_layers, int num_chunks, void* stream);
  * d_accumulated_heights: 147456 floats, overwritten with the accumulated lift (may be NULL).  Synchronous on return, like the reference.
  * Canonical semantics: synchronous Jacobi passes; the reference's in-place update races between thread blocks. */
 int mmgen_erode_zone(float* d_gathered_layers, float* d_accumulated_heights, void* stream);
-/* Batched form: num_zones buffers of MMGEN_GATHERED_LAYERS_SIZE floats back to back (one launch per pass for all zones);
+/* Batched form: num_zones buffers of MMGEN_GATHERED_LAYERS_SIZE floats back to back (ONE persistent launch relaxes all zones to
+ * convergence: the host loop of chunk.cu:682-705 runs on the device, a zone's workgroups meet at a barrier after every block of passes);
  * *max_passes (nullable) receives the largest number of relaxation passes any zone needed. */
 int mmgen_erode_zones(float* d_gathered_layers, int num_zones, float* d_accumulated_heights, int* max_passes, void* stream);
 

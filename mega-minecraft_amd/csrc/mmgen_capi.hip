@@ -179,8 +179,9 @@ int mmgen_erode_zones(float* d_gathered, int num_zones, float* d_acc, int* max_p
     if (!sc) return (int)hipErrorInvalidDevice;
     int e = ensure_erosion(*sc, num_zones, stream);
     if (e) return e;
+    int dummy = 0;       // asking for the pass count is what makes the call synchronous (the contract of the per-stage entry points)
     return mmk::erode_zones(d_gathered, (size_t)MMGEN_GATHERED_LAYERS_SIZE, num_zones, sc->erodeWork, sc->erodeState, d_acc,
-                            (size_t)MMGEN_EROSION_GRID_NUM_COLS, (hipStream_t)stream, max_passes);
+                            (size_t)MMGEN_EROSION_GRID_NUM_COLS, (hipStream_t)stream, max_passes ? max_passes : &dummy);
 }
 
 int mmgen_erode_zone(float* d_gathered, float* d_acc, void* stream) { return mmgen_erode_zones(d_gathered, 1, d_acc, nullptr, stream); }

@@ -27,7 +27,10 @@ struct ErosionPhase {       // state of the relaxation loop of one zone as seen 
 // workgroup (0,0) stores it to slot[t & 1] for launch t+1.  Kernel boundaries on the stream order everything.
 struct ErosionState {
     ErosionPhase slot[2];
-    unsigned changed[4];    // launch t ORs into changed[t & 3] and clears changed[(t + 1) & 3]
+    unsigned changed[4];    // round t ORs into changed[t & 3] and clears changed[(t + 1) & 3]
+    unsigned barrier;       // arrivals of the zone's workgroups at the end of their rounds (round t is over at perZone * (t + 1))
+    unsigned tileTicket[2]; // round t deals its tiles out of tileTicket[t & 1] (the zone's first workgroup clears the other one)
+    unsigned pad;
 };
 }  // namespace mm
 
@@ -37,7 +40,7 @@ size_t erosion_state_bytes(int zones);
 // layersOut != null (region path): the kept 12 x 12 chunks of every zone (zoneChunkIdxOut, [zones][144], -1 = skip) go straight into the
 // chunk-major layers and `gathered` is left as it was; else the final planes are written back into `gathered` (Chunk::erodeZone's contract)
 int erode_zones(float* gathered, size_t strideFloats, int zones, float* work, mm::ErosionState* states, float* accOut, size_t accStride,
-                hipStream_t s, int* maxPasses, const int* zoneChunkIdxOut = nullptr, float* layersOut = nullptr);
+                hipStream_t s, int* maxPasses, const int* zoneChunkIdxOut = nullptr, float* layersOut = nullptr, int* maxPassesDev = nullptr);
 int erosion_gather(const float* layers, const float* hf, const int* zoneChunkIdx, int zones, float* gathered, size_t strideFloats, hipStream_t s);
 int erosion_scatter(const float* gathered, size_t strideFloats, const int* zoneChunkIdxOut, int zones, float* layersOut, hipStream_t s);
 }  // namespace mmk

@@ -19,7 +19,7 @@
 //    publishes the mask.  The host enqueues launches back to back and reads the states every few launches;
 //  * many zones per launch (blockIdx.z = zone); the zone working set stays L2 / Infinity-Cache resident.
 #include <hip/hip_runtime.h>
-#include <vector>
+#include <cstdlib>
 #include "mm_biome.cuh"
 #include "mmgen_erosion.h"
 #include "mmgen_prof.h"
@@ -64,6 +64,12 @@ MM_DEV ErosionPhase next_phase(const ErosionPhase& prev, unsigned maskPrev)
     else { cur.layer = L - 1; cur.isFirst = 1; }
     return cur;
 }
+
+// Planes, masks and phases travel between the workgroups of a zone INSIDE one launch.  They are read and written with device-scope
+// relaxed atomics (global_load / global_store with sc1: served at the level every XCD sees) and ordered by the zone's barrier - no
+// cache write-back / invalidate fences, which every workgroup of the chip would pay for at every barrier of every other zone.
+MM_DEV float ld_dev(const float* p) { return __int_as_float(__hip_atomic_load((const int*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); }
+MM_DEV void st_dev(float* p, float v) { __hip_atomic_store((int*)p, __float_as_int(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // One Jacobi pass of one lane: column ex of the extended tile, rows [r0, r1].  sIn / tIn = start plane and thickness (end - start)
 // of the previous state, read through a sliding 3 x 3 register window (6 LDS reads per cell); sOut / tOut receive the new state.
@@ -110,36 +116,41 @@ MM_DEV int relax_strip(const float* __restrict__ sIn, const float* __restrict__ 
         }
         sOut[c] = outStart;
         tOut[c] = s_end[c] - outStart;
-        if (LIFT && ownCol && ez >= EROSION_K && ez < EROSION_K + 32) startFirst[(size_t)ZS * ez] = outStart;
+        if (LIFT && ownCol && ez >= EROSION_K && ez < EROSION_K + 32) st_dev(startFirst + (size_t)ZS * ez, outStart);
         aS0 = bS0; aS1 = bS1; aS2 = bS2; aT0 = bT0; aT1 = bT1; aT2 = bT2;
         bS0 = cS0; bS1 = cS1; bS2 = cS2; bT0 = cT0; bT1 = cT1; bT2 = cT2;
     }
     return flags;
 }
 
-__global__ void __launch_bounds__(EROSION_THREADS)
-k_erode_pass(const float* __restrict__ gatheredBase, size_t gatheredStride, float* __restrict__ workBase, ErosionState* __restrict__ states, int t)
+// a phase another workgroup stored before the zone's barrier (word-wise device-scope loads: never from a stale scalar / vector cache line)
+MM_DEV ErosionPhase load_phase(const ErosionPhase* p)
 {
-    __shared__ float s_s[2][EROSION_CELLS_EXT];            // start planes, ping-pong over the passes
-    __shared__ float s_t[2][EROSION_CELLS_EXT];            // thickness = end - start of the same states (what the neighbours compare)
-    __shared__ float s_end[EROSION_CELLS_EXT];
-    __shared__ float s_acc[EROSION_CELLS_EXT];             // accumulated heights; after the load every cell is touched by its own lane only
-    __shared__ unsigned s_mask;
+    static_assert(sizeof(ErosionPhase) == 7 * sizeof(int), "seven words");
+    ErosionPhase r;
+    const int* src = (const int*)p;
+    int* dst = (int*)&r;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) dst[i] = __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return r;
+}
+MM_DEV void store_phase(ErosionPhase* p, const ErosionPhase& v)
+{
+    const int* src = (const int*)&v;
+    int* dst = (int*)p;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) __hip_atomic_store(dst + i, src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
-    const int zone = blockIdx.z;
-    ErosionState* st = states + zone;
+// One launch-equivalent ("round") of one 32 x 32 tile: EROSION_K Jacobi passes of the phase's layer on the (32 + 2 K)^2 extended tile.
+// Called by every thread of the workgroup; the LDS planes are the caller's.  Returns nothing; the tile's "changed" bits are ORed into
+// *zoneMask (device scope) by one thread.
+MM_DEV void erode_tile(const float* __restrict__ gathered, float* work, const ErosionPhase& ph, int tileX, int tileZ, unsigned* zoneMask,
+                       float (*s_s)[EROSION_CELLS_EXT], float (*s_t)[EROSION_CELLS_EXT], float* s_end, float* s_acc, unsigned* s_mask)
+{
     const int tid = threadIdx.x;
-    const ErosionPhase ph = next_phase(st->slot[(t + 1) & 1], st->changed[(t + 3) & 3]);
-    if (tid == 0 && blockIdx.x == 0 && blockIdx.y == 0) {
-        st->slot[t & 1] = ph;
-        st->changed[(t + 1) & 3] = 0;
-    }
-    if (ph.done) return;
     const int layer = ph.layer;
     const bool isFirst = ph.isFirst != 0;
-
-    const float* gathered = gatheredBase + gatheredStride * zone;
-    float* work = workBase + ZONE_WORK_FLOATS * zone;
     const float* accIn = work + (size_t)24 * ZN + (size_t)ph.accSel * ZN;
     float* accOut = work + (size_t)24 * ZN + (size_t)(1 - ph.accSel) * ZN;
     const float* startIn = isFirst ? (gathered + (size_t)layer * ZN) : (work + ((size_t)layer * 3 + ph.plane(layer)) * ZN);
@@ -150,7 +161,7 @@ k_erode_pass(const float* __restrict__ gatheredBase, size_t gatheredStride, floa
                                                                    : (work + ((size_t)(layer + 1) * 3 + ph.plane(layer + 1)) * ZN);
 
     // extended tile: ex, ez in [0, EXT) <-> grid (gx0 + ex, gz0 + ez); cells beyond the grid do not exist (neighbours clamp to the edge)
-    const int gx0 = blockIdx.x * 32 - EROSION_K, gz0 = blockIdx.y * 32 - EROSION_K;
+    const int gx0 = tileX * 32 - EROSION_K, gz0 = tileZ * 32 - EROSION_K;
     const int exMin = imax(0, -gx0), exMax = imin(EROSION_EXT - 1, ZS - 1 - gx0);
     const int ezMin = imax(0, -gz0), ezMax = imin(EROSION_EXT - 1, ZS - 1 - gz0);
     const int ex = tid % EROSION_EXT, strip = tid / EROSION_EXT;
@@ -158,13 +169,13 @@ k_erode_pass(const float* __restrict__ gatheredBase, size_t gatheredStride, floa
     const bool colExists = ex >= exMin && ex <= exMax;
     const int exL = imax(ex - 1, exMin), exR = imin(ex + 1, exMax);
     const bool ownCol = ex >= EROSION_K && ex < EROSION_K + 32;
-    if (tid == 0) s_mask = 0u;
+    if (tid == 0) *s_mask = 0u;
 
     // load: a first launch stages the un-raised start in plane 0 and the RAISED start / thickness in plane 1 (the input of pass 0)
     if (colExists) {
         for (int ez = imax(rowLo, ezMin); ez <= imin(rowHi, ezMax); ++ez) {
             const int c = EROSION_EXT * ez + ex, g = (gx0 + ex) + ZS * (gz0 + ez);
-            const float sv = startIn[g], ev = endIn[g], av = accIn[g];
+            const float sv = ld_dev(startIn + g), ev = ld_dev(endIn + g), av = ld_dev(accIn + g);
             s_s[0][c] = sv; s_end[c] = ev; s_acc[c] = av;
             if (isFirst) { const float ls = sv + av; s_s[1][c] = ls; s_t[1][c] = (ev + av) - ls; }
             else s_t[0][c] = ev - sv;
@@ -198,17 +209,85 @@ k_erode_pass(const float* __restrict__ gatheredBase, size_t gatheredStride, floa
         const int any = __syncthreads_or(flags & 1);
         if (!any && !(isFirst && j == 0)) break;
     }
-    if (myMask) atomicOr(&s_mask, myMask);
+    if (myMask) atomicOr(s_mask, myMask);
     // results of the centre
     if (ownCol) {
         for (int ez = imax(rowLo, EROSION_K); ez <= imin(rowHi, EROSION_K + 31); ++ez) {
             const int c = EROSION_EXT * ez + ex, g = (gx0 + ex) + ZS * (gz0 + ez);
-            startOut[g] = s_s[cur][c];
-            accOut[g] = s_acc[c];
+            st_dev(startOut + g, s_s[cur][c]);
+            st_dev(accOut + g, s_acc[c]);
         }
     }
     __syncthreads();
-    if (tid == 0 && s_mask) atomicOr(&st->changed[t & 3], s_mask);
+    if (tid == 0 && *s_mask) atomicOr(zoneMask, *s_mask);
+}
+
+// The whole relaxation of a batch of zones in ONE launch (the host loop of Chunk::erodeZone chunk.cu:682-705 on the device).  A zone is
+// worked on by `perZone` persistent workgroups; a round = what one launch of the round-3 kernel did (EROSION_K passes of the zone's current
+// layer on each of its 144 tiles, the workgroup's share of them one after the other), then a barrier among the zone's workgroups
+// (release: fence + counter; acquire: spin + fence), then every workgroup derives the next phase from the zone's "changed" mask exactly
+// like the launches did.  Zones do not wait for each other and the host is not involved: no launch gaps, no state read-backs.
+// Workgroups take their (zone, member) from a ticket, zone-major: whatever order the dispatcher places workgroups in, the zones with the
+// lowest tickets are complete and make progress, so the barrier cannot deadlock even when the launch does not fit the chip at once.
+__global__ void __launch_bounds__(EROSION_THREADS)
+k_erode_zones(const float* __restrict__ gatheredBase, size_t gatheredStride, float* workBase, ErosionState* states, unsigned* ticket, int perZone,
+              int* maxPasses, int* maxPassesAlso)
+{
+    __shared__ float s_s[2][EROSION_CELLS_EXT];            // start planes, ping-pong over the passes
+    __shared__ float s_t[2][EROSION_CELLS_EXT];            // thickness = end - start of the same states (what the neighbours compare)
+    __shared__ float s_end[EROSION_CELLS_EXT];
+    __shared__ float s_acc[EROSION_CELLS_EXT];             // accumulated heights; after the load every cell is touched by its own lane only
+    __shared__ unsigned s_mask;
+    __shared__ unsigned s_ticket, s_tile;
+    __shared__ ErosionPhase s_ph;
+
+    const int tid = threadIdx.x;
+    if (tid == 0) s_ticket = atomicAdd(ticket, 1u);
+    __syncthreads();
+    const int zone = (int)(s_ticket / (unsigned)perZone), member = (int)(s_ticket % (unsigned)perZone);
+    ErosionState* st = states + zone;
+    const float* gathered = gatheredBase + gatheredStride * zone;
+    float* work = workBase + ZONE_WORK_FLOATS * zone;
+
+#pragma unroll 1
+    for (int t = 0;; ++t) {
+        if (tid == 0) {
+            const ErosionPhase prev = load_phase(&st->slot[(t + 1) & 1]);
+            const unsigned maskPrev = __hip_atomic_load(&st->changed[(t + 3) & 3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const ErosionPhase ph = next_phase(prev, maskPrev);
+            s_ph = ph;
+            if (member == 0) {
+                store_phase(&st->slot[t & 1], ph);
+                if (ph.done) {                                       // both slots final: the finish kernels read slot[0]
+                    store_phase(&st->slot[(t + 1) & 1], ph);
+                    atomicMax(maxPasses, ph.passes);
+                    if (maxPassesAlso) atomicMax(maxPassesAlso, ph.passes);
+                }
+                __hip_atomic_store(&st->changed[(t + 1) & 3], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&st->tileTicket[(t + 1) & 1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            s_tile = ph.done ? 144u : __hip_atomic_fetch_add(&st->tileTicket[t & 1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        const ErosionPhase ph = s_ph;
+        if (ph.done) break;
+        // the zone's 144 tiles are dealt out on demand: a tile costs anything between one pass (nothing moves any more) and EROSION_K
+        unsigned tile = s_tile;
+        while (tile < 144u) {
+            __syncthreads();                                          // everyone has read s_tile
+            if (tid == 0) s_tile = __hip_atomic_fetch_add(&st->tileTicket[t & 1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // the next draw is in flight while this tile is worked on
+            erode_tile(gathered, work, ph, (int)(tile % 12u), (int)(tile / 12u), &st->changed[t & 3], s_s, s_t, s_end, s_acc, &s_mask);
+            tile = s_tile;                                            // (erode_tile ends with a workgroup barrier)
+        }
+        // ---- barrier among the zone's workgroups: every store above is a device-scope store this wave has waited for (__syncthreads)
+        __syncthreads();
+        if (tid == 0) {
+            __hip_atomic_fetch_add(&st->barrier, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned want = (unsigned)perZone * (unsigned)(t + 1);
+            while (__hip_atomic_load(&st->barrier, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) __builtin_amdgcn_s_sleep(4);
+        }
+        __syncthreads();
+    }
 }
 
 // final planes back into the caller's gathered-layers buffer (in-place contract of Chunk::erodeZone) and the accumulated heights
@@ -226,7 +305,7 @@ k_erode_writeback(float* __restrict__ gatheredBase, size_t gatheredStride, const
     if (accOutBase) accOutBase[accStride * zone + c] = work[(size_t)24 * ZN + (size_t)st->accSel * ZN + c];
 }
 
-__global__ void k_erode_init(ErosionState* states, float* workBase, int zones)
+__global__ void k_erode_init(ErosionState* states, float* workBase, int zones, unsigned* ticket)
 {
     const int zone = blockIdx.y;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -241,6 +320,8 @@ __global__ void k_erode_init(ErosionState* states, float* workBase, int zones)
         states[zone].slot[1] = s;            // launch 0 reads slot[(0 - 1) & 1]
         states[zone].slot[0] = s;
         for (int k = 0; k < 4; ++k) states[zone].changed[k] = 0u;
+        states[zone].barrier = 0u; states[zone].tileTicket[0] = 0u; states[zone].tileTicket[1] = 0u;
+        if (zone == 0) { ticket[0] = 0u; ticket[1] = 0u; }
     }
 }
 
@@ -296,49 +377,54 @@ k_erode_finish(const float* __restrict__ workBase, const ErosionState* __restric
 namespace mmk {
 
 size_t erosion_work_bytes(int zones) { return (size_t)zones * ZONE_WORK_FLOATS * sizeof(float); }
-size_t erosion_state_bytes(int zones) { return (size_t)zones * sizeof(mm::ErosionState); }
+// the zones' states, then one more record's worth of words: [0] = the launch's ticket counter, [1] = largest pass count of the zones
+size_t erosion_state_bytes(int zones) { return (size_t)(zones + 1) * sizeof(mm::ErosionState); }
 
-// Runs the relaxation to convergence for `zones` packed zone buffers (stride in floats).  Synchronises the stream (the
-// reference's erodeZone is synchronous too).  Returns 0 or a hipError_t; *maxPasses receives the largest pass count.
+// workgroups of k_erode_zones the chip holds at once (LDS-bound: three per CU on gfx950)
+static int erosion_resident_workgroups()
+{
+    static int cached[16] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
+    if (cached[dev]) return cached[dev];
+    int perCu = 0, cus = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, mm::k_erode_zones, EROSION_THREADS, 0) != hipSuccess || perCu < 1) perCu = 1;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 1;
+    const char* e = getenv("MMGEN_EROSION_WG_PER_CU");
+    if (e && atoi(e) > 0 && atoi(e) < perCu) perCu = atoi(e);
+    return cached[dev] = perCu * cus;
+}
+
+// Enqueues the relaxation of `zones` packed zone buffers (stride in floats) to convergence: ONE persistent launch, then the kernel that
+// moves the final planes out.  Nothing is read back unless the caller asks for the pass count (maxPasses != null: the stream is
+// synchronised, like the reference's erodeZone); maxPassesDev (device, may be null) is raised to the largest pass count with the stream.
 int erode_zones(float* gathered, size_t strideFloats, int zones, float* work, mm::ErosionState* states, float* accOut, size_t accStride,
-                hipStream_t s, int* maxPasses, const int* zoneChunkIdxOut, float* layersOut)
+                hipStream_t s, int* maxPasses, const int* zoneChunkIdxOut, float* layersOut, int* maxPassesDev)
 {
     if (zones <= 0) return 0;
-    MMK_LAUNCH(KID_ERODE_INIT, mm::k_erode_init, dim3((2 * ZN + 255) / 256, zones), dim3(256), s, states, work, zones);
-    hipError_t e = hipSuccess;
-
-    std::vector<mm::ErosionState> h(zones);
-    const dim3 grid(12, 12, zones), block(EROSION_THREADS);
-    int launched = 0;
-    for (;;) {
-        // a zone needs one launch per layer plus one for every further EROSION_K passes of a layer (27 - 39 passes in total); a launch
-        // whose zones are all done costs ~10 us, a host round trip to find out ~50 us
-        const int batch = launched == 0 ? 8 + 32 / EROSION_K : 4;
-        // one event pair around the whole batch of launches (an event per launch would perturb what it measures)
-        const bool prof_ = profile_enabled();
-        if (prof_) profile_begin(KID_ERODE_PASS, s);
-        for (int i = 0; i < batch; ++i) hipLaunchKernelGGL(mm::k_erode_pass, grid, block, 0, s, gathered, strideFloats, work, states, launched + i);
-        if (prof_) profile_end(s);
-        launched += batch;
-        e = hipMemcpyAsync(h.data(), states, sizeof(mm::ErosionState) * zones, hipMemcpyDeviceToHost, s);
+    unsigned* ticket = (unsigned*)(states + zones);
+    int* passesWord = (int*)(ticket + 1);
+    MMK_LAUNCH(KID_ERODE_INIT, mm::k_erode_init, dim3((2 * ZN + 255) / 256, zones), dim3(256), s, states, work, zones, ticket);
+    // as many workgroups per zone as keep the whole launch resident (a zone's 144 tiles are dealt out to them round by round)
+    int perZone = erosion_resident_workgroups() / zones;
+    perZone = perZone < 1 ? 1 : (perZone > 144 ? 144 : perZone);
+    perZone = (144 + (144 + perZone - 1) / perZone - 1) / ((144 + perZone - 1) / perZone);      // fewest workgroups with the same tiles per round
+    MMK_LAUNCH(KID_ERODE_PASS, mm::k_erode_zones, dim3(zones * perZone), dim3(EROSION_THREADS), s, (const float*)gathered, strideFloats, work, states, ticket,
+               perZone, passesWord, maxPassesDev);
+    if (layersOut) {
+        // region path: no in-place contract to honour, the kept chunks' planes go straight to the layers
+        MMK_LAUNCH(KID_EROSION_SCATTER, mm::k_erode_finish, dim3(144, 8, zones), dim3(256), s, (const float*)work, (const mm::ErosionState*)states, 0,
+                   zoneChunkIdxOut, layersOut);
+    } else {
+        MMK_LAUNCH(KID_ERODE_WRITEBACK, mm::k_erode_writeback, dim3(ZN / 256, 1, zones), dim3(256), s, gathered, strideFloats, work, states, accOut,
+                   accStride, 0);
+    }
+    if (maxPasses) {
+        hipError_t e = hipMemcpyAsync(maxPasses, passesWord, sizeof(int), hipMemcpyDeviceToHost, s);
         if (e != hipSuccess) return (int)e;
         e = hipStreamSynchronize(s);
         if (e != hipSuccess) return (int)e;
-        // slot[(launched - 1) & 1] = the phase the last launch ran with; `done` shows up there one launch after convergence
-        bool all = true;
-        for (auto& z : h) all = all && z.slot[(launched - 1) & 1].done;
-        if (all) break;
-        if (launched > 100000) return (int)hipErrorLaunchFailure;
     }
-    if (maxPasses) { int m = 0; for (auto& z : h) { const int ps = z.slot[(launched - 1) & 1].passes; m = ps > m ? ps : m; } *maxPasses = m; }
-    if (layersOut) {
-        // region path: no in-place contract to honour, the kept chunks' planes go straight to the layers
-        MMK_LAUNCH(KID_EROSION_SCATTER, mm::k_erode_finish, dim3(144, 8, zones), dim3(256), s, (const float*)work, (const mm::ErosionState*)states, launched - 1,
-                   zoneChunkIdxOut, layersOut);
-        return 0;
-    }
-    MMK_LAUNCH(KID_ERODE_WRITEBACK, mm::k_erode_writeback, dim3(ZN / 256, 1, zones), dim3(256), s, gathered, strideFloats, work, states, accOut,
-               accStride, launched - 1);
     return 0;
 }
 

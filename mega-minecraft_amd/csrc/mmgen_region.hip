@@ -159,7 +159,10 @@ struct mmgen_region {
     DevBuf posA, hfA, bwA, gathA, layersA;
     DevBuf layersP, caveP, colInfo, fp, cfp, counts;
     DevBuf zoneIdx, zoneIdxOut, gathered, erodeWork, erodeState, computeList, targets, gfp, gcfp, bounds, fillQueue, cellLazy, colNeed, applyWork;
-    int lastMaxPasses = 0;
+    bool passesPending = false;
+    int* hostPasses = nullptr;    // pinned: largest erosion pass count of the last begin, valid once evPasses has fired
+    DevBuf devPasses;
+    hipEvent_t evPasses = nullptr;
     // layout cache: the host-built index tables (positions, A->P selection, compute list, zone gather / scatter lists, fill targets)
     // depend only on (rectangle, flags, mask); a caller that regenerates the same layout (bench loop, fixed tiles) re-uses the
     // device copies and region_begin / region_finish issue no host rebuild, no H2D copy and no stream synchronisation.
@@ -207,7 +210,9 @@ struct mmgen_region {
     ~mmgen_region()
     {
         if (hostMax) (void)hipHostFree(hostMax);
-        devMax.release();
+        if (hostPasses) (void)hipHostFree(hostPasses);
+        if (evPasses) (void)hipEventDestroy(evPasses);
+        devMax.release(); devPasses.release();
         if (sErode) {
             (void)hipStreamSynchronize(sErode); (void)hipStreamSynchronize(sFill); (void)hipStreamSynchronize(sApply);
             (void)hipStreamDestroy(sErode); (void)hipStreamDestroy(sFill); (void)hipStreamDestroy(sApply);
@@ -235,6 +240,9 @@ int mmgen_region_create(mmgen_region** out)
         if (he == hipSuccess) { *r->hostMax = 0; he = hipHostGetDevicePointer((void**)&r->hostMaxDev, r->hostMax, 0); }
         if (he == hipSuccess && r->devMax.ensure(sizeof(int)) == 0) he = hipMemset(r->devMax.p, 0, sizeof(int));
         else if (he == hipSuccess) he = hipErrorOutOfMemory;
+        if (he == hipSuccess) he = hipHostMalloc((void**)&r->hostPasses, sizeof(int), hipHostMallocDefault);
+        if (he == hipSuccess) { *r->hostPasses = 0; he = hipEventCreateWithFlags(&r->evPasses, hipEventDisableTiming); }
+        if (he == hipSuccess && r->devPasses.ensure(sizeof(int)) != 0) he = hipErrorOutOfMemory;
         if (he != hipSuccess) { delete r; *out = nullptr; return (int)he; }
     }
     const char* e = getenv("MMGEN_REGION_SERIAL");
@@ -421,7 +429,6 @@ int mmgen_region_begin(mmgen_region* r, int cx0, int cz0, int nx, int nz, unsign
         CK(mmk::launch_fix_backward(layersP, np, s));
     }
 
-    // ---- K4 caves on the caller's stream (enqueued BEFORE the erosion loop below blocks the host on its own stream)
     const int* list = r->computeList.as<int>();
     const uint8_t* colNeed = nullptr;
     if (r->nLazy && features) {
@@ -430,39 +437,39 @@ int mmgen_region_begin(mmgen_region* r, int cx0, int cz0, int nx, int nz, unsign
                                  r->colNeed.as<uint8_t>(), s));
         colNeed = r->colNeed.as<uint8_t>();
     }
-    auto caves = [&]() -> int {
-        mmk::StageRange sr("mmgen:caves");
-        // (the cave work as 8 - 64 launches alternating between two streams, so that the erosion branch's short launches get their turn
-        // between them: measured, profiles/README.md r03 - an erosion launch still only completes when the cave launches in flight beside it
-        // do; no gain at 8 - 32 slices, -4 % at 64)
-        return mmk::launch_caves(hfP, bwP, posP, r->nCompute, r->caveP.as<mmgen_cave_layer>(), r->colInfo.as<float>(), list, colNeed, s);
-    };
-    if (par) CK(caves());
 
+    // ---- E1 / K3 / E3: the erosion branch, enqueued FIRST.  The relaxation is one persistent launch per zone batch (no host reads): its
+    // workgroups are on the chip before the caves' launch starts to fill every free slot, and then run beside it
     if (erosion) {
         mmk::StageRange sr("mmgen:erosion");
+        CK(hipMemsetAsync(r->devPasses.p, 0, sizeof(int), sE));
         CK(hipMemcpyAsync(layersP, r->layersA.p, sizeof(float) * MMGEN_LAYERS_SIZE * (size_t)np, hipMemcpyDeviceToDevice, sE));
-        // ---- E1 / K3 / E3 per zone batch
         const int Z = r->nZones;
         const int batch = Z < MMGEN_EROSION_ZONE_BATCH ? Z : MMGEN_EROSION_ZONE_BATCH;
         CK(r->gathered.ensure(sizeof(float) * (size_t)MMGEN_GATHERED_LAYERS_SIZE * batch));
         CK(r->erodeWork.ensure(mmk::erosion_work_bytes(batch)));
         CK(r->erodeState.ensure(mmk::erosion_state_bytes(batch)));
-        r->lastMaxPasses = 0;
         for (int z0 = 0; z0 < Z; z0 += batch) {
             const int nb = (Z - z0) < batch ? (Z - z0) : batch;
             CK(mmk::erosion_gather(r->layersA.as<float>(), r->hfA.as<float>(), r->zoneIdx.as<int>() + (size_t)z0 * 576, nb, r->gathered.as<float>(),
                                    (size_t)MMGEN_GATHERED_LAYERS_SIZE, sE));
-            int mp = 0;
             CK(mmk::erode_zones(r->gathered.as<float>(), (size_t)MMGEN_GATHERED_LAYERS_SIZE, nb, r->erodeWork.as<float>(),
-                                r->erodeState.as<mm::ErosionState>(), nullptr, 0, sE, &mp, r->zoneIdxOut.as<int>() + (size_t)z0 * 144, layersP));
-            if (mp > r->lastMaxPasses) r->lastMaxPasses = mp;
+                                r->erodeState.as<mm::ErosionState>(), nullptr, 0, sE, nullptr, r->zoneIdxOut.as<int>() + (size_t)z0 * 144, layersP,
+                                r->devPasses.as<int>()));
         }
         // ---- E3 fix-up
         CK(mmk::launch_fix_backward(layersP, np, sE));
-        if (par) { CK(hipEventRecord(r->evErosion, sE)); CK(hipStreamWaitEvent(s, r->evErosion, 0)); }
+        CK(hipMemcpyAsync(r->hostPasses, r->devPasses.p, sizeof(int), hipMemcpyDeviceToHost, sE));
+        CK(hipEventRecord(r->evPasses, sE));
+        r->passesPending = true;
     }
-    if (!par) CK(caves());
+
+    // ---- K4 caves on the caller's stream
+    {
+        mmk::StageRange sr("mmgen:caves");
+        CK(mmk::launch_caves(hfP, bwP, posP, r->nCompute, r->caveP.as<mmgen_cave_layer>(), r->colInfo.as<float>(), list, colNeed, s));
+    }
+    if (erosion && par) { CK(hipEventRecord(r->evErosion, sE)); CK(hipStreamWaitEvent(s, r->evErosion, 0)); }
 
     // ---- F1 placements (eroded layers + cave layers of every computed cell)
     if (features) {
@@ -603,7 +610,12 @@ int mmgen_region_generate(mmgen_region* r, int cx0, int cz0, int nx, int nz, uns
     return mmgen_region_finish(r, d_blocks, d_heightfields, nullptr, nullptr, stream);
 }
 
-int mmgen_region_last_erosion_passes(const mmgen_region* r) { return r ? r->lastMaxPasses : -1; }
+int mmgen_region_last_erosion_passes(const mmgen_region* r)
+{
+    if (!r) return -1;
+    if (r->passesPending && hipEventSynchronize(r->evPasses) != hipSuccess) return -1;
+    return *r->hostPasses;
+}
 
 int mmgen_copy_placements(const mmgen_feature_placement* d_src_fp, const mmgen_cave_feature_placement* d_src_cfp, const int32_t* d_src_counts,
                           const int32_t* d_src_idx, mmgen_feature_placement* d_dst_fp, mmgen_cave_feature_placement* d_dst_cfp, int32_t* d_dst_counts,
