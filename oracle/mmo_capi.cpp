@@ -333,22 +333,14 @@ void mmo_region_begin(void* ctx, int cx0, int cz0, int nx, int nz, int flags, co
         parallel_for((int)zones.size(), nthreads, [&](int zi) {
             const ivec2 zc = zones[zi];
             std::vector<float> g((size_t)9 * EROSION_GRID_NUM_COLS);
-            // E1 copyLayers(to) chunk.cu:603-656
-            for (int cz = 0; cz < 24; ++cz) for (int cx = 0; cx < 24; ++cx) {
-                const int ai = (zc.x - 6 + cx - ax0) + anx * (zc.y - 6 + cz - az0);
-                for (int l = 0; l < 9; ++l) for (int bz = 0; bz < 16; ++bz) {
-                    const float* src = (l == 8) ? (ahf.data() + (size_t)256 * ai + 16 * bz) : (alayers.data() + (size_t)5120 * ai + 256 * (12 + l) + 16 * bz);
-                    std::memcpy(g.data() + (size_t)EROSION_GRID_NUM_COLS * l + (size_t)EROSION_GRID_SIDE * (cz * 16 + bz) + cx * 16, src, 16 * sizeof(float));
-                }
-            }
+            // E1 copyLayers(to) chunk.cu:603-656: the zone's 24 x 24 gathered chunks, RAW layers + heightfields
+            std::vector<int> gatheredIdx(4 * ZONE_SIZE * ZONE_SIZE), ownIdx(ZONE_SIZE * ZONE_SIZE);
+            for (int cz = 0; cz < 24; ++cz) for (int cx = 0; cx < 24; ++cx) gatheredIdx[cx + 24 * cz] = (zc.x - 6 + cx - ax0) + anx * (zc.y - 6 + cz - az0);
+            for (int cz = 0; cz < 12; ++cz) for (int cx = 0; cx < 12; ++cx) ownIdx[cx + 12 * cz] = (zc.x + cx - ax0) + anx * (zc.y + cz - az0);
+            zoneCopyLayers(alayers.data(), ahf.data(), gatheredIdx.data(), g.data(), true);
             erodeZonePlanes(g.data());
-            // E3 copyLayers(from): centre 12x12 chunks, 8 eroded planes
-            for (int cz = 0; cz < 12; ++cz) for (int cx = 0; cx < 12; ++cx) {
-                const int ai = (zc.x + cx - ax0) + anx * (zc.y + cz - az0);
-                for (int l = 0; l < 8; ++l) for (int bz = 0; bz < 16; ++bz)
-                    std::memcpy(eroded.data() + (size_t)5120 * ai + 256 * (12 + l) + 16 * bz,
-                                g.data() + (size_t)EROSION_GRID_NUM_COLS * l + (size_t)EROSION_GRID_SIDE * ((cz + 6) * 16 + bz) + (cx + 6) * 16, 16 * sizeof(float));
-            }
+            // E3 copyLayers(from): the zone's own 12 x 12 chunks, 8 eroded planes
+            zoneCopyLayers(eroded.data(), nullptr, ownIdx.data(), g.data(), false);
         });
         for (int z = 0; z < pnz; ++z) for (int x = 0; x < pnx; ++x) {
             const int pi = x + pnx * z, ai = (px0 + x - ax0) + anx * (pz0 + z - az0);

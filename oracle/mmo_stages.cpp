@@ -3,14 +3,29 @@
 #include "mmo_stages.h"
 #include <cstring>
 #include <algorithm>
+#include <array>
+#include <memory>
+#include <cmath>
 
 namespace mmo {
 
 UbCounters g_ub = {0, 0, 0};
 
 static inline int posTo2dIndex16(int x, int z) { return x + 16 * z; }
-static inline int posTo2dIndex(int x, int z) { return x + 16 * z; }                          // posTo2dIndex<16>, biomeFuncs.hpp:11-16
-static inline int posTo3dIndex(ivec3 pos) { return pos.y + 384 * posTo2dIndex(pos.x, pos.z); }   // biomeFuncs.hpp:25-37
+template <int xSize = 16> static inline int posTo2dIndex(const int x, const int z) { return x + xSize * z; }          // biomeFuncs.hpp:11-16
+template <int xSize = 16> static inline int posTo2dIndex(const ivec2 pos) { return posTo2dIndex<xSize>(pos.x, pos.y); }   // biomeFuncs.hpp:18-23
+template <int xSize = 16, int ySize = 384> static inline int posTo3dIndex(const int x, const int y, const int z) { return y + ySize * posTo2dIndex<xSize>(x, z); }
+template <int xSize = 16, int ySize = 384> static inline int posTo3dIndex(const ivec3 pos) { return posTo3dIndex<xSize, ySize>(pos.x, pos.y, pos.z); }   // biomeFuncs.hpp:25-37
+// The bodies of the reference's CUDA kernels are restated below as they are written, per thread: the thread / block indices are plain
+// values handed in by the caller (which plays the launch), __shared__ arrays are the caller's, and a barrier is the boundary between
+// two functions of the same kernel (every thread of the block runs the first, then every thread runs the second).
+struct dim3 { int x = 1, y = 1, z = 1; };
+#define __syncthreads() ((void)0)
+// staging sizes of terrain.hpp:40-51
+static constexpr int devHeightfieldSize = 18 * 18;
+static constexpr int devBiomeWeightsSize = 256 * numBiomes;
+static constexpr int devLayersSize = 256 * numMaterials;
+#define EROSION_GRID_SIDE_LENGTH_BLOCKS EROSION_GRID_SIDE
 // the three places where the canonical semantics add a statement to a member function of the reference; all are named
 // macros so that tools/extract_ref_literals.py can list and drop exactly these
 #define CANONICAL_RETURN_FALSE return false
@@ -18,6 +33,12 @@ static inline int posTo3dIndex(ivec3 pos) { return pos.y + 384 * posTo2dIndex(po
 #define CANONICAL_DECORATOR_RANGE(pos) if ((pos).y < 0 || (pos).y > 383) { ++g_ub.decoratorOutOfRange; return; }
 // the reference's __constant__ / host copies of BiomeUtils' tables (biomeFuncs.hpp:709-723)
 #define dev_materialInfos (T().materialInfos)
+#define dev_biomeMaterialWeights (T().biomeMaterialWeights)
+#define dev_dirVecs2d (T().dirVecs2d)
+#define dev_featureHeightBounds (T().featureHeightBounds)
+#define dev_caveFeatureHeightBounds (T().caveFeatureHeightBounds)
+#define host_featureHeightBounds (T().featureHeightBounds)
+#define host_caveFeatureHeightBounds (T().caveFeatureHeightBounds)
 #define dev_biomeBlocks (T().biomeBlocks)
 #define host_biomeFeatureGens (T().biomeFeatureGens)
 #define host_caveBiomeFeatureGens (T().caveBiomeFeatureGens)
@@ -28,30 +49,45 @@ static inline int posTo2dIndex18(int x, int z) { return x + 18 * z; }
 // ===================================================================================================
 // K1 — kernGenerateHeightfield chunk.cu:150-185
 // ===================================================================================================
+// the body of the kernel for the thread of column (x, z) of chunk chunkIdx (chunk.cu:156-184; threads are 1 x 16 x 16 per chunk)
+static void kernGenerateHeightfield(const ivec2* chunkWorldBlockPositions, float* heightfield, float* biomeWeights, const int chunkIdx, const int x, const int z)
+{
+    const int idx = posTo2dIndex(x, z);
+
+    const vec2 worldPos = chunkWorldBlockPositions[chunkIdx] + ivec2(x, z);
+    const auto biomeNoise = getBiomeNoise(worldPos);
+
+    float* columnBiomeWeights = biomeWeights + (devBiomeWeightsSize * chunkIdx) + (idx);
+    float height = 0.f;
+    for (int biomeIdx = 0; biomeIdx < numBiomes; ++biomeIdx)
+    {
+        Biome biome = (Biome)biomeIdx;
+
+        float weight = getBiomeWeight(biome, biomeNoise);
+        if (weight > 0.f)
+        {
+            height += weight * getHeight(biome, worldPos);
+        }
+
+        columnBiomeWeights[256 * biomeIdx] = weight;
+    }
+
+    heightfield[(256 * chunkIdx) + idx] = height;
+}
+
+// one column on its own (the slope ring of G1: a neighbour's height is the kernel's value for that world position)
 float columnHeight(ivec2 worldPosI, float* weights24)
 {
-    const vec2 worldPos = vec2(worldPosI);     // int add, then convert (chunk.cu:162)
-    const BiomeNoise biomeNoise = getBiomeNoise(worldPos);
-    float height = 0.f;
-    for (int biomeIdx = 0; biomeIdx < numBiomes; ++biomeIdx) {
-        Biome biome = (Biome)biomeIdx;
-        float weight = getBiomeWeight(biome, biomeNoise);
-        if (weight > 0.f) height += weight * getHeight(biome, worldPos);
-        if (weights24) weights24[biomeIdx] = weight;
-    }
+    float height, weights[256 * (numBiomes - 1) + 1];
+    kernGenerateHeightfield(&worldPosI, &height, weights, 0, 0, 0);
+    if (weights24) for (int biomeIdx = 0; biomeIdx < numBiomes; ++biomeIdx) weights24[biomeIdx] = weights[256 * biomeIdx];
     return height;
 }
 
 void generateHeightfield(ivec2 chunkWorldBlockPos, float* heightfield, float* biomeWeights)
 {
-    for (int z = 0; z < 16; ++z) {
-        for (int x = 0; x < 16; ++x) {
-            const int idx = posTo2dIndex16(x, z);
-            float w[numBiomes];
-            heightfield[idx] = columnHeight(chunkWorldBlockPos + ivec2{x, z}, w);
-            for (int b = 0; b < numBiomes; ++b) biomeWeights[256 * b + idx] = w[b];
-        }
-    }
+    for (int z = 0; z < 16; ++z)
+        for (int x = 0; x < 16; ++x) kernGenerateHeightfield(&chunkWorldBlockPos, heightfield, biomeWeights, 0, x, z);
 }
 
 // ===================================================================================================
@@ -79,67 +115,95 @@ static float getStratifiedMaterialThickness(int layerIdx, float materialWeight, 
 {
     if (materialWeight > 0) {
         const auto& materialInfo = dev_materialInfos[layerIdx];
-        vec2 noisePos = worldPos * materialInfo.noiseScaleOrMaxSlope + vec2((float)layerIdx * 5283.64f);
+        vec2 noisePos = worldPos * materialInfo.noiseScaleOrMaxSlope + vec2(layerIdx * 5283.64f);
         return g_max(0.f, materialInfo.thickness + materialInfo.noiseAmplitudeOrTanAngleOfRepose * fbm(noisePos)) * materialWeight;
     }
     else return 0;
 }
 
+// the body of the kernel after its barrier, for the thread of column (x, z) (chunk.cu:346-414); shared_heightfield = the chunk's 18 x 18
+// gathered heights, staged by the block before the barrier (chunk.cu:337-344: a copy)
+static void kernGenerateLayers(const float* shared_heightfield, const float* biomeWeights, const ivec2* chunkWorldBlockPositions, float* layers,
+                               const int chunkIdx, const int x, const int z)
+{
+    const int idx = posTo2dIndex(x, z);
+
+    const vec2 worldPos = chunkWorldBlockPositions[chunkIdx] + ivec2(x, z);
+
+    float totalMaterialWeights[numMaterials];
+    for (int materialIdx = 0; materialIdx < numMaterials; ++materialIdx)
+    {
+        totalMaterialWeights[materialIdx] = 0;
+    }
+
+    const float* columnBiomeWeights = biomeWeights + (devBiomeWeightsSize * chunkIdx) + (idx);
+    for (int biomeIdx = 0; biomeIdx < numBiomes; ++biomeIdx)
+    {
+        const float biomeWeight = columnBiomeWeights[256 * biomeIdx];
+
+        for (int materialIdx = 0; materialIdx < numMaterials; ++materialIdx)
+        {
+            totalMaterialWeights[materialIdx] += biomeWeight * dev_biomeMaterialWeights[posTo2dIndex<numMaterials>(materialIdx, biomeIdx)];
+        }
+    }
+
+    const ivec2 pos18 = ivec2(x + 1, z + 1);
+    const float maxHeight = shared_heightfield[posTo2dIndex<18>(pos18)];
+
+    float slope = 0;
+    for (int i = 0; i < 8; ++i)
+    {
+        float neighborHeight = shared_heightfield[posTo2dIndex<18>(pos18 + dev_dirVecs2d[i])];
+        slope = g_max(slope, fabsf(neighborHeight - maxHeight) * (i % 2 == 1 ? SQRT_2 : 1));
+    }
+
+    float* columnLayers = layers + (devLayersSize * chunkIdx) + (idx);
+
+    float height = 0;
+    for (int layerIdx = 0; layerIdx < numForwardMaterials; ++layerIdx)
+    {
+        columnLayers[256 * layerIdx] = height;
+
+        if (height > maxHeight || layerIdx == numForwardMaterials - 1)
+        {
+            break;
+        }
+
+        height += getStratifiedMaterialThickness(layerIdx, totalMaterialWeights[layerIdx], worldPos);
+    }
+
+    height = 0;
+    for (int layerIdx = numStratifiedMaterials - 1; layerIdx >= numForwardMaterials; --layerIdx)
+    {
+        height += getStratifiedMaterialThickness(layerIdx, totalMaterialWeights[layerIdx], worldPos);
+        columnLayers[256 * layerIdx] = height;
+    }
+
+    height = maxHeight;
+    for (int layerIdx = numMaterials - 1; layerIdx >= numStratifiedMaterials; --layerIdx)
+    {
+        const auto& materialInfo = dev_materialInfos[layerIdx];
+
+        float materialWeight = totalMaterialWeights[layerIdx];
+        float layerHeight = g_max(0.f, materialInfo.thickness * ((materialInfo.noiseScaleOrMaxSlope - slope) / materialInfo.noiseScaleOrMaxSlope)) * materialWeight;
+
+        height -= layerHeight;
+        columnLayers[256 * layerIdx] = height;
+    }
+}
+
 void generateLayers(ivec2 chunkWorldBlockPos, const float* gatheredHeightfield, const float* biomeWeights, float* layers)
 {
-    const Tables& t = T();
     for (int z = 0; z < 16; ++z) {
         for (int x = 0; x < 16; ++x) {
-            const int idx = posTo2dIndex16(x, z);
-            const vec2 worldPos = vec2(chunkWorldBlockPos + ivec2{x, z});
-
-            float totalMaterialWeights[numMaterials];
-            for (int m = 0; m < numMaterials; ++m) totalMaterialWeights[m] = 0;
-            const float* columnBiomeWeights = biomeWeights + idx;
-            for (int b = 0; b < numBiomes; ++b) {
-                const float biomeWeight = columnBiomeWeights[256 * b];
-                for (int m = 0; m < numMaterials; ++m)
-                    totalMaterialWeights[m] += biomeWeight * t.biomeMaterialWeights[m + numMaterials * b];
-            }
-
-            const ivec2 pos18 = {x + 1, z + 1};
-            const float maxHeight = gatheredHeightfield[posTo2dIndex18(pos18.x, pos18.y)];
-
-            float slope = 0;
-            for (int i = 0; i < 8; ++i) {
-                const ivec2 p = pos18 + t.dirVecs2d[i];
-                float neighborHeight = gatheredHeightfield[posTo2dIndex18(p.x, p.y)];
-                slope = g_max(slope, fabsf(neighborHeight - maxHeight) * (i % 2 == 1 ? SQRT_2 : 1.f));
-            }
-
-            float* columnLayers = layers + idx;
-
-            float height = 0;
-            int layerIdx = 0;
-            for (; layerIdx < numForwardMaterials; ++layerIdx) {
-                columnLayers[256 * layerIdx] = height;
-                if (height > maxHeight || layerIdx == numForwardMaterials - 1) break;
-                height += getStratifiedMaterialThickness(layerIdx, totalMaterialWeights[layerIdx], worldPos);
-            }
-            // CANONICAL: forward layers after the early break are never written by the reference (stale device memory,
-            // chunk.cu:383-393); they cannot influence blocks (the layer search in fill finds an earlier layer first), so the
-            // canonical value is the running height.
-            for (++layerIdx; layerIdx < numForwardMaterials; ++layerIdx) columnLayers[256 * layerIdx] = height;
-
-            height = 0;
-            for (int l = numStratifiedMaterials - 1; l >= numForwardMaterials; --l) {
-                height += getStratifiedMaterialThickness(l, totalMaterialWeights[l], worldPos);
-                columnLayers[256 * l] = height;
-            }
-
-            height = maxHeight;
-            for (int l = numMaterials - 1; l >= numStratifiedMaterials; --l) {
-                const auto& materialInfo = t.materialInfos[l];
-                float materialWeight = totalMaterialWeights[l];
-                float layerHeight = g_max(0.f, materialInfo.thickness * ((materialInfo.noiseScaleOrMaxSlope - slope) / materialInfo.noiseScaleOrMaxSlope)) * materialWeight;
-                height -= layerHeight;
-                columnLayers[256 * l] = height;
-            }
+            // CANONICAL: forward layers after the early break are never written by the reference (stale device memory, chunk.cu:383-393);
+            // they cannot influence blocks (the layer search in fill finds an earlier layer first), so the canonical value is the running
+            // height, i.e. the last value the loop did write.  The kernel body is run as it is written on a column of "not written" marks.
+            float* columnLayers = layers + posTo2dIndex(x, z);
+            for (int layerIdx = 0; layerIdx < numForwardMaterials; ++layerIdx) columnLayers[256 * layerIdx] = NAN;
+            kernGenerateLayers(gatheredHeightfield, biomeWeights, &chunkWorldBlockPos, layers, 0, x, z);
+            for (int layerIdx = 1; layerIdx < numForwardMaterials; ++layerIdx)
+                if (std::isnan(columnLayers[256 * layerIdx])) columnLayers[256 * layerIdx] = columnLayers[256 * (layerIdx - 1)];
         }
     }
 }
@@ -151,68 +215,171 @@ void generateLayers(ivec2 chunkWorldBlockPos, const float* gatheredHeightfield, 
 // :578,585), so its result depends on block scheduling; the snapshot semantics is the schedule-free reading of the same
 // arithmetic.
 // ===================================================================================================
+static constexpr int gatheredLayersBaseSize = EROSION_GRID_NUM_COLS * (numErodedMaterials + 1); // +1 for heightfield
+
+// kernDoErosion up to its first barrier, for one thread of a 32 x 32 block (chunk.cu:487-556): the thread's indices, its own cell and
+// (threads 0 - 131) one cell of the 34 x 34 tile's border into the block's shared tiles.  CANONICAL: gatheredLayers / accumulatedHeights
+// are the SNAPSHOT of the state before the pass.
+static void kernDoErosion_stage(const float* gatheredLayers, const float* accumulatedHeights, int layerIdx, bool isFirst,
+                                float* shared_layerStart, float* shared_layerEnd, bool& shared_didChange,
+                                const dim3& threadIdx, const dim3& blockIdx, const dim3& blockDim)
+{
+    const int localX = threadIdx.x;
+    const int localZ = threadIdx.y;
+    const int localIdx2d = posTo2dIndex<32>(localX, localZ);
+
+    const int blockStartX = (blockIdx.x * blockDim.x);
+    const int blockStartZ = (blockIdx.y * blockDim.y);
+
+    const int globalX = blockStartX + localX;
+    const int globalZ = blockStartZ + localZ;
+    const int globalIdx2d = posTo2dIndex<EROSION_GRID_SIDE_LENGTH_BLOCKS>(globalX, globalZ);
+
+    if (localIdx2d == 0)
+    {
+        shared_didChange = false;
+    }
+
+    const ivec2 sharedLayerPos = ivec2(localX + 1, localZ + 1);
+    const int sharedLayerIdx = posTo2dIndex<34>(sharedLayerPos);
+    const int gatheredLayersIdx = globalIdx2d + (EROSION_GRID_NUM_COLS * layerIdx);
+
+    float thisAccumulatedHeight = isFirst ? accumulatedHeights[globalIdx2d] : 0;
+
+    const float thisLayerStart = gatheredLayers[gatheredLayersIdx] + thisAccumulatedHeight;
+    const float thisLayerEnd = gatheredLayers[gatheredLayersIdx + EROSION_GRID_NUM_COLS] + thisAccumulatedHeight;
+    shared_layerStart[sharedLayerIdx] = thisLayerStart;
+    shared_layerEnd[sharedLayerIdx] = thisLayerEnd;
+
+    ivec2 storePos = ivec2(-1);
+    if (localIdx2d < 64)
+    {
+        storePos = ivec2((localIdx2d % 32) + 1, localIdx2d < 32 ? 0 : 33);
+    }
+    else if (localIdx2d < 128)
+    {
+        storePos = ivec2(localIdx2d < 96 ? 0 : 33, (localIdx2d % 32) + 1);
+    }
+    else
+    {
+        switch (localIdx2d)
+        {
+        case 128:
+            storePos = ivec2(0, 0);
+            break;
+        case 129:
+            storePos = ivec2(33, 0);
+            break;
+        case 130:
+            storePos = ivec2(0, 33);
+            break;
+        case 131:
+            storePos = ivec2(33, 33);
+            break;
+        }
+    }
+
+    if (storePos.x != -1)
+    {
+        ivec2 loadPos = ivec2(blockStartX - 1, blockStartZ - 1) + storePos;
+        loadPos = g_clamp(loadPos, 0, EROSION_GRID_SIDE_LENGTH_BLOCKS - 1);
+
+        const int loadIdx2d = posTo2dIndex<EROSION_GRID_SIDE_LENGTH_BLOCKS>(loadPos);
+        const int loadIdx = loadIdx2d + (EROSION_GRID_NUM_COLS * layerIdx);
+        const int storeIdx = posTo2dIndex<34>(storePos);
+
+        thisAccumulatedHeight = isFirst ? accumulatedHeights[loadIdx2d] : 0;
+
+        shared_layerStart[storeIdx] = gatheredLayers[loadIdx] + thisAccumulatedHeight;
+        shared_layerEnd[storeIdx] = gatheredLayers[loadIdx + EROSION_GRID_NUM_COLS] + thisAccumulatedHeight;
+    }
+
+    __syncthreads();
+}
+
+// kernDoErosion between its two barriers (chunk.cu:558-591): the relaxation of the thread's own cell against the shared tiles, written
+// to the live planes.  (The thread's indices are derived again; its own start / end are what it staged.)
+static void kernDoErosion_relax(float* gatheredLayers, float* accumulatedHeights, int layerIdx, const float* shared_layerStart, const float* shared_layerEnd,
+                                bool& shared_didChange, const dim3& threadIdx, const dim3& blockIdx, const dim3& blockDim)
+{
+    const int localX = threadIdx.x, localZ = threadIdx.y;
+    const int globalIdx2d = posTo2dIndex<EROSION_GRID_SIDE_LENGTH_BLOCKS>((blockIdx.x * blockDim.x) + localX, (blockIdx.y * blockDim.y) + localZ);
+    const ivec2 sharedLayerPos = ivec2(localX + 1, localZ + 1);
+    const int gatheredLayersIdx = globalIdx2d + (EROSION_GRID_NUM_COLS * layerIdx);
+    const float thisLayerStart = shared_layerStart[posTo2dIndex<34>(sharedLayerPos)];
+    const float thisLayerEnd = shared_layerEnd[posTo2dIndex<34>(sharedLayerPos)];
+
+    float newLayerStart = thisLayerStart;
+    float maxThickness = thisLayerEnd - thisLayerStart;
+    const float tanAngleOfRepose = dev_materialInfos[numStratifiedMaterials + layerIdx].noiseAmplitudeOrTanAngleOfRepose;
+
+    for (int i = 0; i < 8; ++i)
+    {
+        const auto& neighborDir = dev_dirVecs2d[i];
+        int neighborIdx = posTo2dIndex<34>(sharedLayerPos + neighborDir);
+
+        float neighborLayerStart = shared_layerStart[neighborIdx];
+        newLayerStart = g_max(newLayerStart, neighborLayerStart - tanAngleOfRepose * (i % 2 == 1 ? SQRT_2 : 1));
+
+        maxThickness = g_max(maxThickness, shared_layerEnd[neighborIdx] - neighborLayerStart);
+    }
+
+    newLayerStart = g_min(newLayerStart, thisLayerEnd);
+
+    if (maxThickness > 0)
+    {
+        gatheredLayers[gatheredLayersIdx] = newLayerStart;
+
+        if (newLayerStart != thisLayerStart)
+        {
+            shared_didChange = true;
+
+            accumulatedHeights[globalIdx2d] += newLayerStart - thisLayerStart;
+        }
+    }
+
+    __syncthreads();
+}
+
+// The host loop of Chunk::erodeZone (chunk.cu:672-705) over the kernel above, one launch = one pass; the launch is played block by
+// block (12 x 12 blocks of 32 x 32 threads), every block staging from the snapshot taken before the pass.
 int erodeZonePlanes(float* g)
 {
-    const Tables& t = T();
-    const int N = EROSION_GRID_NUM_COLS, S = EROSION_GRID_SIDE;
-    std::vector<float> acc(N, 0.f), startOld(N), accOld(N);
+    const int N = EROSION_GRID_NUM_COLS;
+    std::vector<float> accumulatedHeights(N, 0.f), snapshot(g, g + (size_t)gatheredLayersBaseSize), accumulatedSnapshot(N);
+    std::vector<float> shared_layerStart(34 * 34), shared_layerEnd(34 * 34);
+    const dim3 blockSize2d{32, 32, 1};
+    constexpr int blocksPerGrid = (ZONE_SIZE * 2 * 16) / 32;
     int passes = 0;
 
     for (int layerIdx = numErodedMaterials - 1; layerIdx >= 0; --layerIdx) {
-        float* startPlane = g + (size_t)N * layerIdx;
-        const float* endPlane = g + (size_t)N * (layerIdx + 1);
-        const float tanAngleOfRepose = t.materialInfos[numStratifiedMaterials + layerIdx].noiseAmplitudeOrTanAngleOfRepose;
         bool isFirst = true;
-        bool changed;
+        bool flagDidChange;
         do {
-            changed = false;
-            std::memcpy(startOld.data(), startPlane, sizeof(float) * N);
-            std::memcpy(accOld.data(), acc.data(), sizeof(float) * N);
-            for (int gz = 0; gz < S; ++gz) {
-                for (int gx = 0; gx < S; ++gx) {
-                    const int c = gx + S * gz;
-                    const float thisAcc = isFirst ? accOld[c] : 0;
-                    const float thisLayerStart = startOld[c] + thisAcc;
-                    const float thisLayerEnd = endPlane[c] + thisAcc;
-
-                    float newLayerStart = thisLayerStart;
-                    float maxThickness = thisLayerEnd - thisLayerStart;
-                    for (int i = 0; i < 8; ++i) {
-                        const int nx = g_clamp(gx + t.dirVecs2d[i].x, 0, S - 1);
-                        const int nz = g_clamp(gz + t.dirVecs2d[i].y, 0, S - 1);
-                        const int n = nx + S * nz;
-                        const float nAcc = isFirst ? accOld[n] : 0;
-                        const float neighborLayerStart = startOld[n] + nAcc;
-                        const float neighborLayerEnd = endPlane[n] + nAcc;
-                        newLayerStart = g_max(newLayerStart, neighborLayerStart - tanAngleOfRepose * (i % 2 == 1 ? SQRT_2 : 1.f));
-                        maxThickness = g_max(maxThickness, neighborLayerEnd - neighborLayerStart);
-                    }
-                    newLayerStart = g_min(newLayerStart, thisLayerEnd);
-
-                    if (maxThickness > 0) {
-                        startPlane[c] = newLayerStart;
-                        if (newLayerStart != thisLayerStart) {
-                            changed = true;
-                            acc[c] += newLayerStart - thisLayerStart;
-                        }
-                    }
+            flagDidChange = false;
+            // the two planes this pass reads: the layer's own start plane and its end plane (the eroded start plane of the layer above)
+            std::memcpy(snapshot.data() + (size_t)N * layerIdx, g + (size_t)N * layerIdx, sizeof(float) * 2 * N);
+            accumulatedSnapshot = accumulatedHeights;
+            for (int by = 0; by < blocksPerGrid; ++by) {
+                for (int bx = 0; bx < blocksPerGrid; ++bx) {
+                    const dim3 blockIdx{bx, by, 0};
+                    bool shared_didChange = false;
+                    for (int ty = 0; ty < 32; ++ty)
+                        for (int tx = 0; tx < 32; ++tx)
+                            kernDoErosion_stage(snapshot.data(), accumulatedSnapshot.data(), layerIdx, isFirst, shared_layerStart.data(), shared_layerEnd.data(),
+                                                shared_didChange, dim3{tx, ty, 0}, blockIdx, blockSize2d);
+                    for (int ty = 0; ty < 32; ++ty)
+                        for (int tx = 0; tx < 32; ++tx)
+                            kernDoErosion_relax(g, accumulatedHeights.data(), layerIdx, shared_layerStart.data(), shared_layerEnd.data(), shared_didChange,
+                                                dim3{tx, ty, 0}, blockIdx, blockSize2d);
+                    if (shared_didChange) flagDidChange = true;          // chunk.cu:596-599: the block's flag into the launch's
                 }
             }
             isFirst = false;
             ++passes;
-        } while (changed);
+        } while (flagDidChange);
     }
     return passes;
-}
-
-// E3 — fixBackwardStratifiedLayers chunk.cu:725-749
-void fixBackwardStratifiedLayers(float* layers)
-{
-    for (int idx2d = 0; idx2d < 256; ++idx2d) {
-        const float erodedStart = layers[256 * numStratifiedMaterials + idx2d];
-        for (int l = numForwardMaterials; l < numStratifiedMaterials; ++l)
-            layers[256 * l + idx2d] = erodedStart - layers[256 * l + idx2d];
-    }
 }
 
 // ===================================================================================================
@@ -332,11 +499,15 @@ template <class E> struct Staging {
 };
 struct Chunk {
     ivec3 worldBlockPos;
-    Staging<const float> heightfield, biomeWeights, layers;
+    Staging<float> heightfield, biomeWeights, layers;            // (copyLayers and fixBackwardStratifiedLayers write the layers)
     Staging<const CaveLayer> caveLayers;
     Staging<Block> blocks;
     std::vector<FeaturePlacement>& featurePlacements;
     std::vector<CaveFeaturePlacement>& caveFeaturePlacements;
+    std::vector<FeaturePlacement> gatheredFeaturePlacements;
+    std::vector<CaveFeaturePlacement> gatheredCaveFeaturePlacements;
+
+    void fixBackwardStratifiedLayers();
 
     bool tryGenerateCaveFeaturePlacement(const CaveFeatureGen& caveFeatureGen, const CaveLayer& caveLayer, bool top, int caveFeaturePlacementSeed,
                                          float rand, ivec2 worldBlockPos2d);
@@ -344,6 +515,123 @@ struct Chunk {
     void tryPlaceSingleDecorator(ivec3 pos, const DecoratorGen& gen);
     void placeDecorators();
 };
+
+// E3 — Chunk::fixBackwardStratifiedLayers chunk.cu:725-749
+void Chunk::fixBackwardStratifiedLayers()
+{
+    std::array<float, 256> erodedStartHeights;
+
+    for (int layerIdx = numForwardMaterials; layerIdx < numStratifiedMaterials; ++layerIdx)
+    {
+        const int layerIdx256 = 256 * layerIdx;
+
+        for (int localZ = 0; localZ < 16; ++localZ)
+        {
+            for (int localX = 0; localX < 16; ++localX)
+            {
+                const int idx2d = posTo2dIndex(localX, localZ);
+                float* columnLayers = this->layers.data() + idx2d;
+
+                if (layerIdx == numForwardMaterials)
+                {
+                    erodedStartHeights[idx2d] = columnLayers[256 * numStratifiedMaterials];
+                }
+
+                columnLayers[layerIdx256] = erodedStartHeights[idx2d] - columnLayers[layerIdx256];
+            }
+        }
+    }
+}
+
+static std::vector<FeaturePlacement> g_noPlacements;
+static std::vector<CaveFeaturePlacement> g_noCavePlacements;
+static Chunk layersView(float* heightfield, float* layers)
+{
+    return Chunk{ivec3(0), {heightfield}, {nullptr}, {layers}, {nullptr}, {nullptr}, g_noPlacements, g_noCavePlacements, {}, {}};
+}
+
+void fixBackwardStratifiedLayers(float* layers)
+{
+    Chunk chunk = layersView(nullptr, layers);
+    chunk.fixBackwardStratifiedLayers();
+}
+
+// E1 / E3 — copyLayers chunk.cu:603-656.  The reference's Zone as copyLayers sees it (terrain.hpp:28-37).
+struct Zone {
+    std::vector<Chunk*> gatheredChunks;
+    std::array<std::unique_ptr<Chunk>, ZONE_SIZE * ZONE_SIZE> chunks;
+};
+
+void copyLayers(Zone* zonePtr, float* gatheredLayers, bool toGatheredLayers)
+{
+    const int maxDim = toGatheredLayers ? ZONE_SIZE * 2 : ZONE_SIZE;
+    const int maxLayerIdx = toGatheredLayers ? numMaterials + 1 : numMaterials;
+
+    for (int chunkZ = 0; chunkZ < maxDim; ++chunkZ)
+    {
+        for (int chunkX = 0; chunkX < maxDim; ++chunkX)
+        {
+            Chunk* chunkPtr;
+            ivec2 chunkBlockPos;
+            if (toGatheredLayers)
+            {
+                chunkPtr = zonePtr->gatheredChunks[posTo2dIndex<ZONE_SIZE * 2>(chunkX, chunkZ)];
+                chunkBlockPos = ivec2(chunkX, chunkZ) * 16;
+            }
+            else
+            {
+                chunkPtr = zonePtr->chunks[posTo2dIndex<ZONE_SIZE>(chunkX, chunkZ)].get();
+                chunkBlockPos = (ivec2(chunkX, chunkZ) + ivec2(ZONE_SIZE / 2)) * 16;
+            }
+
+            for (int layerIdx = numStratifiedMaterials; layerIdx < maxLayerIdx; ++layerIdx)
+            {
+                for (int blockZ = 0; blockZ < 16; ++blockZ)
+                {
+                    const int globalBlockZ = chunkBlockPos.y + blockZ;
+
+                    float* srcLayers;
+                    if (toGatheredLayers && layerIdx == maxLayerIdx - 1)
+                    {
+                        srcLayers = chunkPtr->heightfield.data() + (16 * blockZ);
+                    }
+                    else
+                    {
+                        srcLayers = chunkPtr->layers.data() + (16 * blockZ) + (256 * layerIdx);
+                    }
+
+                    float* dstLayers = gatheredLayers
+                        + (chunkBlockPos.x)
+                        + (EROSION_GRID_SIDE_LENGTH_BLOCKS * globalBlockZ)
+                        + (EROSION_GRID_NUM_COLS * (layerIdx - numStratifiedMaterials));
+
+                    if (!toGatheredLayers)
+                    {
+                        std::swap(srcLayers, dstLayers);
+                    }
+
+                    std::memcpy(dstLayers, srcLayers, 16 * sizeof(float));
+                }
+            }
+        }
+    }
+}
+
+// copyLayers for a zone whose 24 x 24 gathered chunks / 12 x 12 own chunks live in chunk-major staging arrays (chunkIdx: index of each
+// chunk in those arrays, row-major over the zone's grid): toGatheredLayers packs raw layers + heightfields into the zone planes, the
+// other direction writes the eroded planes of the centre chunks back into `layers`
+void zoneCopyLayers(float* layers, float* heightfields, const int* chunkIdx, float* gatheredLayers, bool toGatheredLayers)
+{
+    Zone zone;
+    std::vector<Chunk> views;
+    const int n = toGatheredLayers ? 4 * ZONE_SIZE * ZONE_SIZE : ZONE_SIZE * ZONE_SIZE;
+    views.reserve(n);
+    for (int i = 0; i < n; ++i)
+        views.push_back(layersView(heightfields ? heightfields + (size_t)256 * chunkIdx[i] : nullptr, layers + (size_t)devLayersSize * chunkIdx[i]));
+    if (toGatheredLayers) for (int i = 0; i < n; ++i) zone.gatheredChunks.push_back(&views[i]);
+    else for (int i = 0; i < n; ++i) zone.chunks[i] = std::make_unique<Chunk>(views[i]);
+    copyLayers(&zone, gatheredLayers, toGatheredLayers);
+}
 
 bool Chunk::tryGenerateCaveFeaturePlacement(const CaveFeatureGen& caveFeatureGen, const CaveLayer& caveLayer, bool top,
                                             int caveFeaturePlacementSeed, float rand, ivec2 worldBlockPos2d)    // chunk.cu:1010-1038
@@ -494,7 +782,7 @@ void generateFeaturePlacements(ivec2 chunkWorldBlockPos, const float* heightfiel
                                const CaveLayer* caveLayers, std::vector<FeaturePlacement>& out, std::vector<CaveFeaturePlacement>& caveOut)
 {
     const size_t n0 = out.size(), c0 = caveOut.size();
-    Chunk chunk{ivec3(chunkWorldBlockPos.x, 0, chunkWorldBlockPos.y), {heightfield}, {biomeWeights}, {layers}, {caveLayers}, {nullptr}, out, caveOut};
+    Chunk chunk{ivec3(chunkWorldBlockPos.x, 0, chunkWorldBlockPos.y), {(float*)heightfield}, {(float*)biomeWeights}, {(float*)layers}, {caveLayers}, {nullptr}, out, caveOut, {}, {}};
     for (int localZ = 0; localZ < 16; ++localZ)                           // chunk.cu:1147-1156
         for (int localX = 0; localX < 16; ++localX)
             chunk.generateColumnFeaturePlacements(localX, localZ);
@@ -656,79 +944,199 @@ static void chunkFillPlaceBlock(
 }
 
 // ===================================================================================================
-// K6 — kernFill chunk.cu:1382-1510 + host side of Chunk::fill chunk.cu:1555-1601
+// K6 — kernFill chunk.cu:1382-1510 + heightBoundsMinMax :1512-1516 + host side of Chunk::fill :1518-1632
 // ===================================================================================================
-void fillChunk(ivec3 chunkWorldBlockPos, const float* heightfield, const float* biomeWeights, const float* layers, const CaveLayer* caveLayers,
-               const FeaturePlacement* features, int nFeatures, const CaveFeaturePlacement* caveFeatures, int nCaveFeatures, Block* blocks)
+// the body of the kernel after its barrier, for the thread of voxel (x, y, z) (chunk.cu:1427-1509); the three shared arrays are the
+// column's biome weights, its layers + height and its cave layers, staged by the block before the barrier (chunk.cu:1404-1423: copies)
+static void kernFill(
+    Block* blocks,
+    const float* shared_biomeWeights,
+    const float* shared_layersAndHeight,
+    const CaveLayer* shared_caveLayers,
+    const FeaturePlacement* featurePlacements,
+    ivec2 allFeaturesHeightBounds,
+    const CaveFeaturePlacement* caveFeaturePlacements,
+    ivec2 allCaveFeaturesHeightBounds,
+    ivec3 chunkWorldBlockPos,
+    const int x, const int y, const int z)
 {
-    const Tables& t = T();
-    // host: union of height bounds over the un-truncated gathered lists (chunk.cu:1555-1570)
-    ivec2 allFeaturesHeightBounds = {384, -1};
-    for (int i = 0; i < nFeatures; ++i) {
-        const ivec2 b = t.featureHeightBounds[(int)features[i].feature];
-        allFeaturesHeightBounds.x = g_min(allFeaturesHeightBounds.x, features[i].pos.y + b.x);
-        allFeaturesHeightBounds.y = g_max(allFeaturesHeightBounds.y, features[i].pos.y + b.y);
-    }
-    ivec2 allCaveFeaturesHeightBounds = {384, -1};
-    for (int i = 0; i < nCaveFeatures; ++i) {
-        const ivec2 b = t.caveFeatureHeightBounds[(int)caveFeatures[i].feature];
-        const int featureY = caveFeatures[i].pos.y;
-        allCaveFeaturesHeightBounds.x = g_min(allCaveFeaturesHeightBounds.x, featureY + b.x);
-        allCaveFeaturesHeightBounds.y = g_max(allCaveFeaturesHeightBounds.y, featureY + caveFeatures[i].layerHeight + b.y);
-    }
-    // truncation (chunk.cu:1573-1601): at most 2048 / 4096 entries are visible to the kernel
-    const int nF = g_min(nFeatures, MAX_GATHERED_FEATURES_PER_CHUNK);
-    const int nCF = g_min(nCaveFeatures, MAX_GATHERED_CAVE_FEATURES_PER_CHUNK);
+    const int idx = posTo3dIndex(x, y, z);
 
-    for (int z = 0; z < 16; ++z) {
-        for (int x = 0; x < 16; ++x) {
-            const int idx2d = posTo2dIndex16(x, z);
-            float colBiomeWeights[numBiomes];
-            float layersAndHeight[numMaterials + 1];
-            for (int b = 0; b < numBiomes; ++b) colBiomeWeights[b] = biomeWeights[256 * b + idx2d];
-            for (int l = 0; l < numMaterials; ++l) layersAndHeight[l] = layers[256 * l + idx2d];
-            layersAndHeight[numMaterials] = heightfield[idx2d];
-            const CaveLayer* colCaveLayers = caveLayers + MAX_CAVE_LAYERS_PER_COLUMN * idx2d;
-            const float height = layersAndHeight[numMaterials];
+    const float height = shared_layersAndHeight[numMaterials];
 
-            for (int y = 0; y < 384; ++y) {
-                const ivec3 worldBlockPos = chunkWorldBlockPos + ivec3{x, y, z};
-                Rng rng = makeSeededRandomEngine(worldBlockPos.x, worldBlockPos.y, worldBlockPos.z);
+    const ivec3 worldBlockPos = chunkWorldBlockPos + ivec3(x, y, z);
+    auto rng = makeSeededRandomEngine(worldBlockPos.x, worldBlockPos.y, worldBlockPos.z);
 
-                Block block = Block::AIR;
-                chunkFillPlaceBlock(&block, colBiomeWeights, layersAndHeight, colCaveLayers, y, height, worldBlockPos, rng);
+    Block block;
+    chunkFillPlaceBlock(&block, shared_biomeWeights, shared_layersAndHeight, shared_caveLayers, y, height, worldBlockPos, rng);
 
-                bool isInFeatureBounds = y >= allFeaturesHeightBounds.x && y <= allFeaturesHeightBounds.y;
-                bool isInCaveFeatureBounds = y >= allCaveFeaturesHeightBounds.x && y <= allCaveFeaturesHeightBounds.y;
+    bool isInFeatureBounds = y >= allFeaturesHeightBounds[0] && y <= allFeaturesHeightBounds[1];
+    bool isInCaveFeatureBounds = y >= allCaveFeaturesHeightBounds[0] && y <= allCaveFeaturesHeightBounds[1];
 
-                Block featureBlock = Block::AIR;
-                bool placedFeature = false;
-                if (isInFeatureBounds) {
-                    for (int i = 0; i < nF; ++i) {
-                        const FeaturePlacement& fp = features[i];
-                        if (fp.feature == Feature::NONE) break;
-                        if (block != Block::AIR && !fp.canReplaceBlocks) continue;
-                        const ivec2 b = t.featureHeightBounds[(int)fp.feature];
-                        if (y < b.x + fp.pos.y || y > b.y + fp.pos.y) continue;
-                        if (placeFeature(fp, worldBlockPos, &featureBlock)) { placedFeature = true; break; }
-                    }
-                }
-                if (isInCaveFeatureBounds && !placedFeature) {
-                    for (int i = 0; i < nCF; ++i) {
-                        const CaveFeaturePlacement& cfp = caveFeatures[i];
-                        if (cfp.feature == CaveFeature::NONE) break;
-                        if (block != Block::AIR && !cfp.canReplaceBlocks) continue;
-                        const int featureY = cfp.pos.y;
-                        const ivec2 b = t.caveFeatureHeightBounds[(int)cfp.feature];
-                        if (y < featureY + b.x || y > featureY + cfp.layerHeight + b.y) continue;
-                        if (placeCaveFeature(cfp, worldBlockPos, &featureBlock)) { placedFeature = true; break; }
-                    }
-                }
-                if (placedFeature) block = featureBlock;
-                blocks[y + 384 * idx2d] = block;
+    Block featureBlock;
+    bool placedFeature = false;
+    if (isInFeatureBounds)
+    {
+        for (int featureIdx = 0; featureIdx < MAX_GATHERED_FEATURES_PER_CHUNK; ++featureIdx)
+        {
+            const auto& featurePlacement = featurePlacements[featureIdx];
+
+            if (featurePlacement.feature == Feature::NONE)
+            {
+                break;
+            }
+
+            if (block != Block::AIR && !featurePlacement.canReplaceBlocks)
+            {
+                continue;
+            }
+
+            ivec2 featureHeightBounds = dev_featureHeightBounds[(int)featurePlacement.feature] + ivec2(featurePlacement.pos.y);
+            if (y < featureHeightBounds[0] || y > featureHeightBounds[1])
+            {
+                continue;
+            }
+
+            if (placeFeature(featurePlacement, worldBlockPos, &featureBlock))
+            {
+                placedFeature = true;
+                break;
             }
         }
     }
+
+    if (isInCaveFeatureBounds && !placedFeature)
+    {
+        for (int caveFeatureIdx = 0; caveFeatureIdx < MAX_GATHERED_CAVE_FEATURES_PER_CHUNK; ++caveFeatureIdx)
+        {
+            const auto& caveFeaturePlacement = caveFeaturePlacements[caveFeatureIdx];
+
+            if (caveFeaturePlacement.feature == CaveFeature::NONE)
+            {
+                break;
+            }
+
+            if (block != Block::AIR && !caveFeaturePlacement.canReplaceBlocks)
+            {
+                continue;
+            }
+
+            const int featureY = caveFeaturePlacement.pos.y;
+            ivec2 caveFeatureHeightBounds = ivec2(featureY, featureY + caveFeaturePlacement.layerHeight) + dev_caveFeatureHeightBounds[(int)caveFeaturePlacement.feature];
+            if (y < caveFeatureHeightBounds[0] || y > caveFeatureHeightBounds[1])
+            {
+                continue;
+            }
+
+            if (placeCaveFeature(caveFeaturePlacement, worldBlockPos, &featureBlock))
+            {
+                placedFeature = true;
+                break;
+            }
+        }
+    }
+
+    if (placedFeature)
+    {
+        block = featureBlock;
+    }
+
+    blocks[idx] = block;
+}
+
+void heightBoundsMinMax(ivec2& in, const ivec2& v)
+{
+    in[0] = g_min(in[0], v[0]);
+    in[1] = g_max(in[1], v[1]);
+}
+
+// the copies of the reference's host code are plain memory copies here
+enum cudaMemcpyKind { cudaMemcpyHostToDevice };
+typedef int cudaStream_t;
+static inline void cudaMemcpyAsync(void* dst, const void* src, size_t count, cudaMemcpyKind, cudaStream_t) { std::memcpy(dst, src, count); }
+
+// Chunk::fill for chunk i of a batch, from the gathered lists to the launch (chunk.cu:1555-1616): the union of the lists' height bounds
+// over the UN-truncated lists, the truncation to 2 048 / 4 096 entries with the NONE terminator, then the kernel over the chunk's voxels
+static void Chunk_fill(Chunk* chunkPtr, int i, FeaturePlacement* dev_featurePlacements, CaveFeaturePlacement* dev_caveFeaturePlacements, Block* dev_blocks,
+                       cudaStream_t stream)
+{
+        ivec2 allFeaturesHeightBounds = ivec2(384, -1);
+        for (const auto& featurePlacement : chunkPtr->gatheredFeaturePlacements)
+        {
+            const auto& featureHeightBounds = host_featureHeightBounds[(int)featurePlacement.feature];
+            const ivec2 thisFeatureHeightBounds = ivec2(featurePlacement.pos.y) + featureHeightBounds;
+            heightBoundsMinMax(allFeaturesHeightBounds, thisFeatureHeightBounds);
+        }
+
+        ivec2 allCaveFeaturesHeightBounds = ivec2(384, -1);
+        for (const auto& caveFeaturePlacement : chunkPtr->gatheredCaveFeaturePlacements)
+        {
+            const auto& caveFeatureHeightBounds = host_caveFeatureHeightBounds[(int)caveFeaturePlacement.feature];
+            const int featureY = caveFeaturePlacement.pos.y;
+            const ivec2 thisCaveFeatureHeightBounds = ivec2(featureY, featureY + caveFeaturePlacement.layerHeight) + caveFeatureHeightBounds;
+            heightBoundsMinMax(allCaveFeaturesHeightBounds, thisCaveFeatureHeightBounds);
+        }
+
+        int numFeaturePlacements = g_min((int)chunkPtr->gatheredFeaturePlacements.size(), MAX_GATHERED_FEATURES_PER_CHUNK);
+        if (numFeaturePlacements < MAX_GATHERED_FEATURES_PER_CHUNK)
+        {
+            chunkPtr->gatheredFeaturePlacements.push_back({ Feature::NONE });
+            ++numFeaturePlacements;
+        }
+        cudaMemcpyAsync(
+            dev_featurePlacements + (i * MAX_GATHERED_FEATURES_PER_CHUNK),
+            chunkPtr->gatheredFeaturePlacements.data(),
+            numFeaturePlacements * sizeof(FeaturePlacement),
+            cudaMemcpyHostToDevice,
+            stream
+        );
+        chunkPtr->gatheredFeaturePlacements.clear();
+
+        int numCaveFeaturePlacements = g_min((int)chunkPtr->gatheredCaveFeaturePlacements.size(), MAX_GATHERED_CAVE_FEATURES_PER_CHUNK);
+        if (numCaveFeaturePlacements < MAX_GATHERED_CAVE_FEATURES_PER_CHUNK)
+        {
+            chunkPtr->gatheredCaveFeaturePlacements.push_back({ CaveFeature::NONE });
+            ++numCaveFeaturePlacements;
+        }
+        cudaMemcpyAsync(
+            dev_caveFeaturePlacements + (i * MAX_GATHERED_CAVE_FEATURES_PER_CHUNK),
+            chunkPtr->gatheredCaveFeaturePlacements.data(),
+            numCaveFeaturePlacements * sizeof(CaveFeaturePlacement),
+            cudaMemcpyHostToDevice,
+            stream
+        );
+        chunkPtr->gatheredCaveFeaturePlacements.clear();
+
+        const dim3 blockSize3d{1, 128, 1};
+        const dim3 blocksPerGrid3d{16, 3, 16};
+        // the launch: one block = 128 voxels of one column; its shared arrays are staged once per column here
+        for (int z = 0; z < blocksPerGrid3d.z; ++z) {
+            for (int x = 0; x < blocksPerGrid3d.x; ++x) {
+                const int idx2d = posTo2dIndex(x, z);
+                float shared_biomeWeights[numBiomes];
+                float shared_layersAndHeight[numMaterials + 1];
+                for (int loadIdx = 0; loadIdx < numBiomes; ++loadIdx) shared_biomeWeights[loadIdx] = chunkPtr->biomeWeights[idx2d + 256 * loadIdx];
+                for (int loadIdx = 0; loadIdx < numMaterials; ++loadIdx) shared_layersAndHeight[loadIdx] = chunkPtr->layers[idx2d + 256 * loadIdx];
+                shared_layersAndHeight[numMaterials] = chunkPtr->heightfield[idx2d];
+                const CaveLayer* shared_caveLayers = chunkPtr->caveLayers.data() + (MAX_CAVE_LAYERS_PER_COLUMN * idx2d);
+                for (int y = 0; y < blocksPerGrid3d.y * blockSize3d.y; ++y)
+                    kernFill(dev_blocks, shared_biomeWeights, shared_layersAndHeight, shared_caveLayers, dev_featurePlacements + (i * MAX_GATHERED_FEATURES_PER_CHUNK),
+                             allFeaturesHeightBounds, dev_caveFeaturePlacements + (i * MAX_GATHERED_CAVE_FEATURES_PER_CHUNK), allCaveFeaturesHeightBounds,
+                             chunkPtr->worldBlockPos, x, y, z);
+            }
+        }
+}
+
+void fillChunk(ivec3 chunkWorldBlockPos, const float* heightfield, const float* biomeWeights, const float* layers, const CaveLayer* caveLayers,
+               const FeaturePlacement* features, int nFeatures, const CaveFeaturePlacement* caveFeatures, int nCaveFeatures, Block* blocks)
+{
+    std::vector<FeaturePlacement> none;
+    std::vector<CaveFeaturePlacement> caveNone;
+    Chunk chunk{chunkWorldBlockPos, {(float*)heightfield}, {(float*)biomeWeights}, {(float*)layers}, {caveLayers}, {blocks}, none, caveNone,
+                std::vector<FeaturePlacement>(features, features + nFeatures), std::vector<CaveFeaturePlacement>(caveFeatures, caveFeatures + nCaveFeatures)};
+    std::vector<FeaturePlacement> dev_featurePlacements(MAX_GATHERED_FEATURES_PER_CHUNK);
+    std::vector<CaveFeaturePlacement> dev_caveFeaturePlacements(MAX_GATHERED_CAVE_FEATURES_PER_CHUNK);
+    Chunk_fill(&chunk, 0, dev_featurePlacements.data(), dev_caveFeaturePlacements.data(), blocks, 0);
 }
 
 // ===================================================================================================
@@ -857,7 +1265,7 @@ void placeDecorators(ivec3 chunkWorldBlockPos, const float* heightfield, const f
 {
     std::vector<FeaturePlacement> none;
     std::vector<CaveFeaturePlacement> caveNone;
-    Chunk chunk{chunkWorldBlockPos, {heightfield}, {biomeWeights}, {nullptr}, {caveLayers}, {blocks}, none, caveNone};
+    Chunk chunk{chunkWorldBlockPos, {(float*)heightfield}, {(float*)biomeWeights}, {nullptr}, {caveLayers}, {blocks}, none, caveNone, {}, {}};
     chunk.placeDecorators();
 }
 

@@ -32,6 +32,9 @@ void generateLayers(ivec2 chunkWorldBlockPos, const float* gatheredHeightfield /
 // E1+K3  copyLayers(to) + kernDoErosion loop chunk.cu:477-705 on the packed zone planes.
 // gathered: [9][384*384] (8 eroded-layer starts + heightfield), eroded in place.  Returns the number of relaxation passes.
 int erodeZonePlanes(float* gathered);
+// E1 / E3  copyLayers chunk.cu:603-656 over chunk-major staging arrays (chunkIdx[576] with heightfields: into the zone planes;
+// chunkIdx[144], heightfields = null: the eroded planes of the zone's own chunks back into `layers`)
+void zoneCopyLayers(float* layers, float* heightfields, const int* chunkIdx, float* gatheredLayers, bool toGatheredLayers);
 // E3  fixBackwardStratifiedLayers chunk.cu:725-749
 void fixBackwardStratifiedLayers(float* layers /*20*256*/);
 

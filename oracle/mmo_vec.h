@@ -24,6 +24,8 @@ struct vec2;
 struct vec3;
 struct ivec2 {
     int x, y;
+    int& operator[](int i) { return i == 0 ? x : y; }
+    const int& operator[](int i) const { return i == 0 ? x : y; }
     ivec2() : x(0), y(0) {}
     template <class A, class = std::enable_if_t<std::is_arithmetic<A>::value>> explicit ivec2(A s) : x((int)s), y((int)s) {}
     template <class A, class B> ivec2(A x_, B y_) : x((int)x_), y((int)y_) {}
@@ -71,6 +73,7 @@ static inline ivec3 operator-(ivec3 a, ivec3 b) { return {a.x - b.x, a.y - b.y, 
 static inline ivec3 operator*(ivec3 a, int s) { return {a.x * s, a.y * s, a.z * s}; }
 static inline ivec3 operator/(ivec3 a, int s) { return {a.x / s, a.y / s, a.z / s}; }
 static inline bool operator==(ivec3 a, ivec3 b) { return a.x == b.x && a.y == b.y && a.z == b.z; }
+static inline ivec2 g_clamp(ivec2 v, int lo, int hi) { return {(v.x < lo) ? lo : ((hi < v.x) ? hi : v.x), (v.y < lo) ? lo : ((hi < v.y) ? hi : v.y)}; }   // glm::clamp = min(max(x, lo), hi)
 static inline ivec2 g_abs(ivec2 v) { return {std::abs(v.x), std::abs(v.y)}; }
 static inline ivec3 g_abs(ivec3 v) { return {std::abs(v.x), std::abs(v.y), std::abs(v.z)}; }
 static inline int compAdd(ivec2 v) { return v.x + v.y; }                  // glm/gtx/component_wise.inl

@@ -12,7 +12,8 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
-from extract_ref_literals import ORACLE_FILES, REFERENCE_SECTIONS, literals, oracle_signature, sections, skeleton_digest, strip_comments   # noqa: E402
+from extract_ref_literals import (ANCHORS, ORACLE_FILES, REFERENCE_SECTIONS, canonical_blocks, literals, oracle_signature, sections, skeleton,   # noqa: E402
+                                  skeleton_digest, strip_comments)
 
 REF = json.load(open(os.path.join(ROOT, "tests", "golden", "ref_literals.json")))
 
@@ -35,7 +36,7 @@ def _oracle_sections():
         base = os.path.basename(rel)
         if base not in cache:
             cache[base] = _read(ORACLE_FILES[base])
-        secs = sections(cache[base], oracle_signature(f"{base}::{key}", sig), prefixes)
+        secs = sections(cache[base], oracle_signature(f"{base}::{key}", sig), prefixes, ANCHORS.get(key))
         for name, code in secs.items():
             out[f"{base}::{key}" + (f"::{name}" if name else "")] = literals(code)
     return out
@@ -151,6 +152,17 @@ DEVICE_ALLOW = {
 }
 
 
+# The sections cut out of the reference's kernels and host stages (tools/extract_ref_literals.py::ANCHORS and the plain functions beside
+# them) write no constant of the world definition: their numbers are index strides (16, 256, 384), loop bounds (8 neighbours, 18 x 18
+# gathered heights) and CUDA thread-block geometry (which thread of a 32 x 32 block loads which cell of the 34 x 34 shared tile).  The
+# device kernels index and tile differently (lane = column, 44 x 44 LDS tiles, chunk lists), so there is no set of constants to hold
+# them to; their ARITHMETIC is pinned statement for statement in the oracle (digests below) and the device is held to the oracle by
+# the bit-exact stage tests (tests/test_gpu_parity.py: layers, one erosion zone incl. its pass count, fill, gathered lists and bounds).
+DEVICE_NO_OWN_CONSTANTS = {"chunk.cu::kernGenerateHeightfield", "chunk.cu::kernGenerateLayers", "chunk.cu::kernDoErosion.stage", "chunk.cu::kernDoErosion.relax",
+                           "chunk.cu::copyLayers", "chunk.cu::fixBackwardStratifiedLayers", "chunk.cu::kernFill", "chunk.cu::heightBoundsMinMax",
+                           "chunk.cu::Chunk.fill.lists"}
+
+
 def test_device_sections_hold_every_reference_constant():
     problems = []
     covered = set()
@@ -203,7 +215,7 @@ def test_device_sections_hold_every_reference_constant():
             extra = sorted(set(literals(secs[case])) - set(REF[k]) - DEVICE_BENIGN - set(DEVICE_EXTRA.get(k, ())))
             if extra:
                 problems.append(f"{k}: values in the device code that the reference's section does not contain: {extra}")
-    not_mapped = sorted(k for k in REF if k not in covered and not k.startswith("chunk.cu::kernGenerateCaves"))
+    not_mapped = sorted(k for k in REF if k not in covered and not k.startswith("chunk.cu::kernGenerateCaves") and k not in DEVICE_NO_OWN_CONSTANTS)
     assert not not_mapped, f"reference sections without a device counterpart in DEVICE_MAP: {not_mapped}"
     assert not problems, "\n".join(problems)
 
@@ -221,7 +233,8 @@ SKELETON_DIFFERS = {
     "chunk.cu::kernGenerateCaves",
 }
 # What the normaliser (tools/extract_ref_literals.py::skeleton) treats as equal, all of it listed there: comments, qualifiers
-# (const / static / inline / __device__ / __host__), braces, (float) casts, namespaces (glm:: thrust:: std::), printf diagnostics,
+# (const / static / inline / __device__ / __host__), OPTIONAL braces (canonical_blocks: every control statement's body gets exactly one
+# pair, scope-only braces go - which statements a condition or loop governs IS part of the digest), (float) casts, namespaces (glm:: thrust:: std::), printf diagnostics,
 # `default: break;`, `(void)x;`, `#pragma unroll`, the reference's own compile-time switches resolved as its `#define`s set them, the
 # table of renamed helpers (g_* glm look-alikes, mm_* libm, hash_u32, Rng = default_random_engine), and four named oracle-only
 # insertions: vec3_ltr (= vec3 with the canonical left-to-right evaluation of its arguments), CANONICAL_RETURN_FALSE,
@@ -234,7 +247,7 @@ def _skeleton_report():
         base = os.path.basename(rel)
         if base not in cache:
             cache[base] = _read(ORACLE_FILES[base])
-        secs = sections(cache[base], oracle_signature(f"{base}::{key}", sig), prefixes)
+        secs = sections(cache[base], oracle_signature(f"{base}::{key}", sig), prefixes, ANCHORS.get(key))
         for k in SKEL:
             parts = k.split("::")
             if parts[0] != base or parts[1] != key:
@@ -250,13 +263,32 @@ def test_oracle_sections_are_token_identical_to_the_reference():
     assert not unexpected, "oracle sections that no longer match the reference's statement skeleton: " + ", ".join(unexpected)
     stale = sorted(SKELETON_DIFFERS - set(differs))
     assert not stale, "sections listed as different that are identical now (move them out of SKELETON_DIFFERS): " + ", ".join(stale)
-    # what is pinned this way: every function and switch case on the path except the one kernel above
-    assert len(SKEL) >= 127 and len(identical) == len(SKEL) - 1
+    # what is pinned this way: every function and switch case on the path, and the arithmetic written inline in the kernels / host stages
+    # (ANCHORS), except the one kernel above
+    assert len(SKEL) >= 136 and len(identical) == len(SKEL) - 1
     count = lambda prefix: sum(k.startswith(prefix) for k in identical)
     assert count("biomeFuncs.hpp::getHeight::") == 24
     assert count("featurePlacement.hpp::placeFeature::") == 21 and count("featurePlacement.hpp::placeCaveFeature::") == 10
-    assert count("rng.hpp::") == 24 and count("chunk.cu::") == 8 and count("biomeFuncs.hpp::") == 51 and count("featurePlacement.hpp::") == 43
+    assert count("rng.hpp::") == 24 and count("chunk.cu::") == 17 and count("biomeFuncs.hpp::") == 51 and count("featurePlacement.hpp::") == 43
     assert all(SKEL[k]["tokens"] > 0 for k in SKEL)
+
+
+def test_block_structure_is_part_of_the_digest():
+    """optional braces are canonical, block scope is not: `if (c) { a; b; }` and `if (c) a; b;` must differ (round 3's normaliser dropped
+    every brace and could not tell them apart)"""
+    sk = lambda code: " ".join(skeleton(code))
+    assert sk("if (c) a = 1;") == sk("if (c) { a = 1; }")
+    assert sk("if (c) { a = 1; b = 2; }") != sk("if (c) a = 1; b = 2;")
+    assert sk("if (c) { a = 1; } b = 2;") == sk("if (c) a = 1; b = 2;")
+    assert sk("for (int i = 0; i < n; ++i) { x += i; y += i; }") != sk("for (int i = 0; i < n; ++i) x += i; y += i;")
+    assert sk("if (a) x = 1; else if (b) x = 2; else x = 3;") == sk("if (a) { x = 1; } else { if (b) { x = 2; } else { x = 3; } }")
+    assert sk("if (a) { if (b) x = 1; } else x = 2;") != sk("if (a) if (b) x = 1; else x = 2;")         # the dangling else binds to the inner if
+    assert sk("{ int t = f(); g(t); }") == sk("int t = f(); g(t);")                                       # a scope governs nothing
+    assert sk("while (c) { a(); } b();") != sk("while (c) { a(); b(); }")
+    assert sk("do { a(); } while (c); b();") != sk("do { a(); b(); } while (c);")
+    assert sk("switch (k) { case 1: a(); break; case 2: b(); }") != sk("switch (k) { case 1: a(); break; } case 2: b();")
+    assert sk("float v[3] = { 1.f, 2.f, 3.f };") != sk("float v[3] = 1.f, 2.f, 3.f;")                    # braces inside an expression stay
+    assert canonical_blocks("if ( c ) return ; }".split()) == "if ( c ) { return ; }".split()               # stray closer of a cut section
 
 
 # one mutation per family of sections: a change of operation order, of an operand or of control flow in the oracle must break the digest
@@ -280,10 +312,29 @@ MUTATIONS = [
      "chunk.cu::generateColumnFeaturePlacements"),
     ("oracle/mmo_stages.cpp", "if (layerStart <= y && y < layerEnd)", "if (layerStart < y && y <= layerEnd)", "chunk.cu::chunkFillPlaceBlock"),
     ("oracle/mmo_biome.cpp", "if (rand <= 0.f) return caveBiome;", "if (rand < 0.f) return caveBiome;", "biomeFuncs.hpp::getCaveBiome"),
+    # ---- block structure: a statement moved out of the block its condition governs (same tokens, different braces)
+    ("oracle/mmo_stages.cpp", "            shared_didChange = true;\n\n            accumulatedHeights[globalIdx2d] += newLayerStart - thisLayerStart;\n        }",
+     "            shared_didChange = true;\n        }\n            accumulatedHeights[globalIdx2d] += newLayerStart - thisLayerStart;\n", "chunk.cu::kernDoErosion.relax"),
+    ("oracle/mmo_stages.cpp", "            caveBottomDepth = -384;\n            break;\n        }", "            caveBottomDepth = -384;\n        }\n            break;\n",
+     "chunk.cu::chunkFillPlaceBlock"),
+    # ---- the arithmetic written inline in the kernels and host stages
+    ("oracle/mmo_stages.cpp", "if (weight > 0.f)\n        {\n            height += weight * getHeight(biome, worldPos);", "if (weight >= 0.f)\n        {\n            height += weight * getHeight(biome, worldPos);",
+     "chunk.cu::kernGenerateHeightfield"),
+    ("oracle/mmo_stages.cpp", "fabsf(neighborHeight - maxHeight) * (i % 2 == 1 ? SQRT_2 : 1)", "fabsf(neighborHeight - maxHeight) * (i % 2 == 0 ? SQRT_2 : 1)", "chunk.cu::kernGenerateLayers"),
+    ("oracle/mmo_stages.cpp", "neighborLayerStart - tanAngleOfRepose * (i % 2 == 1 ? SQRT_2 : 1)", "neighborLayerStart + tanAngleOfRepose * (i % 2 == 1 ? SQRT_2 : 1)",
+     "chunk.cu::kernDoErosion.relax"),
+    ("oracle/mmo_stages.cpp", "loadPos = g_clamp(loadPos, 0, EROSION_GRID_SIDE_LENGTH_BLOCKS - 1);", "loadPos = g_clamp(loadPos, 1, EROSION_GRID_SIDE_LENGTH_BLOCKS - 1);",
+     "chunk.cu::kernDoErosion.stage"),
+    ("oracle/mmo_stages.cpp", "chunkBlockPos = (ivec2(chunkX, chunkZ) + ivec2(ZONE_SIZE / 2)) * 16;", "chunkBlockPos = (ivec2(chunkX, chunkZ) + ivec2(ZONE_SIZE / 4)) * 16;", "chunk.cu::copyLayers"),
+    ("oracle/mmo_stages.cpp", "columnLayers[layerIdx256] = erodedStartHeights[idx2d] - columnLayers[layerIdx256];", "columnLayers[layerIdx256] = columnLayers[layerIdx256] - erodedStartHeights[idx2d];",
+     "chunk.cu::fixBackwardStratifiedLayers"),
+    ("oracle/mmo_stages.cpp", "if (block != Block::AIR && !featurePlacement.canReplaceBlocks)", "if (block != Block::AIR || !featurePlacement.canReplaceBlocks)", "chunk.cu::kernFill"),
+    ("oracle/mmo_stages.cpp", "in[0] = g_min(in[0], v[0]);", "in[0] = g_max(in[0], v[0]);", "chunk.cu::heightBoundsMinMax"),
+    ("oracle/mmo_stages.cpp", "if (numFeaturePlacements < MAX_GATHERED_FEATURES_PER_CHUNK)", "if (numFeaturePlacements <= MAX_GATHERED_FEATURES_PER_CHUNK)", "chunk.cu::Chunk.fill.lists"),
 ]
 
 
-@pytest.mark.parametrize("path,old,new,prefix", MUTATIONS, ids=[m[3].split("::", 1)[1] for m in MUTATIONS])
+@pytest.mark.parametrize("path,old,new,prefix", MUTATIONS, ids=[f"{i}-" + m[3].split("::", 1)[1] for i, m in enumerate(MUTATIONS)])
 def test_skeleton_digest_sees_a_mutated_oracle_statement(path, old, new, prefix, monkeypatch):
     """the digests are not vacuous: each listed one-statement change of the oracle's TEXT (never built) moves a section of that family
     out of the identical set"""

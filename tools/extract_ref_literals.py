@@ -104,15 +104,23 @@ def body_after(text, start):
     raise ValueError("unbalanced braces")
 
 
-def sections(text, signature, case_prefixes=()):
+def sections(text, signature, case_prefixes=(), anchors=None):
     """{section: code}.  `signature` is a regex matching the start of the function definition; with case_prefixes the body is cut at
-    `case <prefix>NAME:` labels (consecutive labels share the code that follows; code before the first label is section '')."""
+    `case <prefix>NAME:` labels (consecutive labels share the code that follows; code before the first label is section '').
+    anchors = (start regex, end regex or None): only the part of the body from the first match of `start` up to the first match of `end`
+    behind it (or the body's end) counts - the arithmetic core of a CUDA kernel without its thread-index preamble and barriers."""
     out = {}
     for m in re.finditer(signature, text):
         try:
             body = body_after(text, m.end() - 1 if text[m.end() - 1] == "{" else m.end())
         except ValueError:
             continue
+        if anchors:
+            a = re.search(anchors[0], body)
+            if not a:
+                continue
+            e = re.search(anchors[1], body[a.start():]) if anchors[1] else None
+            body = body[a.start():a.start() + e.start()] if e else body[a.start():]
         if not case_prefixes:
             out[""] = out.get("", "") + body
             continue
@@ -147,7 +155,101 @@ RENAME = {"g_smoothstep": "smoothstep", "g_mix": "mix", "g_clamp": "clamp", "g_m
           # C++ leaves the order of evaluation of call arguments unspecified; where the reference draws from one random stream in several
           # arguments of one vec3(...) the oracle fixes the canonical left-to-right order with a braced list behind this macro (mmo_vec.h)
           "vec3_ltr": "vec3"}
-DROPPED = {"const", "__device__", "__host__", "static", "inline", "{", "}", "glm", "thrust", "std", "::"}
+DROPPED = {"const", "__device__", "__host__", "static", "inline", "glm", "thrust", "std", "::"}
+CONTROL = {"if", "for", "while", "switch"}
+
+
+def canonical_blocks(toks):
+    """Block structure made canonical instead of dropped: the body of every if / else / for / while / do / switch is wrapped in ONE pair of
+    braces whether the source wrote them or not (`if (c) a;` == `if (c) { a; }`, `else if` == `else { if ... }`), and braces that are not
+    the body of a control statement (a scope around a case's statements, the function's own, the stray closers of a section cut out of
+    a switch) are dropped.  `if (c) { a; b; }` and `if (c) a; b;` therefore differ: which statements a condition or a loop governs is
+    part of the digest.  Braces inside an expression statement (initialiser lists) stay as written."""
+    n = len(toks)
+    out = []
+
+    def close_paren(i):                                       # toks[i] == "(" -> index after its ")"
+        depth = 0
+        while i < n:
+            depth += toks[i] == "("
+            depth -= toks[i] == ")"
+            i += 1
+            if depth == 0:
+                break
+        return i
+
+    def body(i):
+        out.append("{")
+        if i < n and toks[i] == "{":
+            i += 1
+            while i < n and toks[i] != "}":
+                i = statement(i)
+            i += 1
+        else:
+            i = statement(i)
+        out.append("}")
+        return i
+
+    def statement(i):
+        if i >= n:
+            return i
+        t = toks[i]
+        if t == "{":                                          # a plain scope
+            i += 1
+            while i < n and toks[i] != "}":
+                i = statement(i)
+            return i + 1
+        if t in CONTROL:
+            out.append(t)
+            i += 1
+            if i < n and toks[i] == "(":
+                j = close_paren(i)
+                out.extend(toks[i:j])
+                i = j
+            i = body(i)
+            if t == "if" and i < n and toks[i] == "else":
+                out.append("else")
+                i = body(i + 1)
+            return i
+        if t == "else":                                       # (a section that starts between an if and its else)
+            out.append("else")
+            return body(i + 1)
+        if t == "do":
+            out.append("do")
+            i = body(i + 1)
+            while i < n and toks[i] != ";":
+                out.append(toks[i])
+                i += 1
+            out.append(";")
+            return i + 1
+        if t == "case" or (t == "default" and i + 1 < n and toks[i + 1] == ":"):
+            while i < n and toks[i] != ":":
+                out.append(toks[i])
+                i += 1
+            out.append(":")
+            return i + 1
+        depth = 0                                             # expression / declaration statement: up to its ';'
+        while i < n:
+            t = toks[i]
+            if t in "([{" and len(t) == 1:
+                depth += 1
+            elif t in ")]}" and len(t) == 1:
+                if depth == 0:
+                    return i                                  # the closer of an enclosing block: not ours
+                depth -= 1
+            out.append(t)
+            i += 1
+            if t == ";" and depth == 0:
+                break
+        return i
+
+    i = 0
+    while i < n:
+        if toks[i] == "}":                                    # closer of a block that was opened before this section
+            i += 1
+            continue
+        i = statement(i)
+    return out
 
 
 def _number(tok):
@@ -161,6 +263,7 @@ def _number(tok):
 
 def skeleton(code):
     """normalised token list of a piece of (comment-free) code"""
+    code = re.sub(r"^([ \t]*#[ \t]*(?:define|undef)\b[^\n]*)$", r"\1 ;", code, flags=re.M)      # a function-local macro is a statement of its own
     toks = [m.group(0) for m in TOKEN.finditer(code)]
     out, i = [], 0
     while i < len(toks):
@@ -179,7 +282,7 @@ def skeleton(code):
     txt = txt.replace(" CANONICAL_NO_LAYER_FOUND ( thisLayerIdx , blockPtr )", " ")
     txt = re.sub(r" \( void \) \w+ ;", " ", txt)
     txt = txt.replace(" . r ", " . x ").replace(" . g ", " . y ").replace(" . b ", " . z ")      # glm colour aliases of the components
-    return txt.split()
+    return canonical_blocks(txt.split())
 
 
 def skeleton_digest(code):
@@ -248,7 +351,28 @@ REFERENCE_SECTIONS = [
     ("terrain/chunk.cu", "placeDecorators", r"void\s+Chunk::placeDecorators\s*\([^)]*\)\s*\{", ()),
     ("terrain/chunk.cu", "chunkFillPlaceBlock", r"void\s+chunkFillPlaceBlock\s*\([^{]*\)\s*\{", ()),
     ("terrain/chunk.cu", "kernGenerateCaves", r"void\s+kernGenerateCaves\s*\([^{]*\)\s*\{", ()),
+    # the arithmetic that is written inline in the CUDA kernels and host stages (no callee to pin): whole functions where they are plain
+    # C++, the part between ANCHORS where the function is a kernel (its thread-index preamble, shared-memory staging copies and barriers
+    # are orchestration; what a thread computes is not)
+    ("terrain/chunk.cu", "kernGenerateHeightfield", r"void\s+kernGenerateHeightfield\s*\([^{]*\)\s*\{", ()),
+    ("terrain/chunk.cu", "kernGenerateLayers", r"void\s+kernGenerateLayers\s*\([^{]*\)\s*\{", ()),
+    ("terrain/chunk.cu", "kernDoErosion.stage", r"void\s+kernDoErosion\s*\([^{]*\)\s*\{", ()),
+    ("terrain/chunk.cu", "kernDoErosion.relax", r"void\s+kernDoErosion\s*\([^{]*\)\s*\{", ()),
+    ("terrain/chunk.cu", "copyLayers", r"void\s+copyLayers\s*\([^{]*\)\s*\{", ()),
+    ("terrain/chunk.cu", "fixBackwardStratifiedLayers", r"void\s+Chunk::fixBackwardStratifiedLayers\s*\(\s*\)\s*\{", ()),
+    ("terrain/chunk.cu", "kernFill", r"void\s+kernFill\s*\([^{]*\)\s*\{", ()),
+    ("terrain/chunk.cu", "heightBoundsMinMax", r"void\s+heightBoundsMinMax\s*\([^{]*\)\s*\{", ()),
+    ("terrain/chunk.cu", "Chunk.fill.lists", r"void\s+Chunk::fill\s*\([^{]*\)\s*\{", ()),
 ]
+# key -> (start, end): the section is the part of the function body from `start` up to `end` (None = the body's end)
+ANCHORS = {
+    "kernGenerateHeightfield": (r"const\s+int\s+idx\s*=", None),                                             # chunk.cu:160-184
+    "kernGenerateLayers": (r"float\s+totalMaterialWeights\s*\[", None),                                      # chunk.cu:346-414
+    "kernDoErosion.stage": (r"const\s+int\s+localX\s*=\s*threadIdx", r"__syncthreads"),                       # chunk.cu:487-555
+    "kernDoErosion.relax": (r"float\s+newLayerStart\s*=\s*thisLayerStart", r"__syncthreads"),                 # chunk.cu:558-590
+    "kernFill": (r"const\s+float\s+height\s*=\s*shared_layersAndHeight", None),                              # chunk.cu:1427-1509
+    "Chunk.fill.lists": (r"ivec2\s+allFeaturesHeightBounds\s*=\s*ivec2", r"const\s+dim3\s+blockSize3d"),      # chunk.cu:1555-1601
+}
 
 
 # where the oracle restates each reference file
@@ -256,7 +380,11 @@ ORACLE_FILES = {"biomeFuncs.hpp": ["oracle/mmo_biome.h", "oracle/mmo_biome.cpp"]
                 "rng.hpp": ["oracle/mmo_noise.h"], "chunk.cu": ["oracle/mmo_stages.cpp"]}
 
 # the oracle's spelling of a reference signature (free functions instead of Chunk:: members, its own kernel-less stage names)
-ORACLE_SIGNATURES = {"rng.hpp::hash": r"uint32_t\s+hash_u32\s*\([^)]*\)\s*\{"}
+ORACLE_SIGNATURES = {"rng.hpp::hash": r"uint32_t\s+hash_u32\s*\([^)]*\)\s*\{",
+                     # a kernel with a barrier is two functions in the oracle (every thread runs the first, then every thread the second)
+                     "chunk.cu::kernDoErosion.stage": r"void\s+kernDoErosion_stage\s*\([^{]*\)\s*\{",
+                     "chunk.cu::kernDoErosion.relax": r"void\s+kernDoErosion_relax\s*\([^{]*\)\s*\{",
+                     "chunk.cu::Chunk.fill.lists": r"void\s+Chunk_fill\s*\([^{]*\)\s*\{"}
 
 
 def oracle_signature(key, sig):
@@ -271,7 +399,7 @@ def main(out_path):
     for rel, key, sig, prefixes in REFERENCE_SECTIONS:
         if rel not in cache:
             cache[rel] = strip_comments(open(os.path.join(REF, rel)).read())
-        secs = sections(cache[rel], sig, prefixes)
+        secs = sections(cache[rel], sig, prefixes, ANCHORS.get(key))
         assert secs, (rel, key)
         for name, code in secs.items():
             vals = literals(code)
@@ -281,7 +409,7 @@ def main(out_path):
     print(f"wrote {out_path}: {len(out)} sections, {sum(len(v) for v in out.values())} literal values")
     skel = {}
     for rel, key, sig, prefixes in REFERENCE_SECTIONS:
-        for name, code in sections(cache[rel], sig, prefixes).items():
+        for name, code in sections(cache[rel], sig, prefixes, ANCHORS.get(key)).items():
             skel[f"{os.path.basename(rel)}::{key}" + (f"::{name}" if name else "")] = skeleton_digest(code)
     skel_path = os.path.join(os.path.dirname(out_path), "ref_skeletons.json")
     json.dump(skel, open(skel_path, "w"), indent=0, sort_keys=True)
