@@ -135,6 +135,12 @@ int mmgen_region_placement_buffers(mmgen_region* region, mmgen_feature_placement
 /* optional middle step: the base blocks of the rectangle (kernFill without feature lists, chunk.cu:1202-1510).  It needs nothing from the
  * placement ring, so a tiling caller issues it while the ring exchange is in flight; finish (same d_blocks) then skips it. */
 int mmgen_region_fill(mmgen_region* region, uint8_t* d_blocks, void* stream);
+/* optional, BEFORE a begin: names the block buffer the region is going to be finished into, which lets that begin issue the base fill
+ * itself as soon as the caves' extents and the eroded layers exist - beside the cave biomes and the placement stages, which only the
+ * rasterisers wait for - instead of when mmgen_region_fill / _finish is called (then a no-op for the same pointer).  The fill is ordered
+ * behind what the stream held when begin was CALLED: the caller promises that nothing it enqueues between that begin and the finish
+ * reads or writes d_blocks.  One-shot (cleared by the begin); ignored in the serial schedule.  mmgen_region_generate does this itself. */
+int mmgen_region_set_output(mmgen_region* region, uint8_t* d_blocks);
 int mmgen_region_finish(mmgen_region* region, uint8_t* d_blocks, float* d_heightfields /*nullable*/, float* d_layers /*[n][20][256], nullable*/,
                         mmgen_cave_layer* d_cave_layers /*[n][256][32], nullable*/, void* stream);
 int mmgen_region_last_erosion_passes(const mmgen_region* region);

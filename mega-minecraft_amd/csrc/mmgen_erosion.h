@@ -40,7 +40,11 @@ size_t erosion_state_bytes(int zones);
 // layersOut != null (region path): the kept 12 x 12 chunks of every zone (zoneChunkIdxOut, [zones][144], -1 = skip) go straight into the
 // chunk-major layers and `gathered` is left as it was; else the final planes are written back into `gathered` (Chunk::erodeZone's contract)
 int erode_zones(float* gathered, size_t strideFloats, int zones, float* work, mm::ErosionState* states, float* accOut, size_t accStride,
-                hipStream_t s, int* maxPasses, const int* zoneChunkIdxOut = nullptr, float* layersOut = nullptr, int* maxPassesDev = nullptr);
+                hipStream_t s, int* maxPasses, const int* zoneChunkIdxOut = nullptr, float* layersOut = nullptr, int* maxPassesDev = nullptr,
+                hipEvent_t beforeRelaxation = nullptr /* recorded on s right before the persistent launch */,
+                // gathered == null (region path): the raw planes are read straight from the chunk-major raw layers / heightfields through
+                // the zones' 24 x 24 chunk lists ([zones][576]) - no k_erosion_gather, no packed copy
+                const float* rawLayers = nullptr, const float* rawHf = nullptr, const int* zoneChunkIdx = nullptr);
 int erosion_gather(const float* layers, const float* hf, const int* zoneChunkIdx, int zones, float* gathered, size_t strideFloats, hipStream_t s);
 int erosion_scatter(const float* gathered, size_t strideFloats, const int* zoneChunkIdxOut, int zones, float* layersOut, hipStream_t s);
 }  // namespace mmk

@@ -38,6 +38,9 @@ namespace mm {
 #ifndef EROSION_STRIPS
 #define EROSION_STRIPS 11                                  // row groups: one lane = one column of the extended tile x EROSION_ROWS rows (mmgen_erosion.h: K x row groups)
 #endif
+#ifndef EROSION_WG_PER_CU
+#define EROSION_WG_PER_CU 2
+#endif
 #define EROSION_ROWS (EROSION_EXT / EROSION_STRIPS)
 #define EROSION_THREADS (EROSION_EXT * EROSION_STRIPS)
 static_assert(EROSION_EXT % EROSION_STRIPS == 0, "strips must tile the extended tile");
@@ -145,7 +148,23 @@ MM_DEV void store_phase(ErosionPhase* p, const ErosionPhase& v)
 // One launch-equivalent ("round") of one 32 x 32 tile: EROSION_K Jacobi passes of the phase's layer on the (32 + 2 K)^2 extended tile.
 // Called by every thread of the workgroup; the LDS planes are the caller's.  Returns nothing; the tile's "changed" bits are ORed into
 // *zoneMask (device scope) by one thread.
-MM_DEV void erode_tile(const float* __restrict__ gathered, float* work, const ErosionPhase& ph, int tileX, int tileZ, unsigned* zoneMask,
+// The raw planes of a zone (its 8 eroded layers' starts + the heightfield), read-only for the whole relaxation: either packed by
+// k_erosion_gather (the per-stage ABI: Chunk::erodeZone's gathered buffer) or, in the region path, straight from the chunk-major
+// layers / heightfields through the zone's 24 x 24 chunk list (copyLayers' index math, chunk.cu:603-656, without the copy).
+struct RawPlanes {
+    const float* gathered;            // [9][ZN] or null
+    const float* layers;              // chunk-major raw layers [chunk][20][256]
+    const float* hf;                  // chunk-major heightfields [chunk][256]
+    const int* chunkIdx;              // the zone's [24 * 24] chunks
+    MM_DEV float at(int plane, int gx, int gz) const
+    {
+        if (gathered) return gathered[(size_t)plane * ZN + gx + ZS * gz];
+        const int chunk = chunkIdx[(gz >> 4) * 24 + (gx >> 4)], idx2d = (gz & 15) * 16 + (gx & 15);
+        return plane == 8 ? hf[(size_t)256 * chunk + idx2d] : layers[(size_t)MMGEN_LAYERS_SIZE * chunk + 256 * (MMGEN_NUM_STRATIFIED_MATERIALS + plane) + idx2d];
+    }
+};
+
+MM_DEV void erode_tile(const RawPlanes& raw, float* work, const ErosionPhase& ph, int tileX, int tileZ, unsigned* zoneMask,
                        float (*s_s)[EROSION_CELLS_EXT], float (*s_t)[EROSION_CELLS_EXT], float* s_end, float* s_acc, unsigned* s_mask)
 {
     const int tid = threadIdx.x;
@@ -153,12 +172,12 @@ MM_DEV void erode_tile(const float* __restrict__ gathered, float* work, const Er
     const bool isFirst = ph.isFirst != 0;
     const float* accIn = work + (size_t)24 * ZN + (size_t)ph.accSel * ZN;
     float* accOut = work + (size_t)24 * ZN + (size_t)(1 - ph.accSel) * ZN;
-    const float* startIn = isFirst ? (gathered + (size_t)layer * ZN) : (work + ((size_t)layer * 3 + ph.plane(layer)) * ZN);
+    const float* startIn = work + ((size_t)layer * 3 + ph.plane(layer)) * ZN;                     // (a layer's first round reads the raw plane instead)
     float* startOut = work + ((size_t)layer * 3 + (isFirst ? 0 : 1 - ph.plane(layer))) * ZN;
     float* startFirst = work + ((size_t)layer * 3 + 2) * ZN;
     // end plane = final start plane of the layer above (already eroded), or the heightfield plane for the top layer
-    const float* endIn = (layer == MMGEN_NUM_ERODED_MATERIALS - 1) ? (gathered + (size_t)8 * ZN)
-                                                                   : (work + ((size_t)(layer + 1) * 3 + ph.plane(layer + 1)) * ZN);
+    const bool rawEnd = layer == MMGEN_NUM_ERODED_MATERIALS - 1;
+    const float* endIn = work + ((size_t)(rawEnd ? layer : layer + 1) * 3 + ph.plane(rawEnd ? layer : layer + 1)) * ZN;
 
     // extended tile: ex, ez in [0, EXT) <-> grid (gx0 + ex, gz0 + ez); cells beyond the grid do not exist (neighbours clamp to the edge)
     const int gx0 = tileX * 32 - EROSION_K, gz0 = tileZ * 32 - EROSION_K;
@@ -175,7 +194,9 @@ MM_DEV void erode_tile(const float* __restrict__ gathered, float* work, const Er
     if (colExists) {
         for (int ez = imax(rowLo, ezMin); ez <= imin(rowHi, ezMax); ++ez) {
             const int c = EROSION_EXT * ez + ex, g = (gx0 + ex) + ZS * (gz0 + ez);
-            const float sv = ld_dev(startIn + g), ev = ld_dev(endIn + g), av = ld_dev(accIn + g);
+            const float sv = isFirst ? raw.at(layer, gx0 + ex, gz0 + ez) : ld_dev(startIn + g);
+            const float ev = rawEnd ? raw.at(8, gx0 + ex, gz0 + ez) : ld_dev(endIn + g);
+            const float av = ld_dev(accIn + g);
             s_s[0][c] = sv; s_end[c] = ev; s_acc[c] = av;
             if (isFirst) { const float ls = sv + av; s_s[1][c] = ls; s_t[1][c] = (ev + av) - ls; }
             else s_t[0][c] = ev - sv;
@@ -230,8 +251,9 @@ MM_DEV void erode_tile(const float* __restrict__ gathered, float* work, const Er
 // Workgroups take their (zone, member) from a ticket, zone-major: whatever order the dispatcher places workgroups in, the zones with the
 // lowest tickets are complete and make progress, so the barrier cannot deadlock even when the launch does not fit the chip at once.
 __global__ void __launch_bounds__(EROSION_THREADS)
-k_erode_zones(const float* __restrict__ gatheredBase, size_t gatheredStride, float* workBase, ErosionState* states, unsigned* ticket, int perZone,
-              int* maxPasses, int* maxPassesAlso)
+k_erode_zones(const float* __restrict__ gatheredBase, size_t gatheredStride, const float* __restrict__ rawLayers, const float* __restrict__ rawHf,
+              const int* __restrict__ zoneChunkIdx /*[zones][576]*/, float* workBase, ErosionState* states, unsigned* ticket, int perZone, int* maxPasses,
+              int* maxPassesAlso)
 {
     __shared__ float s_s[2][EROSION_CELLS_EXT];            // start planes, ping-pong over the passes
     __shared__ float s_t[2][EROSION_CELLS_EXT];            // thickness = end - start of the same states (what the neighbours compare)
@@ -246,7 +268,7 @@ k_erode_zones(const float* __restrict__ gatheredBase, size_t gatheredStride, flo
     __syncthreads();
     const int zone = (int)(s_ticket / (unsigned)perZone), member = (int)(s_ticket % (unsigned)perZone);
     ErosionState* st = states + zone;
-    const float* gathered = gatheredBase + gatheredStride * zone;
+    const RawPlanes raw = {gatheredBase ? gatheredBase + gatheredStride * zone : nullptr, rawLayers, rawHf, zoneChunkIdx ? zoneChunkIdx + 576 * zone : nullptr};
     float* work = workBase + ZONE_WORK_FLOATS * zone;
 
 #pragma unroll 1
@@ -276,7 +298,7 @@ k_erode_zones(const float* __restrict__ gatheredBase, size_t gatheredStride, flo
         while (tile < 144u) {
             __syncthreads();                                          // everyone has read s_tile
             if (tid == 0) s_tile = __hip_atomic_fetch_add(&st->tileTicket[t & 1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // the next draw is in flight while this tile is worked on
-            erode_tile(gathered, work, ph, (int)(tile % 12u), (int)(tile / 12u), &st->changed[t & 3], s_s, s_t, s_end, s_acc, &s_mask);
+            erode_tile(raw, work, ph, (int)(tile % 12u), (int)(tile / 12u), &st->changed[t & 3], s_s, s_t, s_end, s_acc, &s_mask);
             tile = s_tile;                                            // (erode_tile ends with a workgroup barrier)
         }
         // ---- barrier among the zone's workgroups: every store above is a device-scope store this wave has waited for (__syncthreads)
@@ -380,7 +402,7 @@ size_t erosion_work_bytes(int zones) { return (size_t)zones * ZONE_WORK_FLOATS *
 // the zones' states, then one more record's worth of words: [0] = the launch's ticket counter, [1] = largest pass count of the zones
 size_t erosion_state_bytes(int zones) { return (size_t)(zones + 1) * sizeof(mm::ErosionState); }
 
-// workgroups of k_erode_zones the chip holds at once (LDS-bound: three per CU on gfx950)
+// workgroups of k_erode_zones per launch: what the chip holds at once (LDS-bound: three per CU on gfx950), capped
 static int erosion_resident_workgroups()
 {
     static int cached[16] = {};
@@ -390,8 +412,10 @@ static int erosion_resident_workgroups()
     int perCu = 0, cus = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, mm::k_erode_zones, EROSION_THREADS, 0) != hipSuccess || perCu < 1) perCu = 1;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 1;
-    const char* e = getenv("MMGEN_EROSION_WG_PER_CU");
-    if (e && atoi(e) > 0 && atoi(e) < perCu) perCu = atoi(e);
+    // Two per CU, not the three that fit: the relaxation waits more than it issues (2.2 ms alone at two, 1.7 at three), and the region
+    // runs it BESIDE the caves, whose workgroups take the rest of every CU - at three per CU no cave workgroup fits (LDS) and nothing
+    // overlaps; at two or at one the step is equally long (profiles/README.md r04), two leaves the chip to the caves sooner
+    if (perCu > EROSION_WG_PER_CU) perCu = EROSION_WG_PER_CU;
     return cached[dev] = perCu * cus;
 }
 
@@ -399,8 +423,10 @@ static int erosion_resident_workgroups()
 // moves the final planes out.  Nothing is read back unless the caller asks for the pass count (maxPasses != null: the stream is
 // synchronised, like the reference's erodeZone); maxPassesDev (device, may be null) is raised to the largest pass count with the stream.
 int erode_zones(float* gathered, size_t strideFloats, int zones, float* work, mm::ErosionState* states, float* accOut, size_t accStride,
-                hipStream_t s, int* maxPasses, const int* zoneChunkIdxOut, float* layersOut, int* maxPassesDev)
+                hipStream_t s, int* maxPasses, const int* zoneChunkIdxOut, float* layersOut, int* maxPassesDev, hipEvent_t beforeRelaxation,
+                const float* rawLayers, const float* rawHf, const int* zoneChunkIdx)
 {
+    if (!gathered && !(rawLayers && rawHf && zoneChunkIdx && layersOut)) return (int)hipErrorInvalidValue;
     if (zones <= 0) return 0;
     unsigned* ticket = (unsigned*)(states + zones);
     int* passesWord = (int*)(ticket + 1);
@@ -409,8 +435,9 @@ int erode_zones(float* gathered, size_t strideFloats, int zones, float* work, mm
     int perZone = erosion_resident_workgroups() / zones;
     perZone = perZone < 1 ? 1 : (perZone > 144 ? 144 : perZone);
     perZone = (144 + (144 + perZone - 1) / perZone - 1) / ((144 + perZone - 1) / perZone);      // fewest workgroups with the same tiles per round
-    MMK_LAUNCH(KID_ERODE_PASS, mm::k_erode_zones, dim3(zones * perZone), dim3(EROSION_THREADS), s, (const float*)gathered, strideFloats, work, states, ticket,
-               perZone, passesWord, maxPassesDev);
+    if (beforeRelaxation) { hipError_t e = hipEventRecord(beforeRelaxation, s); if (e != hipSuccess) return (int)e; }
+    MMK_LAUNCH(KID_ERODE_PASS, mm::k_erode_zones, dim3(zones * perZone), dim3(EROSION_THREADS), s, (const float*)gathered, strideFloats, rawLayers, rawHf,
+               zoneChunkIdx, work, states, ticket, perZone, passesWord, maxPassesDev);
     if (layersOut) {
         // region path: no in-place contract to honour, the kept chunks' planes go straight to the layers
         MMK_LAUNCH(KID_EROSION_SCATTER, mm::k_erode_finish, dim3(144, 8, zones), dim3(256), s, (const float*)work, (const mm::ErosionState*)states, 0,

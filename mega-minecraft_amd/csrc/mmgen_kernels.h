@@ -9,10 +9,14 @@ int launch_heightfield(const int32_t* pos, int n, float* hf, float* bw, float* g
 int launch_layers(const float* gathered, const float* bw, const int32_t* pos, int n, float* layers, hipStream_t s);
 int launch_fix_backward(float* layers, int n, hipStream_t s);
 int launch_caves(const float* hf, const float* bw, const int32_t* pos, int n, mmgen_cave_layer* caveLayers, float* colInfoScratch,
-                 const int* chunkList /*nullable: chunks to process*/, const uint8_t* colNeed /*nullable: [chunk][256], lazy ring*/, hipStream_t s);
+                 const int* chunkList /*nullable: chunks to process*/, const uint8_t* colNeed /*nullable: [chunk][256], lazy ring*/, hipStream_t s,
+                 hipEvent_t afterVoxels = nullptr /*recorded once the layers' extents are final (before their biomes)*/,
+                 int biomeWorkgroupsPerCu = 0 /*0 = as many as fit; fewer leave room for a kernel that runs beside k_cave_biomes*/);
 int launch_fill(const float* hf, const float* bw, const float* layers, const mmgen_cave_layer* caveLayers, const int32_t* pos, int n,
                 uint8_t* blocks, const int* srcIdx /*nullable: input chunk of each output chunk*/,
-                unsigned* lushQueue /*nullable device scratch: deferred clay / moss voxels*/, size_t lushQueueBytes, bool allInPruneDomain /* every chunk within MM_PRUNE_DOMAIN blocks of the origin: k_fill_far is not launched */, hipStream_t s);
+                unsigned* lushQueue /*nullable device scratch: deferred clay / moss voxels*/, size_t lushQueueBytes, bool allInPruneDomain /* every chunk within MM_PRUNE_DOMAIN blocks of the origin: k_fill_far is not launched */, hipStream_t s,
+                bool countersCleared = false /* launch_fill_clear already ran on this scratch */);
+int launch_fill_clear(int n, unsigned* lushQueue, size_t lushQueueBytes, hipStream_t s);
 size_t fill_queue_bytes(int n);      // launch_fill's scratch for n chunks: lush queue (2 048 deferred voxels per chunk on average; overflow is evaluated in place) + row lists (393 KB per chunk, at most 8 192 chunks' worth) + work counters
 void debug_set_lush_queue_cap(int entries);      // test-only (include/mmgen.h mmgen_debug_set_lush_queue_cap)
 int launch_probe(int fn, const float* in, int n, float* out, hipStream_t s);

@@ -1446,11 +1446,13 @@ int launch_fix_backward(float* layers, int n, hipStream_t s)
 }
 
 int launch_caves(const float* hf, const float* bw, const int32_t* pos, int n, mmgen_cave_layer* caveLayers, float* colInfoScratch,
-                 const int* chunkList, const uint8_t* colNeed, hipStream_t s)
+                 const int* chunkList, const uint8_t* colNeed, hipStream_t s, hipEvent_t afterVoxels, int biomeWorkgroupsPerCu)
 {
     if (n <= 0) return 0;
     LAUNCH(KID_CAVE_COLUMNS, mm::k_cave_columns, dim3(n), dim3(256), s, bw, (const int2*)pos, (float2*)colInfoScratch, chunkList);
     LAUNCH(KID_CAVE_VOXELS, mm::k_cave_voxels, dim3(n * 16), dim3(CAVE_THREADS), s, hf, (const float2*)colInfoScratch, (const int2*)pos, caveLayers, chunkList, colNeed);
+    // the layers' extents are final here (what the base fill reads); their biomes follow
+    if (afterVoxels) { const hipError_t ee = hipEventRecord(afterVoxels, s); if (ee != hipSuccess) return (int)ee; }
     // k_cave_voxels was the last reader of the per-column info: its first KB becomes k_cave_biomes' work counters
     static int cus = 0;
     if (!cus) {
@@ -1462,7 +1464,7 @@ int launch_caves(const float* hf, const float* bw, const int32_t* pos, int n, mm
     static_assert(64 * CB_COUNTERS <= 256 * sizeof(float2), "the counters fit the per-column info of one chunk");
     const hipError_t e = hipMemsetAsync(colInfoScratch, 0, 64 * CB_COUNTERS, s);
     if (e != hipSuccess) return (int)e;
-    const long long units = (long long)n * (256 / CB_UNIT_COLS), fit = (long long)cus * MM_CB_WAVES;       // persistent: MM_CB_WAVES 4-wave workgroups per CU
+    const long long units = (long long)n * (256 / CB_UNIT_COLS), fit = (long long)cus * (biomeWorkgroupsPerCu > 0 && biomeWorkgroupsPerCu < MM_CB_WAVES ? biomeWorkgroupsPerCu : MM_CB_WAVES);   // persistent: MM_CB_WAVES 4-wave workgroups per CU at most
     if (units >= (1LL << 18) * (256 / CB_UNIT_COLS)) return (int)hipErrorInvalidValue;                  // item ids carry the list index in 18 bits
     LAUNCH(KID_CAVE_BIOMES, mm::k_cave_biomes, dim3((unsigned)(units / 4 + 1 < fit ? units / 4 + 1 : fit)), dim3(CB_THREADS), s, hf, (const int2*)pos, caveLayers, chunkList,
            (int)units, (unsigned*)colInfoScratch);
@@ -1499,7 +1501,7 @@ size_t fill_queue_bytes(int n) { return n <= 0 ? 0 : fill_scratch((char*)0x1000,
 void debug_set_lush_queue_cap(int entries) { g_lushCapOverride.store(entries > 0 ? (unsigned)entries : 0u, std::memory_order_relaxed); }
 
 int launch_fill(const float* hf, const float* bw, const float* layers, const mmgen_cave_layer* caveLayers, const int32_t* pos, int n,
-                uint8_t* blocks, const int* srcIdx, unsigned* scratch, size_t scratchBytes, bool allInPruneDomain, hipStream_t s)
+                uint8_t* blocks, const int* srcIdx, unsigned* scratch, size_t scratchBytes, bool allInPruneDomain, hipStream_t s, bool countersCleared)
 {
     if (n <= 0) return 0;
     if (!scratch || scratchBytes < fill_queue_bytes(n)) return (int)hipErrorInvalidValue;
@@ -1522,11 +1524,12 @@ int launch_fill(const float* hf, const float* bw, const float* layers, const mmg
         const float* bwB = bw + (size_t)MMGEN_BIOME_WEIGHTS_SIZE * in0;
         const float* layB = layers + (size_t)MMGEN_LAYERS_SIZE * in0;
         const mmgen_cave_layer* clB = caveLayers + (size_t)MMGEN_CAVE_LAYERS_SIZE * in0;
-        hipError_t e = hipMemsetAsync(f.lush, 0, 4, s);                          // the counter; entries are (re)written by every launch
+        hipError_t e = hipSuccess;
+        if (!(countersCleared && b0 == 0)) e = hipMemsetAsync(f.lush, 0, 4, s);      // the counter; entries are (re)written by every launch
         if (e != hipSuccess) return (int)e;
         for (int c0 = 0; c0 < nb; c0 += kFillSub) {
             const int nc = nb - c0 < kFillSub ? nb - c0 : kFillSub, nRows = nc * (256 / FILL_ROW), row0 = c0 * (256 / FILL_ROW);
-            e = hipMemsetAsync(f.work, 0, 64 * FILL_COUNTERS, s);
+            if (!(countersCleared && b0 == 0 && c0 == 0)) e = hipMemsetAsync(f.work, 0, 64 * FILL_COUNTERS, s);
             if (e != hipSuccess) return (int)e;
             LAUNCH(KID_FILL_BASE, mm::k_fill_base, dim3(nRows), dim3(FILLB_THREADS), s, hfB, bwB, layB, clB, p, out, idx, row0, f.lists, f.counts);
             // a row lists ~28 batches; enough ranges for every wave to draw a few (a 256-chunk call would otherwise hand 2 ranges to each)
@@ -1543,6 +1546,17 @@ int launch_fill(const float* hf, const float* bw, const float* layers, const mmg
         LAUNCH(KID_FILL_LUSH, mm::k_fill_lush, dim3(grid), dim3(256), s, (const unsigned*)f.lush, f.lushCap, p, idx, out);
     }
     return 0;
+}
+
+// the two memsets launch_fill starts with, for a caller that has the scratch long before the fill's inputs exist (countersCleared = true)
+int launch_fill_clear(int n, unsigned* scratch, size_t scratchBytes, hipStream_t s)
+{
+    if (n <= 0) return 0;
+    if (!scratch || scratchBytes < fill_queue_bytes(n)) return (int)hipErrorInvalidValue;
+    const FillScratch f = fill_scratch((char*)scratch, n);
+    hipError_t e = hipMemsetAsync(f.lush, 0, 4, s);
+    if (e == hipSuccess) e = hipMemsetAsync(f.work, 0, 64 * FILL_COUNTERS, s);
+    return (int)e;
 }
 
 int launch_probe(int fn, const float* in, int n, float* out, hipStream_t s)

@@ -173,6 +173,7 @@ struct mmgen_region {
     std::vector<uint8_t> kMask;
     bool filled = false;          // mmgen_region_fill already ran for the current begin
     uint8_t* filledInto = nullptr;
+    uint8_t* earlyBlocks = nullptr;      // mmgen_region_set_output: where the next begin may already put the base blocks
     // ---- stage DAG.  The caller's stream carries K1 / K2, the caves and the placement stages; the erosion branch
     // runs beside the caves on sErode; the base fill runs on sFill in z slices, the rasterisers / decorators of slice i follow on sApply
     // beside the fill of slice i + 1.  serial = everything on the caller's stream in the reference's stage order (per-kernel
@@ -184,7 +185,7 @@ struct mmgen_region {
     int wantSlices = 0;           // 0 = automatic
     hipStream_t sErode = nullptr, sFill = nullptr, sApply = nullptr;
     static constexpr int kMaxSlices = 16;
-    hipEvent_t evK2 = nullptr, evErosion = nullptr, evGather = nullptr, evTail = nullptr, evFill[kMaxSlices] = {}, evEntry = nullptr;
+    hipEvent_t evK2 = nullptr, evResident = nullptr, evCaveVoxels = nullptr, evBegin = nullptr, evErosion = nullptr, evGather = nullptr, evTail = nullptr, evFill[kMaxSlices] = {}, evEntry = nullptr;
     int nSlices = 1;
     int sliceRow[kMaxSlices + 1] = {};        // rows of R per slice: [sliceRow[i], sliceRow[i + 1])
     int init_streams()
@@ -201,7 +202,7 @@ struct mmgen_region {
         if ((e = hipStreamCreateWithPriority(&sErode, hipStreamNonBlocking, pr)) != hipSuccess) return (int)e;
         if ((e = hipStreamCreateWithFlags(&sFill, hipStreamNonBlocking)) != hipSuccess) return (int)e;
         if ((e = hipStreamCreateWithFlags(&sApply, hipStreamNonBlocking)) != hipSuccess) return (int)e;
-        hipEvent_t* ev[] = {&evK2, &evErosion, &evGather, &evTail, &evEntry};
+        hipEvent_t* ev[] = {&evK2, &evResident, &evCaveVoxels, &evBegin, &evErosion, &evGather, &evTail, &evEntry};
         for (hipEvent_t* x : ev) if ((e = hipEventCreateWithFlags(x, hipEventDisableTiming)) != hipSuccess) return (int)e;
         for (int i = 0; i < kMaxSlices; ++i)
             if ((e = hipEventCreateWithFlags(&evFill[i], hipEventDisableTiming)) != hipSuccess) return (int)e;
@@ -216,7 +217,7 @@ struct mmgen_region {
         if (sErode) {
             (void)hipStreamSynchronize(sErode); (void)hipStreamSynchronize(sFill); (void)hipStreamSynchronize(sApply);
             (void)hipStreamDestroy(sErode); (void)hipStreamDestroy(sFill); (void)hipStreamDestroy(sApply);
-            hipEvent_t ev[] = {evK2, evErosion, evGather, evTail, evEntry};
+            hipEvent_t ev[] = {evK2, evResident, evCaveVoxels, evBegin, evErosion, evGather, evTail, evEntry};
             for (hipEvent_t x : ev) if (x) (void)hipEventDestroy(x);
             for (int i = 0; i < kMaxSlices; ++i) if (evFill[i]) (void)hipEventDestroy(evFill[i]);
         }
@@ -380,6 +381,11 @@ int mmgen_region_max_cave_placements(mmgen_region* r, int* out_max, void* stream
     return 0;
 }
 
+static int region_fill_on(mmgen_region* r, uint8_t* d_blocks, hipEvent_t after0, hipEvent_t after1, hipEvent_t after2);
+// with the base fill starting the moment the caves' extents exist, the cave biomes (which only the placement stages wait for) leave it
+// most of every CU: persistent workgroups per CU of k_cave_biomes then
+static constexpr int kCaveBiomeWorkgroupsBesideFill = 1;      // (1 / 2 / 3 / 6 per CU: 24.60 / 24.73 / 24.77 / 24.81 ms per step, profiles/README.md r04)
+
 int mmgen_region_begin(mmgen_region* r, int cx0, int cz0, int nx, int nz, unsigned flags, const uint8_t* h_local_mask, void* stream)
 {
     if (!r || nx <= 0 || nz <= 0) return (int)hipErrorInvalidValue;
@@ -387,10 +393,12 @@ int mmgen_region_begin(mmgen_region* r, int cx0, int cz0, int nx, int nz, unsign
     hipStream_t s = (hipStream_t)stream;
     const bool erosion = flags & MMGEN_REGION_EROSION, features = flags & MMGEN_REGION_FEATURES;
     const bool par = !r->serial;
+    // a begin -> fill without a finish leaves the fill stream unjoined: order it before this begin's writes (whatever the mode is now:
+    // the streams exist if the earlier fill ran on them)
+    if (r->filled && r->sFill) CK(hipStreamWaitEvent(s, r->evFill[r->nSlices - 1], 0));
     if (par) {
         CK(r->init_streams());
-        // a begin -> fill without a finish leaves the fill stream unjoined: order it before this begin's writes
-        if (r->filled) CK(hipStreamWaitEvent(s, r->evFill[r->nSlices - 1], 0));
+        CK(hipEventRecord(r->evBegin, s));          // what the caller's stream held when this begin was called
     }
     r->began = false; r->filled = false; r->filledInto = nullptr;
     CK(region_layout(r, cx0, cz0, nx, nz, flags, h_local_mask, s));
@@ -446,16 +454,14 @@ int mmgen_region_begin(mmgen_region* r, int cx0, int cz0, int nx, int nz, unsign
         CK(hipMemcpyAsync(layersP, r->layersA.p, sizeof(float) * MMGEN_LAYERS_SIZE * (size_t)np, hipMemcpyDeviceToDevice, sE));
         const int Z = r->nZones;
         const int batch = Z < MMGEN_EROSION_ZONE_BATCH ? Z : MMGEN_EROSION_ZONE_BATCH;
-        CK(r->gathered.ensure(sizeof(float) * (size_t)MMGEN_GATHERED_LAYERS_SIZE * batch));
         CK(r->erodeWork.ensure(mmk::erosion_work_bytes(batch)));
         CK(r->erodeState.ensure(mmk::erosion_state_bytes(batch)));
         for (int z0 = 0; z0 < Z; z0 += batch) {
             const int nb = (Z - z0) < batch ? (Z - z0) : batch;
-            CK(mmk::erosion_gather(r->layersA.as<float>(), r->hfA.as<float>(), r->zoneIdx.as<int>() + (size_t)z0 * 576, nb, r->gathered.as<float>(),
-                                   (size_t)MMGEN_GATHERED_LAYERS_SIZE, sE));
-            CK(mmk::erode_zones(r->gathered.as<float>(), (size_t)MMGEN_GATHERED_LAYERS_SIZE, nb, r->erodeWork.as<float>(),
-                                r->erodeState.as<mm::ErosionState>(), nullptr, 0, sE, nullptr, r->zoneIdxOut.as<int>() + (size_t)z0 * 144, layersP,
-                                r->devPasses.as<int>()));
+            // (no E1 copy: the relaxation reads the zones' raw planes through their chunk lists)
+            CK(mmk::erode_zones(nullptr, 0, nb, r->erodeWork.as<float>(), r->erodeState.as<mm::ErosionState>(), nullptr, 0, sE, nullptr,
+                                r->zoneIdxOut.as<int>() + (size_t)z0 * 144, layersP, r->devPasses.as<int>(), par ? r->evResident : nullptr,
+                                r->layersA.as<float>(), r->hfA.as<float>(), r->zoneIdx.as<int>() + (size_t)z0 * 576));
         }
         // ---- E3 fix-up
         CK(mmk::launch_fix_backward(layersP, np, sE));
@@ -464,12 +470,24 @@ int mmgen_region_begin(mmgen_region* r, int cx0, int cz0, int nx, int nz, unsign
         r->passesPending = true;
     }
 
-    // ---- K4 caves on the caller's stream
+    // ---- K4 caves on the caller's stream, behind the point at which the relaxation's persistent launch is next in its queue: that launch
+    // is a few hundred workgroups and must be on the chip before the caves' 150 000 start taking every slot that frees up
     {
+        if (erosion && par) CK(hipStreamWaitEvent(s, r->evResident, 0));
         mmk::StageRange sr("mmgen:caves");
-        CK(mmk::launch_caves(hfP, bwP, posP, r->nCompute, r->caveP.as<mmgen_cave_layer>(), r->colInfo.as<float>(), list, colNeed, s));
+        CK(mmk::launch_caves(hfP, bwP, posP, r->nCompute, r->caveP.as<mmgen_cave_layer>(), r->colInfo.as<float>(), list, colNeed, s,
+                             par ? r->evCaveVoxels : nullptr, (par && r->earlyBlocks) ? kCaveBiomeWorkgroupsBesideFill : 0));
     }
     if (erosion && par) { CK(hipEventRecord(r->evErosion, sE)); CK(hipStreamWaitEvent(s, r->evErosion, 0)); }
+    r->began = true;
+    // ---- the base fill as soon as its inputs exist (the caves' extents, the eroded layers), beside the cave biomes and the placement
+    // stages that only the rasterisers wait for (mmgen_region_set_output)
+    if (par && r->earlyBlocks) {
+        uint8_t* out = r->earlyBlocks;
+        r->earlyBlocks = nullptr;
+        CK(region_fill_on(r, out, /*after*/ r->evBegin, r->evCaveVoxels, erosion ? r->evErosion : nullptr));
+    }
+    r->earlyBlocks = nullptr;
 
     // ---- F1 placements (eroded layers + cave layers of every computed cell)
     if (features) {
@@ -478,7 +496,6 @@ int mmgen_region_begin(mmgen_region* r, int cx0, int cz0, int nx, int nz, unsign
         CK(mmk::launch_feature_placements(hfP, bwP, layersP, r->caveP.as<mmgen_cave_layer>(), posP, r->nCompute, r->fp.as<mmgen_feature_placement>(),
                                           r->cfp.as<mmgen_cave_feature_placement>(), r->counts.as<int>(), list, colNeed, s));
     }
-    r->began = true;
     return 0;
 }
 
@@ -512,12 +529,10 @@ static size_t slice_queue_bytes(const mmgen_region* r)
     return (mmk::fill_queue_bytes(rows * r->nx) + 255) / 256 * 256;
 }
 
-int mmgen_region_fill(mmgen_region* r, uint8_t* d_blocks, void* stream)
+// the base fill of the rectangle on the fill stream, behind the given events (parallel schedule only)
+static int region_fill_on(mmgen_region* r, uint8_t* d_blocks, hipEvent_t after0, hipEvent_t after1, hipEvent_t after2)
 {
-    if (!r || !r->began || !d_blocks) return (int)hipErrorInvalidValue;
-    hipStream_t s = (hipStream_t)stream;
     const bool erosion = r->flags & MMGEN_REGION_EROSION;
-    const bool par = !r->serial;
     float* hfP = r->hfA.as<float>();        // the P grid's arrays are the first np chunks of A's
     float* bwP = r->bwA.as<float>();
     float* layersP = erosion ? r->layersP.as<float>() : r->layersA.as<float>();
@@ -525,19 +540,52 @@ int mmgen_region_fill(mmgen_region* r, uint8_t* d_blocks, void* stream)
     mmk::StageRange sr("mmgen:fill");
     const size_t qb = slice_queue_bytes(r);
     CK(r->fillQueue.ensure(qb * r->nSlices));
-    hipStream_t sF = par ? r->sFill : s;
-    if (par) {
+    hipStream_t sF = r->sFill;
+    // the scratch's counters before the waits (the stream's previous fill is over by stream order): when the inputs are ready the first
+    // thing in the queue is k_fill_base, not a memset that has to find a free slot beside whatever is running then
+    for (int i = 0; i < r->nSlices; ++i)
+        CK(mmk::launch_fill_clear((r->sliceRow[i + 1] - r->sliceRow[i]) * r->nx, (unsigned*)((char*)r->fillQueue.p + qb * i), qb, sF));
+    hipEvent_t after[3] = {after0, after1, after2};
+    for (hipEvent_t e : after) if (e) CK(hipStreamWaitEvent(sF, e, 0));
+    for (int i = 0; i < r->nSlices; ++i) {
+        const int c0 = r->sliceRow[i] * r->nx, n = (r->sliceRow[i + 1] - r->sliceRow[i]) * r->nx;
+        CK(mmk::launch_fill(hfP, bwP, layersP, r->caveP.as<mmgen_cave_layer>(), posP, n, d_blocks + (size_t)MMGEN_BLOCKS_PER_CHUNK * c0, r->targets.as<int>() + c0,
+                            (unsigned*)((char*)r->fillQueue.p + qb * i), qb, region_in_prune_domain(r), sF, true));
+        CK(hipEventRecord(r->evFill[i], sF));
+    }
+    r->filled = true; r->filledInto = d_blocks;
+    return 0;
+}
+
+int mmgen_region_set_output(mmgen_region* r, uint8_t* d_blocks)
+{
+    if (!r) return (int)hipErrorInvalidValue;
+    r->earlyBlocks = d_blocks;
+    return 0;
+}
+
+int mmgen_region_fill(mmgen_region* r, uint8_t* d_blocks, void* stream)
+{
+    if (!r || !r->began || !d_blocks) return (int)hipErrorInvalidValue;
+    if (r->filled && r->filledInto == d_blocks) return 0;          // begin already issued it (mmgen_region_set_output)
+    hipStream_t s = (hipStream_t)stream;
+    if (!r->serial) {
         // d_blocks is the caller's: whatever its stream holds at this point (a consumer of the buffer's previous contents, e.g. a copy of
         // the last tile out of memory that the caller's allocator has just handed back) comes before the first write.  That also orders
         // the fill behind this region's caves and erosion (both joined into the caller's stream by begin).
         CK(hipEventRecord(r->evEntry, s));
-        CK(hipStreamWaitEvent(sF, r->evEntry, 0));
+        return region_fill_on(r, d_blocks, r->evEntry, nullptr, nullptr);
     }
+    const bool erosion = r->flags & MMGEN_REGION_EROSION;
+    float* layersP = erosion ? r->layersP.as<float>() : r->layersA.as<float>();
+    mmk::StageRange sr("mmgen:fill");
+    const size_t qb = slice_queue_bytes(r);
+    CK(r->fillQueue.ensure(qb * r->nSlices));
     for (int i = 0; i < r->nSlices; ++i) {
         const int c0 = r->sliceRow[i] * r->nx, n = (r->sliceRow[i + 1] - r->sliceRow[i]) * r->nx;
-        CK(mmk::launch_fill(hfP, bwP, layersP, r->caveP.as<mmgen_cave_layer>(), posP, n, d_blocks + (size_t)MMGEN_BLOCKS_PER_CHUNK * c0, r->targets.as<int>() + c0,
-                            (unsigned*)((char*)r->fillQueue.p + qb * i), qb, region_in_prune_domain(r), sF));
-        if (par) CK(hipEventRecord(r->evFill[i], sF));
+        CK(mmk::launch_fill(r->hfA.as<float>(), r->bwA.as<float>(), layersP, r->caveP.as<mmgen_cave_layer>(), r->posA.as<int32_t>(), n,
+                            d_blocks + (size_t)MMGEN_BLOCKS_PER_CHUNK * c0, r->targets.as<int>() + c0, (unsigned*)((char*)r->fillQueue.p + qb * i), qb,
+                            region_in_prune_domain(r), s));
     }
     r->filled = true; r->filledInto = d_blocks;
     return 0;
@@ -606,6 +654,7 @@ int mmgen_region_generate(mmgen_region* r, int cx0, int cz0, int nx, int nz, uns
     const uint8_t* mask = nullptr;
     std::vector<uint8_t> lazyMask;
     if (r && (flags & MMGEN_REGION_FEATURES) && nx > 0 && nz > 0) { lazyMask.assign((size_t)(nx + 6) * (nz + 6), 2); mask = lazyMask.data(); }
+    if (r) r->earlyBlocks = d_blocks;          // nothing of the caller's can touch d_blocks between this call's begin and its fill
     CK(mmgen_region_begin(r, cx0, cz0, nx, nz, flags, mask, stream));
     return mmgen_region_finish(r, d_blocks, d_heightfields, nullptr, nullptr, stream);
 }

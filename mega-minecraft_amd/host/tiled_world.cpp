@@ -105,6 +105,7 @@ int TiledWorld::generate(unsigned flags, uint8_t* d_blocks, float* d_heightfield
     if (initStatus) return initStatus;
     const bool exch = (flags & MMGEN_REGION_FEATURES) && (layout.worldSize() > 1 || loopback) && !plan.peers.empty();
     haloBytes = 0;
+    TW_MM(mmgen_region_set_output(region, d_blocks));       // the base fill starts as soon as the caves' extents and the eroded layers exist
     TW_MM(mmgen_region_begin(region, r[0], r[1], r[2], r[3], flags, (flags & MMGEN_REGION_FEATURES) ? mask.data() : nullptr, sMain));
     if (exch) {
         if (!comm) return (int)hipErrorInvalidValue;

@@ -249,6 +249,8 @@ class MMGen:
             self.lib.mmgen_region_begin.argtypes = [vp, i32, i32, i32, i32, ctypes.c_uint, vp, vp]
             self.lib.mmgen_region_finish.argtypes = [vp, vp, vp, vp, vp, vp]
             self.lib.mmgen_region_fill.argtypes = [vp, vp, vp]
+            if hasattr(self.lib, "mmgen_region_set_output"):
+                self.lib.mmgen_region_set_output.argtypes = [vp, vp]
             self.lib.mmgen_ring_header.argtypes = [vp, vp, i32, vp, vp]
             self.lib.mmgen_ring_offsets.argtypes = [vp, i32, vp, vp]
             self.lib.mmgen_ring_pack.argtypes = [vp, vp, vp, vp, vp, i32, vp, vp]
@@ -274,12 +276,17 @@ class MMGen:
         mask = None
         if local_mask is not None:
             mask = local_mask if isinstance(local_mask, ctypes.Array) else (ctypes.c_uint8 * len(local_mask))(*[int(m) for m in local_mask])
+        # the output buffer is named up front (mmgen_region_set_output): begin then issues the base fill as soon as its inputs exist.  The
+        # tensor is fresh from torch's stream-ordered allocator and nothing touches it before region_finish hands it out
+        self._region_blocks = self._empty((nx * nz, BLOCKS), self.torch.uint8)
+        if hasattr(self.lib, "mmgen_region_set_output"):      # (absent only in the older A/B builds MMGEN_LIB may point at)
+            self._check(self.lib.mmgen_region_set_output(self._region(), self._p(self._region_blocks)), "mmgen_region_set_output")
         self._check(self.lib.mmgen_region_begin(self._region(), cx0, cz0, nx, nz, flags, mask, self._stream()), "mmgen_region_begin")
-        self._region_blocks = None
 
     def region_fill(self, nx, nz):
         """Base blocks of the rectangle (no feature lists needed): issued while the placement-ring exchange is in flight."""
-        self._region_blocks = self._empty((nx * nz, BLOCKS), self.torch.uint8)
+        if getattr(self, "_region_blocks", None) is None:
+            self._region_blocks = self._empty((nx * nz, BLOCKS), self.torch.uint8)
         self._check(self.lib.mmgen_region_fill(self._region(), self._p(self._region_blocks), self._stream()), "mmgen_region_fill")
 
     # compact ring exchange (include/mmgen.h mmgen_ring_*): all tensors int32 on the device
