@@ -186,6 +186,20 @@ int mmgen_ring_pack(const mmgen_feature_placement* d_fp, const mmgen_cave_featur
 int mmgen_ring_unpack(const int32_t* d_payload, const int32_t* d_header, const int32_t* d_offsets, const int32_t* d_cells, int n,
                       mmgen_feature_placement* d_fp, mmgen_cave_feature_placement* d_cfp, int32_t* d_counts, void* stream);
 
+/* The same exchange in ONE phase, with no host read between counting and sending (what a host that must never synchronise mid-step
+ * wants: nothing it needs to know depends on the lists).  The cells of each peer form one message whose size follows from the layout alone:
+ *   [2 words per cell: its two raw list lengths][the cells' entries packed back to back, as above][slack up to the message's capacity].
+ * d_slots [n][4] (built once per layout by the host): word index of the cell's two lengths in d_messages, first payload word of its
+ * peer's message, index (into d_cells) of that peer's first cell, the message's payload capacity in words.  A typical cell carries
+ * 250 - 750 words; 5 * MMGEN_FP_CAP + 6 * MMGEN_CFP_CAP = 7 424 words per cell can never overflow.  If a message's entries do not fit,
+ * sender and receiver both see it from the lengths: *d_overflow (device, cleared by the caller) is raised to the number of payload words
+ * that message needed and the cells that did not fit arrive EMPTY - check it before trusting the step, and retry with more slack.
+ * d_scratch: 3 n + 1 words.  Same kernels on both sides; cells of several peers in one call. */
+int mmgen_ring_pack_messages(const mmgen_feature_placement* d_fp, const mmgen_cave_feature_placement* d_cfp, const int32_t* d_counts, const int32_t* d_cells,
+                             const int32_t* d_slots, int n, int32_t* d_scratch, int32_t* d_messages, int32_t* d_overflow, void* stream);
+int mmgen_ring_unpack_messages(const int32_t* d_messages, const int32_t* d_cells, const int32_t* d_slots, int n, int32_t* d_scratch,
+                               mmgen_feature_placement* d_fp, mmgen_cave_feature_placement* d_cfp, int32_t* d_counts, int32_t* d_overflow, void* stream);
+
 /* Measurement hooks (not part of the reference's interface): when enabled every kernel launch is bracketed by HIP events on its
  * launch stream; mmgen_profile_collect() waits for them and returns total milliseconds and launch counts per kernel id
  * (arrays of mmgen_profile_num_kernels() entries), then clears the records. */

@@ -666,6 +666,37 @@ k_cave_biomes(const float* __restrict__ hf, const int2* __restrict__ chunkPos, m
 //      (9 simplex3D + 12 simplex2D) is the expensive part of fill, and a dense list keeps every lane of every wave on it instead
 //      of interleaving it with lanes that returned "air" long ago.  Order inside the list is irrelevant (voxels are independent).
 // =========================================================================================================
+// ---- cave voxels of a column as a 384-bit mask: bit y = voxel y is inside a cave layer (start < y <= end).  Eight 64-bit words per
+// column, the mask in words 1 .. 6 between two words of zeros, so that the 32-bit windows below never leave the column's words.
+#define CAVE_MASK_WORDS 8
+MM_DEV void cave_mask_add(unsigned long long* colMask /*LDS, zeroed*/, int start, int end)
+{
+    if (start == 384) return;
+    const int lo = start + 1, hi = imin(end, 383);
+#pragma unroll
+    for (int w = 0; w < 6; ++w) {
+        const int a = imax(lo, 64 * w), b = imin(hi, 64 * w + 63);
+        if (a <= b) atomicOr(&colMask[1 + w], (~0ull >> (63 - (b - a))) << (a - 64 * w));
+    }
+}
+MM_DEV bool cave_mask_test(const unsigned long long* colMask, int y) { return (((const unsigned*)colMask)[2 + (y >> 5)] >> (y & 31)) & 1u; }
+// the two cave-surface distances of chunkFillPlaceBlock's layer walk (chunk.cu:1264-1292) for a voxel OUTSIDE every cave, as the 5-bit
+// codes the cave-biome rules read them through: caveBottomDepth = start - y of the first layer that starts at or above y = the number of
+// solid voxels between y and the next cave voxel above; caveTopDepth = y - (end + 1) of the last layer that ends below y = the same
+// downwards.  The rules only ask "== 0" and "0 .. threshold" with threshold = 1.5 + 4.5 * simplex3 < 17.25 (|simplex3| < 3.5 by the
+// crudest bound: 42 * 4 corners * max((0.6 - r^2)^4 r)), so a distance of 30 or more, or no cave at all in that direction (negative in the
+// reference), are the same to them: code 31 = nothing within the 32 voxels of the window.
+MM_DEV void depth_codes(const unsigned long long* colMask, int y, unsigned& bdc, unsigned& tdc)
+{
+    const unsigned* w = (const unsigned*)colMask + 2;                // word i = voxels 32 i .. 32 i + 31; w[-2], w[-1], w[12], w[13] are zero
+    const int iu = (y + 1) >> 5, su = (y + 1) & 31;                  // voxels y + 1 .. y + 32, bit 0 = y + 1
+    const unsigned up = __funnelshift_r(w[iu], w[iu + 1], su);
+    const int id = (y - 32) >> 5, sd = (y - 32) & 31;                // voxels y - 32 .. y - 1, bit 31 = y - 1 (arithmetic shift: -1 for y < 32)
+    const unsigned dn = __funnelshift_r(w[id], w[id + 1], sd);
+    bdc = up ? (unsigned)imin(__builtin_ctz(up), 30) : 31u;
+    tdc = dn ? (unsigned)imin(__builtin_clz(dn), 30) : 31u;
+}
+
 struct BaseBlock { uint8_t block; bool needCave; int bottomDepth, topDepth; };
 
 // The column's biome weights in the compact form getRandomBiome (biomeFuncs.hpp:39-53) can be walked in: biome 0 (returned by a draw of
@@ -712,7 +743,10 @@ MM_DEV uint8_t material_block(int layer)
     return (uint8_t)((v >> (8 * (layer & 7))) & 255ull);
 }
 
-MM_DEV BaseBlock place_block_base(const ColumnBiomes& cbi, const float* s_lh, const mmgen_cave_layer* s_cl, int y, float height, int wx, int wz)
+// MASKED (k_fill_base): s_cl is the column's 384-bit mask of cave voxels (six 64-bit words, cave_mask_add) instead of its layer list, the
+// two cave-surface distances are left to the caller (depth_codes, only for the voxels that need them).
+template <bool MASKED = false, class CaveT = mmgen_cave_layer>
+MM_DEV BaseBlock place_block_base(const ColumnBiomes& cbi, const float* s_lh, const CaveT* s_cl, int y, float height, int wx, int wz)
 {
     BaseBlock r; r.needCave = false; r.bottomDepth = -384; r.topDepth = -384;
     if (y == 0) { r.block = MMB_BEDROCK; return r; }
@@ -737,9 +771,10 @@ MM_DEV BaseBlock place_block_base(const ColumnBiomes& cbi, const float* s_lh, co
     }
 
     int bottomDepth = -384, topDepth = -384;
-#ifdef MM_FILL_BASE_EXP
-    if (!(MM_FILL_BASE_EXP & 1))
-#endif
+    if constexpr (MASKED) {
+        // inside a cave: air or lava (see below)
+        if (cave_mask_test(s_cl, y)) { r.block = (y <= MMGEN_LAVA_LEVEL) ? MMB_LAVA : MMB_AIR; return r; }
+    } else
     for (int k = 0; k < MMGEN_MAX_CAVE_LAYERS_PER_COLUMN; ++k) {
         const int start = s_cl[k].start, end = s_cl[k].end;
         if (start == 384) { bottomDepth = -384; break; }
@@ -764,9 +799,6 @@ MM_DEV BaseBlock place_block_base(const ColumnBiomes& cbi, const float* s_lh, co
 
     const int l0 = (fy >= s_lh[MMGEN_NUM_FORWARD_MATERIALS]) ? MMGEN_NUM_FORWARD_MATERIALS : 0;
     int layer = -1;
-#ifdef MM_FILL_BASE_EXP
-    if (!(MM_FILL_BASE_EXP & 2))
-#endif
     if (cbi.layersSorted) {
         // Both runs of layer starts - forward 0 .. 9, backward + eroded 10 .. 20 (the last entry is the height) - are non-decreasing in
         // nearly every column.  Then the first l >= l0 with s_lh[l] <= fy < s_lh[l + 1] is the last layer of fy's run that starts at or
@@ -1016,7 +1048,7 @@ k_fill_base(const float* __restrict__ hf, const float* __restrict__ bw, const fl
 {
     __shared__ float s_bw[FILL_ROW][MMGEN_NUM_BIOMES];
     __shared__ float s_lh[FILL_ROW][MMGEN_NUM_MATERIALS + 1];
-    __shared__ mmgen_cave_layer s_cl[FILL_ROW][MMGEN_MAX_CAVE_LAYERS_PER_COLUMN];
+    __shared__ unsigned long long s_cave[FILL_ROW][CAVE_MASK_WORDS];      // the columns' cave voxels, one bit each (cave_mask_add)
     __shared__ int s_count, s_needTables;
     __shared__ float s_nzW[FILL_ROW][FILL_NZ_CAP];
     __shared__ uint8_t s_nzIdx[FILL_ROW][FILL_NZ_CAP], s_nzN[FILL_ROW], s_ocean[FILL_ROW], s_drawWater[FILL_ROW];
@@ -1032,8 +1064,13 @@ k_fill_base(const float* __restrict__ hf, const float* __restrict__ bw, const fl
         return;
     }
     const int idxBase = FILL_ROW * row;
+    static_assert(FILLB_THREADS == 16 * FILL_ROW && MMGEN_MAX_CAVE_LAYERS_PER_COLUMN == 32, "16 lanes per column, two cave layers per lane");
 
-    // the row's plane attributes, once: 24 weights + 20 layer starts + height per column.  A row of a plane is one 64-byte line, read whole
+    // the row's cave layers straight into registers (lane g of a column's 16: slots g and g + 16; 16 columns x 32 slots x 12 bytes are
+    // contiguous) while the plane attributes are on their way to LDS: 24 weights + 20 layer starts + height per column, a row of a plane
+    // is one 64-byte line, read whole
+    const mmgen_cave_layer* ccl = caveLayers + (size_t)MMGEN_MAX_CAVE_LAYERS_PER_COLUMN * (chunk * 256 + idxBase + (t >> 4));
+    const int cs0 = ccl[t & 15].start, ce0 = ccl[t & 15].end, cs1 = ccl[(t & 15) + 16].start, ce1 = ccl[(t & 15) + 16].end;
     for (int i = t; i < FILL_ROW * 45; i += FILLB_THREADS) {
         const int k = i / FILL_ROW, c = i % FILL_ROW;               // consecutive lanes = consecutive columns of one plane
         const int idx2d = idxBase + c;
@@ -1041,15 +1078,15 @@ k_fill_base(const float* __restrict__ hf, const float* __restrict__ bw, const fl
         else if (k < MMGEN_NUM_BIOMES + MMGEN_NUM_MATERIALS) s_lh[c][k - MMGEN_NUM_BIOMES] = layers[(size_t)MMGEN_LAYERS_SIZE * chunk + 256 * (k - MMGEN_NUM_BIOMES) + idx2d];
         else s_lh[c][MMGEN_NUM_MATERIALS] = hf[chunk * 256 + idx2d];
     }
-    // the row's cave layers: 16 columns x 32 layers x 12 bytes, contiguous
-    for (int i = t; i < FILL_ROW * 96; i += FILLB_THREADS)
-        ((int*)s_cl)[i] = ((const int*)(caveLayers + (size_t)MMGEN_MAX_CAVE_LAYERS_PER_COLUMN * (chunk * 256 + idxBase)))[i];
+    if (t < FILL_ROW * CAVE_MASK_WORDS) (&s_cave[0][0])[t] = 0ull;
     if (t == 0) { s_count = 0; s_needTables = 0; }
     __syncthreads();
+    cave_mask_add(s_cave[t >> 4], cs0, ce0);
+    cave_mask_add(s_cave[t >> 4], cs1, ce1);
     {
         // per column: the biomes of positive weight (plus biome 0) in ascending order, and what the voxel loop needs to know about them -
         // 16 lanes per column (lane g looks at biomes g and g + 16, at layer pairs g and g + 16), ordered by ballots
-        static_assert(FILLB_THREADS == 16 * FILL_ROW && MMGEN_NUM_BIOMES <= 32 && MMGEN_NUM_MATERIALS <= 32, "16 lanes per column");
+        static_assert(MMGEN_NUM_BIOMES <= 32 && MMGEN_NUM_MATERIALS <= 32, "16 lanes per column");
         const int c = t >> 4, g = t & 15, shift = 16 * ((t & 63) >> 4);
         auto group = [&](bool p) { return (unsigned)(__ballot(p) >> shift) & 0xffffu; };      // the predicate over this column's 16 lanes
         const float height = s_lh[c][MMGEN_NUM_MATERIALS];
@@ -1078,13 +1115,11 @@ k_fill_base(const float* __restrict__ hf, const float* __restrict__ bw, const fl
     __syncthreads();
     // simplex tables only for the rows in which a biome with a noise rule has weight (a biome is only drawn at positive weight)
     if (s_needTables) noise_tables_init();
-
     uint8_t* outBase = blocks + (size_t)MMGEN_BLOCKS_PER_CHUNK * outChunk + 384 * idxBase;     // the 16 columns are contiguous: 6 144 bytes
     unsigned* list = rowLists + (size_t)FILL_VOX * lrow;
 
-    // The two cave-surface distances only matter as "== 0" and "0 .. threshold" with threshold = 1.5 + 4.5 * simplex3 (|simplex3| < 3.5 by
-    // the crudest bound: 42 * 4 corners * max((0.6 - r^2)^4 r) = 3.5, threshold < 17.25), so they travel as 5-bit codes: negative -> 31,
-    // 30 and beyond -> 30.
+    // A listed voxel: its position in the row (FILL_VBITS), its block, and the two cave-surface distances of the layer walk as 5-bit codes
+    // (depth_codes), read off the column's mask.
     // Walk: a wave = 16 consecutive y of four neighbouring columns (16-byte pieces per column in a wave's store), the four column groups
     // of a 16-y block in four consecutive waves: the list comes out ordered by depth, and the exits of the cave-biome evaluation - which
     // go by depth zone - retire whole waves of k_fill_cave instead of idling lanes
@@ -1103,19 +1138,12 @@ k_fill_base(const float* __restrict__ hf, const float* __restrict__ bw, const fl
         // block-rule noises out of the loop into six VGPRs
         asm volatile("" : "+v"(wz));
         const ColumnBiomes cbi = {s_nzN[c], s_ocean[c] != 0, s_nzIdx[c], s_nzW[c], s_bw[c], s_drawMinY[c], (s_drawWater[c] & 1) != 0, (s_drawWater[c] & 2) != 0};
-        const BaseBlock r = place_block_base(cbi, s_lh[c], s_cl[c], y, s_lh[c][MMGEN_NUM_MATERIALS], wx, wz);
-#ifdef MM_FILL_BASE_EXP
-        if (!(MM_FILL_BASE_EXP & 4) || r.block == 255)
-#endif
+        const BaseBlock r = place_block_base<true>(cbi, s_lh[c], s_cave[c], y, s_lh[c][MMGEN_NUM_MATERIALS], wx, wz);
         outBase[v] = r.block;                                       // k_fill_cave only writes the voxels it changes
-#ifdef MM_FILL_BASE_EXP
-        if (!(MM_FILL_BASE_EXP & 8) || r.block == 255)
-#endif
         if (r.needCave) {
-            const int slot = atomicAdd(&s_count, 1);
-            const unsigned bdc = r.bottomDepth < 0 ? 31u : (unsigned)imin(r.bottomDepth, 30);
-            const unsigned tdc = r.topDepth < 0 ? 31u : (unsigned)imin(r.topDepth, 30);
-            list[slot] = (unsigned)v | ((unsigned)r.block << FILL_VBITS) | (bdc << (FILL_VBITS + 8)) | (tdc << (FILL_VBITS + 13));
+            unsigned bdc, tdc;
+            depth_codes(s_cave[c], y, bdc, tdc);
+            list[atomicAdd(&s_count, 1)] = (unsigned)v | ((unsigned)r.block << FILL_VBITS) | (bdc << (FILL_VBITS + 8)) | (tdc << (FILL_VBITS + 13));
         }
     }
     __syncthreads();

@@ -147,6 +147,60 @@ k_ring_move(mmgen_feature_placement* __restrict__ fp, mmgen_cave_feature_placeme
     }
 }
 
+// ---- one-phase ring exchange: fixed-size messages, list lengths in-band (no host read between counting and sending) ----------------
+// The cells of every peer form one message of a size both sides know from the layout alone: the cells' raw list lengths (2 words per
+// cell), then their entries packed back to back, then slack up to `cap` payload words.  slot[i] = {word of the cell's two lengths, first
+// payload word of its peer's message, index of that peer's first cell in the cell list, the message's payload capacity}.  A message
+// whose entries do not fit is incomplete: both sides see it from the lengths (same arithmetic) and raise *overflow.
+__global__ void __launch_bounds__(256)
+k_ring_msg_header(const int32_t* __restrict__ counts, const int32_t* __restrict__ cells, const int4* __restrict__ slot, int n, int32_t* __restrict__ header,
+                  int32_t* __restrict__ messages)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int c = cells[i];
+    const int c0 = counts[2 * c], c1 = counts[2 * c + 1];
+    header[2 * i] = c0; header[2 * i + 1] = c1;
+    messages[slot[i].x] = c0; messages[slot[i].x + 1] = c1;
+}
+
+__global__ void __launch_bounds__(256)
+k_ring_msg_read_header(const int32_t* __restrict__ messages, const int4* __restrict__ slot, int n, int32_t* __restrict__ header)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    header[2 * i] = messages[slot[i].x]; header[2 * i + 1] = messages[slot[i].x + 1];
+}
+
+template <bool PACK>
+__global__ void __launch_bounds__(256)
+k_ring_msg_move(mmgen_feature_placement* __restrict__ fp, mmgen_cave_feature_placement* __restrict__ cfp, int32_t* __restrict__ counts,
+                const int32_t* __restrict__ cells, const int4* __restrict__ slot, const int32_t* __restrict__ header, const int32_t* __restrict__ offsets,
+                int32_t* __restrict__ messages, int* __restrict__ overflow)
+{
+    const int i = blockIdx.x, t = threadIdx.x;
+    const int c = cells[i];
+    const int4 sl = slot[i];
+    const int n0 = 5 * min(header[2 * i], MMGEN_FP_CAP), n1 = 6 * min(header[2 * i + 1], MMGEN_CFP_CAP);
+    const int rel = offsets[i] - offsets[sl.z];                        // payload words of the peer's earlier cells
+    if (rel + n0 + n1 > sl.w) {                                       // this cell's entries do not fit the message
+        if (t == 0) atomicMax(overflow, rel + n0 + n1);
+        if (!PACK && t < 2) counts[2 * c + t] = 0;
+        return;
+    }
+    int32_t* a = (int32_t*)(fp + (size_t)MMGEN_FP_CAP * c);
+    int32_t* b = (int32_t*)(cfp + (size_t)MMGEN_CFP_CAP * c);
+    int32_t* w = messages + sl.y + rel;
+    if (PACK) {
+        for (int k = t; k < n0; k += 256) w[k] = a[k];
+        for (int k = t; k < n1; k += 256) w[n0 + k] = b[k];
+    } else {
+        for (int k = t; k < n0; k += 256) a[k] = w[k];
+        for (int k = t; k < n1; k += 256) b[k] = w[n0 + k];
+        if (t < 2) counts[2 * c + t] = header[2 * i + t];
+    }
+}
+
 }  // namespace
 
 struct mmgen_region {
@@ -710,6 +764,36 @@ int mmgen_ring_unpack(const int32_t* d_payload, const int32_t* d_header, const i
     if (n == 0) return 0;
     MMK_LAUNCH(mmk::KID_RING_UNPACK, k_ring_move<false>, dim3(n), dim3(256), (hipStream_t)stream, d_fp, d_cfp, d_counts, d_cells, d_header, d_offsets,
                (int32_t*)d_payload);
+    return 0;
+}
+
+int mmgen_ring_pack_messages(const mmgen_feature_placement* d_fp, const mmgen_cave_feature_placement* d_cfp, const int32_t* d_counts, const int32_t* d_cells,
+                             const int32_t* d_slots, int n, int32_t* d_scratch, int32_t* d_messages, int32_t* d_overflow, void* stream)
+{
+    if (n < 0 || (n > 0 && (!d_fp || !d_cfp || !d_counts || !d_cells || !d_slots || !d_scratch || !d_messages || !d_overflow))) return (int)hipErrorInvalidValue;
+    if (n == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    int32_t* header = d_scratch;                 // [n][2]
+    int32_t* offsets = d_scratch + 2 * (size_t)n; // [n + 1]
+    MMK_LAUNCH(mmk::KID_RING_PACK, k_ring_msg_header, dim3((n + 255) / 256), dim3(256), s, d_counts, d_cells, (const int4*)d_slots, n, header, d_messages);
+    MMK_LAUNCH(mmk::KID_RING_PACK, k_ring_offsets, dim3(1), dim3(1024), s, (const int32_t*)header, n, offsets);
+    MMK_LAUNCH(mmk::KID_RING_PACK, k_ring_msg_move<true>, dim3(n), dim3(256), s, (mmgen_feature_placement*)d_fp, (mmgen_cave_feature_placement*)d_cfp,
+               (int32_t*)nullptr, d_cells, (const int4*)d_slots, (const int32_t*)header, (const int32_t*)offsets, d_messages, (int*)d_overflow);
+    return 0;
+}
+
+int mmgen_ring_unpack_messages(const int32_t* d_messages, const int32_t* d_cells, const int32_t* d_slots, int n, int32_t* d_scratch,
+                               mmgen_feature_placement* d_fp, mmgen_cave_feature_placement* d_cfp, int32_t* d_counts, int32_t* d_overflow, void* stream)
+{
+    if (n < 0 || (n > 0 && (!d_messages || !d_cells || !d_slots || !d_scratch || !d_fp || !d_cfp || !d_counts || !d_overflow))) return (int)hipErrorInvalidValue;
+    if (n == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    int32_t* header = d_scratch;
+    int32_t* offsets = d_scratch + 2 * (size_t)n;
+    MMK_LAUNCH(mmk::KID_RING_UNPACK, k_ring_msg_read_header, dim3((n + 255) / 256), dim3(256), s, d_messages, (const int4*)d_slots, n, header);
+    MMK_LAUNCH(mmk::KID_RING_UNPACK, k_ring_offsets, dim3(1), dim3(1024), s, (const int32_t*)header, n, offsets);
+    MMK_LAUNCH(mmk::KID_RING_UNPACK, k_ring_msg_move<false>, dim3(n), dim3(256), s, d_fp, d_cfp, d_counts, d_cells, (const int4*)d_slots, (const int32_t*)header,
+               (const int32_t*)offsets, (int32_t*)d_messages, (int*)d_overflow);
     return 0;
 }
 

@@ -10,17 +10,20 @@ The world rectangle is cut into tiles_x x tiles_z tiles of tile_nx x tile_nz chu
     (up to 8) neighbouring tiles, between region_begin and region_finish.  Ring cells outside the world rectangle have no owner and
     are computed locally.
 
-Wire protocol (compact: "counts, then payload"), two batched point-to-point phases per step with every peer at once:
-  1. headers: the two list lengths of every cell the peer needs (8 bytes per cell);
-  2. payload: only the entries that exist (20 B per surface placement, 24 B per cave placement), packed on the device by
-     mmgen_ring_pack; the receiver sizes its buffer from the header it got in phase 1.  A dense cell would be 29.7 KB; a typical
-     cell carries 1 - 3 KB.
-The base fill of the tile (kernFill without feature lists) needs nothing from the ring and is issued while phase 2 is in flight.
+Wire protocol: ONE batched point-to-point phase per step with every peer at once, and no host read anywhere in the step.  The cells a
+peer needs travel as one message whose size follows from the layout alone (include/mmgen.h mmgen_ring_pack_messages):
+  [2 words per cell: its two list lengths][only the entries that exist (20 B per surface placement, 24 B per cave placement), packed
+  back to back on the device][slack up to words_per_cell words per cell on average].
+A dense cell would be 29.7 KB (7 424 words); a typical cell carries 1 - 3 KB (250 - 750 words); the default budget is 2 048 words per
+cell.  A message whose entries do not fit is seen by both sides from the lengths: the cells that did not fit arrive empty and the
+context's overflow word is raised - TileContext.check() (one device read, after the step) raises, the caller retries with more slack
+(7 424 can never overflow).  The base fill of the tile needs nothing from the ring: region_begin issues it as soon as the caves and the
+eroded layers exist, and it runs while the messages are in flight.
 No all-reduce / all-gather on the data path.  Results are bit-identical to the single-process region pipeline (tests:
 tests/test_distributed_cpu.py with gloo + the CPU oracle as backend, tests/test_gpu_features.py on the device).
 
-`backend` is any object with region_begin / region_placement_buffers / region_fill / region_finish and ring_header / ring_offsets /
-ring_pack / ring_unpack (MMGen on a GPU).
+`backend` is any object with region_begin / region_placement_buffers / region_fill / region_finish and ring_pack_messages /
+ring_unpack_messages (MMGen on a GPU).
 """
 import ctypes
 from dataclasses import dataclass
@@ -108,8 +111,9 @@ class TileContext:
     """Everything about one rank's tile that does not change from step to step: region rectangle, local mask, the exchange plan as
     device index tensors.  Built once; generate_tile() then does no host-side planning per step."""
 
-    def __init__(self, layout, rank, torch, device, loopback=False):
+    def __init__(self, layout, rank, torch, device, loopback=False, words_per_cell=2048):
         self.layout, self.rank = layout, rank
+        self.words_per_cell = int(words_per_cell)
         self.region = layout.region(rank)
         self.multi = layout.world_size > 1
         self.loopback = bool(loopback)
@@ -138,50 +142,76 @@ class TileContext:
             self.recv_seg.append(len(recv))
         self.send_cells = torch.tensor(send, dtype=torch.int32, device=device)
         self.recv_cells = torch.tensor(recv, dtype=torch.int32, device=device)
-        self.bound_idx = torch.tensor(self.send_seg + [len(send) + 1 + i for i in self.recv_seg], dtype=torch.long, device=device)
+        # message layout (include/mmgen.h mmgen_ring_pack_messages): per peer [2 n lengths][n * words_per_cell payload words]
+        self.send_msg, send_slots = message_layout(self.send_seg, self.words_per_cell)
+        self.recv_msg, recv_slots = message_layout(self.recv_seg, self.words_per_cell)
+        self.send_slots = torch.tensor(send_slots, dtype=torch.int32, device=device).reshape(-1, 4)
+        self.recv_slots = torch.tensor(recv_slots, dtype=torch.int32, device=device).reshape(-1, 4)
+        self.send_buf = torch.zeros((max(self.send_msg[-1], 1),), dtype=torch.int32, device=device)
+        self.recv_buf = torch.zeros((max(self.recv_msg[-1], 1),), dtype=torch.int32, device=device)
+        self.send_scratch = torch.zeros((3 * len(send) + 1,), dtype=torch.int32, device=device)
+        self.recv_scratch = torch.zeros((3 * len(recv) + 1,), dtype=torch.int32, device=device)
+        self.overflow = torch.zeros((1,), dtype=torch.int32, device=device)
+
+    def check(self):
+        """Reads the overflow word (a device read: call it after the step, not inside it).  Raises when a ring message did not fit."""
+        need = int(self.overflow.item())
+        if need:
+            self.overflow.zero_()
+            raise RuntimeError(f"ring message overflow: a peer's cells needed {need} payload words, the budget is {self.words_per_cell} per cell "
+                               f"on average - rebuild the TileContext with a larger words_per_cell (7424 can never overflow)")
 
 
-def exchange_placements(backend, ctx, bufs, dist, torch, overlap=None):
-    """Compact two-phase exchange of the ring placement lists (module docstring).  bufs: dict(fp, cfp, counts) int32 tensors aliasing the
-    backend's placement grid (written in place).  overlap: callable issued while the payload is in flight.  Returns bytes received."""
+def message_layout(seg, words_per_cell):
+    """seg: the peers' segment boundaries in a cell list.  Returns (message boundaries in words, flat slots [4 per cell]): slot =
+    (word of the cell's two lengths, first payload word of its peer's message, index of the peer's first cell, payload capacity)."""
+    bounds, slots = [0], []
+    for k in range(len(seg) - 1):
+        a, b = seg[k], seg[k + 1]
+        n = b - a
+        base = bounds[-1]
+        for i in range(n):
+            slots += [base + 2 * i, base + 2 * n, a, words_per_cell * n]
+        bounds.append(base + 2 * n + words_per_cell * n)
+    return bounds, slots
+
+
+def exchange_placements(backend, ctx, bufs, dist, torch, overlap=None, timing=None):
+    """One-phase exchange of the ring placement lists (module docstring).  bufs: dict(fp, cfp, counts) int32 tensors aliasing the backend's
+    placement grid (written in place).  overlap: callable issued while the messages are in flight.  timing: optional dict of event
+    lists (bench.py) - records events around pack / wait / unpack on the current stream.  Returns bytes received.  No host reads."""
     if not ctx.peers:
         if overlap:
             overlap()
         return 0
-    ns, nr = ctx.send_cells.shape[0], ctx.recv_cells.shape[0]
-    hdr_s = backend.ring_header(bufs, ctx.send_cells)
-    hdr_r = torch.empty((nr, 2), dtype=torch.int32, device=hdr_s.device)
+    mark = (lambda name: timing[name].append(_event(torch))) if timing is not None else (lambda name: None)
+    mark("pack0")
+    backend.ring_pack_messages(bufs, ctx.send_cells, ctx.send_slots, ctx.send_scratch, ctx.send_buf, ctx.overflow)
+    mark("pack1")
     ops = []
     for k, peer in enumerate(ctx.peers):
-        a, b = ctx.send_seg[k], ctx.send_seg[k + 1]
-        c, d = ctx.recv_seg[k], ctx.recv_seg[k + 1]
-        if b > a:
-            ops.append(dist.P2POp(dist.isend, hdr_s[a:b], peer))
-        if d > c:
-            ops.append(dist.P2POp(dist.irecv, hdr_r[c:d], peer))
-    for req in dist.batch_isend_irecv(ops):
-        req.wait()
-    off_s, off_r = backend.ring_offsets(hdr_s), backend.ring_offsets(hdr_r)
-    bounds = torch.cat([off_s, off_r])[ctx.bound_idx].tolist()        # the one host read of the step: message boundaries in words
-    sb, rb = bounds[:len(ctx.send_seg)], bounds[len(ctx.send_seg):]
-    payload_s = backend.ring_pack(bufs, ctx.send_cells, hdr_s, off_s, sb[-1])
-    payload_r = torch.empty((max(rb[-1], 1),), dtype=torch.int32, device=hdr_s.device)
-    ops = []
-    for k, peer in enumerate(ctx.peers):
-        if sb[k + 1] > sb[k]:
-            ops.append(dist.P2POp(dist.isend, payload_s[sb[k]:sb[k + 1]], peer))
-        if rb[k + 1] > rb[k]:
-            ops.append(dist.P2POp(dist.irecv, payload_r[rb[k]:rb[k + 1]], peer))
+        if ctx.send_msg[k + 1] > ctx.send_msg[k]:
+            ops.append(dist.P2POp(dist.isend, ctx.send_buf[ctx.send_msg[k]:ctx.send_msg[k + 1]], peer))
+        if ctx.recv_msg[k + 1] > ctx.recv_msg[k]:
+            ops.append(dist.P2POp(dist.irecv, ctx.recv_buf[ctx.recv_msg[k]:ctx.recv_msg[k + 1]], peer))
     reqs = dist.batch_isend_irecv(ops) if ops else []
     if overlap:
         overlap()
     for req in reqs:
-        req.wait()
-    backend.ring_unpack(bufs, ctx.recv_cells, hdr_r, off_r, payload_r)
-    return 8 * nr + 4 * rb[-1]
+        req.wait()                          # (orders the current stream behind the transfers; does not block the host under nccl)
+    mark("arrived")
+    backend.ring_unpack_messages(bufs, ctx.recv_cells, ctx.recv_slots, ctx.recv_scratch, ctx.recv_buf, ctx.overflow)
+    mark("unpack1")
+    return 4 * ctx.recv_msg[-1]
 
 
-def generate_tile(backend, layout, rank, flags, dist=None, torch=None, want=(), ctx=None):
+def _event(torch):
+    e = torch.cuda.Event(enable_timing=True)
+    e.record()
+    return e
+
+
+def generate_tile(backend, layout, rank, flags, dist=None, torch=None, want=(), ctx=None, timing=None):
     """Generates this rank's tile of the world through all stages selected by `flags` (MMGEN_REGION_* bits).  Pass a TileContext to
     keep the per-layout planning out of the step."""
     if ctx is None:
@@ -199,7 +229,7 @@ def generate_tile(backend, layout, rank, flags, dist=None, torch=None, want=(), 
             backend.region_fill(nx, nz)
             if ctx.loopback:                  # the packed payload is on its way: wipe the local copies, only the wire can restore them
                 bufs["counts"][ctx.recv_cells.long()] = 0
-        halo_bytes = exchange_placements(backend, ctx, bufs, dist, torch, overlap=overlap)
+        halo_bytes = exchange_placements(backend, ctx, bufs, dist, torch, overlap=overlap, timing=timing)
     out = backend.region_finish(nx, nz, want)
     out["halo_bytes_received"] = halo_bytes
     return out

@@ -8,10 +8,27 @@ namespace mmhost {
 #define TW_MM(expr) do { int e_ = (expr); if (e_) return e_; } while (0)
 #define TW_NCCL(expr) do { ncclResult_t r_ = (expr); if (r_ != ncclSuccess) { std::fprintf(stderr, "RCCL: %s\n", ncclGetErrorString(r_)); return 1000 + (int)r_; } } while (0)
 
-TiledWorld::TiledWorld(const TileLayout& lay, int rk, ncclComm_t c, bool loop)
-    : layout(lay), rank(rk), comm(c), plan(lay, rk, loop), mask(loop ? std::vector<uint8_t>((size_t)lay.gridW() * lay.gridH(), 1) : lay.localMask(rk)), loopback(loop)
+TiledWorld::TiledWorld(const TileLayout& lay, int rk, ncclComm_t c, bool loop, int wpc)
+    : layout(lay), rank(rk), comm(c), plan(lay, rk, loop), mask(loop ? std::vector<uint8_t>((size_t)lay.gridW() * lay.gridH(), 1) : lay.localMask(rk)),
+      wordsPerCell(wpc), loopback(loop)
 {
-    initStatus = (loop && lay.worldSize() != 1) ? (int)hipErrorInvalidValue : init();
+    initStatus = ((loop && lay.worldSize() != 1) || wpc < 1) ? (int)hipErrorInvalidValue : init();
+}
+
+// message layout of include/mmgen.h mmgen_ring_pack_messages (distributed.py::message_layout): per peer [2 n lengths][n * wordsPerCell]
+static void message_layout(const std::vector<int>& seg, int wordsPerCell, std::vector<size_t>& bounds, std::vector<int32_t>& slots)
+{
+    bounds.assign(1, 0);
+    slots.clear();
+    for (size_t k = 0; k + 1 < seg.size(); ++k) {
+        const int a = seg[k], n = seg[k + 1] - seg[k];
+        const size_t base = bounds.back();
+        for (int i = 0; i < n; ++i) {
+            slots.push_back((int32_t)(base + 2 * (size_t)i)); slots.push_back((int32_t)(base + 2 * (size_t)n));
+            slots.push_back(a); slots.push_back(wordsPerCell * n);
+        }
+        bounds.push_back(base + 2 * (size_t)n + (size_t)wordsPerCell * n);
+    }
 }
 
 int TiledWorld::init()
@@ -21,15 +38,23 @@ int TiledWorld::init()
     TW_HIP(hipStreamCreateWithFlags(&sComm, hipStreamNonBlocking));
     TW_HIP(hipEventCreateWithFlags(&evPacked, hipEventDisableTiming));
     TW_HIP(hipEventCreateWithFlags(&evArrived, hipEventDisableTiming));
-    const size_t ns = plan.sendCells.size(), nr = plan.recvCells.size();
-    if (ns) {
-        TW_HIP(hipMalloc((void**)&d_sendCells, 4 * ns)); TW_HIP(hipMalloc((void**)&d_hdrS, 8 * ns)); TW_HIP(hipMalloc((void**)&d_offS, 4 * (ns + 1)));
-        TW_HIP(hipMemcpy(d_sendCells, plan.sendCells.data(), 4 * ns, hipMemcpyHostToDevice));
-    }
-    if (nr) {
-        TW_HIP(hipMalloc((void**)&d_recvCells, 4 * nr)); TW_HIP(hipMalloc((void**)&d_hdrR, 8 * nr)); TW_HIP(hipMalloc((void**)&d_offR, 4 * (nr + 1)));
-        TW_HIP(hipMemcpy(d_recvCells, plan.recvCells.data(), 4 * nr, hipMemcpyHostToDevice));
-    }
+    TW_HIP(hipMalloc((void**)&d_overflow, 4));
+    TW_HIP(hipMemset(d_overflow, 0, 4));
+    std::vector<int32_t> slots;
+    auto side = [&](const std::vector<int>& cells, const std::vector<int>& seg, std::vector<size_t>& bounds, int32_t*& d_cells, int32_t*& d_slots, int32_t*& d_scratch,
+                    int32_t*& d_msg) -> int {
+        const size_t n = cells.size();
+        message_layout(seg, wordsPerCell, bounds, slots);
+        if (!n) return 0;
+        if (bounds.back() >= (size_t)1 << 31) return (int)hipErrorInvalidValue;      // word indices travel as int32
+        TW_HIP(hipMalloc((void**)&d_cells, 4 * n)); TW_HIP(hipMalloc((void**)&d_slots, 16 * n)); TW_HIP(hipMalloc((void**)&d_scratch, 4 * (3 * n + 1)));
+        TW_HIP(hipMalloc((void**)&d_msg, 4 * bounds.back()));
+        TW_HIP(hipMemcpy(d_cells, cells.data(), 4 * n, hipMemcpyHostToDevice));
+        TW_HIP(hipMemcpy(d_slots, slots.data(), 16 * n, hipMemcpyHostToDevice));
+        return 0;
+    };
+    TW_MM(side(plan.sendCells, plan.sendSeg, msgS, d_sendCells, d_sendSlots, d_scratchS, d_msgS));
+    TW_MM(side(plan.recvCells, plan.recvSeg, msgR, d_recvCells, d_recvSlots, d_scratchR, d_msgR));
     return 0;
 }
 
@@ -37,7 +62,8 @@ TiledWorld::~TiledWorld()
 {
     if (sMain) (void)hipStreamSynchronize(sMain);
     if (sComm) (void)hipStreamSynchronize(sComm);
-    for (void* p : {(void*)d_sendCells, (void*)d_recvCells, (void*)d_hdrS, (void*)d_hdrR, (void*)d_offS, (void*)d_offR, (void*)d_payS, (void*)d_payR})
+    for (void* p : {(void*)d_sendCells, (void*)d_recvCells, (void*)d_sendSlots, (void*)d_recvSlots, (void*)d_scratchS, (void*)d_scratchR, (void*)d_msgS, (void*)d_msgR,
+                    (void*)d_overflow})
         if (p) (void)hipFree(p);
     if (evPacked) (void)hipEventDestroy(evPacked);
     if (evArrived) (void)hipEventDestroy(evArrived);
@@ -46,34 +72,17 @@ TiledWorld::~TiledWorld()
     if (region) mmgen_region_destroy(region);
 }
 
-// Two grouped point-to-point phases with every peer at once (<= 8 peers): list lengths, then the entries that exist.
+// One grouped point-to-point phase with every peer at once (<= 8 peers): fixed-size messages, list lengths in-band.  Nothing here reads
+// device memory on the host or synchronises a stream.
 int TiledWorld::exchange(uint8_t* d_blocks)
 {
     mmgen_feature_placement* fp; mmgen_cave_feature_placement* cfp; int32_t* counts;
     TW_MM(mmgen_region_placement_buffers(region, &fp, &cfp, &counts, nullptr, nullptr, nullptr, nullptr));
     const int ns = (int)plan.sendCells.size(), nr = (int)plan.recvCells.size(), np = (int)plan.peers.size();
-    TW_MM(mmgen_ring_header(counts, d_sendCells, ns, d_hdrS, sMain));
-    TW_NCCL(ncclGroupStart());
-    for (int k = 0; k < np; ++k) {
-        const int a = plan.sendSeg[k], b = plan.sendSeg[k + 1], c = plan.recvSeg[k], d = plan.recvSeg[k + 1];
-        if (b > a) TW_NCCL(ncclSend(d_hdrS + 2 * a, 2 * (size_t)(b - a), ncclInt32, plan.peers[k], comm, sMain));
-        if (d > c) TW_NCCL(ncclRecv(d_hdrR + 2 * c, 2 * (size_t)(d - c), ncclInt32, plan.peers[k], comm, sMain));
-    }
-    TW_NCCL(ncclGroupEnd());
-    TW_MM(mmgen_ring_offsets(d_hdrS, ns, d_offS, sMain));
-    TW_MM(mmgen_ring_offsets(d_hdrR, nr, d_offR, sMain));
-    // the one host read of the step: message boundaries in words
-    std::vector<int32_t> offS(ns + 1), offR(nr + 1);
-    TW_HIP(hipMemcpyAsync(offS.data(), d_offS, 4 * (size_t)(ns + 1), hipMemcpyDeviceToHost, sMain));
-    TW_HIP(hipMemcpyAsync(offR.data(), d_offR, 4 * (size_t)(nr + 1), hipMemcpyDeviceToHost, sMain));
-    TW_HIP(hipStreamSynchronize(sMain));
-    const size_t totS = (size_t)offS[ns], totR = (size_t)offR[nr];
-    if (totS > payCapS) { if (d_payS) TW_HIP(hipFree(d_payS)); payCapS = totS + totS / 4 + 1024; TW_HIP(hipMalloc((void**)&d_payS, 4 * payCapS)); }
-    if (totR > payCapR) { if (d_payR) TW_HIP(hipFree(d_payR)); payCapR = totR + totR / 4 + 1024; TW_HIP(hipMalloc((void**)&d_payR, 4 * payCapR)); }
-    if (totS) TW_MM(mmgen_ring_pack(fp, cfp, d_sendCells, d_hdrS, d_offS, ns, d_payS, sMain));
+    TW_MM(mmgen_ring_pack_messages(fp, cfp, counts, d_sendCells, d_sendSlots, ns, d_scratchS, d_msgS, d_overflow, sMain));
     if (loopback) {
-        // the packed payload is on its way: wipe the ring's list lengths in the placement grid (top / bottom 3 rows, left / right 3
-        // columns of the rows between), only the wire can restore them
+        // the messages are packed: wipe the ring's list lengths in the placement grid (top / bottom 3 rows, left / right 3 columns of the
+        // rows between), only the wire can restore them
         const int w = layout.gridW(), h = layout.gridH(), R = TileLayout::RING;
         TW_HIP(hipMemsetAsync(counts, 0, 8 * (size_t)w * R, sMain));
         TW_HIP(hipMemsetAsync(counts + 2 * (size_t)w * (h - R), 0, 8 * (size_t)w * R, sMain));
@@ -84,22 +93,20 @@ int TiledWorld::exchange(uint8_t* d_blocks)
     TW_HIP(hipStreamWaitEvent(sComm, evPacked, 0));
     TW_NCCL(ncclGroupStart());
     for (int k = 0; k < np; ++k) {
-        const size_t a = (size_t)offS[plan.sendSeg[k]], b = (size_t)offS[plan.sendSeg[k + 1]];
-        const size_t c = (size_t)offR[plan.recvSeg[k]], d = (size_t)offR[plan.recvSeg[k + 1]];
-        if (b > a) TW_NCCL(ncclSend(d_payS + a, b - a, ncclInt32, plan.peers[k], comm, sComm));
-        if (d > c) TW_NCCL(ncclRecv(d_payR + c, d - c, ncclInt32, plan.peers[k], comm, sComm));
+        if (msgS[k + 1] > msgS[k]) TW_NCCL(ncclSend(d_msgS + msgS[k], msgS[k + 1] - msgS[k], ncclInt32, plan.peers[k], comm, sComm));
+        if (msgR[k + 1] > msgR[k]) TW_NCCL(ncclRecv(d_msgR + msgR[k], msgR[k + 1] - msgR[k], ncclInt32, plan.peers[k], comm, sComm));
     }
     TW_NCCL(ncclGroupEnd());
     TW_HIP(hipEventRecord(evArrived, sComm));
-    // the base fill needs nothing from the ring: it runs while the payload travels
+    // the base fill needs nothing from the ring: begin has issued it on the region's own stream (mmgen_region_set_output), this is a no-op then
     TW_MM(mmgen_region_fill(region, d_blocks, sMain));
     TW_HIP(hipStreamWaitEvent(sMain, evArrived, 0));
-    if (totR) TW_MM(mmgen_ring_unpack(d_payR, d_hdrR, d_offR, d_recvCells, nr, fp, cfp, counts, sMain));
-    haloBytes = 8 * (size_t)nr + 4 * totR;
+    TW_MM(mmgen_ring_unpack_messages(d_msgR, d_recvCells, d_recvSlots, nr, d_scratchR, fp, cfp, counts, d_overflow, sMain));
+    haloBytes = 4 * msgR.back();
     return 0;
 }
 
-int TiledWorld::generate(unsigned flags, uint8_t* d_blocks, float* d_heightfields)
+int TiledWorld::generateAsync(unsigned flags, uint8_t* d_blocks, float* d_heightfields)
 {
     const auto r = layout.region(rank);
     if (initStatus) return initStatus;
@@ -112,8 +119,27 @@ int TiledWorld::generate(unsigned flags, uint8_t* d_blocks, float* d_heightfield
         TW_MM(exchange(d_blocks));
     }
     TW_MM(mmgen_region_finish(region, d_blocks, d_heightfields, nullptr, nullptr, sMain));
-    TW_HIP(hipStreamSynchronize(sMain));
     return 0;
+}
+
+int TiledWorld::finishStep()
+{
+    int32_t need = 0;
+    TW_HIP(hipMemcpyAsync(&need, d_overflow, 4, hipMemcpyDeviceToHost, sMain));
+    TW_HIP(hipStreamSynchronize(sMain));
+    if (need) {
+        TW_HIP(hipMemset(d_overflow, 0, 4));
+        std::fprintf(stderr, "mmgen: a ring message needed %d payload words, the budget is %d per cell on average: construct TiledWorld with a larger wordsPerCell\n",
+                     need, wordsPerCell);
+        return kRingOverflow;
+    }
+    return 0;
+}
+
+int TiledWorld::generate(unsigned flags, uint8_t* d_blocks, float* d_heightfields)
+{
+    TW_MM(generateAsync(flags, d_blocks, d_heightfields));
+    return finishStep();
 }
 
 }  // namespace mmhost

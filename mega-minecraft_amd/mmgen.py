@@ -312,6 +312,21 @@ class MMGen:
         self._check(self.lib.mmgen_ring_unpack(self._p(payload), self._p(header), self._p(offsets), self._p(cells), cells.shape[0],
                                                self._p(bufs["fp"]), self._p(bufs["cfp"]), self._p(bufs["counts"]), self._stream()), "mmgen_ring_unpack")
 
+    # one-phase exchange (include/mmgen.h mmgen_ring_pack_messages / _unpack_messages): fixed-size messages, lengths in-band, no host read
+    def ring_pack_messages(self, bufs, cells, slots, scratch, messages, overflow):
+        vp = ctypes.c_void_p
+        self.lib.mmgen_ring_pack_messages.argtypes = [vp, vp, vp, vp, vp, ctypes.c_int, vp, vp, vp, vp]
+        self._check(self.lib.mmgen_ring_pack_messages(self._p(bufs["fp"]), self._p(bufs["cfp"]), self._p(bufs["counts"]), self._p(cells), self._p(slots),
+                                                      cells.shape[0], self._p(scratch), self._p(messages), self._p(overflow), self._stream()),
+                    "mmgen_ring_pack_messages")
+
+    def ring_unpack_messages(self, bufs, cells, slots, scratch, messages, overflow):
+        vp = ctypes.c_void_p
+        self.lib.mmgen_ring_unpack_messages.argtypes = [vp, vp, vp, ctypes.c_int, vp, vp, vp, vp, vp, vp]
+        self._check(self.lib.mmgen_ring_unpack_messages(self._p(messages), self._p(cells), self._p(slots), cells.shape[0], self._p(scratch),
+                                                        self._p(bufs["fp"]), self._p(bufs["cfp"]), self._p(bufs["counts"]), self._p(overflow), self._stream()),
+                    "mmgen_ring_unpack_messages")
+
     def region_placement_buffers(self):
         """Torch views (no copy) of the region's ring-extended placement grid: fp [cells,256,5], cfp [cells,1024,6], counts [cells,2]."""
         vp, i32 = ctypes.c_void_p, ctypes.c_int

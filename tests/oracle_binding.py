@@ -181,6 +181,40 @@ class OracleBackend:
             bufs["cfp"][c, :n1] = payload[o + 5 * n0:o + 5 * n0 + 6 * n1].reshape(n1, 6)
             bufs["counts"][c] = header[i]
 
+    # CPU statement of the one-phase message format (include/mmgen.h mmgen_ring_pack_messages): per peer [2 n lengths][entries packed back
+    # to back][slack]; slot = (word of the cell's lengths, first payload word of the peer's message, the peer's first cell, capacity)
+    def ring_pack_messages(self, bufs, cells, slots, scratch, messages, overflow):
+        hdr = self.ring_header(bufs, cells)
+        off = self.ring_offsets(hdr)
+        for i, c in enumerate(cells.tolist()):
+            hp, base, first, cap = (int(v) for v in slots[i])
+            messages[hp:hp + 2] = hdr[i]
+            n0, n1 = min(int(hdr[i, 0]), self.FP_CAP), min(int(hdr[i, 1]), self.CFP_CAP)
+            rel = int(off[i]) - int(off[first])
+            if rel + 5 * n0 + 6 * n1 > cap:
+                overflow[0] = max(int(overflow[0]), rel + 5 * n0 + 6 * n1)
+                continue
+            o = base + rel
+            messages[o:o + 5 * n0] = bufs["fp"][c, :n0].reshape(-1)
+            messages[o + 5 * n0:o + 5 * n0 + 6 * n1] = bufs["cfp"][c, :n1].reshape(-1)
+
+    def ring_unpack_messages(self, bufs, cells, slots, scratch, messages, overflow):
+        t = self.torch
+        hdr = t.stack([messages[slots[:, 0].long()], messages[slots[:, 0].long() + 1]], 1)
+        off = self.ring_offsets(hdr)
+        for i, c in enumerate(cells.tolist()):
+            hp, base, first, cap = (int(v) for v in slots[i])
+            n0, n1 = min(int(hdr[i, 0]), self.FP_CAP), min(int(hdr[i, 1]), self.CFP_CAP)
+            rel = int(off[i]) - int(off[first])
+            if rel + 5 * n0 + 6 * n1 > cap:
+                overflow[0] = max(int(overflow[0]), rel + 5 * n0 + 6 * n1)
+                bufs["counts"][c] = 0
+                continue
+            o = base + rel
+            bufs["fp"][c, :n0] = messages[o:o + 5 * n0].reshape(n0, 5)
+            bufs["cfp"][c, :n1] = messages[o + 5 * n0:o + 5 * n0 + 6 * n1].reshape(n1, 6)
+            bufs["counts"][c] = hdr[i]
+
     def region_finish(self, nx, nz, want=()):
         n = nx * nz
         blocks = np.zeros((n, 98304), np.uint8); hf = np.zeros((n, 256), np.float32)

@@ -93,7 +93,7 @@ def test_four_rank_2x2_tiling_with_features_compact_exchange(oracle, tmp_path):
     ref = oracle.generate_region(1486, -1112, 4, 4, erosion=True, features=True, decorators=True)
     assert np.array_equal(_stitch(tiles, layout_args), ref["blocks"])
     # each rank receives 2*2 + 2*2 + 2*2 = 12 remote ring cells... (tile 2x2: the 3 peers' whole tiles lie inside its ring)
-    assert all(0 < h < 12 * 29704 // 4 for h in halo), halo
+    assert all(0 < h < 12 * 29704 // 2 for h in halo), halo
 
 
 def test_compact_wire_format_round_trip():
@@ -122,6 +122,50 @@ def test_compact_wire_format_round_trip():
         assert torch.equal(dst["fp"][c, :n0], bufs["fp"][c, :n0]) and torch.equal(dst["cfp"][c, :n1], bufs["cfp"][c, :n1])
         assert torch.equal(dst["counts"][c], bufs["counts"][c])          # raw count travels, also beyond the cap
     assert int(dst["counts"][0].sum()) == 0 and int(dst["fp"][5].abs().sum()) == 0
+
+
+def test_one_phase_messages_round_trip_and_overflow():
+    """ring_pack_messages / ring_unpack_messages of the CPU backend (the statement the device kernels are held to in
+    tests/test_gpu_features.py): two peers' cells in one call, lengths in-band, entries packed back to back; a message whose entries do
+    not fit raises the overflow word on BOTH sides and the cells that did not fit arrive empty."""
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle_binding import OracleBackend
+    d = importlib.import_module("mega-minecraft_amd.distributed")
+    b = OracleBackend.__new__(OracleBackend)
+    b.torch = torch
+    g = torch.Generator().manual_seed(7)
+    cells = 7
+    bufs = dict(fp=torch.randint(0, 1000, (cells, 256, 5), dtype=torch.int32, generator=g),
+                cfp=torch.randint(0, 1000, (cells, 1024, 6), dtype=torch.int32, generator=g),
+                counts=torch.tensor([[0, 0], [3, 0], [0, 5], [40, 30], [2, 1500], [1, 1], [7, 9]], dtype=torch.int32))
+    sel = torch.tensor([6, 1, 4, 2, 3], dtype=torch.int32)
+    seg = [0, 2, 5]                                                    # peer A gets cells 6, 1; peer B gets 4, 2, 3
+
+    def run(words_per_cell):
+        bounds, slots = d.message_layout(seg, words_per_cell)
+        slots = torch.tensor(slots, dtype=torch.int32).reshape(-1, 4)
+        msg = torch.zeros(bounds[-1], dtype=torch.int32)
+        of_s, of_r = torch.zeros(1, dtype=torch.int32), torch.zeros(1, dtype=torch.int32)
+        b.ring_pack_messages(bufs, sel, slots, None, msg, of_s)
+        dst = dict(fp=torch.zeros_like(bufs["fp"]), cfp=torch.zeros_like(bufs["cfp"]), counts=torch.full_like(bufs["counts"], -1))
+        b.ring_unpack_messages(dst, sel, slots, None, msg, of_r)
+        return bounds, msg, dst, int(of_s), int(of_r)
+
+    bounds, msg, dst, of_s, of_r = run(3200)
+    assert bounds == [0, 2 * 2 + 2 * 3200, 6404 + 2 * 3 + 3 * 3200] and of_s == 0 and of_r == 0
+    assert msg[0:4].tolist() == [7, 9, 3, 0] and msg[6404:6410].tolist() == [2, 1500, 0, 5, 40, 30]       # raw lengths, also beyond the cap
+    assert torch.equal(msg[4:4 + 35], bufs["fp"][6, :7].reshape(-1)) and torch.equal(msg[4 + 35:4 + 35 + 54], bufs["cfp"][6, :9].reshape(-1))
+    for c in sel.tolist():
+        n0, n1 = min(int(bufs["counts"][c, 0]), 256), min(int(bufs["counts"][c, 1]), 1024)
+        assert torch.equal(dst["fp"][c, :n0], bufs["fp"][c, :n0]) and torch.equal(dst["cfp"][c, :n1], bufs["cfp"][c, :n1])
+        assert torch.equal(dst["counts"][c], bufs["counts"][c])
+    assert dst["counts"][0].tolist() == [-1, -1]                       # a cell that was not on the wire is not touched
+    # peer B needs 10 + 6144 | 30 | 200 + 180 = 6564 payload words: at 2 100 words per cell (6 300) the last cell does not fit
+    bounds, msg, dst, of_s, of_r = run(2100)
+    assert of_s == 6564 and of_r == 6564
+    assert dst["counts"][3].tolist() == [0, 0] and dst["counts"][2].tolist() == [0, 5] and dst["counts"][4].tolist() == [2, 1500]
+    assert torch.equal(dst["cfp"][4, :1024], bufs["cfp"][4, :1024])
 
 
 @pytest.mark.parametrize("layout_args", [(-5, 7, 2, 2, 4, 5), (-128, -128, 4, 2, 64, 128), (0, 0, 3, 1, 3, 3), (10, -20, 2, 1, 2, 2)])
@@ -191,7 +235,7 @@ def test_loopback_exchange_restores_the_wiped_ring(oracle):
         def batch_isend_irecv(self, ops):
             reqs = super().batch_isend_irecv(ops)
             for op, t, _ in ops:
-                if op == self.irecv and t.numel() > 2 * len(ctx.recv_cells):       # the payload (the headers are 2 words per cell)
+                if op == self.irecv:                                                # the message: lengths and entries
                     t.zero_()
             return reqs
     bad = d.generate_tile(ob, lay, 0, 7, dist=_Lossy(), torch=torch, ctx=ctx)

@@ -330,8 +330,8 @@ def _two_process_worker(rank, world, port, layout_args, outdir):
 def test_two_process_tiling_on_one_gpu_runs_the_real_exchange(gen, tmp_path):
     """The product's N > 1 path end to end on the device with a real process group: two PROCESSES (gloo group, device tensors staged
     through the host by tests/host_staged_dist.py because RCCL refuses two ranks on one GPU) generate the two 6x4-chunk tiles of a
-    12x4 world with distributed.generate_tile - TileContext, mmgen_ring_header / offsets / pack / unpack on the device, the two-phase
-    exchange, region_fill overlapped with it, lazy world-border ring cells - and the stitched tiles equal the single region."""
+    12x4 world with distributed.generate_tile - TileContext, mmgen_ring_pack_messages / _unpack_messages on the device, the one-phase
+    exchange, the base fill under it, lazy world-border ring cells - and the stitched tiles equal the single region."""
     import socket
     import torch.multiprocessing as mp
     layout_args = (1484, -1112, 2, 1, 6, 4)
@@ -346,8 +346,9 @@ def test_two_process_tiling_on_one_gpu_runs_the_real_exchange(gen, tmp_path):
             for x in range(6):
                 world[(6 * r + x) + 12 * z] = t[x + 6 * z]
     assert np.array_equal(world, single), f"{int((world != single).sum())} block ids differ between the two-process tiling and the single region"
-    # 3 x 4 ring cells arrive per rank: headers (8 B per cell) + only the entries that exist, far below the dense 29.7 KB per cell
-    assert all(12 * 8 < h < 12 * 29704 // 4 for h in halo), halo
+    # 3 x 4 ring cells arrive per rank in one fixed-size message: 2 length words + the default budget of 2 048 payload words per cell
+    # (a dense cell would be 29.7 KB)
+    assert halo == [12 * (2 + 2048) * 4] * 2, halo
 
 
 def test_cpp_tiled_world_host_single_tile(mmgen_pkg):
@@ -476,6 +477,29 @@ def test_ring_wire_format_on_the_device(gen):
         assert torch.equal(dst["fp"][c, :n0].cpu(), bufs_cpu["fp"][c, :n0]) and torch.equal(dst["cfp"][c, :n1].cpu(), bufs_cpu["cfp"][c, :n1])
         assert torch.equal(dst["counts"][c].cpu(), bufs_cpu["counts"][c])
     assert int(dst["counts"].cpu().sum()) == int(bufs_cpu["counts"][cells.long()].sum())
+    # the one-phase messages (mmgen_ring_pack_messages / _unpack_messages): two peers' cells in one call, word for word the CPU statement,
+    # with room to spare and with a budget the second peer's message does not fit
+    import importlib as il
+    d = il.import_module("mega-minecraft_amd.distributed")
+    for wpc in (3000, 1200):
+        bounds, slots = d.message_layout([0, 3, 7], wpc)
+        slots_cpu = torch.tensor(slots, dtype=torch.int32).reshape(-1, 4)
+        slots_dev = slots_cpu.to(gen.device)
+        msg_cpu, of_cpu = torch.zeros(bounds[-1], dtype=torch.int32), torch.zeros(1, dtype=torch.int32)
+        cpu.ring_pack_messages(bufs_cpu, cells, slots_cpu, None, msg_cpu, of_cpu)
+        msg = torch.zeros(bounds[-1], dtype=torch.int32, device=gen.device)
+        scratch = torch.zeros(3 * len(cells) + 1, dtype=torch.int32, device=gen.device)
+        of = torch.zeros(1, dtype=torch.int32, device=gen.device)
+        gen.ring_pack_messages(b, dcells, slots_dev, scratch, msg, of)
+        assert torch.equal(msg.cpu(), msg_cpu) and int(of) == int(of_cpu) and (int(of) > 0) == (wpc == 1200)
+        dst = dict(fp=torch.zeros_like(b["fp"]), cfp=torch.zeros_like(b["cfp"]), counts=torch.full_like(b["counts"], -1))
+        dst_cpu = dict(fp=torch.zeros_like(bufs_cpu["fp"]), cfp=torch.zeros_like(bufs_cpu["cfp"]), counts=torch.full_like(bufs_cpu["counts"], -1))
+        of.zero_(); of_cpu.zero_()
+        gen.ring_unpack_messages(dst, dcells, slots_dev, scratch, msg, of)
+        cpu.ring_unpack_messages(dst_cpu, cells, slots_cpu, None, msg_cpu, of_cpu)
+        assert int(of) == int(of_cpu)
+        for k in ("fp", "cfp", "counts"):
+            assert torch.equal(dst[k].cpu(), dst_cpu[k]), (k, wpc)
     gen.region_finish(2, 2)
     assert gen.region_max_cave_placements() == 1500          # the over-the-cap cell was noticed by finish; acknowledged here
 
