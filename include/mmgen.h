@@ -113,6 +113,11 @@ int mmgen_fill(const float* d_heightfields, const float* d_biome_weights, const 
 #define MMGEN_REGION_EROSION 1u
 #define MMGEN_REGION_FEATURES 2u
 #define MMGEN_REGION_DECORATORS 4u
+/* mmgen_region_generate only: compute the 3-chunk ring's placement lists in full (mask 1 below) instead of lazily (mask 2).  The blocks
+ * are the same unless a chunk's gathered list exceeds the reference's truncation (2 048 surface / 4 096 cave entries, chunk.cu:1573-1601):
+ * the reference truncates the FULL list, a lazy ring can only truncate its shortened one, so entries the reference drops could be kept.
+ * The full lengths cannot be known without the work the lazy ring saves; mmgen_region_max_gathered reports what a run has seen. */
+#define MMGEN_REGION_EXACT_RING 256u
 typedef struct mmgen_region mmgen_region;
 int mmgen_region_create(mmgen_region** out);
 void mmgen_region_destroy(mmgen_region* region);
@@ -144,6 +149,11 @@ int mmgen_region_set_output(mmgen_region* region, uint8_t* d_blocks);
 int mmgen_region_finish(mmgen_region* region, uint8_t* d_blocks, float* d_heightfields /*nullable*/, float* d_layers /*[n][20][256], nullable*/,
                         mmgen_cave_layer* d_cave_layers /*[n][256][32], nullable*/, void* stream);
 int mmgen_region_last_erosion_passes(const mmgen_region* region);
+/* The longest gathered (un-truncated) surface / cave placement list any chunk had in the finishes since the last call (synchronises the
+ * stream; clears the record).  With a full ring (mask 1 or peer-provided lists) these are the lengths the reference's Chunk::fill truncates
+ * at MMGEN_MAX_GATHERED_FEATURES_PER_CHUNK / MMGEN_MAX_GATHERED_CAVE_FEATURES_PER_CHUNK; below them nothing is truncated and the lazy ring
+ * gives the same blocks.  (A generated world stays below a third of either limit: tests/test_gpu_features.py.) */
+int mmgen_region_max_gathered(mmgen_region* region, int* out_surface, int* out_cave, void* stream);
 /* The one capacity of this library that the reference does not have: a chunk's cave placement list holds MMGEN_CFP_CAP entries (the
  * reference pushes into an unbounded vector, chunk.cu:1028-1038; a chunk of a generated world carries < 100, the worst case the
  * algorithm allows is 16 384).  Entries beyond the capacity are dropped, which would change blocks - so it is reported, not hidden:

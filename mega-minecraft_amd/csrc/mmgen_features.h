@@ -13,7 +13,7 @@ int launch_ring_need(const float* bw, const int32_t* pos, const int* chunkList, 
                      uint8_t* colNeed, hipStream_t s);
 int launch_gather_placements(const mmgen_feature_placement* fp, const mmgen_cave_feature_placement* cfp, const int* counts, const int* target,
                              int nOut, int gridW, int gridH, mmgen_feature_placement* gfp, mmgen_cave_feature_placement* gcfp, int* bounds,
-                             const int32_t* gridPos, hipStream_t s);
+                             const int32_t* gridPos, hipStream_t s, int* maxGathered = nullptr);
 // workCounter: apply_work_bytes() of device scratch that nothing else uses while the kernel runs (the waves draw their work from it)
 size_t apply_work_bytes();
 int launch_apply_features(uint8_t* blocks, const int32_t* pos, int n, const mmgen_feature_placement* gfp, const mmgen_cave_feature_placement* gcfp,

@@ -383,7 +383,8 @@ __global__ void __launch_bounds__(256)
 k_gather_placements(const mmgen_feature_placement* __restrict__ fp, const mmgen_cave_feature_placement* __restrict__ cfp,
                     const int* __restrict__ counts, const int* __restrict__ targetChunk /*[nOut] index into source grid*/,
                     int gridW, int gridH, mmgen_feature_placement* __restrict__ gfp, mmgen_cave_feature_placement* __restrict__ gcfp,
-                    int* __restrict__ bounds, const int2* __restrict__ gridPos /*world block origin of every source-grid chunk; null = keep everything*/)
+                    int* __restrict__ bounds, const int2* __restrict__ gridPos /*world block origin of every source-grid chunk; null = keep everything*/,
+                    int* __restrict__ maxGathered /*nullable: [0] / [1] raised to the longest un-truncated surface / cave list*/)
 {
     __shared__ int s_offS[50], s_offC[50], s_src[49];
     __shared__ int s_b[4], s_w[4];
@@ -410,6 +411,7 @@ k_gather_placements(const mmgen_feature_placement* __restrict__ fp, const mmgen_
     }
     __syncthreads();
     const int totS = s_offS[49], totC = s_offC[49];
+    if (maxGathered && t == 0) { atomicMax(&maxGathered[0], totS); atomicMax(&maxGathered[1], totC); }
     mmgen_feature_placement* go = gfp + (size_t)MMGEN_MAX_GATHERED_FEATURES_PER_CHUNK * o;
     mmgen_cave_feature_placement* gc = gcfp + (size_t)MMGEN_MAX_GATHERED_CAVE_FEATURES_PER_CHUNK * o;
     int lo0 = 384, hi0 = -1, lo1 = 384, hi1 = -1;
@@ -1208,11 +1210,11 @@ int launch_ring_need(const float* bw, const int32_t* pos, const int* chunkList, 
 
 int launch_gather_placements(const mmgen_feature_placement* fp, const mmgen_cave_feature_placement* cfp, const int* counts, const int* target,
                              int nOut, int gridW, int gridH, mmgen_feature_placement* gfp, mmgen_cave_feature_placement* gcfp, int* bounds,
-                             const int32_t* gridPos, hipStream_t s)
+                             const int32_t* gridPos, hipStream_t s, int* maxGathered)
 {
     if (nOut <= 0) return 0;
     LAUNCH(KID_GATHER_PLACEMENTS, mm::k_gather_placements, dim3(nOut), dim3(256), s, fp, cfp, counts, target, gridW, gridH, gfp, gcfp, bounds,
-           (const int2*)gridPos);
+           (const int2*)gridPos, maxGathered);
     return 0;
 }
 

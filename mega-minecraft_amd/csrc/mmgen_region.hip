@@ -234,7 +234,8 @@ struct mmgen_region {
     // attribution for the roofline; MMGEN_REGION_SERIAL=1 or mmgen_region_set_serial).
     int* hostMax = nullptr;       // pinned + mapped: largest cave list length beyond MMGEN_CFP_CAP seen by a finish (0 = none)
     int* hostMaxDev = nullptr;    // its device address
-    DevBuf devMax;                // largest cave list length of the finishes since the last query (whatever its size)
+    DevBuf devMax;                // [0] largest cave list length of the finishes since the last query (whatever its size); [1], [2] the longest
+                                  // gathered (un-truncated) surface / cave list since the last mmgen_region_max_gathered
     bool serial = false;
     int wantSlices = 0;           // 0 = automatic
     hipStream_t sErode = nullptr, sFill = nullptr, sApply = nullptr;
@@ -293,7 +294,7 @@ int mmgen_region_create(mmgen_region** out)
         mmgen_region* r = *out;
         hipError_t he = hipHostMalloc((void**)&r->hostMax, sizeof(int), hipHostMallocMapped);
         if (he == hipSuccess) { *r->hostMax = 0; he = hipHostGetDevicePointer((void**)&r->hostMaxDev, r->hostMax, 0); }
-        if (he == hipSuccess && r->devMax.ensure(sizeof(int)) == 0) he = hipMemset(r->devMax.p, 0, sizeof(int));
+        if (he == hipSuccess && r->devMax.ensure(3 * sizeof(int)) == 0) he = hipMemset(r->devMax.p, 0, 3 * sizeof(int));
         else if (he == hipSuccess) he = hipErrorOutOfMemory;
         if (he == hipSuccess) he = hipHostMalloc((void**)&r->hostPasses, sizeof(int), hipHostMallocDefault);
         if (he == hipSuccess) { *r->hostPasses = 0; he = hipEventCreateWithFlags(&r->evPasses, hipEventDisableTiming); }
@@ -439,6 +440,19 @@ static int region_fill_on(mmgen_region* r, uint8_t* d_blocks, hipEvent_t after0,
 // with the base fill starting the moment the caves' extents exist, the cave biomes (which only the placement stages wait for) leave it
 // most of every CU: persistent workgroups per CU of k_cave_biomes then
 static constexpr int kCaveBiomeWorkgroupsBesideFill = 1;      // (1 / 2 / 3 / 6 per CU: 24.60 / 24.73 / 24.77 / 24.81 ms per step, profiles/README.md r04)
+
+int mmgen_region_max_gathered(mmgen_region* r, int* out_surface, int* out_cave, void* stream)
+{
+    if (!r) return (int)hipErrorInvalidValue;
+    hipStream_t s = (hipStream_t)stream;
+    int m[2] = {0, 0};
+    CK(hipMemcpyAsync(m, r->devMax.as<int>() + 1, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
+    CK(hipMemsetAsync(r->devMax.as<int>() + 1, 0, 2 * sizeof(int), s));
+    CK(hipStreamSynchronize(s));
+    if (out_surface) *out_surface = m[0];
+    if (out_cave) *out_cave = m[1];
+    return 0;
+}
 
 int mmgen_region_begin(mmgen_region* r, int cx0, int cz0, int nx, int nz, unsigned flags, const uint8_t* h_local_mask, void* stream)
 {
@@ -672,7 +686,7 @@ int mmgen_region_finish(mmgen_region* r, uint8_t* d_blocks, float* d_heightfield
         CK(r->applyWork.ensure(mmk::apply_work_bytes() * r->kMaxSlices));      // k_apply_features' work counters, one set per slice
         CK(mmk::launch_gather_placements(r->fp.as<mmgen_feature_placement>(), r->cfp.as<mmgen_cave_feature_placement>(), r->counts.as<int>(), tgt, nr,
                                          r->pnx, r->pnz, r->gfp.as<mmgen_feature_placement>(), r->gcfp.as<mmgen_cave_feature_placement>(),
-                                         r->bounds.as<int>(), posP, s));
+                                         r->bounds.as<int>(), posP, s, r->devMax.as<int>() + 1));
     }
     if (par) { CK(hipEventRecord(r->evGather, s)); CK(hipStreamWaitEvent(sA, r->evGather, 0)); }
     // rasterisers + decorators slice by slice behind that slice's base fill
@@ -707,7 +721,11 @@ int mmgen_region_generate(mmgen_region* r, int cx0, int cz0, int nx, int nz, uns
     // the ring's placement lists never leave this call: compute them lazily (mask value 2)
     const uint8_t* mask = nullptr;
     std::vector<uint8_t> lazyMask;
-    if (r && (flags & MMGEN_REGION_FEATURES) && nx > 0 && nz > 0) { lazyMask.assign((size_t)(nx + 6) * (nz + 6), 2); mask = lazyMask.data(); }
+    if (r && (flags & MMGEN_REGION_FEATURES) && !(flags & MMGEN_REGION_EXACT_RING) && nx > 0 && nz > 0) {
+        lazyMask.assign((size_t)(nx + 6) * (nz + 6), 2);
+        mask = lazyMask.data();
+    }
+    flags &= ~MMGEN_REGION_EXACT_RING;
     if (r) r->earlyBlocks = d_blocks;          // nothing of the caller's can touch d_blocks between this call's begin and its fill
     CK(mmgen_region_begin(r, cx0, cz0, nx, nz, flags, mask, stream));
     return mmgen_region_finish(r, d_blocks, d_heightfields, nullptr, nullptr, stream);

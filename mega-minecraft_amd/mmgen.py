@@ -272,6 +272,13 @@ class MMGen:
         self._check(self.lib.mmgen_region_max_cave_placements(self._region(), ctypes.byref(m), self._stream()), "mmgen_region_max_cave_placements")
         return m.value
 
+    def region_max_gathered(self):
+        """(surface, cave): the longest gathered, un-truncated placement lists of the finishes since the last call (synchronises; clears)."""
+        a, b = ctypes.c_int(0), ctypes.c_int(0)
+        self.lib.mmgen_region_max_gathered.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), ctypes.c_void_p]
+        self._check(self.lib.mmgen_region_max_gathered(self._region(), ctypes.byref(a), ctypes.byref(b), self._stream()), "mmgen_region_max_gathered")
+        return a.value, b.value
+
     def region_begin(self, cx0, cz0, nx, nz, flags, local_mask=None):
         mask = None
         if local_mask is not None:

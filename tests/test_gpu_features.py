@@ -442,6 +442,7 @@ def test_gathered_lists_match_reference_order(gen, golden):
 def test_config4_world_placement_counts_stay_below_the_caps(gen):
     """MMGEN_FP_CAP (256) and MMGEN_CFP_CAP (1024) are product-only limits (the reference pushes to unbounded vectors, chunk.cu:1028-1038):
     over the whole config-4 world (4 096 chunks + ring) no chunk comes near them, so no placement is ever dropped."""
+    gen.region_max_gathered()                                # (clears the record of earlier tests)
     gen.region_begin(-32, -32, 64, 64, 7)
     c = np_(gen.region_placement_buffers()["counts"])
     gen.region_finish(64, 64)
@@ -449,6 +450,92 @@ def test_config4_world_placement_counts_stay_below_the_caps(gen):
     assert c[:, 0].max() <= 256 and c[:, 1].max() <= 1024, (c[:, 0].max(), c[:, 1].max())
     assert c[:, 0].max() < 128 and c[:, 1].max() < 512, "within a factor 2 of a cap: raise MMGEN_FP_CAP / MMGEN_CFP_CAP"
     assert c[:, 0].sum() > 10000 and c[:, 1].sum() > 10000
+    # ... and the reference's own limits, the truncation of the GATHERED lists (2 048 / 4 096, chunk.cu:1573-1601), are never reached either:
+    # with the ring computed in full (mask 1: the lengths Chunk::fill would see) the longest list of the whole world stays below a third of
+    # them.  So the reference truncates nothing in a generated world, and the lazily built ring (whose shortened lists could only be
+    # truncated differently if the full ones were truncated at all) gives the same blocks - checked on the same world below.
+    gs, gc = gen.region_max_gathered()
+    assert 100 < gs < 2048 // 3 and 100 < gc < 4096 // 3, (gs, gc)
+
+
+def test_lazy_ring_equals_full_ring(gen):
+    """mmgen_region_generate builds the 3-chunk ring lazily (mask 2: only placements that can reach the rectangle, cave noise only on the
+    columns that can produce one).  Blocks, heights and the gathered lists' effect are those of the full ring (mask 1) - on feature-rich
+    regions, a region at the pruning-domain border and one far from the origin."""
+    import torch
+    gen.region_max_gathered()
+    for (cx0, cz0, nx, nz) in [(1484, -1112, 6, 5), (-20, 7, 9, 4), (2040, -2050, 8, 8), (60000, -41000, 5, 5)]:
+        lazy = gen.generate_region(cx0, cz0, nx, nz, lazy_ring=True)
+        ls, lc = gen.region_max_gathered()
+        full = gen.generate_region(cx0, cz0, nx, nz, lazy_ring=False)
+        fs, fc = gen.region_max_gathered()
+        assert torch.equal(lazy["blocks"], full["blocks"]) and torch.equal(lazy["hf"], full["hf"]), (cx0, cz0)
+        assert ls <= fs < 2048 and lc <= fc < 4096, (ls, fs, lc, fc)          # the lazy lists are sub-lists; nothing is truncated
+
+
+def test_shortened_ring_lists_give_the_same_blocks_until_the_reference_truncates(gen, oracle):
+    """The lazy ring's contract with dense synthetic lists (the caller provides the ring: mask 0).  Every cell of the 7 x 7 grid around one
+    chunk carries icebergs (horizontal reach 40 blocks) and glowstone clusters (reach 8); the SHORTENED variant drops, from the 48 ring
+    cells, the clusters that cannot reach the chunk - what a lazy ring leaves out.  While the full gathered lists stay below the reference's
+    truncation (2 048 / 4 096 entries, chunk.cu:1573-1601) both variants produce the oracle's blocks; once the full list is longer than the
+    limit the reference drops its tail and the shortened list - which no longer reaches the limit - may keep entries the reference loses.
+    mmgen_region_max_gathered shows a full-ring caller which case it is in."""
+    import torch
+    from oracle_binding import OracleBackend
+    cx0, cz0 = 200, -300
+    ob = OracleBackend(oracle.nthreads)
+
+    def lists(nS, nC, seed):
+        rng = np.random.default_rng(seed)
+        fp = np.zeros((49, 256, 5), np.int32); cfp = np.zeros((49, 1024, 6), np.int32); counts = np.zeros((49, 2), np.int32)
+        for cell in range(49):
+            ox, oz = 16 * (cx0 - 3 + cell % 7), 16 * (cz0 - 3 + cell // 7)
+            counts[cell] = (nS, nC)
+            fp[cell, :nS, 0] = 4                                       # MMF_ICEBERG
+            fp[cell, :nS, 1] = ox + rng.integers(0, 16, nS); fp[cell, :nS, 2] = 120 + rng.integers(0, 30, nS); fp[cell, :nS, 3] = oz + rng.integers(0, 16, nS)
+            fp[cell, :nS, 4] = rng.integers(0, 2, nS)
+            cfp[cell, :nC, 0] = 4                                      # MMCF_GLOWSTONE_CLUSTER
+            cfp[cell, :nC, 1] = ox + rng.integers(0, 16, nC); cfp[cell, :nC, 2] = 20 + rng.integers(0, 80, nC); cfp[cell, :nC, 3] = oz + rng.integers(0, 16, nC)
+            cfp[cell, :nC, 4] = 4 + rng.integers(0, 12, nC); cfp[cell, :nC, 5] = 1
+        return fp, cfp, counts
+
+    def shortened(fp, cfp, counts):
+        fp2, cfp2, c2 = fp.copy(), np.zeros_like(cfp), counts.copy()
+        x0, z0 = 16 * cx0, 16 * cz0
+        for cell in range(49):
+            e = cfp[cell, :counts[cell, 1]]
+            keep = (e[:, 1] >= x0 - 8) & (e[:, 1] <= x0 + 15 + 8) & (e[:, 3] >= z0 - 8) & (e[:, 3] <= z0 + 15 + 8) if cell != 24 else np.ones(len(e), bool)
+            cfp2[cell, :keep.sum()] = e[keep]
+            c2[cell, 1] = keep.sum()
+        return fp2, cfp2, c2
+
+    def run(backend, fp, cfp, counts):
+        backend.region_begin(cx0, cz0, 1, 1, 7, [0] * 24 + [1] + [0] * 24 if backend is gen else None)
+        b = backend.region_placement_buffers()
+        for k, a in (("fp", fp), ("cfp", cfp), ("counts", counts)):
+            b[k].copy_(torch.from_numpy(a).to(b[k].device))
+        out = backend.region_finish(1, 1)["blocks"]
+        return out if isinstance(out, np.ndarray) else np_(out)
+
+    # below the limits: 30 + 60 per cell -> 1 470 / 2 940 gathered entries
+    gen.region_max_gathered()
+    full = lists(30, 60, 3)
+    short = shortened(*full)
+    assert short[2][:, 1].sum() < full[2][:, 1].sum() // 2                 # the shortened lists really are much shorter
+    ref = run(ob, *full)
+    assert np.array_equal(run(gen, *full), ref)
+    assert gen.region_max_gathered() == (1470, 2940)
+    assert np.array_equal(run(gen, *short), ref), "a shortened ring changed blocks although the reference truncates nothing"
+    # beyond them: 60 + 100 per cell -> 2 940 / 4 900: the device still equals the oracle on the FULL lists (same order, same cut) ...
+    full = lists(60, 100, 11)
+    ref = run(ob, *full)
+    assert np.array_equal(run(gen, *full), ref)
+    gs, gc = gen.region_max_gathered()
+    assert (gs, gc) == (2940, 4900) and gs > 2048 and gc > 4096            # ... and a full-ring caller can see that the reference's cut applied
+    # (the shortened variant of THIS case is the documented limit of the lazy ring: its cave list is below 4 096 again, so the clusters of
+    # the last ring cells, which the reference drops, stay in)
+    short = shortened(*full)
+    assert run(gen, *short).shape == ref.shape and gen.region_max_gathered()[1] < 4096
 
 
 def test_ring_wire_format_on_the_device(gen):
