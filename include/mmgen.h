@@ -29,12 +29,13 @@ extern "C" {
  * single-threaded, terrain.cpp:587-960).  A mmgen_region owns its scratch. */
 int mmgen_init(int device);
 const char* mmgen_error_string(int code);
-/* pre-size the library-internal scratch of the per-stage calls on `stream` (per-column cave info, fill's voxel lists: 393 KB per chunk, at most 8 192 chunks' worth) so that later
+/* pre-size the library-internal scratch of the per-stage calls on `stream` (per-column cave info, fill's voxel lists: 393 KB per chunk, at most 8 192 chunks' worth = 3.2 GB per (device, stream) for a full reserve) so that later
  * calls on that stream allocate nothing (graph capture).  Scratch is keyed by (device, stream). */
 int mmgen_reserve(int max_chunks_per_call, void* stream);
 /* frees the library-internal scratch kept for `stream` on the current device (synchronises it first): call before destroying a stream,
  * so that the entry does not outlive it and a recycled handle does not inherit its buffers.  mmgen_release_all: every stream, every
- * device entry (synchronises the current device). */
+ * device entry (synchronises the current device).  Threading: per-stage calls on ONE (device, stream) and a release of that stream must
+ * not run concurrently (a stage call launches with pointers into the entry the release frees); different streams are independent. */
 int mmgen_release(void* stream);
 int mmgen_release_all(void);
 

@@ -112,6 +112,9 @@ int mmgen_release(void* stream)
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return (int)e;
+    // the stream first: if that fails the entry (and the buffers queued work may still use) stays where it is
+    e = hipStreamSynchronize((hipStream_t)stream);
+    if (e != hipSuccess) return (int)e;
     Scratch sc;
     {
         std::lock_guard<std::mutex> lk(g_mu);
@@ -120,23 +123,24 @@ int mmgen_release(void* stream)
         sc = it->second;
         g_scratch.erase(it);
     }
-    e = hipStreamSynchronize((hipStream_t)stream);
-    if (e != hipSuccess) return (int)e;
+    // every buffer is freed even when one hipFree fails; the first error is reported
+    hipError_t first = hipSuccess;
     for (void* p : {(void*)sc.colInfo, (void*)sc.erodeWork, (void*)sc.erodeState, (void*)sc.fillQueue})
-        if (p && (e = hipFree(p)) != hipSuccess) return (int)e;
-    return 0;
+        if (p && (e = hipFree(p)) != hipSuccess && first == hipSuccess) first = e;
+    return (int)first;
 }
 
 int mmgen_release_all()
 {
+    hipError_t e = hipDeviceSynchronize();                      // first: on failure nothing has been taken out of the map
+    if (e != hipSuccess) return (int)e;
     std::map<std::pair<int, void*>, Scratch> all;
     { std::lock_guard<std::mutex> lk(g_mu); all.swap(g_scratch); }
-    hipError_t e = hipDeviceSynchronize();
-    if (e != hipSuccess) return (int)e;
+    hipError_t first = hipSuccess;
     for (auto& kv : all)
         for (void* p : {(void*)kv.second.colInfo, (void*)kv.second.erodeWork, (void*)kv.second.erodeState, (void*)kv.second.fillQueue})
-            if (p && (e = hipFree(p)) != hipSuccess) return (int)e;
-    return 0;
+            if (p && (e = hipFree(p)) != hipSuccess && first == hipSuccess) first = e;
+    return (int)first;
 }
 
 int mmgen_reserve(int max_chunks_per_call, void* stream)

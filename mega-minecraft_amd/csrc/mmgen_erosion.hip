@@ -19,7 +19,7 @@
 //    publishes the mask.  The host enqueues launches back to back and reads the states every few launches;
 //  * many zones per launch (blockIdx.z = zone); the zone working set stays L2 / Infinity-Cache resident.
 #include <hip/hip_runtime.h>
-#include <cstdlib>
+#include <atomic>
 #include "mm_biome.cuh"
 #include "mmgen_erosion.h"
 #include "mmgen_prof.h"
@@ -405,18 +405,18 @@ size_t erosion_state_bytes(int zones) { return (size_t)(zones + 1) * sizeof(mm::
 // workgroups of k_erode_zones per launch: what the chip holds at once (LDS-bound: three per CU on gfx950), capped
 static int erosion_resident_workgroups()
 {
-    static int cached[16] = {};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
-    if (cached[dev]) return cached[dev];
-    int perCu = 0, cus = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, mm::k_erode_zones, EROSION_THREADS, 0) != hipSuccess || perCu < 1) perCu = 1;
-    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 1;
-    // Two per CU, not the three that fit: the relaxation waits more than it issues (2.2 ms alone at two, 1.7 at three), and the region
-    // runs it BESIDE the caves, whose workgroups take the rest of every CU - at three per CU no cave workgroup fits (LDS) and nothing
-    // overlaps; at two or at one the step is equally long (profiles/README.md r04), two leaves the chip to the caves sooner
-    if (perCu > EROSION_WG_PER_CU) perCu = EROSION_WG_PER_CU;
-    return cached[dev] = perCu * cus;
+    static std::atomic<int> perCuCached{0};                 // (the kernel's occupancy is the same on every gfx950)
+    int perCu = perCuCached.load(std::memory_order_relaxed);
+    if (!perCu) {
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, mm::k_erode_zones, EROSION_THREADS, 0) != hipSuccess || perCu < 1) perCu = 1;
+        // Two per CU, not the three that fit: the relaxation waits more than it issues (2.2 ms alone at two, 1.7 at three), and the region
+        // runs it BESIDE the caves, whose workgroups take the rest of every CU - at three per CU no cave workgroup fits (LDS) and nothing
+        // overlaps; at two or at one the step is equally long (profiles/README.md r04), two leaves the chip to the caves sooner
+        if (perCu > EROSION_WG_PER_CU) perCu = EROSION_WG_PER_CU;
+        perCuCached.store(perCu, std::memory_order_relaxed);
+    }
+    const int cus = device_cus();
+    return perCu * (cus > 0 ? cus : 1);
 }
 
 // Enqueues the relaxation of `zones` packed zone buffers (stride in floats) to convergence: ONE persistent launch, then the kernel that

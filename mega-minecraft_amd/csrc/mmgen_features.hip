@@ -754,15 +754,6 @@ MM_DEV int filter_round(const Entry* __restrict__ list, int r0, int wx0, int wz0
     return __popcll(cm);
 }
 
-#ifndef MM_APPLY_EXP
-#define MM_APPLY_EXP 0       // timing experiments only (tools/build_variant.sh)
-#endif
-#ifndef MM_APPLY_STATS
-#define MM_APPLY_STATS 0     // debugging aid: work census of every launch on stderr (units with items, placements, pairs, items)
-#endif
-#if MM_APPLY_STATS
-__device__ unsigned long long g_applyStats[8];
-#endif
 #ifndef MM_APPLY_WAVES
 #define MM_APPLY_WAVES 3        // 168 VGPRs: the union of the 31 rasterisers
 #endif
@@ -835,9 +826,6 @@ k_apply_features(uint8_t* __restrict__ blocks, const int2* __restrict__ chunkPos
     int phase = doS ? 0 : 1, r0 = 0;                        // list being walked (0 surface, 1 cave, 2 = both at their end) and the next round
     int nU = 0, nUS = 0;                                    // gathered placements, and how many of them are surface placements
     bool staged = false;                                    // the unit's air bits are in LDS, the claims cleared
-#if MM_APPLY_STATS
-    unsigned long long stS = 0, stC = 0, stEnt = 0, stItems = 0;
-#endif
     for (;;) {
         // ---- A. gather placements until another round might not fit or the lists end
         while (phase < 2 && nU + 64 <= APPLY_UNIT_CAP) {
@@ -853,12 +841,6 @@ k_apply_features(uint8_t* __restrict__ blocks, const int2* __restrict__ chunkPos
         }
         if (nU == 0) break;                                 // (only when the lists are at their end)
         wave_lds_sync();
-#if MM_APPLY_STATS
-        stS += nUS; stC += nU - nUS;
-#endif
-#if MM_APPLY_EXP == 6
-        nU = 0;                                             // timing experiment: the list walk only
-#endif
 
         // ---- B + C. pairs of the gathered placements, items whenever the pair buffer fills up and at the end
         const int nPairs = nU * APPLY_UNIT_NCOL;
@@ -893,12 +875,6 @@ k_apply_features(uint8_t* __restrict__ blocks, const int2* __restrict__ chunkPos
                     }
                     if (lane == 0) pref[nEnt] = (unsigned short)total;
                     wave_lds_sync();
-#if MM_APPLY_STATS
-                    stEnt += nEnt; stItems += total;
-#endif
-#if MM_APPLY_EXP == 1
-                    total = 0;                                          // timing experiment: fixed per-unit work only
-#endif
                     for (int j0 = 0; j0 < total; j0 += 64) {
                         const int j = j0 + lane;
                         bool placed = false;
@@ -914,12 +890,8 @@ k_apply_features(uint8_t* __restrict__ blocks, const int2* __restrict__ chunkPos
                             const int4 rc = unit[k];
                             if (((air[v >> 5] >> (v & 31)) & 1u) || ((rc.z >> 14) & 1)) {
                                 const int fy = rc.z & 511, feature = (rc.z >> 9) & 31, wx = wx0 + c % APPLY_UNIT_W, wz = wz0 + c / APPLY_UNIT_W;
-#if MM_APPLY_EXP == 2
-                                placed = (rc.x + fy + rc.y + y) == 0x7fffffff;        // timing experiment: no rasteriser
-#else
                                 placed = k >= nUS ? place_cave_feature(feature, rc.x, fy, rc.y, (rc.z >> 15) & 511, wx, y, wz, (uint32_t)rc.w, fb)
                                                   : place_feature(feature, rc.x, fy, rc.y, wx, y, wz, (uint32_t)rc.w, fb);
-#endif
                             }
                         }
                         // first match in list order wins: the batch's placements in ascending order, one masked write each (a placement has one item per voxel)
@@ -973,12 +945,6 @@ k_apply_features(uint8_t* __restrict__ blocks, const int2* __restrict__ chunkPos
         nU = 0; nUS = 0;                                    // the placement buffer is free again
         if (phase == 2) break;
     }
-#if MM_APPLY_STATS
-    if (lane == 0 && staged) {
-        atomicAdd(&g_applyStats[0], 1ull); atomicAdd(&g_applyStats[1], stS); atomicAdd(&g_applyStats[2], stC);
-        atomicAdd(&g_applyStats[3], stEnt); atomicAdd(&g_applyStats[4], stItems);
-    }
-#endif
     if (!staged) continue;
     // ---- D. the claimed voxels back to the chunk
     wave_lds_sync();
@@ -1225,13 +1191,8 @@ int launch_apply_features(uint8_t* blocks, const int32_t* pos, int n, const mmge
 {
     if (n <= 0) return 0;
     if (!workCounter) return (int)hipErrorInvalidValue;
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return (int)hipErrorInvalidDevice;
-        cus = prop.multiProcessorCount;
-    }
+    const int cus = device_cus();
+    if (!cus) return (int)hipErrorInvalidDevice;
     // persistent: MM_APPLY_WAVES waves per SIMD = that many 4-wave workgroups per CU; every wave walks its own units
     const long long units = (long long)n * APPLY_UNITS_PER_CHUNK, groups = (units + APPLY_COLS - 1) / APPLY_COLS, fit = (long long)cus * MM_APPLY_WAVES;
     if (units > 0x7fffffffLL) return (int)hipErrorInvalidValue;
@@ -1239,13 +1200,6 @@ int launch_apply_features(uint8_t* blocks, const int32_t* pos, int n, const mmge
     if (e != hipSuccess) return (int)e;
     LAUNCH(KID_APPLY_FEATURES, mm::k_apply_features, dim3((unsigned)(groups < fit ? groups : fit)), dim3(APPLY_THREADS), s, blocks, (const int2*)pos, gfp, gcfp,
            bounds, srcIdx, (int)units, workCounter);
-#if MM_APPLY_STATS
-    {
-        unsigned long long h[8];
-        (void)hipStreamSynchronize(s); (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(mm::g_applyStats), sizeof h);
-        fprintf(stderr, "apply census (cumulative): chunks %d units-with-items %llu surface placements %llu cave placements %llu pairs %llu items %llu\n", n, h[0], h[1], h[2], h[3], h[4]);
-    }
-#endif
     return 0;
 }
 

@@ -371,7 +371,13 @@ k_cave_voxels(const float* __restrict__ hf, const float2* __restrict__ colInfo, 
         // (float)y > ravineY  <=>  y > floor(ravineY) for an integer y; no ravine = +inf
         const int cut = ravineY >= 383.f ? 383 : (int)__builtin_floorf(ravineY);
         const int lo = imax(CAVE_YEVAL, 64 * w) - 64 * w, hi = imin(imin(s_top[c], cut), 64 * w + 63) - 64 * w;      // bit range inside the word
-        if (hi >= lo) atomicOr(&s_solid[c][w], (~0ull >> (63 - hi)) & (~0ull << lo));
+        if (hi >= lo) {
+            // through the same 32-bit halves as the walk below, which ORs y 128 .. 143 into the low half of word 2 with no barrier in between
+            const unsigned long long bits = (~0ull >> (63 - hi)) & (~0ull << lo);
+            unsigned* half = (unsigned*)&s_solid[c][w];
+            if ((unsigned)bits) atomicOr(half, (unsigned)bits);
+            if ((unsigned)(bits >> 32)) atomicOr(half + 1, (unsigned)(bits >> 32));
+        }
     }
     static_assert(CAVE_THREADS == 256 && CAVE_ROW == 16 && CAVE_YEVAL == 144, "the walk below: thread t = column t % 16, y = t / 16 + 16 i, i < 9");
     {
@@ -824,9 +830,6 @@ MM_DEV BaseBlock place_block_base(const ColumnBiomes& cbi, const float* s_lh, co
     return r;
 }
 
-#ifndef MM_FILL_EXP
-#define MM_FILL_EXP 0      // timing experiments only (tools/build_variant.sh): 1 = no cave-biome phase, 2 = no cave-biome block rules
-#endif
 #define FILL_ROW 16          // columns per workgroup: one row of the chunk, staged with whole-line loads
 #define FILL_VOX (FILL_ROW * 384)     // 6 144 voxels per row
 #define FILL_VBITS 13        // bits of a voxel's position in the row
@@ -964,7 +967,6 @@ MM_DEV void fill_body(const float* __restrict__ hf, const float* __restrict__ bw
         const int bdc = (e >> (FILL_VBITS + 8)) & 31;
         const int c = v / 384, y = v - 384 * c;
         const int wx = cp.x + c, wz = cp.y + row;
-#if MM_FILL_EXP != 1
         // WARPED / AMBER only act on the top DEEPSLATE / BLACKSTONE block of a cave floor (caveBottomDepth == 0)
         const bool wantDeep = bdc == 0 && (block == MMB_DEEPSLATE || block == MMB_BLACKSTONE);
         // LUSH_CAVES only converts within 1.5 + 4.5 simplex3 <= 1.5 + 4.5 * 1.37 = 7.67 blocks of a cave surface: further away only CRYSTAL_CAVES
@@ -973,14 +975,13 @@ MM_DEV void fill_body(const float* __restrict__ hf, const float* __restrict__ bw
         static_assert(1.5f + 4.5f * MM_SIMPLEX3_BOUND < 8.f, "depth beyond which LUSH_CAVES cannot convert");
         const bool crystalOnly = NEAR && !wantDeep && bdc > 7 && tdc > 7;
         const int cb = cave_biome_t<NEAR>(wx, y, wz, s_lh[c][MMGEN_NUM_MATERIALS], 190249401, wantDeep, crystalOnly);
-        if (MM_FILL_EXP != 2 && (cb == MMCB_CRYSTAL_CAVES || cb == MMCB_LUSH_CAVES)) {
+        if (cb == MMCB_CRYSTAL_CAVES || cb == MMCB_LUSH_CAVES) {
             const int k = atomicAdd(&s_count[1], 1);
             if (k < FILL_L2_CAP) s_list2[k] = (unsigned short)(i | (cb == MMCB_LUSH_CAVES ? (1 << FILL_VBITS) : 0));
             else noise_rule(i, cb);                                   // list 2 is full: in place
             continue;
         }
         if (wantDeep && cb != MMCB_NONE) cave_biome_block_post(block, cb, wx, y, wz, 0, -1);      // WARPED / AMBER re-skin, no noise
-#endif
         outBase[v] = block;
     }
     __syncthreads();
@@ -1010,7 +1011,7 @@ MM_DEV void fill_body(const float* __restrict__ hf, const float* __restrict__ bw
         if (queued) { lushQueue[1 + qbase + k] = ((unsigned)outChunk << 17) | ((unsigned)idx2d << 9) | (unsigned)y; continue; }
         // a reservation that straddles the capacity marks its in-range slots as holes (they hold the previous launch's entries)
         if (lushQueue && qbase < lushCap && (unsigned)k < lushCap - qbase) lushQueue[1 + qbase + k] = 0xffffffffu;
-        outBase[v] = MM_FILL_EXP == 3 ? (uint8_t)MMB_MOSS : lush_clay_or_moss(cp.x + c, y, cp.y + row, CellDirect());
+        outBase[v] = lush_clay_or_moss(cp.x + c, y, cp.y + row, CellDirect());
     }
 }
 
@@ -1347,11 +1348,7 @@ k_fill_cave(const float* __restrict__ hf, const int2* __restrict__ chunkPos, uin
             // WARPED / AMBER only act on the top DEEPSLATE / BLACKSTONE block of a cave floor (caveBottomDepth == 0)
             const bool wantDeep = bdc == 0 && (base == MMB_DEEPSLATE || base == MMB_BLACKSTONE);
             const float maxHeight = hf[(srcIdx ? srcIdx[x.outChunk] : x.outChunk) * 256 + FILL_ROW * ((row0 + lrow) & 15) + x.c];
-#if MM_FILL_EXP == 4
-            on = (x.wx + x.y + x.wz == 0x7fffffff && maxHeight == 1.f && wantDeep);      // timing experiment: the machinery without the cave biome
-#else
             on = !cave_biome_py<true>(x.wx, x.y, x.wz, maxHeight, wantDeep, py);
-#endif
         }
         const unsigned long long om = __ballot(on);
         if (on) { const int at = nS2 + __popcll(om & below); s2[at] = make_uint2(e, (unsigned)lrow); s2py[at] = py; }
@@ -1482,13 +1479,8 @@ int launch_caves(const float* hf, const float* bw, const int32_t* pos, int n, mm
     // the layers' extents are final here (what the base fill reads); their biomes follow
     if (afterVoxels) { const hipError_t ee = hipEventRecord(afterVoxels, s); if (ee != hipSuccess) return (int)ee; }
     // k_cave_voxels was the last reader of the per-column info: its first KB becomes k_cave_biomes' work counters
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return (int)hipErrorInvalidDevice;
-        cus = prop.multiProcessorCount;
-    }
+    const int cus = device_cus();
+    if (!cus) return (int)hipErrorInvalidDevice;
     static_assert(64 * CB_COUNTERS <= 256 * sizeof(float2), "the counters fit the per-column info of one chunk");
     const hipError_t e = hipMemsetAsync(colInfoScratch, 0, 64 * CB_COUNTERS, s);
     if (e != hipSuccess) return (int)e;
@@ -1534,13 +1526,8 @@ int launch_fill(const float* hf, const float* bw, const float* layers, const mmg
     if (n <= 0) return 0;
     if (!scratch || scratchBytes < fill_queue_bytes(n)) return (int)hipErrorInvalidValue;
     const FillScratch f = fill_scratch((char*)scratch, n);
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return (int)hipErrorInvalidDevice;
-        cus = prop.multiProcessorCount;
-    }
+    const int cus = device_cus();
+    if (!cus) return (int)hipErrorInvalidDevice;
     for (int b0 = 0; b0 < n; b0 += kFillBatch) {
         const int nb = n - b0 < kFillBatch ? n - b0 : kFillBatch;
         // without an index list inputs and outputs are both dense: shift every per-chunk pointer; with one only the list and the output move

@@ -26,6 +26,9 @@ int profile_collect(double* total_ms, long long* counts);
 void profile_begin(int kid, hipStream_t s);
 void profile_end(hipStream_t s);
 
+// compute units of the CURRENT device (cached per device: a process may drive several GPUs); 0 on error
+int device_cus();
+
 struct StageRange {
     explicit StageRange(const char* name);
     ~StageRange();

@@ -17,7 +17,7 @@ thread_local ProfRec t_open;
 
 const char* const kKernelNames[KID_COUNT] = {
     "k_heightfield", "k_layers", "k_fix_backward", "k_cave_columns", "k_cave_voxels", "k_cave_biomes", "k_fill_cave", "k_fill_far", "k_fill_lush", "k_fill_base", "k_fill_scan", "k_probe",
-    "k_erosion_gather", "k_erode_init", "k_erode_pass", "k_erode_writeback", "k_erosion_scatter",
+    "k_erosion_gather", "k_erode_init", "k_erode_zones", "k_erode_writeback", "k_erosion_scatter",
     "k_feature_placements", "k_gather_placements", "k_apply_features", "k_decorators", "k_feature_box",
     "k_select", "k_ring_need", "k_copy_placements", "k_ring_pack", "k_ring_unpack",
     "k_mesh_count", "k_mesh_fill", "k_pack_count", "k_pack_fill", "k_unpack"};
@@ -30,6 +30,18 @@ hipEvent_t get_event()
     return e;
 }
 }  // namespace
+
+int device_cus()
+{
+    static std::atomic<int> cached[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+    int c = cached[dev].load(std::memory_order_relaxed);
+    if (c) return c;
+    if (hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || c < 1) return 0;
+    cached[dev].store(c, std::memory_order_relaxed);
+    return c;
+}
 
 void profile_enable(bool on) { std::lock_guard<std::mutex> lk(g_mu); g_prof.store(on, std::memory_order_relaxed); }
 bool profile_enabled() { return g_prof.load(std::memory_order_relaxed); }

@@ -212,7 +212,7 @@ struct mmgen_region {
     bool began = false;
     DevBuf posA, hfA, bwA, gathA, layersA;
     DevBuf layersP, caveP, colInfo, fp, cfp, counts;
-    DevBuf zoneIdx, zoneIdxOut, gathered, erodeWork, erodeState, computeList, targets, gfp, gcfp, bounds, fillQueue, cellLazy, colNeed, applyWork;
+    DevBuf zoneIdx, zoneIdxOut, erodeWork, erodeState, computeList, targets, gfp, gcfp, bounds, fillQueue, cellLazy, colNeed, applyWork;
     bool passesPending = false;
     int* hostPasses = nullptr;    // pinned: largest erosion pass count of the last begin, valid once evPasses has fired
     DevBuf devPasses;
@@ -247,14 +247,11 @@ struct mmgen_region {
     {
         if (sErode) return 0;
         hipError_t e;
-        // the erosion branch is a chain of ~25 short dependent launches: on an equal-priority queue its workgroups only get the slots
-        // the cave kernel's own queue leaves over (every pass then lasts as long as a whole cave launch, profiles/README.md r03); at the
-        // highest priority they take the next free slot and the chain hides under the caves
+        // the erosion branch at the highest stream priority: its one persistent launch is ordered ahead of the caves' by an event, the
+        // priority only helps its short tail kernels (finish, fix-up) to a free slot beside the caves
         int prLeast = 0, prGreatest = 0;
         if ((e = hipDeviceGetStreamPriorityRange(&prLeast, &prGreatest)) != hipSuccess) return (int)e;
-        const char* pe = getenv("MMGEN_REGION_EROSION_PRIORITY");
-        const int pr = (pe && *pe == '0') ? prLeast : prGreatest;
-        if ((e = hipStreamCreateWithPriority(&sErode, hipStreamNonBlocking, pr)) != hipSuccess) return (int)e;
+        if ((e = hipStreamCreateWithPriority(&sErode, hipStreamNonBlocking, prGreatest)) != hipSuccess) return (int)e;
         if ((e = hipStreamCreateWithFlags(&sFill, hipStreamNonBlocking)) != hipSuccess) return (int)e;
         if ((e = hipStreamCreateWithFlags(&sApply, hipStreamNonBlocking)) != hipSuccess) return (int)e;
         hipEvent_t* ev[] = {&evK2, &evResident, &evCaveVoxels, &evBegin, &evErosion, &evGather, &evTail, &evEntry};
@@ -277,7 +274,7 @@ struct mmgen_region {
             for (int i = 0; i < kMaxSlices; ++i) if (evFill[i]) (void)hipEventDestroy(evFill[i]);
         }
         DevBuf* all[] = {&posA, &hfA, &bwA, &gathA, &layersA, &layersP, &caveP, &colInfo, &fp, &cfp, &counts, &zoneIdx,
-                         &zoneIdxOut, &gathered, &erodeWork, &erodeState, &computeList, &targets, &gfp, &gcfp, &bounds, &fillQueue, &cellLazy, &colNeed, &applyWork};
+                         &zoneIdxOut, &erodeWork, &erodeState, &computeList, &targets, &gfp, &gcfp, &bounds, &fillQueue, &cellLazy, &colNeed, &applyWork};
         for (DevBuf* b : all) b->release();
     }
 };
