@@ -1471,10 +1471,12 @@ int launch_fix_backward(float* layers, int n, hipStream_t s)
 }
 
 int launch_caves(const float* hf, const float* bw, const int32_t* pos, int n, mmgen_cave_layer* caveLayers, float* colInfoScratch,
-                 const int* chunkList, const uint8_t* colNeed, hipStream_t s, hipEvent_t afterVoxels, int biomeWorkgroupsPerCu)
+                 const int* chunkList, const uint8_t* colNeed, hipStream_t s, hipEvent_t afterVoxels, int biomeWorkgroupsPerCu, hipEvent_t beforeVoxels)
 {
     if (n <= 0) return 0;
     LAUNCH(KID_CAVE_COLUMNS, mm::k_cave_columns, dim3(n), dim3(256), s, bw, (const int2*)pos, (float2*)colInfoScratch, chunkList);
+    // (the per-column pass is small and runs beside whatever the event stands for; the voxel launch is the one that takes the chip)
+    if (beforeVoxels) { const hipError_t ew = hipStreamWaitEvent(s, beforeVoxels, 0); if (ew != hipSuccess) return (int)ew; }
     LAUNCH(KID_CAVE_VOXELS, mm::k_cave_voxels, dim3(n * 16), dim3(CAVE_THREADS), s, hf, (const float2*)colInfoScratch, (const int2*)pos, caveLayers, chunkList, colNeed);
     // the layers' extents are final here (what the base fill reads); their biomes follow
     if (afterVoxels) { const hipError_t ee = hipEventRecord(afterVoxels, s); if (ee != hipSuccess) return (int)ee; }

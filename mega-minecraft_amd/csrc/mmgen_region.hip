@@ -538,10 +538,10 @@ int mmgen_region_begin(mmgen_region* r, int cx0, int cz0, int nx, int nz, unsign
     // ---- K4 caves on the caller's stream, behind the point at which the relaxation's persistent launch is next in its queue: that launch
     // is a few hundred workgroups and must be on the chip before the caves' 150 000 start taking every slot that frees up
     {
-        if (erosion && par) CK(hipStreamWaitEvent(s, r->evResident, 0));
         mmk::StageRange sr("mmgen:caves");
         CK(mmk::launch_caves(hfP, bwP, posP, r->nCompute, r->caveP.as<mmgen_cave_layer>(), r->colInfo.as<float>(), list, colNeed, s,
-                             par ? r->evCaveVoxels : nullptr, (par && r->earlyBlocks) ? kCaveBiomeWorkgroupsBesideFill : 0));
+                             par ? r->evCaveVoxels : nullptr, (par && r->earlyBlocks) ? kCaveBiomeWorkgroupsBesideFill : 0,
+                             (erosion && par) ? r->evResident : nullptr));
     }
     if (erosion && par) { CK(hipEventRecord(r->evErosion, sE)); CK(hipStreamWaitEvent(s, r->evErosion, 0)); }
     r->began = true;
