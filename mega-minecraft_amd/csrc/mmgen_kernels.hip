@@ -1071,7 +1071,11 @@ k_fill_base(const float* __restrict__ hf, const float* __restrict__ bw, const fl
     // contiguous) while the plane attributes are on their way to LDS: 24 weights + 20 layer starts + height per column, a row of a plane
     // is one 64-byte line, read whole
     const mmgen_cave_layer* ccl = caveLayers + (size_t)MMGEN_MAX_CAVE_LAYERS_PER_COLUMN * (chunk * 256 + idxBase + (t >> 4));
-    const int cs0 = ccl[t & 15].start, ce0 = ccl[t & 15].end, cs1 = ccl[(t & 15) + 16].start, ce1 = ccl[(t & 15) + 16].end;
+    const int cs0 = ccl[t & 15].start, ce0 = ccl[t & 15].end;
+    // a column's slots are used in order (the first unused one starts at 384): the upper 16 are only read where slot 15 is in use - a
+    // handful of columns of a generated world, and half of the 96 KB per chunk that were this kernel's largest input
+    int cs1 = 384, ce1 = 384;
+    if (__shfl(cs0, (t & 48) | 15) != 384) { cs1 = ccl[(t & 15) + 16].start; ce1 = ccl[(t & 15) + 16].end; }
     for (int i = t; i < FILL_ROW * 45; i += FILLB_THREADS) {
         const int k = i / FILL_ROW, c = i % FILL_ROW;               // consecutive lanes = consecutive columns of one plane
         const int idx2d = idxBase + c;
