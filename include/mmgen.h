@@ -166,13 +166,15 @@ int mmgen_region_max_gathered(mmgen_region* region, int* out_surface, int* out_c
 #define MMGEN_ERROR_PLACEMENT_OVERFLOW 20001
 int mmgen_region_max_cave_placements(mmgen_region* region, int* out_max, void* stream);
 /* How the region schedules its stages.  Default (serial = 0): a stage DAG over the caller's stream and three
- * internal ones - the erosion branch (select, gather, ~25 dependent relaxation launches with their host reads, scatter, fix-up) beside
- * the caves, which need none of it (the reference rotates five streams over its stages, terrain.cpp:129,179-182); the base fill on its
- * own stream, ordered behind whatever the caller's stream holds when d_blocks is first passed in; the rectangle optionally cut into
- * `slices` z slices (0 = automatic = 1) with the rasterisers / decorators of slice i beside the fill of slice i + 1.  Every internal
- * stream is joined into the caller's stream before mmgen_region_finish returns, so callers order against that one stream only.  serial = 1:
- * every kernel on the caller's stream in the reference's stage order (what per-kernel timing and the counters want); also selected
- * by MMGEN_REGION_SERIAL=1 in the environment.  Results are identical. */
+ * internal ones - the erosion branch (one persistent relaxation launch per zone batch, no host read-backs, finish, fix-up) beside the
+ * caves, which need none of it (the reference rotates five streams over its stages, terrain.cpp:129,179-182); the base fill on its own
+ * stream, ordered behind whatever the caller's stream holds when d_blocks is first passed in - or, after mmgen_region_set_output, behind
+ * what it held when begin was called, and then started by begin itself; the rectangle optionally cut into `slices` z slices (0 =
+ * automatic = 1) with the rasterisers / decorators of slice i beside the fill of slice i + 1.  Every internal stream is joined into the
+ * caller's stream before mmgen_region_finish returns, so callers order against that one stream only; no region call blocks the host
+ * except the three queries (last_erosion_passes, max_cave_placements, max_gathered) and set_serial, which waits for the internal streams.
+ * serial = 1: every kernel on the caller's stream in the reference's stage order (what per-kernel timing and the counters want); also
+ * selected by MMGEN_REGION_SERIAL=1 in the environment.  Results are identical. */
 int mmgen_region_set_serial(mmgen_region* region, int serial, int slices);
 /* Copies the placement lists of n whole cells between two placement grids with the per-cell layout of mmgen_region_placement_buffers
  * (fp [cells][MMGEN_FP_CAP], cfp [cells][MMGEN_CFP_CAP], counts [cells][2]): cell d_dst_idx[i] of dst <- cell d_src_idx[i] of src.  A streaming

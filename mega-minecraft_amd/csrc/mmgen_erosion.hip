@@ -38,9 +38,6 @@ namespace mm {
 #ifndef EROSION_STRIPS
 #define EROSION_STRIPS 11                                  // row groups: one lane = one column of the extended tile x EROSION_ROWS rows (mmgen_erosion.h: K x row groups)
 #endif
-#ifndef EROSION_WG_PER_CU
-#define EROSION_WG_PER_CU 2
-#endif
 #define EROSION_ROWS (EROSION_EXT / EROSION_STRIPS)
 #define EROSION_THREADS (EROSION_EXT * EROSION_STRIPS)
 static_assert(EROSION_EXT % EROSION_STRIPS == 0, "strips must tile the extended tile");
@@ -402,19 +399,16 @@ size_t erosion_work_bytes(int zones) { return (size_t)zones * ZONE_WORK_FLOATS *
 // the zones' states, then one more record's worth of words: [0] = the launch's ticket counter, [1] = largest pass count of the zones
 size_t erosion_state_bytes(int zones) { return (size_t)(zones + 1) * sizeof(mm::ErosionState); }
 
-// workgroups of k_erode_zones per launch: what the chip holds at once (LDS-bound: three per CU on gfx950), capped
-static int erosion_resident_workgroups()
+// workgroups of k_erode_zones the chip holds at once (LDS-bound: three per CU on gfx950), or `perCuCap` per CU if that is fewer
+static int erosion_resident_workgroups(int perCuCap)
 {
     static std::atomic<int> perCuCached{0};                 // (the kernel's occupancy is the same on every gfx950)
     int perCu = perCuCached.load(std::memory_order_relaxed);
     if (!perCu) {
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, mm::k_erode_zones, EROSION_THREADS, 0) != hipSuccess || perCu < 1) perCu = 1;
-        // Two per CU, not the three that fit: the relaxation waits more than it issues (2.2 ms alone at two, 1.7 at three), and the region
-        // runs it BESIDE the caves, whose workgroups take the rest of every CU - at three per CU no cave workgroup fits (LDS) and nothing
-        // overlaps; at two or at one the step is equally long (profiles/README.md r04), two leaves the chip to the caves sooner
-        if (perCu > EROSION_WG_PER_CU) perCu = EROSION_WG_PER_CU;
         perCuCached.store(perCu, std::memory_order_relaxed);
     }
+    if (perCuCap > 0 && perCu > perCuCap) perCu = perCuCap;
     const int cus = device_cus();
     return perCu * (cus > 0 ? cus : 1);
 }
@@ -424,7 +418,7 @@ static int erosion_resident_workgroups()
 // synchronised, like the reference's erodeZone); maxPassesDev (device, may be null) is raised to the largest pass count with the stream.
 int erode_zones(float* gathered, size_t strideFloats, int zones, float* work, mm::ErosionState* states, float* accOut, size_t accStride,
                 hipStream_t s, int* maxPasses, const int* zoneChunkIdxOut, float* layersOut, int* maxPassesDev, hipEvent_t beforeRelaxation,
-                const float* rawLayers, const float* rawHf, const int* zoneChunkIdx)
+                const float* rawLayers, const float* rawHf, const int* zoneChunkIdx, int workgroupsPerCu)
 {
     if (!gathered && !(rawLayers && rawHf && zoneChunkIdx && layersOut)) return (int)hipErrorInvalidValue;
     if (zones <= 0) return 0;
@@ -432,7 +426,7 @@ int erode_zones(float* gathered, size_t strideFloats, int zones, float* work, mm
     int* passesWord = (int*)(ticket + 1);
     MMK_LAUNCH(KID_ERODE_INIT, mm::k_erode_init, dim3((2 * ZN + 255) / 256, zones), dim3(256), s, states, work, zones, ticket);
     // as many workgroups per zone as keep the whole launch resident (a zone's 144 tiles are dealt out to them round by round)
-    int perZone = erosion_resident_workgroups() / zones;
+    int perZone = erosion_resident_workgroups(workgroupsPerCu) / zones;
     perZone = perZone < 1 ? 1 : (perZone > 144 ? 144 : perZone);
     perZone = (144 + (144 + perZone - 1) / perZone - 1) / ((144 + perZone - 1) / perZone);      // fewest workgroups with the same tiles per round
     if (beforeRelaxation) { hipError_t e = hipEventRecord(beforeRelaxation, s); if (e != hipSuccess) return (int)e; }

@@ -308,6 +308,9 @@ int mmgen_region_create(mmgen_region** out)
 int mmgen_region_set_serial(mmgen_region* r, int serial, int slices)
 {
     if (!r || slices < 0 || slices > mmgen_region::kMaxSlices) return (int)hipErrorInvalidValue;
+    // a change of schedule in the middle of a step (after a begin or a fill): whatever runs on the internal streams is finished first,
+    // so that the other schedule's ordering assumptions hold from here on
+    if (r->sErode) { CK(hipStreamSynchronize(r->sErode)); CK(hipStreamSynchronize(r->sFill)); CK(hipStreamSynchronize(r->sApply)); }
     r->serial = serial != 0;
     r->wantSlices = slices;
     r->layoutValid = false;
@@ -436,6 +439,12 @@ int mmgen_region_max_cave_placements(mmgen_region* r, int* out_max, void* stream
 static int region_fill_on(mmgen_region* r, uint8_t* d_blocks, hipEvent_t after0, hipEvent_t after1, hipEvent_t after2);
 // with the base fill starting the moment the caves' extents exist, the cave biomes (which only the placement stages wait for) leave it
 // most of every CU: persistent workgroups per CU of k_cave_biomes then
+// Workgroups per CU of the relaxation when it runs beside the caves, not the three that fit: it waits more than it issues (2.2 ms alone
+// at two, 1.7 at three), and at three per CU no cave workgroup fits beside it (LDS) and nothing overlaps; at two or at one the step is
+// equally long (profiles/README.md r04), two leaves the chip to the caves sooner
+#ifndef MMGEN_REGION_EROSION_WG_PER_CU
+#define MMGEN_REGION_EROSION_WG_PER_CU 2
+#endif
 static constexpr int kCaveBiomeWorkgroupsBesideFill = 1;      // (1 / 2 / 3 / 6 per CU: 24.60 / 24.73 / 24.77 / 24.81 ms per step, profiles/README.md r04)
 
 int mmgen_region_max_gathered(mmgen_region* r, int* out_surface, int* out_cave, void* stream)
@@ -453,7 +462,10 @@ int mmgen_region_max_gathered(mmgen_region* r, int* out_surface, int* out_cave, 
 
 int mmgen_region_begin(mmgen_region* r, int cx0, int cz0, int nx, int nz, unsigned flags, const uint8_t* h_local_mask, void* stream)
 {
-    if (!r || nx <= 0 || nz <= 0) return (int)hipErrorInvalidValue;
+    if (!r) return (int)hipErrorInvalidValue;
+    uint8_t* const early = r->earlyBlocks;      // one-shot: whatever this call returns, the next begin starts without it
+    r->earlyBlocks = nullptr;
+    if (nx <= 0 || nz <= 0) return (int)hipErrorInvalidValue;
     if (__atomic_load_n(r->hostMax, __ATOMIC_RELAXED) > MMGEN_CFP_CAP) return MMGEN_ERROR_PLACEMENT_OVERFLOW;
     hipStream_t s = (hipStream_t)stream;
     const bool erosion = flags & MMGEN_REGION_EROSION, features = flags & MMGEN_REGION_FEATURES;
@@ -526,7 +538,8 @@ int mmgen_region_begin(mmgen_region* r, int cx0, int cz0, int nx, int nz, unsign
             // (no E1 copy: the relaxation reads the zones' raw planes through their chunk lists)
             CK(mmk::erode_zones(nullptr, 0, nb, r->erodeWork.as<float>(), r->erodeState.as<mm::ErosionState>(), nullptr, 0, sE, nullptr,
                                 r->zoneIdxOut.as<int>() + (size_t)z0 * 144, layersP, r->devPasses.as<int>(), par ? r->evResident : nullptr,
-                                r->layersA.as<float>(), r->hfA.as<float>(), r->zoneIdx.as<int>() + (size_t)z0 * 576));
+                                r->layersA.as<float>(), r->hfA.as<float>(), r->zoneIdx.as<int>() + (size_t)z0 * 576,
+                                par ? MMGEN_REGION_EROSION_WG_PER_CU : 0));
         }
         // ---- E3 fix-up
         CK(mmk::launch_fix_backward(layersP, np, sE));
@@ -540,19 +553,14 @@ int mmgen_region_begin(mmgen_region* r, int cx0, int cz0, int nx, int nz, unsign
     {
         mmk::StageRange sr("mmgen:caves");
         CK(mmk::launch_caves(hfP, bwP, posP, r->nCompute, r->caveP.as<mmgen_cave_layer>(), r->colInfo.as<float>(), list, colNeed, s,
-                             par ? r->evCaveVoxels : nullptr, (par && r->earlyBlocks) ? kCaveBiomeWorkgroupsBesideFill : 0,
+                             par ? r->evCaveVoxels : nullptr, (par && early) ? kCaveBiomeWorkgroupsBesideFill : 0,
                              (erosion && par) ? r->evResident : nullptr));
     }
     if (erosion && par) { CK(hipEventRecord(r->evErosion, sE)); CK(hipStreamWaitEvent(s, r->evErosion, 0)); }
     r->began = true;
     // ---- the base fill as soon as its inputs exist (the caves' extents, the eroded layers), beside the cave biomes and the placement
     // stages that only the rasterisers wait for (mmgen_region_set_output)
-    if (par && r->earlyBlocks) {
-        uint8_t* out = r->earlyBlocks;
-        r->earlyBlocks = nullptr;
-        CK(region_fill_on(r, out, /*after*/ r->evBegin, r->evCaveVoxels, erosion ? r->evErosion : nullptr));
-    }
-    r->earlyBlocks = nullptr;
+    if (par && early) CK(region_fill_on(r, early, /*after*/ r->evBegin, r->evCaveVoxels, erosion ? r->evErosion : nullptr));
 
     // ---- F1 placements (eroded layers + cave layers of every computed cell)
     if (features) {

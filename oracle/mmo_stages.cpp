@@ -428,50 +428,207 @@ bool shouldGenerateCaveAtBlock(ivec3 worldPos, float maxHeight, float oceanAndBe
 }
 
 // ===================================================================================================
-// K4 — kernGenerateCaves chunk.cu:812-937
+// K4 — kernGenerateCaves chunk.cu:812-937, restated per thread: one block = one column (blockDim = (1, 384, 1), thread y = voxel y), one
+// function per barrier-separated phase; the caller runs every thread of the block through a phase before the next one starts.
+// CANONICAL where the reference is schedule dependent: the threads run in ascending y, so the shared-memory atomicAdd of
+// the 8 ocean + beach weights (chunk.cu:846-850) sums in ascending biome order from 0.f; the layer slots are complete before the biome
+// phase reads them (the reference has no barrier there and relies on the 32 threads being one warp); flips beyond 32 layers, which the
+// reference stores into the next column's slots (chunk.cu:902-907), are dropped and counted.
 // ===================================================================================================
+struct CaveBlock {
+    float shared_maxHeight, shared_oceanAndBeachWeight;
+    int shared_isFilled[384], shared_flipHeights[384];
+    int warp_numFlips[32];                                   // what __shfl_sync hands the first warp's lanes
+};
+#define atomicAdd(ptr, value) (*(ptr) += (value))
+#define __shfl_sync(mask, var, srcLane) (warp_##var[srcLane])
+#define CANONICAL_CAVE_LAYER_OVERFLOW(storeIdx) if ((storeIdx) >= 3 * MAX_CAVE_LAYERS_PER_COLUMN) { ++g_ub.caveLayerOverflow; continue; }
+// the thread's indices (chunk.cu:824-835), for the phases whose section starts behind them
+#define KGC_THREAD                                                                      \
+    const int globalX = (blockIdx.x * blockDim.x) + threadIdx.x;                        \
+    const int chunkIdx = globalX / 16;                                                  \
+    const int x = globalX - (chunkIdx * 16);                                            \
+    const int y = (blockIdx.y * blockDim.y) + threadIdx.y;                              \
+    const int z = (blockIdx.z * blockDim.z) + threadIdx.z;                              \
+    const int idx2d = posTo2dIndex(x, z);                                               \
+    const ivec2 chunkWorldBlockPos2d = chunkWorldBlockPositions[chunkIdx];              \
+    const ivec3 worldPos = ivec3(chunkWorldBlockPos2d.x + x, y, chunkWorldBlockPos2d.y + z); \
+    (void)idx2d; (void)worldPos;
+#define KGC_SHARED                                                                      \
+    float& shared_maxHeight = blk.shared_maxHeight;                                     \
+    float& shared_oceanAndBeachWeight = blk.shared_oceanAndBeachWeight;                 \
+    int* shared_isFilled = blk.shared_isFilled;                                         \
+    int* shared_flipHeights = blk.shared_flipHeights;                                   \
+    int* warp_numFlips = blk.warp_numFlips;                                             \
+    (void)shared_maxHeight; (void)shared_oceanAndBeachWeight; (void)shared_isFilled; (void)shared_flipHeights; (void)warp_numFlips;
+
+static void kernGenerateCaves_init(const float* heightfield, const ivec2* chunkWorldBlockPositions, CaveBlock& blk, const dim3& threadIdx, const dim3& blockIdx,
+                                   const dim3& blockDim)
+{
+    KGC_SHARED
+    const int globalX = (blockIdx.x * blockDim.x) + threadIdx.x;
+
+    const int chunkIdx = globalX / 16;
+    const int x = globalX - (chunkIdx * 16);
+    const int y = (blockIdx.y * blockDim.y) + threadIdx.y;
+    const int z = (blockIdx.z * blockDim.z) + threadIdx.z;
+
+    const int idx2d = posTo2dIndex(x, z);
+
+    const ivec2 chunkWorldBlockPos2d = chunkWorldBlockPositions[chunkIdx];
+    const ivec3 worldPos = ivec3(chunkWorldBlockPos2d.x + x, y, chunkWorldBlockPos2d.y + z);
+
+    if (y == 0)
+    {
+        shared_oceanAndBeachWeight = 0.f;
+    } else if (y == 1)
+    {
+        shared_maxHeight = heightfield[256 * chunkIdx + idx2d];
+    }
+
+    __syncthreads();
+    (void)worldPos;
+}
+
+static void kernGenerateCaves_weights(const float* biomeWeights, const ivec2* chunkWorldBlockPositions, CaveBlock& blk, const dim3& threadIdx, const dim3& blockIdx,
+                                      const dim3& blockDim)
+{
+    KGC_SHARED
+    KGC_THREAD
+    if (y < numOceanAndBeachBiomes)
+    {
+        float biomeWeight = biomeWeights[devBiomeWeightsSize * chunkIdx + 256 * y + idx2d];
+        atomicAdd(&shared_oceanAndBeachWeight, biomeWeight);
+    }
+
+    __syncthreads();
+}
+
+static void kernGenerateCaves_filled(const ivec2* chunkWorldBlockPositions, CaveBlock& blk, const dim3& threadIdx, const dim3& blockIdx, const dim3& blockDim)
+{
+    KGC_SHARED
+    KGC_THREAD
+    int isThisFilled = shouldGenerateCaveAtBlock(worldPos, shared_maxHeight, shared_oceanAndBeachWeight) ? 0 : 1;
+    shared_isFilled[y] = isThisFilled;
+
+    __syncthreads();
+}
+
+static void kernGenerateCaves_flips(const ivec2* chunkWorldBlockPositions, CaveBlock& blk, const dim3& threadIdx, const dim3& blockIdx, const dim3& blockDim)
+{
+    KGC_SHARED
+    KGC_THREAD
+    const int isThisFilled = shared_isFilled[y];
+    int isNextFilled = y < 383 ? shared_isFilled[y + 1] : 0;
+    shared_flipHeights[y] = (isThisFilled != isNextFilled) ? y : -1;
+
+    __syncthreads();
+}
+
+// threads y < 384 / 32: the flips of the thread's 32 voxels moved to the front of its slice; how many there are goes to the shuffle
+static void kernGenerateCaves_compact(const ivec2* chunkWorldBlockPositions, CaveBlock& blk, const dim3& threadIdx, const dim3& blockIdx, const dim3& blockDim)
+{
+    KGC_SHARED
+    KGC_THREAD
+    if (y >= 384 / 32) return;
+        const int startLoadIdx = 32 * y;
+        int endLoadIdx = startLoadIdx;
+        for (int i = startLoadIdx; i < startLoadIdx + 32; ++i)
+        {
+            int flipHeight = shared_flipHeights[i];
+            if (flipHeight != -1)
+            {
+                shared_flipHeights[endLoadIdx] = flipHeight;
+                ++endLoadIdx;
+            }
+        }
+
+        const int numFlips = endLoadIdx - startLoadIdx;
+    warp_numFlips[y] = numFlips;
+}
+
+// threads y < 384 / 32: where the thread's flips go (the flips of the threads below it come first), and the stores into the column's
+// layer slots, two ints per layer with the biome word skipped
+static void kernGenerateCaves_store(const ivec2* chunkWorldBlockPositions, CaveLayer* caveLayers, CaveBlock& blk, const dim3& threadIdx, const dim3& blockIdx,
+                                    const dim3& blockDim)
+{
+    KGC_SHARED
+    KGC_THREAD
+    if (y >= 384 / 32) return;
+    CaveLayer* columnCaveLayers = caveLayers + (256 * MAX_CAVE_LAYERS_PER_COLUMN * chunkIdx) + (MAX_CAVE_LAYERS_PER_COLUMN * idx2d);
+    const int startLoadIdx = 32 * y, numFlips = warp_numFlips[y];
+        int startStoreIdx = 0;
+
+        for (int srcLane = 0; srcLane < 12; ++srcLane)
+        {
+            int srcLaneNumFlips = __shfl_sync(0x00000fffu, numFlips, srcLane);
+            if (srcLane < y)
+            {
+                startStoreIdx += srcLaneNumFlips;
+            }
+        }
+
+        int* columnCaveLayersInts = (int*)columnCaveLayers;
+
+        for (int i = 0; i < numFlips; ++i)
+        {
+            int storeIdx = startStoreIdx + i;
+            storeIdx += (storeIdx >> 1);
+            CANONICAL_CAVE_LAYER_OVERFLOW(storeIdx)
+            columnCaveLayersInts[storeIdx] = shared_flipHeights[startLoadIdx + i];
+        }
+}
+
+// threads y < 32: the cave biomes at the two ends of layer y of the column
+static void kernGenerateCaves_biomes(const ivec2* chunkWorldBlockPositions, CaveLayer* caveLayers, CaveBlock& blk, const dim3& threadIdx, const dim3& blockIdx,
+                                     const dim3& blockDim)
+{
+    KGC_SHARED
+    KGC_THREAD
+    if (y >= MAX_CAVE_LAYERS_PER_COLUMN) return;
+    CaveLayer* columnCaveLayers = caveLayers + (256 * MAX_CAVE_LAYERS_PER_COLUMN * chunkIdx) + (MAX_CAVE_LAYERS_PER_COLUMN * idx2d);
+    {
+        CaveLayer& caveLayer = columnCaveLayers[y];
+        const ivec2 worldBlockPos2d = chunkWorldBlockPos2d + ivec2(x, z);
+
+        if (caveLayer.start != 384)
+        {
+            caveLayer.bottomBiome = getCaveBiome(ivec3(worldBlockPos2d.x, caveLayer.start, worldBlockPos2d.y), shared_maxHeight, 329271348);
+        }
+
+        if (caveLayer.end == 384)
+        {
+            caveLayer.topBiome = CaveBiome::NONE;
+        }
+        else
+        {
+            caveLayer.topBiome = getCaveBiome(ivec3(worldBlockPos2d.x, caveLayer.end + 1, worldBlockPos2d.y), shared_maxHeight, 4982921);
+        }
+    }
+}
+#undef atomicAdd
+
+// Chunk::generateCaves for one chunk (chunk.cu:970-980): every slot {384, 384}, then the launch, one block per column
 void generateCaves(ivec2 chunkWorldBlockPos, const float* heightfield, const float* biomeWeights, CaveLayer* caveLayers)
 {
+    for (int k = 0; k < 256 * MAX_CAVE_LAYERS_PER_COLUMN; ++k) {
+        std::memset(&caveLayers[k], 0, sizeof(CaveLayer));
+        caveLayers[k].start = 384;
+        caveLayers[k].end = 384;
+    }
+    const dim3 blockSize3d{1, 384, 1};
+    CaveBlock blk;
     for (int z = 0; z < 16; ++z) {
         for (int x = 0; x < 16; ++x) {
-            const int idx2d = posTo2dIndex16(x, z);
-            const float maxHeight = heightfield[idx2d];
-            // CANONICAL: the reference sums the 8 ocean+beach weights with shared-memory atomicAdd (order unspecified,
-            // chunk.cu:846-850); canonical order is ascending biome index starting from 0.f.
-            float oceanAndBeachWeight = 0.f;
-            for (int b = 0; b < numOceanAndBeachBiomes; ++b) oceanAndBeachWeight += biomeWeights[256 * b + idx2d];
-
-            const ivec2 wp2 = chunkWorldBlockPos + ivec2{x, z};
-            int isFilled[385];
-            for (int y = 0; y < 384; ++y)
-                isFilled[y] = shouldGenerateCaveAtBlock(ivec3{wp2.x, y, wp2.y}, maxHeight, oceanAndBeachWeight) ? 0 : 1;
-            isFilled[384] = 0;
-
-            CaveLayer* col = caveLayers + MAX_CAVE_LAYERS_PER_COLUMN * idx2d;
-            for (int k = 0; k < MAX_CAVE_LAYERS_PER_COLUMN; ++k) {   // default {384, 384} (chunk.cu:970-972)
-                std::memset(&col[k], 0, sizeof(CaveLayer));
-                col[k].start = 384;
-                col[k].end = 384;
-            }
-            int numFlips = 0;
-            for (int y = 0; y < 384; ++y) {
-                if (isFilled[y] != isFilled[y + 1]) {
-                    // CANONICAL: flips beyond 32 layers overflow into the next column's slot in the reference
-                    // (chunk.cu:902-907); canonical = truncate, counted.
-                    if (numFlips >= 2 * MAX_CAVE_LAYERS_PER_COLUMN) { ++g_ub.caveLayerOverflow; break; }
-                    if ((numFlips & 1) == 0) col[numFlips >> 1].start = y;
-                    else col[numFlips >> 1].end = y;
-                    ++numFlips;
-                }
-            }
-
-            for (int k = 0; k < MAX_CAVE_LAYERS_PER_COLUMN; ++k) {
-                CaveLayer& caveLayer = col[k];
-                if (caveLayer.start != 384)
-                    caveLayer.bottomBiome = getCaveBiome(ivec3{wp2.x, caveLayer.start, wp2.y}, maxHeight, 329271348);
-                if (caveLayer.end == 384) caveLayer.topBiome = CaveBiome::NONE;
-                else caveLayer.topBiome = getCaveBiome(ivec3{wp2.x, caveLayer.end + 1, wp2.y}, maxHeight, 4982921);
-            }
+            const dim3 blockIdx{x, 0, z};
+            auto threads = [&](auto&& phase, int n) { for (int y = 0; y < n; ++y) phase(dim3{0, y, 0}); };
+            threads([&](const dim3& t) { kernGenerateCaves_init(heightfield, &chunkWorldBlockPos, blk, t, blockIdx, blockSize3d); }, 384);
+            threads([&](const dim3& t) { kernGenerateCaves_weights(biomeWeights, &chunkWorldBlockPos, blk, t, blockIdx, blockSize3d); }, 384);
+            threads([&](const dim3& t) { kernGenerateCaves_filled(&chunkWorldBlockPos, blk, t, blockIdx, blockSize3d); }, 384);
+            threads([&](const dim3& t) { kernGenerateCaves_flips(&chunkWorldBlockPos, blk, t, blockIdx, blockSize3d); }, 384);
+            threads([&](const dim3& t) { kernGenerateCaves_compact(&chunkWorldBlockPos, blk, t, blockIdx, blockSize3d); }, 384 / 32);
+            threads([&](const dim3& t) { kernGenerateCaves_store(&chunkWorldBlockPos, caveLayers, blk, t, blockIdx, blockSize3d); }, 384 / 32);
+            threads([&](const dim3& t) { kernGenerateCaves_biomes(&chunkWorldBlockPos, caveLayers, blk, t, blockIdx, blockSize3d); }, MAX_CAVE_LAYERS_PER_COLUMN);
         }
     }
 }

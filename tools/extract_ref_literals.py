@@ -279,7 +279,7 @@ def skeleton(code):
     txt = txt.replace(" default : break ;", " ").replace(" pragma unroll ", " ").replace(" __builtin_unreachable ( ) ;", " ")
     # the two statements the canonical semantics add to member functions of the reference (oracle/mmo_stages.cpp)
     txt = txt.replace(" CANONICAL_RETURN_FALSE ;", " ").replace(" CANONICAL_DECORATOR_RANGE ( pos ) ;", " ")
-    txt = txt.replace(" CANONICAL_NO_LAYER_FOUND ( thisLayerIdx , blockPtr )", " ")
+    txt = txt.replace(" CANONICAL_NO_LAYER_FOUND ( thisLayerIdx , blockPtr )", " ").replace(" CANONICAL_CAVE_LAYER_OVERFLOW ( storeIdx )", " ")
     txt = re.sub(r" \( void \) \w+ ;", " ", txt)
     txt = txt.replace(" . r ", " . x ").replace(" . g ", " . y ").replace(" . b ", " . z ")      # glm colour aliases of the components
     return canonical_blocks(txt.split())
@@ -350,7 +350,15 @@ REFERENCE_SECTIONS = [
     ("terrain/chunk.cu", "generateColumnFeaturePlacements", r"void\s+Chunk::generateColumnFeaturePlacements\s*\([^)]*\)\s*\{", ()),
     ("terrain/chunk.cu", "placeDecorators", r"void\s+Chunk::placeDecorators\s*\([^)]*\)\s*\{", ()),
     ("terrain/chunk.cu", "chunkFillPlaceBlock", r"void\s+chunkFillPlaceBlock\s*\([^{]*\)\s*\{", ()),
-    ("terrain/chunk.cu", "kernGenerateCaves", r"void\s+kernGenerateCaves\s*\([^{]*\)\s*\{", ()),
+    # kernGenerateCaves, phase by phase (its four barriers and the warp shuffle cut it into seven pieces; the oracle states each as a
+    # function of its own and runs every thread of the block through one before the next starts)
+    ("terrain/chunk.cu", "kernGenerateCaves.init", r"void\s+kernGenerateCaves\s*\([^{]*\)\s*\{", ()),
+    ("terrain/chunk.cu", "kernGenerateCaves.weights", r"void\s+kernGenerateCaves\s*\([^{]*\)\s*\{", ()),
+    ("terrain/chunk.cu", "kernGenerateCaves.filled", r"void\s+kernGenerateCaves\s*\([^{]*\)\s*\{", ()),
+    ("terrain/chunk.cu", "kernGenerateCaves.flips", r"void\s+kernGenerateCaves\s*\([^{]*\)\s*\{", ()),
+    ("terrain/chunk.cu", "kernGenerateCaves.compact", r"void\s+kernGenerateCaves\s*\([^{]*\)\s*\{", ()),
+    ("terrain/chunk.cu", "kernGenerateCaves.store", r"void\s+kernGenerateCaves\s*\([^{]*\)\s*\{", ()),
+    ("terrain/chunk.cu", "kernGenerateCaves.biomes", r"void\s+kernGenerateCaves\s*\([^{]*\)\s*\{", ()),
     # the arithmetic that is written inline in the CUDA kernels and host stages (no callee to pin): whole functions where they are plain
     # C++, the part between ANCHORS where the function is a kernel (its thread-index preamble, shared-memory staging copies and barriers
     # are orchestration; what a thread computes is not)
@@ -366,6 +374,13 @@ REFERENCE_SECTIONS = [
 ]
 # key -> (start, end): the section is the part of the function body from `start` up to `end` (None = the body's end)
 ANCHORS = {
+    "kernGenerateCaves.init": (r"const\s+int\s+globalX\s*=", r"__syncthreads"),                                # chunk.cu:824-844
+    "kernGenerateCaves.weights": (r"if\s*\(\s*y\s*<\s*numOceanAndBeachBiomes", r"__syncthreads"),               # chunk.cu:846-850
+    "kernGenerateCaves.filled": (r"int\s+isThisFilled\s*=", r"__syncthreads"),                                  # chunk.cu:854-855
+    "kernGenerateCaves.flips": (r"int\s+isNextFilled\s*=", r"__syncthreads"),                                   # chunk.cu:859-860
+    "kernGenerateCaves.compact": (r"const\s+int\s+startLoadIdx\s*=", r"int\s+startStoreIdx"),                   # chunk.cu:873-886
+    "kernGenerateCaves.store": (r"int\s+startStoreIdx\s*=", r"if\s*\(\s*y\s*<\s*MAX_CAVE_LAYERS_PER_COLUMN\s*\)"),    # chunk.cu:887-908
+    "kernGenerateCaves.biomes": (r"CaveLayer\s*&\s*caveLayer\s*=", None),                                      # chunk.cu:913-936
     "kernGenerateHeightfield": (r"const\s+int\s+idx\s*=", None),                                             # chunk.cu:160-184
     "kernGenerateLayers": (r"float\s+totalMaterialWeights\s*\[", None),                                      # chunk.cu:346-414
     "kernDoErosion.stage": (r"const\s+int\s+localX\s*=\s*threadIdx", r"__syncthreads"),                       # chunk.cu:487-555
@@ -373,6 +388,17 @@ ANCHORS = {
     "kernFill": (r"const\s+float\s+height\s*=\s*shared_layersAndHeight", None),                              # chunk.cu:1427-1509
     "Chunk.fill.lists": (r"ivec2\s+allFeaturesHeightBounds\s*=\s*ivec2", r"const\s+dim3\s+blockSize3d"),      # chunk.cu:1555-1601
 }
+
+
+# where the oracle's section ends differently from the reference's (the oracle hands a value on where the reference's function goes on)
+ORACLE_ANCHORS = {
+    "kernGenerateCaves.compact": (r"const\s+int\s+startLoadIdx\s*=", r"warp_numFlips\s*\["),
+    "kernGenerateCaves.store": (r"int\s+startStoreIdx\s*=", None),
+}
+
+
+def oracle_anchors(key):
+    return ORACLE_ANCHORS.get(key, ANCHORS.get(key))
 
 
 # where the oracle restates each reference file
@@ -384,13 +410,13 @@ ORACLE_SIGNATURES = {"rng.hpp::hash": r"uint32_t\s+hash_u32\s*\([^)]*\)\s*\{",
                      # a kernel with a barrier is two functions in the oracle (every thread runs the first, then every thread the second)
                      "chunk.cu::kernDoErosion.stage": r"void\s+kernDoErosion_stage\s*\([^{]*\)\s*\{",
                      "chunk.cu::kernDoErosion.relax": r"void\s+kernDoErosion_relax\s*\([^{]*\)\s*\{",
-                     "chunk.cu::Chunk.fill.lists": r"void\s+Chunk_fill\s*\([^{]*\)\s*\{"}
+                     "chunk.cu::Chunk.fill.lists": r"void\s+Chunk_fill\s*\([^{]*\)\s*\{",
+                     **{"chunk.cu::kernGenerateCaves." + ph: r"void\s+kernGenerateCaves_" + ph + r"\s*\([^{]*\)\s*\{"
+                        for ph in ("init", "weights", "filled", "flips", "compact", "store", "biomes")}}
 
 
 def oracle_signature(key, sig):
-    if key in ORACLE_SIGNATURES:
-        return ORACLE_SIGNATURES[key]
-    return sig.replace(r"void\s+kernGenerateCaves", r"void\s+generateCaves")
+    return ORACLE_SIGNATURES.get(key, sig)
 
 
 def main(out_path):

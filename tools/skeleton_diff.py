@@ -14,7 +14,7 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from extract_ref_literals import REF, REFERENCE_SECTIONS, sections, skeleton, strip_comments   # noqa: E402
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-from extract_ref_literals import ANCHORS, ORACLE_FILES, oracle_signature   # noqa: E402
+from extract_ref_literals import ANCHORS, ORACLE_FILES, oracle_anchors, oracle_signature   # noqa: E402
 
 
 def main():
@@ -28,7 +28,7 @@ def main():
         if base not in cache_o:
             cache_o[base] = "\n".join(strip_comments(open(os.path.join(ROOT, p)).read()) for p in ORACLE_FILES[base])
         rs = sections(cache_r[rel], sig, prefixes, ANCHORS.get(key))
-        os_ = sections(cache_o[base], oracle_signature(f"{base}::{key}", sig), prefixes, ANCHORS.get(key))
+        os_ = sections(cache_o[base], oracle_signature(f"{base}::{key}", sig), prefixes, oracle_anchors(key))
         for name, code in rs.items():
             k = f"{base}::{key}" + (f"::{name}" if name else "")
             a, b = skeleton(code), skeleton(os_.get(name, ""))
