@@ -759,7 +759,9 @@ MM_DEV int filter_round(const Entry* __restrict__ list, int r0, int wx0, int wz0
 }
 
 #ifndef MM_APPLY_WAVES
-#define MM_APPLY_WAVES 3        // 168 VGPRs: the union of the 31 rasterisers
+#define MM_APPLY_WAVES 4        // waves per SIMD = persistent workgroups per CU.  Left alone the union of the 31 rasterisers takes 155 VGPRs (3 waves);
+                                // held to 128 the compiler still needs no scratch, 4 x 40 080 B of LDS just fit a CU, and a unit's chain of
+                                // dependent round trips has a third more waves to hide behind: 1.36 -> 1.25 ms (round 4)
 #endif
 // Persistent workgroups of four independent WAVES; a wave takes one UNIT (APPLY_UNIT_W x APPLY_UNIT_H columns of a chunk) at a time and
 // STREAMS it through three bounded per-wave LDS buffers (one loop, every step's code exists once):
