@@ -45,9 +45,11 @@ int erode_zones(float* gathered, size_t strideFloats, int zones, float* work, mm
                 // gathered == null (region path): the raw planes are read straight from the chunk-major raw layers / heightfields through
                 // the zones' 24 x 24 chunk lists ([zones][576]) - no k_erosion_gather, no packed copy
                 const float* rawLayers = nullptr, const float* rawHf = nullptr, const int* zoneChunkIdx = nullptr,
-                // workgroups per CU of the persistent launch: 0 = as many as fit (the fastest relaxation on its own); a caller that runs
-                // another kernel beside it leaves room (the region: two - the caves' workgroups take the rest of every CU)
-                int workgroupsPerCu = 0);
+                // workgroups of the persistent launch per FOUR CUs: 0 = as many as fit (the fastest relaxation on its own); a caller that
+                // runs another kernel beside it leaves room (the region: the caves' workgroups take the rest of every CU)
+                int workgroupsPer4Cu = 0,
+                // out (nullable): a device word that counts the persistent launch's workgroups as they start, and the value it reaches
+                const unsigned** startedCounter = nullptr, unsigned* startedTarget = nullptr);
 int erosion_gather(const float* layers, const float* hf, const int* zoneChunkIdx, int zones, float* gathered, size_t strideFloats, hipStream_t s);
 int erosion_scatter(const float* gathered, size_t strideFloats, const int* zoneChunkIdxOut, int zones, float* layersOut, hipStream_t s);
 }  // namespace mmk

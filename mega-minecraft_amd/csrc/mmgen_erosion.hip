@@ -399,8 +399,8 @@ size_t erosion_work_bytes(int zones) { return (size_t)zones * ZONE_WORK_FLOATS *
 // the zones' states, then one more record's worth of words: [0] = the launch's ticket counter, [1] = largest pass count of the zones
 size_t erosion_state_bytes(int zones) { return (size_t)(zones + 1) * sizeof(mm::ErosionState); }
 
-// workgroups of k_erode_zones the chip holds at once (LDS-bound: three per CU on gfx950), or `perCuCap` per CU if that is fewer
-static int erosion_resident_workgroups(int perCuCap)
+// workgroups of k_erode_zones the chip holds at once (LDS-bound: three per CU on gfx950), or `quarterCuCap` / 4 per CU if that is fewer
+static int erosion_resident_workgroups(int quarterCuCap)
 {
     static std::atomic<int> perCuCached{0};                 // (the kernel's occupancy is the same on every gfx950)
     int perCu = perCuCached.load(std::memory_order_relaxed);
@@ -408,9 +408,12 @@ static int erosion_resident_workgroups(int perCuCap)
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, mm::k_erode_zones, EROSION_THREADS, 0) != hipSuccess || perCu < 1) perCu = 1;
         perCuCached.store(perCu, std::memory_order_relaxed);
     }
-    if (perCuCap > 0 && perCu > perCuCap) perCu = perCuCap;
-    const int cus = device_cus();
-    return perCu * (cus > 0 ? cus : 1);
+    int cus = device_cus();
+    if (cus < 1) cus = 1;
+    const int fit = perCu * cus;
+    if (quarterCuCap <= 0) return fit;
+    const int cap = (int)((long long)cus * quarterCuCap / 4);
+    return cap < fit ? (cap > 0 ? cap : 1) : fit;
 }
 
 // Enqueues the relaxation of `zones` packed zone buffers (stride in floats) to convergence: ONE persistent launch, then the kernel that
@@ -418,7 +421,8 @@ static int erosion_resident_workgroups(int perCuCap)
 // synchronised, like the reference's erodeZone); maxPassesDev (device, may be null) is raised to the largest pass count with the stream.
 int erode_zones(float* gathered, size_t strideFloats, int zones, float* work, mm::ErosionState* states, float* accOut, size_t accStride,
                 hipStream_t s, int* maxPasses, const int* zoneChunkIdxOut, float* layersOut, int* maxPassesDev, hipEvent_t beforeRelaxation,
-                const float* rawLayers, const float* rawHf, const int* zoneChunkIdx, int workgroupsPerCu)
+                const float* rawLayers, const float* rawHf, const int* zoneChunkIdx, int workgroupsPer4Cu, const unsigned** startedCounter,
+                unsigned* startedTarget)
 {
     if (!gathered && !(rawLayers && rawHf && zoneChunkIdx && layersOut)) return (int)hipErrorInvalidValue;
     if (zones <= 0) return 0;
@@ -426,10 +430,14 @@ int erode_zones(float* gathered, size_t strideFloats, int zones, float* work, mm
     int* passesWord = (int*)(ticket + 1);
     MMK_LAUNCH(KID_ERODE_INIT, mm::k_erode_init, dim3((2 * ZN + 255) / 256, zones), dim3(256), s, states, work, zones, ticket);
     // as many workgroups per zone as keep the whole launch resident (a zone's 144 tiles are dealt out to them round by round)
-    int perZone = erosion_resident_workgroups(workgroupsPerCu) / zones;
+    int perZone = erosion_resident_workgroups(workgroupsPer4Cu) / zones;
     perZone = perZone < 1 ? 1 : (perZone > 144 ? 144 : perZone);
     perZone = (144 + (144 + perZone - 1) / perZone - 1) / ((144 + perZone - 1) / perZone);      // fewest workgroups with the same tiles per round
     if (beforeRelaxation) { hipError_t e = hipEventRecord(beforeRelaxation, s); if (e != hipSuccess) return (int)e; }
+    // the launch's ticket counts the workgroups that have STARTED (k_erode_init has just cleared it): a caller that wants them on the chip
+    // before it launches something that takes every slot waits for the counter to reach the grid size (launch_caves)
+    if (startedCounter) *startedCounter = ticket;
+    if (startedTarget) *startedTarget = (unsigned)(zones * perZone);
     MMK_LAUNCH(KID_ERODE_PASS, mm::k_erode_zones, dim3(zones * perZone), dim3(EROSION_THREADS), s, (const float*)gathered, strideFloats, rawLayers, rawHf,
                zoneChunkIdx, work, states, ticket, perZone, passesWord, maxPassesDev);
     if (layersOut) {

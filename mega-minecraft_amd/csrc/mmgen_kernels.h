@@ -6,13 +6,16 @@
 
 namespace mmk {
 int launch_heightfield(const int32_t* pos, int n, float* hf, float* bw, float* gathered /*nullable*/, hipStream_t s);
-int launch_layers(const float* gathered, const float* bw, const int32_t* pos, int n, float* layers, hipStream_t s);
+int launch_layers(const float* gathered, const float* bw, const int32_t* pos, int n, float* layers, hipStream_t s,
+                  float* stratifiedCopy = nullptr /*the first nCopy chunks' twelve stratified layers are also stored here ([chunk][20][256] layout)*/,
+                  int nCopy = 0);
 int launch_fix_backward(float* layers, int n, hipStream_t s);
 int launch_caves(const float* hf, const float* bw, const int32_t* pos, int n, mmgen_cave_layer* caveLayers, float* colInfoScratch,
                  const int* chunkList /*nullable: chunks to process*/, const uint8_t* colNeed /*nullable: [chunk][256], lazy ring*/, hipStream_t s,
                  hipEvent_t afterVoxels = nullptr /*recorded once the layers' extents are final (before their biomes)*/,
                  int biomeWorkgroupsPerCu = 0 /*0 = as many as fit; fewer leave room for a kernel that runs beside k_cave_biomes*/,
-                 hipEvent_t beforeVoxels = nullptr /*the stream waits for it between k_cave_columns and k_cave_voxels*/);
+                 hipEvent_t beforeVoxels = nullptr /*the stream waits for it between k_cave_columns and k_cave_voxels*/,
+                 const unsigned* waitCounter = nullptr, unsigned waitTarget = 0 /*... and then until *waitCounter >= waitTarget (bounded)*/);
 int launch_fill(const float* hf, const float* bw, const float* layers, const mmgen_cave_layer* caveLayers, const int32_t* pos, int n,
                 uint8_t* blocks, const int* srcIdx /*nullable: input chunk of each output chunk*/,
                 unsigned* lushQueue /*nullable device scratch: deferred clay / moss voxels*/, size_t lushQueueBytes, bool allInPruneDomain /* every chunk within MM_PRUNE_DOMAIN blocks of the origin: k_fill_far is not launched */, hipStream_t s,

@@ -95,7 +95,8 @@ MM_DEV float stratified_thickness(int layer, float weight, float wx, float wz)
 }
 
 __global__ void __launch_bounds__(256)
-k_layers(const float* __restrict__ gathered, const float* __restrict__ bw, const int2* __restrict__ chunkPos, float* __restrict__ layers)
+k_layers(const float* __restrict__ gathered, const float* __restrict__ bw, const int2* __restrict__ chunkPos, float* __restrict__ layers,
+         float* __restrict__ stratifiedCopy /*nullable*/, int nCopy)
 {
     noise_tables_init();
     __shared__ float s_h[MMGEN_GATHERED_HEIGHTFIELD_SIZE];
@@ -131,6 +132,9 @@ k_layers(const float* __restrict__ gathered, const float* __restrict__ bw, const
     }
 
     float* out = layers + (size_t)MMGEN_LAYERS_SIZE * chunk + t;
+    // region path with erosion: the first nCopy chunks' twelve stratified layers also go straight to the buffer the eroded planes will join
+    // (what a device copy of all twenty layers did on the erosion branch's critical path)
+    float* out2 = (stratifiedCopy && chunk < nCopy) ? stratifiedCopy + (size_t)MMGEN_LAYERS_SIZE * chunk + t : nullptr;
 
     // forward stratified layers 0..9: start = running height; stop accumulating once above the surface.  Layers after
     // the stop carry the running height (the reference leaves them unwritten; they never influence a block).
@@ -139,6 +143,7 @@ k_layers(const float* __restrict__ gathered, const float* __restrict__ bw, const
 #pragma unroll
     for (int l = 0; l < MMGEN_NUM_FORWARD_MATERIALS; ++l) {
         out[256 * l] = height;
+        if (out2) out2[256 * l] = height;
         if (!stopped) {
             if (height > maxHeight || l == MMGEN_NUM_FORWARD_MATERIALS - 1) stopped = true;
             else height += stratified_thickness(l, tw[l], wx, wz);
@@ -150,6 +155,7 @@ k_layers(const float* __restrict__ gathered, const float* __restrict__ bw, const
     for (int l = MMGEN_NUM_STRATIFIED_MATERIALS - 1; l >= MMGEN_NUM_FORWARD_MATERIALS; --l) {
         height += stratified_thickness(l, tw[l], wx, wz);
         out[256 * l] = height;
+        if (out2) out2[256 * l] = height;
     }
     // eroded layers 19..12 from the surface down, thinned by slope
     height = maxHeight;
@@ -179,6 +185,16 @@ __global__ void __launch_bounds__(256) k_fix_backward(float* __restrict__ layers
 //                    reachable 8x8x7 cell box staged in LDS; solid/air bits → LDS bit words → popcount ranks → (start,end) runs
 //   k_cave_biomes  : the occupied layer slots' (bottom, top) cave-biome evaluations, streamed by persistent waves 64 at a time
 // =========================================================================================================
+// one wave, one lane working: returns when *counter >= target or after ~3 ms (the wait is an optimisation, never a condition)
+__global__ void __launch_bounds__(64) k_wait_counter(const unsigned* counter, unsigned target)
+{
+    if (threadIdx.x != 0) return;
+    for (int i = 0; i < 4096; ++i) {
+        if (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) return;
+        __builtin_amdgcn_s_sleep(32);
+    }
+}
+
 __global__ void __launch_bounds__(256)
 k_cave_columns(const float* __restrict__ bw, const int2* __restrict__ chunkPos, float2* __restrict__ colInfo, const int* __restrict__ chunkList)
 {
@@ -1039,7 +1055,7 @@ MM_DEV void fill_body(const float* __restrict__ hf, const float* __restrict__ bw
 #define FILLC_LUSH_CAP 128       // per wave: lush voxels waiting for a queue reservation
 
 #ifndef MM_FILLB_WAVES
-#define MM_FILLB_WAVES 7          // what 21.7 KB of LDS per workgroup allows
+#define MM_FILLB_WAVES 8          // 64 VGPRs without scratch; 16.4 KB of LDS per workgroup would allow nine (7 -> 8: 1.73 -> 1.66 ms, round 4)
 #endif
 __attribute__((amdgpu_waves_per_eu(MM_FILLB_WAVES, MM_FILLB_WAVES)))
 __global__ void __launch_bounds__(FILLB_THREADS)
@@ -1460,10 +1476,10 @@ int launch_heightfield(const int32_t* pos, int n, float* hf, float* bw, float* g
     return 0;
 }
 
-int launch_layers(const float* gathered, const float* bw, const int32_t* pos, int n, float* layers, hipStream_t s)
+int launch_layers(const float* gathered, const float* bw, const int32_t* pos, int n, float* layers, hipStream_t s, float* stratifiedCopy, int nCopy)
 {
     if (n <= 0) return 0;
-    LAUNCH(KID_LAYERS, mm::k_layers, dim3(n), dim3(256), s, gathered, bw, (const int2*)pos, layers);
+    LAUNCH(KID_LAYERS, mm::k_layers, dim3(n), dim3(256), s, gathered, bw, (const int2*)pos, layers, stratifiedCopy, nCopy);
     return 0;
 }
 
@@ -1475,12 +1491,17 @@ int launch_fix_backward(float* layers, int n, hipStream_t s)
 }
 
 int launch_caves(const float* hf, const float* bw, const int32_t* pos, int n, mmgen_cave_layer* caveLayers, float* colInfoScratch,
-                 const int* chunkList, const uint8_t* colNeed, hipStream_t s, hipEvent_t afterVoxels, int biomeWorkgroupsPerCu, hipEvent_t beforeVoxels)
+                 const int* chunkList, const uint8_t* colNeed, hipStream_t s, hipEvent_t afterVoxels, int biomeWorkgroupsPerCu, hipEvent_t beforeVoxels,
+                 const unsigned* waitCounter, unsigned waitTarget)
 {
     if (n <= 0) return 0;
     LAUNCH(KID_CAVE_COLUMNS, mm::k_cave_columns, dim3(n), dim3(256), s, bw, (const int2*)pos, (float2*)colInfoScratch, chunkList);
     // (the per-column pass is small and runs beside whatever the event stands for; the voxel launch is the one that takes the chip)
     if (beforeVoxels) { const hipError_t ew = hipStreamWaitEvent(s, beforeVoxels, 0); if (ew != hipSuccess) return (int)ew; }
+    // ... and, where that something is a persistent launch that must be ON THE CHIP first (the relaxation: a few hundred workgroups that
+    // spin on each other), one lane watches its started-workgroups counter for a moment: an event only orders the two launches' eligibility,
+    // and whichever dispatcher is faster then wins the slots (measured: without this the order flips with a 90 us change upstream)
+    if (waitCounter && waitTarget) LAUNCH(KID_CAVE_COLUMNS, mm::k_wait_counter, dim3(1), dim3(64), s, waitCounter, waitTarget);
     LAUNCH(KID_CAVE_VOXELS, mm::k_cave_voxels, dim3(n * 16), dim3(CAVE_THREADS), s, hf, (const float2*)colInfoScratch, (const int2*)pos, caveLayers, chunkList, colNeed);
     // the layers' extents are final here (what the base fill reads); their biomes follow
     if (afterVoxels) { const hipError_t ee = hipEventRecord(afterVoxels, s); if (ee != hipSuccess) return (int)ee; }

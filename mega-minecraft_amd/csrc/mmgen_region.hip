@@ -439,11 +439,13 @@ int mmgen_region_max_cave_placements(mmgen_region* r, int* out_max, void* stream
 static int region_fill_on(mmgen_region* r, uint8_t* d_blocks, hipEvent_t after0, hipEvent_t after1, hipEvent_t after2);
 // with the base fill starting the moment the caves' extents exist, the cave biomes (which only the placement stages wait for) leave it
 // most of every CU: persistent workgroups per CU of k_cave_biomes then
-// Workgroups per CU of the relaxation when it runs beside the caves, not the three that fit: it waits more than it issues (2.2 ms alone
-// at two, 1.7 at three), and at three per CU no cave workgroup fits beside it (LDS) and nothing overlaps; at two or at one the step is
-// equally long (profiles/README.md r04), two leaves the chip to the caves sooner
-#ifndef MMGEN_REGION_EROSION_WG_PER_CU
-#define MMGEN_REGION_EROSION_WG_PER_CU 2
+// Workgroups of the relaxation per four CUs when it runs beside the caves (46.7 KB of LDS, 8 waves each): ONE per CU.  It waits more than it
+// issues (4.5 ms alone at one per CU, 2.2 at two, 1.7 at three), the caves take the rest of every CU (four of their workgroups fit beside
+// one of these, two beside two, none beside three), and what the relaxation costs the caves is its occupancy-time, which is smallest
+// here: with every workgroup of it on the chip before the caves start (launch_caves' counter watch) 3 / 4 / 5 / 6 per four CUs give
+// 24.18 / 24.11 / 24.17 / 24.45 ms per step (profiles/README.md r04)
+#ifndef MMGEN_REGION_EROSION_WG_PER_4CU
+#define MMGEN_REGION_EROSION_WG_PER_4CU 4
 #endif
 static constexpr int kCaveBiomeWorkgroupsBesideFill = 1;      // (1 / 2 / 3 / 6 per CU: 24.60 / 24.73 / 24.77 / 24.81 ms per step, profiles/README.md r04)
 
@@ -494,11 +496,14 @@ int mmgen_region_begin(mmgen_region* r, int cx0, int cz0, int nx, int nz, unsign
         CK(r->counts.ensure(sizeof(int) * 2 * np));
     }
 
-    // ---- K1 + K2 on the raw area A
+    // ---- K1 + K2 on the raw area A.  With erosion the P grid's layers exist twice (raw in A for the zones' padding, eroded in P): K2 stores
+    // the twelve stratified layers of the P cells - the head of A's order - into both, the eight eroded ones arrive from the relaxation
+    if (erosion) CK(r->layersP.ensure(sizeof(float) * MMGEN_LAYERS_SIZE * (size_t)np));
     {
         mmk::StageRange sr("mmgen:heightfield+layers");
         CK(mmk::launch_heightfield(r->posA.as<int32_t>(), na, r->hfA.as<float>(), r->bwA.as<float>(), r->gathA.as<float>(), s));
-        CK(mmk::launch_layers(r->gathA.as<float>(), r->bwA.as<float>(), r->posA.as<int32_t>(), na, r->layersA.as<float>(), s));
+        CK(mmk::launch_layers(r->gathA.as<float>(), r->bwA.as<float>(), r->posA.as<int32_t>(), na, r->layersA.as<float>(), s,
+                              erosion ? r->layersP.as<float>() : nullptr, erosion ? np : 0));
     }
 
     float *hfP, *bwP, *layersP;
@@ -506,7 +511,6 @@ int mmgen_region_begin(mmgen_region* r, int cx0, int cz0, int nx, int nz, unsign
     if (erosion) {
         // The P grid's arrays are the first np chunks of A's (region_layout orders A that way); only the layers exist twice: eroded planes
         // are scattered into layersP, layersA stays raw for the other zones' padding (the copy goes with the erosion branch).
-        CK(r->layersP.ensure(sizeof(float) * MMGEN_LAYERS_SIZE * (size_t)np));
         hfP = r->hfA.as<float>(); bwP = r->bwA.as<float>(); layersP = r->layersP.as<float>(); posP = r->posA.as<int32_t>();
         if (par) { CK(hipEventRecord(r->evK2, s)); CK(hipStreamWaitEvent(sE, r->evK2, 0)); }
     } else {
@@ -523,23 +527,25 @@ int mmgen_region_begin(mmgen_region* r, int cx0, int cz0, int nx, int nz, unsign
         colNeed = r->colNeed.as<uint8_t>();
     }
 
+    const unsigned* startedCounter = nullptr;      // the relaxation's started-workgroups counter (one zone batch only: the next batch re-uses it)
+    unsigned startedTarget = 0u;
     // ---- E1 / K3 / E3: the erosion branch, enqueued FIRST.  The relaxation is one persistent launch per zone batch (no host reads): its
     // workgroups are on the chip before the caves' launch starts to fill every free slot, and then run beside it
     if (erosion) {
         mmk::StageRange sr("mmgen:erosion");
         CK(hipMemsetAsync(r->devPasses.p, 0, sizeof(int), sE));
-        CK(hipMemcpyAsync(layersP, r->layersA.p, sizeof(float) * MMGEN_LAYERS_SIZE * (size_t)np, hipMemcpyDeviceToDevice, sE));
         const int Z = r->nZones;
         const int batch = Z < MMGEN_EROSION_ZONE_BATCH ? Z : MMGEN_EROSION_ZONE_BATCH;
         CK(r->erodeWork.ensure(mmk::erosion_work_bytes(batch)));
         CK(r->erodeState.ensure(mmk::erosion_state_bytes(batch)));
+        startedCounter = nullptr; startedTarget = 0u;
         for (int z0 = 0; z0 < Z; z0 += batch) {
             const int nb = (Z - z0) < batch ? (Z - z0) : batch;
             // (no E1 copy: the relaxation reads the zones' raw planes through their chunk lists)
             CK(mmk::erode_zones(nullptr, 0, nb, r->erodeWork.as<float>(), r->erodeState.as<mm::ErosionState>(), nullptr, 0, sE, nullptr,
                                 r->zoneIdxOut.as<int>() + (size_t)z0 * 144, layersP, r->devPasses.as<int>(), par ? r->evResident : nullptr,
                                 r->layersA.as<float>(), r->hfA.as<float>(), r->zoneIdx.as<int>() + (size_t)z0 * 576,
-                                par ? MMGEN_REGION_EROSION_WG_PER_CU : 0));
+                                par ? MMGEN_REGION_EROSION_WG_PER_4CU : 0, (par && Z <= batch) ? &startedCounter : nullptr, &startedTarget));
         }
         // ---- E3 fix-up
         CK(mmk::launch_fix_backward(layersP, np, sE));
@@ -554,7 +560,7 @@ int mmgen_region_begin(mmgen_region* r, int cx0, int cz0, int nx, int nz, unsign
         mmk::StageRange sr("mmgen:caves");
         CK(mmk::launch_caves(hfP, bwP, posP, r->nCompute, r->caveP.as<mmgen_cave_layer>(), r->colInfo.as<float>(), list, colNeed, s,
                              par ? r->evCaveVoxels : nullptr, (par && early) ? kCaveBiomeWorkgroupsBesideFill : 0,
-                             (erosion && par) ? r->evResident : nullptr));
+                             (erosion && par) ? r->evResident : nullptr, startedCounter, startedTarget));
     }
     if (erosion && par) { CK(hipEventRecord(r->evErosion, sE)); CK(hipStreamWaitEvent(s, r->evErosion, 0)); }
     r->began = true;
