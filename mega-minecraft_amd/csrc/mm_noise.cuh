@@ -488,6 +488,8 @@ MM_DEV Worley2 worley2(float px, float py)
 
 // Direct (no table) provider of 3D cell points.
 struct CellDirect {
+    static constexpr int kBoxStrideX = 0, kBoxStrideY = 0;
+    MM_DEV const float* box27(int, int, int) const { return nullptr; }     // nothing staged: special_cave_noise takes its generic loop
     MM_DEV f3 operator()(int cx, int cy, int cz) const { return rand3from3((float)cx, (float)cy, (float)cz); }
     MM_DEV void row3(int cx, int cy, int cz, f3 (&out)[3]) const
     {
@@ -525,12 +527,60 @@ MM_DEV Worley3 worley3(float px, float py, float pz, const Cells& cells)
 // specialCaveNoise (rng.hpp:300-320) only uses the VALUES of the first and third smallest distance.  sqrt is monotonic and
 // correctly rounded, so the three smallest sqrt(d2) are the sqrt of the three smallest d2 whatever the tie order: the search
 // runs on squared distances and takes 2 square roots instead of 27.
+// Fast path of the search when the 27 cells are staged in LDS (Cells::box27): same values, fewer instructions.
+//  * The three smallest of a multiset do not depend on the order the cells are visited in, and the update of (s1 <= s2 <= s3) by a
+//    value u is s3' = med3(s2, s3, u), s2' = med3(s1, s2, u), s1' = min(s1, u).  Squared distances are finite, >= +0 and never NaN for
+//    a finite position, so their order as floats is their order as unsigned integers: one v_med3_u32 each, no canonicalisation.
+//  * (float)0 + pt.x is pt.x (a cell point is never -0), so the centre slabs skip that addition.
+//  * Exact skip of whole (x, y) columns of cells.  A cell point lies in [0, 1]^3 of its cell, so in the cells x = -1 the computed
+//    dx = fl(fl(-1 + pt.x) - fx) <= -fx and in x = +1 dx >= fl(1 - fx) >= 0 (rounding is monotone), hence fl(dx dx) >= fl(fx fx) resp.
+//    fl(gx gx) with gx = fl(1 - fx); likewise y; and d2 = fl(fl(dx dx + dy dy) + dz dz) >= fl(bx + by) with those bounds (0 in the centre
+//    slab).  A cell with d2 >= s3 leaves (s1, s2, s3) as they are, so a column whose bound is >= s3 in every lane of the wave is not
+//    evaluated (a NaN bound never skips).  Centre column first, then the four face columns, then the four corner columns: s3 is small by
+//    the time the far ones are tested.  The lanes of a wave are neighbours in space, so they mostly agree.
+#ifndef MM_WORLEY_FAST
+#define MM_WORLEY_FAST 1
+#endif
+MM_DEV unsigned med3_u32(unsigned a, unsigned b, unsigned c)
+{
+    const unsigned lo = a < b ? a : b, hi = a < b ? b : a;
+    const unsigned m = lo > c ? lo : c;          // max(min(a, b), c)
+    return hi < m ? hi : m;                      // min(max(a, b), max(min(a, b), c))
+}
+
 template <class Cells>
 MM_DEV float special_cave_noise(float px, float py, float pz, const Cells& cells)
 {
     const float flx = __builtin_floorf(px), fly = __builtin_floorf(py), flz = __builtin_floorf(pz);
     const int ux = (int)flx, uy = (int)fly, uz = (int)flz;
     const float fx = px - flx, fy = py - fly, fz = pz - flz;
+#if MM_WORLEY_FAST
+    if (const float* box = cells.box27(ux, uy, uz)) {          // the point of cell (ux - 1, uy - 1, uz - 1); x stride Cells::kBoxStrideX, y stride kBoxStrideY, z stride 3
+        unsigned u1 = 0x7f7fffffu, u2 = 0x7f7fffffu, u3 = 0x7f7fffffu;
+        auto column = [&](int x, int y) {
+            const float* p = box + (x + 1) * Cells::kBoxStrideX + (y + 1) * Cells::kBoxStrideY;
+#pragma unroll
+            for (int z = -1; z <= 1; ++z) {
+                const float qx = p[3 * (z + 1)], qy = p[3 * (z + 1) + 1], qz = p[3 * (z + 1) + 2];
+                const float dx = (x == 0 ? qx : (float)x + qx) - fx, dy = (y == 0 ? qy : (float)y + qy) - fy, dz = (z == 0 ? qz : (float)z + qz) - fz;
+                const unsigned u = __float_as_uint((dx * dx + dy * dy) + dz * dz);
+                u3 = med3_u32(u2, u3, u); u2 = med3_u32(u1, u2, u); u1 = u1 < u ? u1 : u;
+            }
+        };
+        const float gx = 1.f - fx, gy = 1.f - fy;
+        const float bxm = fx * fx, bxp = gx * gx, bym = fy * fy, byp = gy * gy;
+        column(0, 0);
+        if (!(bxm >= __uint_as_float(u3))) column(-1, 0);
+        if (!(bxp >= __uint_as_float(u3))) column(1, 0);
+        if (!(bym >= __uint_as_float(u3))) column(0, -1);
+        if (!(byp >= __uint_as_float(u3))) column(0, 1);
+        if (!((bxm + bym) >= __uint_as_float(u3))) column(-1, -1);
+        if (!((bxm + byp) >= __uint_as_float(u3))) column(-1, 1);
+        if (!((bxp + bym) >= __uint_as_float(u3))) column(1, -1);
+        if (!((bxp + byp) >= __uint_as_float(u3))) column(1, 1);
+        return __builtin_sqrtf(__uint_as_float(u3)) / __builtin_sqrtf(__uint_as_float(u1)) - 1.f;
+    }
+#endif
     float s1 = 3.402823466e+38f, s2 = 3.402823466e+38f, s3 = 3.402823466e+38f;
     // 9 rolled (x, y) steps of 3 unrolled z cells: a fully unrolled search hoists all 81 cell-point loads and spills
 #pragma unroll 1

@@ -273,6 +273,14 @@ MM_DEV float cave_huge(float x, float y, float z, float b3 /* MM_SIMPLEX3_BOUND 
 struct CellTile {
     const float* pts;     // LDS, 3 floats per cell
     int ox, oy, oz;
+    static constexpr int kBoxStrideX = 3 * CELL_NY * CELL_NZ, kBoxStrideY = 3 * CELL_NZ;
+    // the staged point of cell (ux - 1, uy - 1, uz - 1) when all 27 cells around (ux, uy, uz) are staged, else null
+    MM_DEV const float* box27(int ux, int uy, int uz) const
+    {
+        const int ix = ux - 1 - ox, iy = uy - 1 - oy, iz = uz - 1 - oz;
+        if ((unsigned)ix <= CELL_NX - 3 && (unsigned)iy <= CELL_NY - 3 && (unsigned)iz <= CELL_NZ - 3) return pts + 3 * ((ix * CELL_NY + iy) * CELL_NZ + iz);
+        return nullptr;
+    }
     MM_DEV f3 operator()(int cx, int cy, int cz) const
     {
         const int ix = cx - ox, iy = cy - oy, iz = cz - oz;
