@@ -240,19 +240,19 @@ MM_DEV bool prune_domain(int wx, int wz) { return wx > -MM_PRUNE_DOMAIN && wx < 
 // the probe tests against real glm).
 // ---------------------------------------------------------------------------------------------------------
 // The corner ordering: g = step(x0.yzx, x0), l = 1 - g, i1 = min(g, l.zxy), i2 = max(g, l.zxy) are all in {0, 1}, so min / max are AND /
-// OR of the three order predicates: a AND NOT b is "a > b", a OR NOT b is "a >= b" on {0, 1}.  Written as comparisons on purpose: the
-// compiler turns them into AND / OR of two lane masks (one s_andn2 / s_orn2 on the scalar unit for the whole wave, each use a single
-// v_cndmask), whereas `a && !b` becomes select(a, !b, false) in its IR and from there a NESTED per-lane select (9 VALU for the six), and
-// `a & !b` is carried out in per-lane integers.
+// OR of the three order predicates and their complements: i1x = gx AND NOT gz, i2x = gx OR NOT gz, ...  The three comparisons are taken
+// as wave masks (ballot: NOT g, i.e. "x0.x < x0.y" - false for NaN exactly like step), the six combinations are s_andn2 / s_orn2 on the
+// scalar unit for the whole wave, and each use is one v_cndmask on that mask (inverse ballot): 3 VALU compares per simplex3.  Written
+// with bools the compiler emits both polarities of every comparison (6 compares), and `a && !b` becomes a nested per-lane select.
 struct Sx3Cell {
     float ix, iy, iz; float x0x, x0y, x0z;
-    bool gx, gy, gz;
-    MM_DEV bool i1x() const { return gx > gz; }
-    MM_DEV bool i1y() const { return gy > gx; }
-    MM_DEV bool i1z() const { return gz > gy; }
-    MM_DEV bool i2x() const { return gx >= gz; }
-    MM_DEV bool i2y() const { return gy >= gx; }
-    MM_DEV bool i2z() const { return gz >= gy; }
+    unsigned long long lx, ly, lz;          // wave masks of NOT gx, NOT gy, NOT gz
+    MM_DEV bool i1x() const { return __builtin_amdgcn_inverse_ballot_w64(~lx & lz); }
+    MM_DEV bool i1y() const { return __builtin_amdgcn_inverse_ballot_w64(~ly & lx); }
+    MM_DEV bool i1z() const { return __builtin_amdgcn_inverse_ballot_w64(~lz & ly); }
+    MM_DEV bool i2x() const { return __builtin_amdgcn_inverse_ballot_w64(~lx | lz); }
+    MM_DEV bool i2y() const { return __builtin_amdgcn_inverse_ballot_w64(~ly | lx); }
+    MM_DEV bool i2z() const { return __builtin_amdgcn_inverse_ballot_w64(~lz | ly); }
 };
 
 MM_DEV float sel_f(bool m, float ifSet, float ifClear) { return m ? ifSet : ifClear; }
@@ -269,7 +269,7 @@ MM_DEV Sx3Cell simplex3_part1(float vx, float vy, float vz)
     const float e = (c.ix * Cx + c.iy * Cx) + c.iz * Cx;
     c.x0x = (vx - c.ix) + e; c.x0y = (vy - c.iy) + e; c.x0z = (vz - c.iz) + e;
     // g = step(x0.yzx, x0)
-    c.gx = !(c.x0x < c.x0y); c.gy = !(c.x0y < c.x0z); c.gz = !(c.x0z < c.x0x);
+    c.lx = __builtin_amdgcn_ballot_w64(c.x0x < c.x0y); c.ly = __builtin_amdgcn_ballot_w64(c.x0y < c.x0z); c.lz = __builtin_amdgcn_ballot_w64(c.x0z < c.x0x);
     return c;
 }
 
