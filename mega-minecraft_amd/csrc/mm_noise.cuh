@@ -177,8 +177,8 @@ MM_DEV float simplex2_inl(float vx, float vy)
     const float ax = (x0x + C0) - i1x, ay = (x0y + C0) - i1y;     // x12.xy
     const float bx = x0x + C2, by = x0y + C2;                     // x12.zw
 
-    // table domain: lattice coordinates below 2^24 - 512 in magnitude (then glm::mod(x, 289) is an integer in [0, 288]); NaN fails the test
-    const bool inDomain = KNOWN_IN || (__builtin_fabsf(ix) < 16776704.f && __builtin_fabsf(iy) < 16776704.f);      // 2^24 - 512, see below
+    // table domain: lattice coordinates below 2^21 in magnitude (see the remainder below); NaN fails the test
+    const bool inDomain = KNOWN_IN || (__builtin_fabsf(ix) < 2097152.f && __builtin_fabsf(iy) < 2097152.f);
 
     // glm::max(x, 0) = (x < 0) ? 0 : x keeps a -0 that v_max_f32 turns into +0; the value is squared next, (-0)^2 = (+0)^2 = +0, and NaN
     // positions are outside every caller's domain: one instruction instead of compare + select
@@ -190,13 +190,14 @@ MM_DEV float simplex2_inl(float vx, float vy)
 
     f3 c0, c1, c2;
     if (inDomain) {
-        // glm::mod(i, 289) = i - 289 floor(i / 289) with an IEEE division (two of them are a quarter of this function's instructions).  For an
-        // integer |i| < 2^24 - 512 the correctly rounded quotient has the true quotient's floor (the nearest multiple of 289 is 1 / 289 =
-        // 0.0035 away, more than half an ulp of any quotient below 2^16), 289 * floor is at most |i| + 288 < 2^24 and therefore exact (for a
-        // negative i just below -2^24 + 288 it is not: found by test_device_simplex_lattice_hash_shortcuts), so is the subtraction: the
-        // integer remainder IS glm's value.
-        int xi = (int)ix % 289, yi = (int)iy % 289;
-        xi += xi < 0 ? 289 : 0; yi += yi < 0 ? 289 : 0;
+        // glm::mod(i, 289) = i - 289 floor(i / 289) with an IEEE division.  For an integer |i| < 2^24 - 512 that is the integer remainder r in
+        // [0, 288] (the correctly rounded quotient has the true quotient's floor, 289 * floor and the subtraction are exact;
+        // test_device_simplex_lattice_hash_shortcuts).  The remainder without a division or an integer multiply (quarter rate): for an integer
+        // |i| <= 2^21, t = i + 0.5 is exact and lies at least 0.5 from every multiple of 289, i.e. t / 289 at least 0.5 / 289 = 1.73e-3 from
+        // every integer, while fl(t * fl(1 / 289)) is within |t / 289| * 2^-23 <= 7257 * 1.2e-7 = 8.7e-4 of t / 289: its floor is
+        // floor(t / 289) = floor(i / 289), and one fused multiply-add returns i - 289 floor(i / 289) exactly (a small integer).
+        const float qx = __builtin_floorf((ix + 0.5f) * (1.f / 289.f)), qy = __builtin_floorf((iy + 0.5f) * (1.f / 289.f));
+        const int xi = (int)__builtin_fmaf(-289.f, qx, ix), yi = (int)__builtin_fmaf(-289.f, qy, iy);
         const int x16 = 16 * xi, y4 = 4 * yi;
         const int py0 = perm16(y4), py1 = perm16(y4 + 4);            // i1.y is 0 or 1: the middle corner re-uses one of the two
         const f4v t0 = grad2_at16((py0 + x16) + 16);
@@ -370,7 +371,8 @@ MM_DEV float fbm2_loop(float x, float y)
     return acc;
 }
 
-// domain test once per stack (see fbm3 below): |floor(v + (vx + vy) * 0.366)| < 2 max|v| + 1, the last octave evaluates at 2^(OCT - 1) v
+// domain test once per stack (see fbm3 below): |floor(v + (vx + vy) * 0.366)| < 2 max|v| + 1, the last octave evaluates at 2^(OCT - 1) v,
+// so max|v| < 2^(20 - OCT) keeps every lattice coordinate below 2^20 + 1 (simplex2_inl's table domain is 2^21)
 // HOIST is opt-in: it pays in the cave-biome bands (k_fill -1.2 %), and it costs k_heightfield 50 % of its time (its two dozen inlined
 // stacks sit in one divergent switch; measured, profiles/README.md r03), so the surface functions keep the per-octave test
 template <int OCT, bool HOIST = false>
@@ -378,7 +380,7 @@ MM_DEV float fbm2(float x, float y)
 {
     if (!HOIST) return fbm2_loop<OCT, false>(x, y);
     const float m = __builtin_fmaxf(__builtin_fabsf(x), __builtin_fabsf(y));
-    if (__builtin_expect(m < (float)(1 << (22 - OCT)), 1)) return fbm2_loop<OCT, true>(x, y);
+    if (__builtin_expect(m < (float)(1 << (20 - OCT)), 1)) return fbm2_loop<OCT, true>(x, y);
     // beyond the table domain (block coordinates of hundreds of millions): the shared out-of-line simplex2 with its per-call test, so that
     // the call sites carry ONE inlined loop body (k_heightfield inlines dozens of stacks: a second body each cost it 50 % of its time)
     float acc = 0.f, amp = 1.f;

@@ -29,10 +29,11 @@ def test_device_simplex_matches_real_glm(gen, golden):
 
 
 def test_device_simplex_lattice_hash_shortcuts(gen, oracle):
-    """The device replaces glm::mod(i, 289)'s IEEE division by an integer remainder (simplex2, |i| < 2^24) and mod289's multiply + subtract by
-    one fused multiply-add (simplex3, |i| < 2^23): exact by the arguments in csrc/mm_noise.cuh.  Held to the oracle (itself held to the real
-    glm on 1.6 M points) where those arguments are tight: lattice coordinates around multiples of 289, negative, up to and across the
-    two domain limits."""
+    """The device replaces glm::mod(i, 289)'s IEEE division by floor((i + 0.5) * fl(1 / 289)) and one fused multiply-add (simplex2, |i| < 2^21)
+    and mod289's multiply + subtract by one fused multiply-add (simplex3, |i| < 2^23): exact by the arguments in csrc/mm_noise.cuh (the
+    first one is also checked for every integer of its domain on the CPU, tests/test_oracle_math.py).  Held to the oracle (itself held to
+    the real glm on 1.6 M points) where those arguments are tight: lattice coordinates around multiples of 289, negative, up to and across
+    the domain limits."""
     import ctypes
     f = np.float32
     rs = np.random.RandomState(9)
@@ -47,7 +48,8 @@ def test_device_simplex_lattice_hash_shortcuts(gen, oracle):
         fn(len(a), a.ctypes.data_as(ctypes.c_void_p), out.ctypes.data_as(ctypes.c_void_p))
         return out
 
-    for scale in (5000, 4_000_000, 8_388_000 * 2, 16_777_000 * 2):             # small; large; across 2^23; across 2^24 (arguments are ~ 1.4 x the lattice coordinate)
+    # small; up to and across 2^21; large; across 2^23; across 2^24 (arguments are ~ 1.4 x the lattice coordinate)
+    for scale in (5000, 1_450_000, 3_000_000, 4_000_000, 8_388_000 * 2, 16_777_000 * 2):
         a2 = pts(2, scale, 20000)
         assert_bit_equal(gen.debug_probe("simplex2", a2, len(a2))[:, 0], ref(oracle.lib.mmo_simplex2, a2), f"simplex2 at scale {scale}")
         a3 = pts(3, scale, 20000)

@@ -144,6 +144,21 @@ def test_noise_table_domains():
     assert -1 + -1 + 0 >= -8 and 288 + 289 + 1 < 600 - 8 + 8       # chained index range vs table range [-8, 600)
 
 
+def test_simplex2_remainder_without_division():
+    """csrc/mm_noise.cuh simplex2_inl: inside its table domain (integer lattice coordinates |i| < 2^21) the device takes glm::mod(i, 289) as
+    i - 289 * floor(fl(fl(i + 0.5) * fl(1 / 289))) with one fused multiply-add.  Every integer of the domain (and a margin): the fp32 floor
+    is the true floor(i / 289), hence the remainder (a small integer, exact under the single rounding of the fma) is glm's value."""
+    f = np.float32
+    i = np.arange(-2 ** 21 - 64, 2 ** 21 + 65, dtype=np.int64)
+    x = i.astype(f)
+    assert np.array_equal(x.astype(np.int64), i)
+    q = np.floor(((x + f(0.5)).astype(f) * (f(1.0) / f(289.0))).astype(f))
+    assert np.array_equal(q.astype(np.int64), i // 289)
+    r = i - 289 * q.astype(np.int64)                                # what the fma returns: exact
+    g = (x - f(289.0) * np.floor(x / f(289.0))).astype(f)            # glm::mod(x, 289) in fp32
+    assert np.array_equal(r, g.astype(np.int64)) and r.min() == 0 and r.max() == 288
+
+
 def _oracle_tables(oracle):
     """The oracle's rule tables in the numeric layout of tools/extract_ref_tables.py."""
     t = {}
