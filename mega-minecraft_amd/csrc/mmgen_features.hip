@@ -481,7 +481,7 @@ k_gather_placements(const mmgen_feature_placement* __restrict__ fp, const mmgen_
 #define APPLY_UNITS_PER_CHUNK ((16 / APPLY_UNIT_W) * (16 / APPLY_UNIT_H))
 #define APPLY_COUNTERS 8                  // work counters per launch, 64 B apart
 #define APPLY_UNIT_CAP 128                // placements that can reach one unit, surface + cave
-#define APPLY_ENT_CAP 256                 // (placement, column) pairs of one unit with a non-empty vertical extent
+#define APPLY_ENT_CAP 192                 // (placement, column) pairs of one unit with a non-empty vertical extent
 #define APPLY_ITEM_CAP 65535              // (placement, voxel) pairs of one unit: item offsets are kept as 16-bit numbers
 static_assert(APPLY_UNIT_NCOL <= 16 && APPLY_UNIT_CAP <= 128, "s_ent packing");
 
