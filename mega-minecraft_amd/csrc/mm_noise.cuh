@@ -6,12 +6,11 @@
 // LDS tables.  The path is VALU-issue bound, so the integer-valued part of simplex noise is served from LDS: glm's permute() only ever
 // sees small integer-valued floats (lattice coordinates mod 289 plus earlier permute results), and the gradient of a lattice corner is a
 // function of the final permute value alone.  Every workgroup loads
-//   perm4[i]  = 4 * permute(i - 8)               (byte offset of the next lookup), i - 8 in [-8, 600)
-//   grad3[j]  = simplex3 corner gradient * taylorInvSqrt of permute(j - 1), j - 1 in [-1, 578]  (every index the last level can produce)
-//   grad2[j]  = simplex2 (a0, h, norm factor) of permute(j - 1) and 16 * permute(j - 1), j - 1 in [-1, 294]
+//   e[v]      = {simplex3 corner gradient * taylorInvSqrt of permute(v), 16 * permute(v)},  v in [-2, 580): every value the chain feeds to permute
+//   grad2[j]  = {simplex2 (a0, h, norm factor) of permute(j - 1), 16 * permute(j - 1)},     j - 1 in [-1, 294]
 // at kernel entry (noise_tables_init) from a per-device image that k_noise_tables_build computed with the SAME fp32 instruction
 // sequences the direct evaluation uses, so a lookup returns bit for bit what the arithmetic would have produced.  A simplex3 then costs
-// 10 LDS reads + 144 VALU instead of 325 VALU, a simplex2 5 reads + ~75 instead of 151.  Domain: mod289 of an integer-valued |x| < 2^24
+// 9 LDS reads + 142 VALU instead of 325 VALU, a simplex2 5 reads + ~75 instead of 151.  Domain: mod289 of an integer-valued |x| < 2^24
 // lies in [-1, 289] and permute of [-16, 700) in [0, 288] (tests/test_oracle_math.py::test_noise_table_domains); lattice coordinates
 // beyond the table domains (2^23 simplex3, 2^21 simplex2; reached only far out in the int32 world, tests "far coordinates") take the
 // direct arithmetic path.  EVERY kernel that can reach simplex2/simplex3 calls noise_tables_init() before its first use.
@@ -74,40 +73,32 @@ MM_DEV f3 simplex3_corner(float p)
     return mk3(g0 * nrm, g1 * nrm, hh * nrm);
 }
 
-#define MM_PERM_LO 8
-#define MM_PERM_N 608
-#define MM_GRAD3_N 580
 #define MM_GRAD2_N 296
-// Fused last level: the gradient of a corner is looked up directly with the index that used to go into the last permute,
-//   gradf[j] = corner(permute(j - 1)),  j - 1 = (b + x + o),  b in [0, 288], x in [-1, 289], o in {0, 1}.
-// simplex3 (4 corners): its table covers the whole index range [-1, 578], every entry computed from its own argument with the functions
-//   above - the lookup returns what the direct evaluation of that argument returns, with no reduction of the index.  Entries are 12 bytes
-//   (a stride of three banks: conflict-free like the 4-byte perm table), the index is 12 (b + x + o + 1) = 3 * (4 b) + 12 x + 12 (o + 1).
-//   perm4[i] = 4 * permute(i - MM_PERM_LO) is the byte offset of the next level's entry as it stands; times 3 (one 24-bit multiply-add
-//   together with the + 12 x) it is the byte offset of the gradient.
+// Fused last level: the gradient of a corner is looked up directly with the value that used to go into the last permute, (b + x + o)
+// with b in [0, 288], x in [-1, 289], o in {0, 1}.
+// simplex3 (4 corners, two perm levels): ONE table of 16-byte entries indexed by the value v fed to permute - entry v = {gradient of
+//   permute(v) (3 floats), 16 * permute(v)}.  Every index of the chain is such a value: z and z + 1 (>= -1), p + y + o and b + x + o (both
+//   in [-1, 578]), and the perm word is the byte offset of the next entry as it stands: a corner is add3, read, add3, read.  The table
+//   covers the whole range, every entry computed from its own argument with the functions above - no reduction of an index mod 289, no
+//   assumption about permute's period.  (History: 296 gradient entries + a wrap of the index cost 10 VALU more per simplex3; 12-byte
+//   gradient entries read as one ds_read_b96 at a 4-byte boundary are legal and took k_cave_voxels from 11.5 to 24.9 ms.)
 // simplex2 (3 corners, one perm level): 296 entries of 16 bytes, indices of 289 and beyond wrap, j' = min_u32(j, j - 289) in [0, 290]
 //   (permute has period 289 exactly in fp32 on this range, tests/test_oracle_math.py::test_noise_table_domains).  The fourth word of entry
-//   j is 16 * permute(j - 1), the one perm level simplex2 needs (j - 1 in [0, 289]), so that its corner index is an add.
+//   j is 16 * permute(j - 1), the one perm level simplex2 needs (j - 1 in [0, 289]).
 // Two objects (known LDS bases, immediate offsets in the non-inlined callees): a kernel that never reaches simplex2 does not reference
 // s_noise2 and does not pay its 4.6 KB.
-struct g3v { float x, y, z; };
-struct alignas(16) NoiseTables3 { g3v grad3[MM_GRAD3_N]; int perm4[MM_PERM_N]; };
+#define MM_T3_LO 2
+#define MM_T3_N 582
+struct alignas(16) NoiseTables3 { f4v e[MM_T3_N]; };
 struct alignas(16) NoiseTables2 { f4v grad2[MM_GRAD2_N]; };
-static_assert(sizeof(NoiseTables3) == 12 * MM_GRAD3_N + 4 * MM_PERM_N && sizeof(NoiseTables3) % 16 == 0 && sizeof(NoiseTables2) % 16 == 0, "copied as 16-byte words");
+static_assert(sizeof(NoiseTables3) % 16 == 0 && sizeof(NoiseTables2) % 16 == 0, "copied as 16-byte words");
 static __shared__ NoiseTables3 s_noise;
 static __shared__ NoiseTables2 s_noise2;
 
 typedef __attribute__((address_space(3))) const char* lds_bytes;
-// off = 4 * index (a byte offset into the table); returns 4 * permute(index)
-MM_DEV int perm4(int off) { return *(__attribute__((address_space(3))) const int*)((lds_bytes)s_noise.perm4 + 4 * MM_PERM_LO + off); }
-// s12 = 12 * (b + x + o + 1): the byte offset of the gradient of permute(b + x + o)
-MM_DEV g3v grad3_at12(int s12)
-{
-    // three dwords at a 4-byte boundary as ds_read2_b32 + ds_read_b32: a ds_read_b96 that is not 16-byte aligned is legal but takes several
-    // times as long (measured: k_cave_voxels 11.5 -> 24.9 ms)
-    const __attribute__((address_space(3))) float* p = (const __attribute__((address_space(3))) float*)((lds_bytes)s_noise.grad3 + s12);
-    return g3v{p[0], p[1], p[2]};
-}
+// off16 = 16 * v: 16 * permute(v) resp. the gradient of permute(v)
+MM_DEV int perm16u(int off16) { return *(__attribute__((address_space(3))) const int*)((lds_bytes)s_noise.e + 16 * MM_T3_LO + 12 + off16); }
+MM_DEV f4v grad3u(int off16) { return *(__attribute__((address_space(3))) const f4v*)((lds_bytes)s_noise.e + 16 * MM_T3_LO + off16); }
 // simplex2: off16 = 16 * index, index in [0, 289]; returns 16 * permute(index)
 MM_DEV int perm16_of2(int off16) { return *(__attribute__((address_space(3))) const int*)((lds_bytes)s_noise2.grad2 + 16 + 12 + off16); }
 // s16 = 16 * (b + x + o + 1): 16 x the table index of the gradient of permute(b + x + o), before the wrap at 289 (j' = min_u32(j, j - 289));
@@ -116,18 +107,18 @@ MM_DEV int grad_wrap16(int s16) { const unsigned j = (unsigned)s16; const unsign
 MM_DEV f4v grad2_at16(int s16) { return *(__attribute__((address_space(3))) const f4v*)((lds_bytes)s_noise2.grad2 + grad_wrap16(s16)); }
 
 // The tables are built ONCE per device and translation unit by k_noise_tables_build (below, with the arithmetic functions above)
-// into this global image; every workgroup then just copies the 14 KB image into LDS at kernel entry (16-byte words, L2 resident)
-// instead of recomputing 1 484 entries - 2 - 9 % of the noise kernels' time went into that.
+// into this global image; every workgroup then just copies the 14 KB image (9.3 + 4.7) into LDS at kernel entry (16-byte words, L2 resident)
+// instead of recomputing 878 entries - 2 - 9 % of the noise kernels' time went into that.
 static __device__ NoiseTables3 g_noise;
 static __device__ NoiseTables2 g_noise2;
 
 static __global__ void __launch_bounds__(256) k_noise_tables_build()
 {
     const int t = threadIdx.x;
-    for (int i = t; i < MM_PERM_N; i += 256) g_noise.perm4[i] = 4 * (int)permute((float)(i - MM_PERM_LO));
-    for (int i = t; i < MM_GRAD3_N; i += 256) {
-        const f3 g3 = simplex3_corner(permute((float)(i - 1)));
-        g_noise.grad3[i] = g3v{g3.x, g3.y, g3.z};
+    for (int i = t; i < MM_T3_N; i += 256) {
+        const float p = permute((float)(i - MM_T3_LO));
+        const f3 g3 = simplex3_corner(p);
+        g_noise.e[i] = f4v{g3.x, g3.y, g3.z, __int_as_float(16 * (int)p)};
     }
     for (int i = t; i < MM_GRAD2_N; i += 256) {
         const float p = permute((float)(i - 1));
@@ -277,8 +268,7 @@ struct Sx3Cell {
 
 MM_DEV float sel_f(bool m, float ifSet, float ifClear) { return m ? ifSet : ifClear; }
 MM_DEV int sel_i(bool m, int ifSet, int ifClear) { return m ? ifSet : ifClear; }
-MM_DEV int sel_4_0(bool m) { return m ? 4 : 0; }
-MM_DEV int sel_24_12(bool m) { return m ? 24 : 12; }
+MM_DEV int sel_16_0(bool m) { return m ? 16 : 0; }
 
 MM_DEV Sx3Cell simplex3_part1(float vx, float vy, float vz)
 {
@@ -323,19 +313,15 @@ MM_DEV void simplex3_gradients(const Sx3Cell& c, float* __restrict__ q)
         ix = __builtin_fmaf(-289.f, __builtin_floorf(ix * (1.f / 289.f)), ix);
         iy = __builtin_fmaf(-289.f, __builtin_floorf(iy * (1.f / 289.f)), iy);
         iz = __builtin_fmaf(-289.f, __builtin_floorf(iz * (1.f / 289.f)), iz);
-        int x12 = __mul24((int)ix, 12);
-        asm("" : "+v"(x12));                                  // one product for the four corners (the compiler otherwise folds 12 x into each corner's multiply-add)
-        const int y4 = 4 * (int)iy, z4 = 4 * (int)iz;
+        const int x16 = 16 * (int)ix, y16 = 16 * (int)iy, z16 = 16 * (int)iz;
         // level z: the four corners only ever need permute(z) and permute(z + 1), as byte offsets of the next level's entries
-        const int pz0 = perm4(z4), pz1 = perm4(z4 + 4);
+        const int pz0 = perm16u(z16), pz1 = perm16u(z16 + 16);
         const int a[4] = {pz0, sel_i(c.i1z(), pz1, pz0), sel_i(c.i2z(), pz1, pz0), pz1};
-        const int oy[4] = {0, sel_4_0(c.i1y()), sel_4_0(c.i2y()), 4};
-        // 12 x + 12 (o + 1): before the lookups, off the dependent chain (the two constant ones become the loads' immediate offsets)
-        const int xo[4] = {x12, x12 + sel_24_12(c.i1x()), x12 + sel_24_12(c.i2x()), x12};
+        const int oy[4] = {0, sel_16_0(c.i1y()), sel_16_0(c.i2y()), 16}, ox[4] = {0, sel_16_0(c.i1x()), sel_16_0(c.i2x()), 16};
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const int b4 = perm4((a[k] + y4) + oy[k]);
-            const g3v g = grad3_at12((__mul24(b4, 3) + xo[k]) + (k == 0 ? 12 : (k == 3 ? 24 : 0)));    // fused: gradient of permute(b + x + o), at 12 * (b + x + o + 1)
+            const int b = perm16u((a[k] + y16) + oy[k]);
+            const f4v g = grad3u((b + x16) + ox[k]);           // fused: gradient of permute(b + x + o)
             q[3 * k] = g.x; q[3 * k + 1] = g.y; q[3 * k + 2] = g.z;
         }
     } else {

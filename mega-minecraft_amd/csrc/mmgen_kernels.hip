@@ -263,7 +263,7 @@ MM_DEV float cave_huge(float x, float y, float z, float b3 /* MM_SIMPLEX3_BOUND 
 #define CAVE_ROW 16        // one workgroup = one 16-column row of a chunk
 #define CAVE_VOXELS (CAVE_ROW * CAVE_YEVAL)       // 2 304 evaluated voxels per row
 #ifndef CAVE_L2_CAP
-#define CAVE_L2_CAP 1056                          // list 2 (typically 40 - 45 % of list 1, which has at most 2 304 entries); a full list resolves the surplus in place
+#define CAVE_L2_CAP 1096                          // list 2 (typically 40 - 45 % of list 1, which has at most 2 304 entries); a full list resolves the surplus in place
 #endif
 #define CAVE_L3_CAP (CAVE_VOXELS / 3)             // list 3 (typically a third of list 2)
 #ifndef CAVE_THREADS

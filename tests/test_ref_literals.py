@@ -131,6 +131,8 @@ DEVICE_EXTRA = {
     # fill_body: lane / batch geometry of the row workgroup (16 columns x 384 y per row, 13-bit positions, 5-bit depth codes 30 / 31, 2^32 queue keys) and the
     # "further than 7 blocks from every cave surface" test of the CRYSTAL-only evaluations (LUSH_CAVES converts within 1.5 + 4.5 |simplex3|)
     "chunk.cu::chunkFillPlaceBlock": (1.5, 4.5, 7.0, 8.0, 13.0, 15.0, 17.0, 30.0, 31.0, 45.0, 96.0, 4294967296.0),
+    # special_cave_noise's staged search keeps the three smallest squared distances as unsigned integers: 0x7f7fffff = the bits of FLT_MAX
+    "rng.hpp::specialCaveNoise": (float(np.float32(0x7f7fffff)),),
     "biomeFuncs.hpp::getBiomeNoise": (float(np.float32(0.32)),),         # overallBiomeScale, a file-level constant in the reference (biomeFuncs.hpp:105)
     # cave_huge: slack of its exact pruning; k_cave_voxels: kCaveFaMax = 0.9375 * MM_SIMPLEX3_BOUND (the octave amplitudes of fbm3<4> sum to
     # 0.9375), 1e30 = "no bound" outside the pruning domain (the bounds themselves are macros of mm_noise.cuh)
