@@ -403,6 +403,9 @@ k_cave_voxels(const float* __restrict__ hf, const float2* __restrict__ colInfo, 
             if ((unsigned)(bits >> 32)) atomicOr(half + 1, (unsigned)(bits >> 32));
         }
     }
+    const bool prune = prune_domain(cp.x, cp.y + row);          // the row's 16 columns: x in [cp.x, cp.x + 15] (cp.x a multiple of 16), z = cp.y + row
+    const float b3 = prune ? MM_SIMPLEX3_BOUND : 3.402823466e+38f;
+    const float kCaveFaMax = prune ? 0.9375f * MM_SIMPLEX3_BOUND : 1e30f;      // outside the domain: a bound no noise reaches
     static_assert(CAVE_THREADS == 256 && CAVE_ROW == 16 && CAVE_YEVAL == 144, "the walk below: thread t = column t % 16, y = t / 16 + 16 i, i < 9");
     {
     // y-major walk (the lists come out ordered by depth): a thread keeps its column, a wave covers four consecutive y of the 16 columns
@@ -426,7 +429,14 @@ k_cave_voxels(const float* __restrict__ hf, const float2* __restrict__ colInfo, 
             const float fy = (float)y;
             const bool inBand = (y != 0) && (y <= topSolid);
             const float topRatio = smoothstep(142.f, 95.f, fy + obw * 50.f);
-            const bool needThr = inBand && topRatio > 0.f;      // threshold is a product with topRatio: 0 -> "threshold > 0.04" is false
+            // the largest threshold the voxel can have (phase B's `bound`, the same expression): at or below 0.04 there is no noise cave
+            // whatever the noise is, so the voxel never enters list 1 (the top few blocks of the band, where topRatio is tiny).
+            // y = yb + 16 i >= 32 for i >= 2, where smoothstep(5, 20, y) is exactly 1
+            const float bottomRatio = i >= 2 ? 1.f : smoothstep(5.f, 20.f, fy);
+            float bound = 0.24f + 0.12f * kCaveFaMax;
+            bound *= (1.f + 1.4f * 1.f);
+            bound *= topRatio * (0.3f + 0.7f * bottomRatio);
+            const bool needThr = inBand && bound > 0.04f;
             // final cave = noise cave || (y != 0 && !inBand) || (inBand && fy > ravineY)   (y == 0 solid, y > topSolid air, ravine cut)
             const bool cave0 = ((y != 0) && !inBand) || (inBand && fy > ravineY);
             if (!cave0) {
@@ -462,9 +472,6 @@ k_cave_voxels(const float* __restrict__ hf, const float2* __restrict__ colInfo, 
     // in huge (IEEE rounding is monotone, the other factors are non-negative), so the SAME expression with fa := kCaveFaMax >= sup |fbm3<4>|
     // = 0.9375 * MM_SIMPLEX3_BOUND and huge := 1 is >= threshold bit for bit: a voxel whose cave noise is not below that bound is solid whatever the
     // two fbm3<4> are, and they are never evaluated for it (56 % of the voxels; half of the rest is decided once huge is known).
-    const bool prune = prune_domain(cp.x, cp.y + row);          // the row's 16 columns: x in [cp.x, cp.x + 15] (cp.x a multiple of 16), z = cp.y + row
-    const float b3 = prune ? MM_SIMPLEX3_BOUND : 3.402823466e+38f;
-    const float kCaveFaMax = prune ? 0.9375f * MM_SIMPLEX3_BOUND : 1e30f;      // outside the domain: a bound no noise reaches
     struct VoxelTerms { int c, y; float npx, npy, npz, T; };      // T = topRatio (0.3 + 0.7 bottomRatio)
     auto terms = [&](int e) {
         VoxelTerms v;
