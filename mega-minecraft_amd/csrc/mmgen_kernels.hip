@@ -255,6 +255,12 @@ MM_DEV float cave_huge(float x, float y, float z, float b3 /* MM_SIMPLEX3_BOUND 
     return smoothstep(0.2f, 0.4f, acc);
 }
 
+// The two height ratios of the cave threshold (chunk.cu shouldGenerateCaveAtBlock).  A smoothstep is exactly 1 once its argument reaches
+// the upper edge (t clamps to 1, 1 * 1 * (3 - 2) = 1), which is where most voxels of a list entry's wave are (the lists are ordered by
+// depth): the division is only evaluated inside the transitions.
+MM_DEV float cave_top_ratio(float x /* fy + obw * 50 */) { return x <= 95.f ? 1.f : smoothstep(142.f, 95.f, x); }
+MM_DEV float cave_bottom_ratio(float fy) { return fy >= 20.f ? 1.f : smoothstep(5.f, 20.f, fy); }
+
 #define CELL_NX 8          // 4 adjacent columns share one tile: +1 cell in x over the single-column reach
 #define CELL_NY 8
 #define CELL_NZ 7
@@ -482,8 +488,8 @@ k_cave_voxels(const float* __restrict__ hf, const float2* __restrict__ colInfo, 
         v.npx = (float)wx * 0.0050f; v.npz = (float)wz * 0.0050f;
         const float fy = (float)v.y;
         v.npy = fy * 0.0050f;
-        const float topRatio = smoothstep(142.f, 95.f, fy + obw * 50.f);
-        const float bottomRatio = smoothstep(5.f, 20.f, fy);
+        const float topRatio = cave_top_ratio(fy + obw * 50.f);
+        const float bottomRatio = cave_bottom_ratio(fy);
         v.T = topRatio * (0.3f + 0.7f * bottomRatio);
         return v;
     };
@@ -517,8 +523,8 @@ k_cave_voxels(const float* __restrict__ hf, const float2* __restrict__ colInfo, 
         const float npx = (float)wx * 0.0050f, npz = (float)wz * 0.0050f;
         const float fy = (float)y;
         const float npy = fy * 0.0050f;
-        const float topRatio = smoothstep(142.f, 95.f, fy + obw * 50.f);
-        const float bottomRatio = smoothstep(5.f, 20.f, fy);
+        const float topRatio = cave_top_ratio(fy + obw * 50.f);
+        const float bottomRatio = cave_bottom_ratio(fy);
         float bound = 0.24f + 0.12f * kCaveFaMax;
         bound *= (1.f + 1.4f * 1.f);
         bound *= topRatio * (0.3f + 0.7f * bottomRatio);
