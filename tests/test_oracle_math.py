@@ -129,8 +129,8 @@ def test_noise_table_domains():
     with the same fp32 operations (csrc/mm_noise.cuh).  Exactness needs only that every lookup index is inside the tables:
       * mod289 (x - floor(x * (1/289)) * 289, fp32) of an integer-valued |x| < 2^24 lies in [-1, 289]   (the guard the device checks),
       * glm::mod(x, 289) (x - 289 * floor(x / 289)) of the same lies in [0, 288]                           (simplex2),
-      * permute of every integer in [-16, 700) is an integer in [0, 288]: so chained indices stay in [-1, 578] within perm16[-8, 600)
-        and gradient indices in [0, 288] within grad[296]."""
+      * permute of every integer in [-16, 700) is an integer in [0, 288]: so chained indices stay in [-1, 578], inside the table's [-2, 580)
+        (simplex3: no reduction of an index) resp. wrap into [0, 290] of simplex2's 296 gradient entries."""
     f = np.float32
     xs = np.arange(-2 ** 24 + 1, 2 ** 24, dtype=np.int64).astype(f)
     m = (xs - np.floor(xs * (f(1.0) / f(289.0))) * f(289.0)).astype(f)
@@ -141,7 +141,11 @@ def test_noise_table_domains():
     t = ((x * f(34.0)) + f(1.0)) * x
     p = (t - np.floor(t * (f(1.0) / f(289.0))) * f(289.0)).astype(f)
     assert p.min() >= 0 and p.max() <= 288 and np.array_equal(p, np.floor(p))
-    assert -1 + -1 + 0 >= -8 and 288 + 289 + 1 < 600 - 8 + 8       # chained index range vs table range [-8, 600)
+    # chained index range vs the one table of csrc/mm_noise.cuh (entry v = {gradient of permute(v), 16 * permute(v)}, v in [-2, 580)):
+    # z and z + 1 >= -1; p + y + o and b + x + o with p, b in [0, 288], x, y in [-1, 289], o in {0, 1}
+    assert -1 + 0 + 0 >= -2 and 288 + 289 + 1 < 580
+    # every entry is computed from its own argument: permute(v) for v up to 579 is exact integer arithmetic in fp32 (< 2^24)
+    assert (579 * 34 + 1) * 579 < 2 ** 24
 
 
 def test_simplex2_remainder_without_division():
@@ -305,3 +309,51 @@ def test_simplex3_bound(oracle):
     out = np.zeros(len(xyz), f)
     oracle.lib.mmo_simplex3(len(xyz), _p(xyz), _p(out))
     assert float(np.abs(out).max()) < bound
+
+
+def test_worley_search_shortcuts_are_exact():
+    """csrc/mm_noise.cuh special_cave_noise, staged path, restated in numpy fp32:
+      * the three smallest of the 27 squared distances kept as unsigned integers with med3 / med3 / min updates, in any order, are the
+        three smallest floats (squared distances are finite and >= +0: float order == order of the bit patterns);
+      * the lower bound of a column of cells, fl(bx + by) with bx in {fl(fx fx), 0, fl(gx gx)}, gx = fl(1 - fx), is never above the squared
+        distance the device computes for a cell of that column - so skipping a column whose bound is >= s3 changes nothing."""
+    f = np.float32
+    rs = np.random.RandomState(5)
+    n = 200000
+    fx, fy, fz = (rs.rand(n).astype(f) for _ in range(3))
+    # edge cases: fractions of exactly 0 and (through rounding of px - floor(px)) 1, cell points of exactly 0 and 1
+    fx[:1000] = 0; fy[1000:2000] = 1; fz[2000:3000] = 0
+    pts = rs.rand(27, 3, n).astype(f)
+    pts[:, :, 3000:3500] = np.round(pts[:, :, 3000:3500])
+    gx, gy = (f(1) - fx).astype(f), (f(1) - fy).astype(f)
+    bx = {-1: (fx * fx).astype(f), 0: np.zeros(n, f), 1: (gx * gx).astype(f)}
+    by = {-1: (fy * fy).astype(f), 0: np.zeros(n, f), 1: (gy * gy).astype(f)}
+    d2s = []
+    k = 0
+    for x in (-1, 0, 1):
+        for y in (-1, 0, 1):
+            bound = (bx[x] + by[y]).astype(f)
+            for z in (-1, 0, 1):
+                qx, qy, qz = pts[k]; k += 1
+                dx = ((qx if x == 0 else (f(x) + qx).astype(f)) - fx).astype(f)
+                dy = ((qy if y == 0 else (f(y) + qy).astype(f)) - fy).astype(f)
+                dz = ((qz if z == 0 else (f(z) + qz).astype(f)) - fz).astype(f)
+                d2 = (((dx * dx).astype(f) + (dy * dy).astype(f)).astype(f) + (dz * dz).astype(f)).astype(f)
+                # the reference's form of the same cell (always adds the offset): identical squared distance
+                rx = ((f(x) + qx).astype(f) - fx).astype(f); ry = ((f(y) + qy).astype(f) - fy).astype(f); rz = ((f(z) + qz).astype(f) - fz).astype(f)
+                ref = (((rx * rx).astype(f) + (ry * ry).astype(f)).astype(f) + (rz * rz).astype(f)).astype(f)
+                assert np.array_equal(d2, ref)
+                assert np.all(bound <= d2), (x, y, z)
+                d2s.append(d2)
+    d2s = np.stack(d2s)                                             # [27][n]
+    u = d2s.view(np.uint32).astype(np.int64)
+    big = np.int64(0x7f7fffff)
+    for order in (np.arange(27), rs.permutation(27), np.arange(27)[::-1]):
+        u1 = np.full(n, big); u2 = u1.copy(); u3 = u1.copy()
+        med3 = lambda a, b, c: np.minimum(np.maximum(a, b), np.maximum(np.minimum(a, b), c))
+        for i in order:
+            v = u[i]
+            u3 = med3(u2, u3, v); u2 = med3(u1, u2, v); u1 = np.minimum(u1, v)
+        srt = np.sort(d2s, axis=0)
+        assert np.array_equal(u1.astype(np.uint32).view(f), srt[0]) and np.array_equal(u2.astype(np.uint32).view(f), srt[1])
+        assert np.array_equal(u3.astype(np.uint32).view(f), srt[2])
