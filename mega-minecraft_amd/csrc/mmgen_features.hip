@@ -760,7 +760,7 @@ MM_DEV int filter_round(const Entry* __restrict__ list, int r0, int wx0, int wz0
 
 #ifndef MM_APPLY_WAVES
 #define MM_APPLY_WAVES 4        // waves per SIMD = persistent workgroups per CU.  Left alone the union of the 31 rasterisers takes 155 VGPRs (3 waves);
-                                // held to 128 the compiler still needs no scratch, 4 x 40 080 B of LDS just fit a CU, and a unit's chain of
+                                // held to 128 the compiler still needs no scratch, 4 x 40 688 B of LDS just fit a CU (the pair buffer holds 192 entries for that), and a unit's chain of
                                 // dependent round trips has a third more waves to hide behind: 1.36 -> 1.25 ms (round 4)
 #endif
 // Persistent workgroups of four independent WAVES; a wave takes one UNIT (APPLY_UNIT_W x APPLY_UNIT_H columns of a chunk) at a time and
@@ -792,7 +792,7 @@ k_apply_features(uint8_t* __restrict__ blocks, const int2* __restrict__ chunkPos
     __shared__ __attribute__((aligned(16))) uint8_t s_claim[APPLY_COLS][APPLY_UNIT_NCOL * 384];      // per voxel: the block of the first placement that claimed it, or 255
     __shared__ unsigned s_air[APPLY_COLS][APPLY_UNIT_NCOL * 384 / 32];      // per voxel: the base block is AIR (all the item test needs of it)
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;      // wave index in an SGPR: so are chunk and column
-    // the simplex tables (12 KB) are staged ONCE per workgroup (most units of a generated world have a coral, a fungus or a redwood in reach)
+    // the simplex tables (14 KB) are staged ONCE per workgroup (most units of a generated world have a coral, a fungus or a redwood in reach)
     noise_tables_init();
     int4* unit = s_unit[wave];
     unsigned* ent = s_ent[wave];

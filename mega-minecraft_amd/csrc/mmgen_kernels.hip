@@ -273,7 +273,7 @@ MM_DEV float cave_bottom_ratio(float fy) { return fy >= 20.f ? 1.f : smoothstep(
 #endif
 #define CAVE_L3_CAP (CAVE_VOXELS / 3)             // list 3 (typically a third of list 2)
 #ifndef CAVE_THREADS
-#define CAVE_THREADS 256                          // 4 waves: six workgroups (26.4 KB of LDS each) fill a CU's 24 wave slots
+#define CAVE_THREADS 256                          // 4 waves: six workgroups (26.8 KB of LDS each: 26 848 of the 26 880 B a sixth of the CU's LDS is) fill a CU's 24 wave slots
 #endif
 
 struct CellTile {
@@ -1076,7 +1076,7 @@ MM_DEV void fill_body(const float* __restrict__ hf, const float* __restrict__ bw
 #define FILLC_LUSH_CAP 128       // per wave: lush voxels waiting for a queue reservation
 
 #ifndef MM_FILLB_WAVES
-#define MM_FILLB_WAVES 8          // 64 VGPRs without scratch; 16.4 KB of LDS per workgroup would allow nine (7 -> 8: 1.73 -> 1.66 ms, round 4)
+#define MM_FILLB_WAVES 8          // 64 VGPRs without scratch; 18.7 KB of LDS per workgroup allows eight (7 -> 8: 1.73 -> 1.66 ms, round 4)
 #endif
 __attribute__((amdgpu_waves_per_eu(MM_FILLB_WAVES, MM_FILLB_WAVES)))
 __global__ void __launch_bounds__(FILLB_THREADS)
