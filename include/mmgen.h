@@ -64,6 +64,12 @@ int mmgen_fix_backward_layers(float* d_layers, int num_chunks, void* stream);
  * d_accumulated_heights: 147456 floats, overwritten with the accumulated lift (may be NULL).  Synchronous on return, like the reference.
  * Canonical semantics: synchronous Jacobi passes; the reference's in-place update races between thread blocks. */
 int mmgen_erode_zone(float* d_gathered_layers, float* d_accumulated_heights, void* stream);
+/* The relaxation loop runs on the device as one persistent launch whose workgroups wait for each other; no wait is unbounded.  If a zone's
+ * workgroups do not meet within MMGEN_EROSION_TIMEOUT_MS (environment; default 2 000 ms, a thousand times the longest healthy wait) the
+ * launch ends itself and the call that synchronises with it returns this code instead of hanging the GPU (the reference's loop cannot
+ * stall: the host launches every pass, chunk.cu:682-705).  Starvation is the realistic cause: several persistent relaxations in flight on
+ * one device (regions on several streams, concurrent mmgen_erode_zones calls, several processes) can hold each other's slots. */
+#define MMGEN_ERROR_EROSION_STALL 20002
 /* Batched form: num_zones buffers of MMGEN_GATHERED_LAYERS_SIZE floats back to back (ONE persistent launch relaxes all zones to
  * convergence: the host loop of chunk.cu:682-705 runs on the device, a zone's workgroups meet at a barrier after every block of passes);
  * *max_passes (nullable) receives the largest number of relaxation passes any zone needed. */
@@ -149,6 +155,8 @@ int mmgen_region_fill(mmgen_region* region, uint8_t* d_blocks, void* stream);
 int mmgen_region_set_output(mmgen_region* region, uint8_t* d_blocks);
 int mmgen_region_finish(mmgen_region* region, uint8_t* d_blocks, float* d_heightfields /*nullable*/, float* d_layers /*[n][20][256], nullable*/,
                         mmgen_cave_layer* d_cave_layers /*[n][256][32], nullable*/, void* stream);
+/* waits for the erosion branch of the last begin; -1 if it failed (a relaxation that gave up: from then on mmgen_region_begin / _finish
+ * return MMGEN_ERROR_EROSION_STALL - the planes of that step are not to be trusted and the region is to be destroyed) */
 int mmgen_region_last_erosion_passes(const mmgen_region* region);
 /* The longest gathered (un-truncated) surface / cave placement list any chunk had in the finishes since the last call (synchronises the
  * stream; clears the record).  With a full ring (mask 1 or peer-provided lists) these are the lengths the reference's Chunk::fill truncates
@@ -257,6 +265,9 @@ int mmgen_debug_probe(int fn, const float* d_in, int n, float* d_out, void* stre
 /* Test-only: caps the queue of deferred clay / moss voxels of mmgen_fill / the region path at `entries` (0 = the library's own size, 2 048 per
  * chunk), so that a test can drive the path that evaluates them in place when a reservation does not fit.  Process-wide. */
 int mmgen_debug_set_lush_queue_cap(int entries);
+/* Test-only: the following persistent relaxation launches are `missing_workgroups` short, so that a zone's barrier can never complete, and
+ * give up after timeout_ms: drives the MMGEN_ERROR_EROSION_STALL path.  (0, 0) restores the defaults.  Process-wide. */
+int mmgen_debug_erosion_stall(int missing_workgroups, int timeout_ms);
 /* Test-only: the library's constant rule tables (BiomeUtils::init, biomeFuncs.hpp:725-1256) as floats in the layout of
  * tools/extract_ref_tables.py, so that a test can hold them to the reference's literals.  d_out == NULL: returns the number of floats. */
 int mmgen_debug_tables(float* d_out, int capacity_floats, void* stream);

@@ -101,6 +101,8 @@ const char* mmgen_error_string(int code)
 {
     if (code == MMGEN_ERROR_PLACEMENT_OVERFLOW)
         return "a chunk's cave placement list exceeded MMGEN_CFP_CAP and lost entries (mmgen_region_max_cave_placements acknowledges)";
+    if (code == MMGEN_ERROR_EROSION_STALL)
+        return "the erosion relaxation gave up: a zone's workgroups did not meet within MMGEN_EROSION_TIMEOUT_MS (starved persistent launch?)";
     return hipGetErrorString((hipError_t)code);
 }
 
@@ -189,6 +191,12 @@ int mmgen_erode_zones(float* d_gathered, int num_zones, float* d_acc, int* max_p
 }
 
 int mmgen_erode_zone(float* d_gathered, float* d_acc, void* stream) { return mmgen_erode_zones(d_gathered, 1, d_acc, nullptr, stream); }
+
+int mmgen_debug_erosion_stall(int missing_workgroups, int timeout_ms)
+{
+    mmk::erosion_debug_stall(missing_workgroups, timeout_ms);
+    return 0;
+}
 
 int mmgen_generate_caves(const float* d_hf, const float* d_bw, const int32_t* d_pos, int n, mmgen_cave_layer* d_cl, void* stream)
 {

@@ -29,8 +29,7 @@ struct ErosionState {
     ErosionPhase slot[2];
     unsigned changed[4];    // round t ORs into changed[t & 3] and clears changed[(t + 1) & 3]
     unsigned barrier;       // arrivals of the zone's workgroups at the end of their rounds (round t is over at perZone * (t + 1))
-    unsigned tileTicket[2]; // round t deals its tiles out of tileTicket[t & 1] (the zone's first workgroup clears the other one)
-    unsigned pad;
+    unsigned reserved[3];
 };
 }  // namespace mm
 
@@ -49,7 +48,12 @@ int erode_zones(float* gathered, size_t strideFloats, int zones, float* work, mm
                 // runs another kernel beside it leaves room (the region: the caves' workgroups take the rest of every CU)
                 int workgroupsPer4Cu = 0,
                 // out (nullable): a device word that counts the persistent launch's workgroups as they start, and the value it reaches
-                const unsigned** startedCounter = nullptr, unsigned* startedTarget = nullptr);
+                const unsigned** startedCounter = nullptr, unsigned* startedTarget = nullptr,
+                // host-visible (mapped) word that receives the error word of a launch that gave up (k_erode_zones); nullable
+                unsigned* errHost = nullptr);
+// test hook: the next persistent launches are `missingWorkgroups` short (a zone's barrier can then never complete) and give up after timeoutMs
+// (0, 0 restores the defaults)
+void erosion_debug_stall(int missingWorkgroups, int timeoutMs);
 int erosion_gather(const float* layers, const float* hf, const int* zoneChunkIdx, int zones, float* gathered, size_t strideFloats, hipStream_t s);
 int erosion_scatter(const float* gathered, size_t strideFloats, const int* zoneChunkIdxOut, int zones, float* layersOut, hipStream_t s);
 }  // namespace mmk

@@ -20,6 +20,12 @@
 //  * many zones per launch (blockIdx.z = zone); the zone working set stays L2 / Infinity-Cache resident.
 #include <hip/hip_runtime.h>
 #include <atomic>
+#include <cstdio>
+#include <cstdlib>
+#include <map>
+#include <mutex>
+#include <vector>
+#include "../../include/mmgen.h"
 #include "mm_biome.cuh"
 #include "mmgen_erosion.h"
 #include "mmgen_prof.h"
@@ -39,7 +45,7 @@ namespace mm {
 #define EROSION_STRIPS 11                                  // row groups: one lane = one column of the extended tile x EROSION_ROWS rows (mmgen_erosion.h: K x row groups)
 #endif
 #define EROSION_ROWS (EROSION_EXT / EROSION_STRIPS)
-#define EROSION_THREADS (EROSION_EXT * EROSION_STRIPS)
+#define EROSION_THREADS 512                                 // 8 waves: 484 lanes relax (lane = column x row group), all 512 move 16-byte pieces
 static_assert(EROSION_EXT % EROSION_STRIPS == 0, "strips must tile the extended tile");
 
 // phase of launch t from the phase and the changed mask of launch t - 1 (bit j = pass j of that launch altered some column)
@@ -66,10 +72,39 @@ MM_DEV ErosionPhase next_phase(const ErosionPhase& prev, unsigned maskPrev)
 }
 
 // Planes, masks and phases travel between the workgroups of a zone INSIDE one launch.  They are read and written with device-scope
-// relaxed atomics (global_load / global_store with sc1: served at the level every XCD sees) and ordered by the zone's barrier - no
-// cache write-back / invalidate fences, which every workgroup of the chip would pay for at every barrier of every other zone.
-MM_DEV float ld_dev(const float* p) { return __int_as_float(__hip_atomic_load((const int*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); }
-MM_DEV void st_dev(float* p, float v) { __hip_atomic_store((int*)p, __float_as_int(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// accesses (sc1: loads served below the per-CU L1, stores written through) and ordered by the zone's barrier - no cache write-back /
+// invalidate fences, which every workgroup of the chip would pay for at every barrier of every other zone.  The hand-off form is the
+// one of the MI355X guide (inter-workgroup visibility, "every store sc1, every load sc1"): EVERY storing wave drains its stores
+// (s_waitcnt vmcnt(0)) before the workgroup barrier behind which one lane arrives at the zone's counter; the consumer polls that
+// counter and every load of a handed-off byte is an sc1 load to registers.  Planes move as 16-byte pieces (one fabric transaction per
+// lane instead of four).
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+struct F4 { float x, y, z, w; };
+#define MM_DRAIN_VMEM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#define MM_AUX_SC1 16
+#define MM_BUF_OOB 0xFFFFFFF0u            /* beyond every descriptor's range: the load returns zeros and moves nothing */
+MM_DEV F4 ld4_dev(__amdgpu_buffer_rsrc_t rs, unsigned byteOff)
+{
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)byteOff, 0, MM_AUX_SC1);
+    return F4{__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
+}
+MM_DEV void st4_dev(__amdgpu_buffer_rsrc_t rs, unsigned byteOff, const F4& f)
+{
+    const u32x4 v = {__float_as_uint(f.x), __float_as_uint(f.y), __float_as_uint(f.z), __float_as_uint(f.w)};
+    __builtin_amdgcn_raw_buffer_store_b128(v, rs, (int)byteOff, 0, MM_AUX_SC1);
+}
+
+// Geometry of a tile's traffic.  Loads: the rows of the extended tile as aligned 16-byte pieces (columns [gx0 - PAD, gx0 - PAD + 4 SEGS) of
+// the grid; the PAD + (4 SEGS - EXT - PAD) columns outside the extended tile are dropped), ROWS x SEGS pieces per plane, three planes
+// (start, end, accumulated heights): 1 584 pieces dealt out flat to the 512 threads, at most EROSION_SLOTS per thread, held in registers
+// while the previous tile is relaxed.  Stores: the 32 x 32 centre as 8 pieces per row, start plane by threads 0..255, accumulator by
+// threads 256..511.
+#define EROSION_PAD ((4 - EROSION_K % 4) % 4)
+#define EROSION_SEGS ((EROSION_EXT + EROSION_PAD + 3) / 4)
+#define EROSION_PLANE_PIECES (EROSION_EXT * EROSION_SEGS)
+#define EROSION_SLOTS ((3 * EROSION_PLANE_PIECES + EROSION_THREADS - 1) / EROSION_THREADS)
+static_assert(EROSION_K % 2 == 0, "8-byte LDS pieces: the extended tile starts at an even column");
+static_assert(EROSION_THREADS == 512 && EROSION_THREADS >= EROSION_EXT * EROSION_STRIPS, "centre stores: 2 x 256 pieces; one lane per column and row group");
 
 // One Jacobi pass of one lane: column ex of the extended tile, rows [r0, r1].  sIn / tIn = start plane and thickness (end - start)
 // of the previous state, read through a sliding 3 x 3 register window (6 LDS reads per cell); sOut / tOut receive the new state.
@@ -79,7 +114,7 @@ MM_DEV void st_dev(float* p, float v) { __hip_atomic_store((int*)p, __float_as_i
 template <bool LIFT>
 MM_DEV int relax_strip(const float* __restrict__ sIn, const float* __restrict__ tIn, float* __restrict__ sOut, float* __restrict__ tOut,
                        const float* __restrict__ s_end, float* __restrict__ s_acc, float k1, float k2, int ex, int exL, int exR, int r0, int r1, int ezMin,
-                       int ezMax, bool ownCol, float* __restrict__ startFirst /*grid pointer of this column, row 0 of the tile*/)
+                       int ezMax, bool ownCol)
 {
     int flags = 0;
     if (r0 > r1) return 0;
@@ -116,7 +151,6 @@ MM_DEV int relax_strip(const float* __restrict__ sIn, const float* __restrict__ 
         }
         sOut[c] = outStart;
         tOut[c] = s_end[c] - outStart;
-        if (LIFT && ownCol && ez >= EROSION_K && ez < EROSION_K + 32) st_dev(startFirst + (size_t)ZS * ez, outStart);
         aS0 = bS0; aS1 = bS1; aS2 = bS2; aT0 = bT0; aT1 = bT1; aT2 = bT2;
         bS0 = cS0; bS1 = cS1; bS2 = cS2; bT0 = cT0; bT1 = cT1; bT2 = cT2;
     }
@@ -142,9 +176,6 @@ MM_DEV void store_phase(ErosionPhase* p, const ErosionPhase& v)
     for (int i = 0; i < 7; ++i) __hip_atomic_store(dst + i, src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// One launch-equivalent ("round") of one 32 x 32 tile: EROSION_K Jacobi passes of the phase's layer on the (32 + 2 K)^2 extended tile.
-// Called by every thread of the workgroup; the LDS planes are the caller's.  Returns nothing; the tile's "changed" bits are ORed into
-// *zoneMask (device scope) by one thread.
 // The raw planes of a zone (its 8 eroded layers' starts + the heightfield), read-only for the whole relaxation: either packed by
 // k_erosion_gather (the per-stage ABI: Chunk::erodeZone's gathered buffer) or, in the region path, straight from the chunk-major
 // layers / heightfields through the zone's 24 x 24 chunk list (copyLayers' index math, chunk.cu:603-656, without the copy).
@@ -153,120 +184,212 @@ struct RawPlanes {
     const float* layers;              // chunk-major raw layers [chunk][20][256]
     const float* hf;                  // chunk-major heightfields [chunk][256]
     const int* chunkIdx;              // the zone's [24 * 24] chunks
-    MM_DEV float at(int plane, int gx, int gz) const
+    // four columns gx .. gx + 3 (gx a multiple of 4: inside one chunk row) of a plane; chunk = chunkIdx[(gz >> 4) * 24 + (gx >> 4)] (region path)
+    MM_DEV F4 at4(int plane, int gx, int gz, int chunk) const
     {
-        if (gathered) return gathered[(size_t)plane * ZN + gx + ZS * gz];
-        const int chunk = chunkIdx[(gz >> 4) * 24 + (gx >> 4)], idx2d = (gz & 15) * 16 + (gx & 15);
-        return plane == 8 ? hf[(size_t)256 * chunk + idx2d] : layers[(size_t)MMGEN_LAYERS_SIZE * chunk + 256 * (MMGEN_NUM_STRATIFIED_MATERIALS + plane) + idx2d];
+        if (gathered) {          // the caller's buffers: a zone's stride is odd (the trailing flag word), so no 16-byte alignment to rely on
+            const float* p = gathered + (size_t)plane * ZN + gx + ZS * gz;
+            return F4{p[0], p[1], p[2], p[3]};
+        }
+        const int idx2d = (gz & 15) * 16 + (gx & 15);
+        const float* p = plane == 8 ? hf + (size_t)256 * chunk + idx2d : layers + (size_t)MMGEN_LAYERS_SIZE * chunk + 256 * (MMGEN_NUM_STRATIFIED_MATERIALS + plane) + idx2d;
+        const float4 v = *reinterpret_cast<const float4*>(p);
+        return F4{v.x, v.y, v.z, v.w};
     }
 };
 
-MM_DEV void erode_tile(const RawPlanes& raw, float* work, const ErosionPhase& ph, int tileX, int tileZ, unsigned* zoneMask,
-                       float (*s_s)[EROSION_CELLS_EXT], float (*s_t)[EROSION_CELLS_EXT], float* s_end, float* s_acc, unsigned* s_mask)
+// What a round of a zone reads and writes (workgroup-uniform; float offsets into the zone's work planes).
+struct RoundPlanes {
+    int layer;
+    bool isFirst, rawEnd, topFirst;       // topFirst: the very first round of the zone - the accumulated heights are zero, not loaded
+    unsigned startIn, endIn, accIn, startOut, accOut, startFirst;
+};
+MM_DEV RoundPlanes round_planes(const ErosionPhase& ph)
 {
-    const int tid = threadIdx.x;
+    RoundPlanes rp;
     const int layer = ph.layer;
-    const bool isFirst = ph.isFirst != 0;
-    const float* accIn = work + (size_t)24 * ZN + (size_t)ph.accSel * ZN;
-    float* accOut = work + (size_t)24 * ZN + (size_t)(1 - ph.accSel) * ZN;
-    const float* startIn = work + ((size_t)layer * 3 + ph.plane(layer)) * ZN;                     // (a layer's first round reads the raw plane instead)
-    float* startOut = work + ((size_t)layer * 3 + (isFirst ? 0 : 1 - ph.plane(layer))) * ZN;
-    float* startFirst = work + ((size_t)layer * 3 + 2) * ZN;
+    rp.layer = layer;
+    rp.isFirst = ph.isFirst != 0;
     // end plane = final start plane of the layer above (already eroded), or the heightfield plane for the top layer
-    const bool rawEnd = layer == MMGEN_NUM_ERODED_MATERIALS - 1;
-    const float* endIn = work + ((size_t)(rawEnd ? layer : layer + 1) * 3 + ph.plane(rawEnd ? layer : layer + 1)) * ZN;
+    rp.rawEnd = layer == MMGEN_NUM_ERODED_MATERIALS - 1;
+    rp.topFirst = rp.rawEnd && rp.isFirst;
+    rp.accIn = (unsigned)((24 + ph.accSel) * ZN);
+    rp.accOut = (unsigned)((24 + 1 - ph.accSel) * ZN);
+    rp.startIn = (unsigned)((layer * 3 + ph.plane(layer)) * ZN);                                // (a layer's first round reads the raw plane instead)
+    rp.startOut = (unsigned)((layer * 3 + (rp.isFirst ? 0 : 1 - ph.plane(layer))) * ZN);
+    rp.startFirst = (unsigned)((layer * 3 + 2) * ZN);
+    const int le = rp.rawEnd ? layer : layer + 1;
+    rp.endIn = (unsigned)((le * 3 + ph.plane(le)) * ZN);
+    return rp;
+}
 
+// A thread's pieces of the next tile, in flight while the current tile is relaxed: slot k is piece threadIdx.x + 512 k of the flat list
+// [plane][row][16-byte piece].
+struct TilePieces { F4 v[EROSION_SLOTS]; };
+// the thread index as a value the compiler cannot see through: the piece / lane geometry derived from it is a handful of integer
+// operations, and hoisting all of it out of the round loop (it is loop invariant) costs more registers than the kernel has
+MM_DEV int opaque_tid() { int t = (int)threadIdx.x; asm volatile("" : "+v"(t)); return t; }
+
+MM_DEV void tile_issue_loads(TilePieces& r, const RawPlanes& raw, const int* s_chunk, __amdgpu_buffer_rsrc_t work, const RoundPlanes& rp, int tileX, int tileZ)
+{
+    const int tid0 = opaque_tid();
+#pragma unroll
+    for (int k = 0; k < EROSION_SLOTS; ++k) {
+        const int p = tid0 + EROSION_THREADS * k;
+        const int plane = p / EROSION_PLANE_PIECES, rem = p % EROSION_PLANE_PIECES;
+        const int row = rem / EROSION_SEGS, seg = rem % EROSION_SEGS;
+        const int gx = tileX * 32 - EROSION_K - EROSION_PAD + 4 * seg, gz = tileZ * 32 - EROSION_K + row;
+        // (a piece lies inside the grid or outside it: 384 is a multiple of 4)
+        const bool ok = p < 3 * EROSION_PLANE_PIECES && gx >= 0 && gx < ZS && gz >= 0 && gz < ZS;
+        // (plane -> round's plane by masks: as a three-way select the compiler builds a table in scratch)
+        const unsigned m0 = plane == 0 ? ~0u : 0u, m1 = plane == 1 ? ~0u : 0u, m2 = ~(m0 | m1);
+        const bool useRaw = ok && ((m0 & (unsigned)rp.isFirst) | (m1 & (unsigned)rp.rawEnd)) != 0u;
+        const bool fromWork = ok && !useRaw && (m2 & (unsigned)rp.topFirst) == 0u;
+        const unsigned base = (rp.startIn & m0) | (rp.endIn & m1) | (rp.accIn & m2);
+        r.v[k] = ld4_dev(work, fromWork ? 4u * (base + (unsigned)(gx + ZS * gz)) : MM_BUF_OOB);      // (zeros, and no traffic, where the piece is not a work plane's)
+        if (useRaw) r.v[k] = raw.at4(plane == 1 ? 8 : rp.layer, gx, gz, raw.gathered ? 0 : s_chunk[(gz >> 4) * 24 + (gx >> 4)]);
+    }
+}
+
+// the pieces into the LDS planes as loaded: start -> plane 0 of s_s, end -> s_end, accumulated heights -> s_acc.  Cells beyond the grid
+// do not exist (neighbours clamp to the edge) and are never read.
+MM_DEV void tile_commit(const TilePieces& r, int tileX, int tileZ, float* s_start, float* s_end, float* s_acc)
+{
+    const int tid0 = opaque_tid();
+#pragma unroll
+    for (int k = 0; k < EROSION_SLOTS; ++k) {
+        const int p = tid0 + EROSION_THREADS * k;
+        const int plane = p / EROSION_PLANE_PIECES, rem = p % EROSION_PLANE_PIECES;
+        const int row = rem / EROSION_SEGS, seg = rem % EROSION_SEGS;
+        const int ex0 = 4 * seg - EROSION_PAD;
+        const int gx = tileX * 32 - EROSION_K + ex0, gz = tileZ * 32 - EROSION_K + row;
+        if (p >= 3 * EROSION_PLANE_PIECES || !(gx >= 0 && gx < ZS && gz >= 0 && gz < ZS)) continue;
+        float* dst = (plane == 0 ? s_start : (plane == 1 ? s_end : s_acc)) + EROSION_EXT * row;
+        if (ex0 >= 0) *reinterpret_cast<float2*>(dst + ex0) = make_float2(r.v[k].x, r.v[k].y);
+        if (ex0 + 3 < EROSION_EXT) *reinterpret_cast<float2*>(dst + ex0 + 2) = make_float2(r.v[k].z, r.v[k].w);
+    }
+}
+
+// what pass 0 reads beside the committed planes: a first round's input is the start RAISED by the accumulated height of the layers above
+// and the thickness of that raised state (plane 1; the un-raised start stays in plane 0), any other round's is the thickness of plane 0
+MM_DEV void tile_derive(bool isFirst, float (*s_s)[EROSION_CELLS_EXT], float (*s_t)[EROSION_CELLS_EXT], const float* s_end, const float* s_acc)
+{
+    for (int c = opaque_tid(); c < EROSION_CELLS_EXT; c += EROSION_THREADS) {
+        const float sv = s_s[0][c], ev = s_end[c];
+        if (isFirst) { const float av = s_acc[c], ls = sv + av; s_s[1][c] = ls; s_t[1][c] = (ev + av) - ls; }
+        else s_t[0][c] = ev - sv;
+    }
+}
+
+// a thread's piece of the tile's 32 x 32 centre out of an LDS plane (q = 0 .. 255: row q / 8, columns 4 (q % 8) .. + 3)
+MM_DEV F4 centre_piece(const float* plane, int q)
+{
+    const int c = EROSION_EXT * (EROSION_K + (q >> 3)) + EROSION_K + 4 * (q & 7);
+    const float2 lo = *reinterpret_cast<const float2*>(plane + c), hi = *reinterpret_cast<const float2*>(plane + c + 2);
+    return F4{lo.x, lo.y, hi.x, hi.y};
+}
+MM_DEV unsigned centre_offset(int tileX, int tileZ, int q) { return (unsigned)((tileX * 32 + 4 * (q & 7)) + ZS * (tileZ * 32 + (q >> 3))); }
+
+// One round of one 32 x 32 tile whose planes tile_commit has staged: EROSION_K Jacobi passes of the round's layer on the (32 + 2 K)^2
+// extended tile, then the centre's results to the round's output planes.  Called by every thread of the workgroup, begins behind a
+// workgroup barrier after the commit and ends with its stores issued (not waited for).  Returns the tile's "changed" bits (bit j = pass
+// j altered a column of the centre), the same value in every thread.
+MM_DEV unsigned relax_tile(__amdgpu_buffer_rsrc_t work, const RoundPlanes& rp, int tileX, int tileZ, float (*s_s)[EROSION_CELLS_EXT],
+                           float (*s_t)[EROSION_CELLS_EXT], float* s_end, float* s_acc, unsigned* s_passFlags /*[EROSION_K], zero*/)
+{
+    const int tid = opaque_tid();
+    const bool isFirst = rp.isFirst;
     // extended tile: ex, ez in [0, EXT) <-> grid (gx0 + ex, gz0 + ez); cells beyond the grid do not exist (neighbours clamp to the edge)
     const int gx0 = tileX * 32 - EROSION_K, gz0 = tileZ * 32 - EROSION_K;
     const int exMin = imax(0, -gx0), exMax = imin(EROSION_EXT - 1, ZS - 1 - gx0);
     const int ezMin = imax(0, -gz0), ezMax = imin(EROSION_EXT - 1, ZS - 1 - gz0);
+    const bool worker = tid < EROSION_EXT * EROSION_STRIPS;          // (the threads beyond only move pieces)
     const int ex = tid % EROSION_EXT, strip = tid / EROSION_EXT;
     const int rowLo = strip * EROSION_ROWS, rowHi = rowLo + EROSION_ROWS - 1;
-    const bool colExists = ex >= exMin && ex <= exMax;
     const int exL = imax(ex - 1, exMin), exR = imin(ex + 1, exMax);
     const bool ownCol = ex >= EROSION_K && ex < EROSION_K + 32;
-    if (tid == 0) *s_mask = 0u;
 
-    // load: a first launch stages the un-raised start in plane 0 and the RAISED start / thickness in plane 1 (the input of pass 0)
-    if (colExists) {
-        for (int ez = imax(rowLo, ezMin); ez <= imin(rowHi, ezMax); ++ez) {
-            const int c = EROSION_EXT * ez + ex, g = (gx0 + ex) + ZS * (gz0 + ez);
-            const float sv = isFirst ? raw.at(layer, gx0 + ex, gz0 + ez) : ld_dev(startIn + g);
-            const float ev = rawEnd ? raw.at(8, gx0 + ex, gz0 + ez) : ld_dev(endIn + g);
-            const float av = ld_dev(accIn + g);
-            s_s[0][c] = sv; s_end[c] = ev; s_acc[c] = av;
-            if (isFirst) { const float ls = sv + av; s_s[1][c] = ls; s_t[1][c] = (ev + av) - ls; }
-            else s_t[0][c] = ev - sv;
-        }
-    }
-    __syncthreads();
-
-    const float k1 = kMaterialAmpOrTan[MMGEN_NUM_STRATIFIED_MATERIALS + layer];
+    const float k1 = kMaterialAmpOrTan[MMGEN_NUM_STRATIFIED_MATERIALS + rp.layer];
     const float k2 = k1 * MM_SQRT_2;
-    float* colFirst = startFirst + (gx0 + ex) + (size_t)ZS * gz0;
     int cur = 0;                                             // plane holding the current state (after a first pass: 0 again)
-    unsigned myMask = 0u;
+    unsigned mask = 0u;
 #pragma unroll 1
     for (int j = 0; j < EROSION_K; ++j) {
         // cells still exact after this pass: at distance > j from every tile border that is not an edge of the grid
         const int xl = gx0 < 0 ? exMin : j + 1, xh = gx0 + EROSION_EXT > ZS ? exMax : EROSION_EXT - 2 - j;
         const int zl = gz0 < 0 ? ezMin : j + 1, zh = gz0 + EROSION_EXT > ZS ? ezMax : EROSION_EXT - 2 - j;
-        const bool colLive = ex >= xl && ex <= xh;
+        const bool colLive = worker && ex >= xl && ex <= xh;
         const int r0 = colLive ? imax(rowLo, zl) : 1, r1 = colLive ? imin(rowHi, zh) : 0;
         int flags;
         if (isFirst && j == 0) {
-            flags = relax_strip<true>(s_s[1], s_t[1], s_s[0], s_t[0], s_end, s_acc, k1, k2, ex, exL, exR, r0, r1, ezMin, ezMax, ownCol, colFirst);
+            flags = relax_strip<true>(s_s[1], s_t[1], s_s[0], s_t[0], s_end, s_acc, k1, k2, ex, exL, exR, r0, r1, ezMin, ezMax, ownCol);
             // the result is in plane 0 again
         } else {
-            flags = relax_strip<false>(s_s[cur], s_t[cur], s_s[1 - cur], s_t[1 - cur], s_end, s_acc, k1, k2, ex, exL, exR, r0, r1, ezMin, ezMax, ownCol,
-                                       colFirst);
+            flags = relax_strip<false>(s_s[cur], s_t[cur], s_s[1 - cur], s_t[1 - cur], s_end, s_acc, k1, k2, ex, exL, exR, r0, r1, ezMin, ezMax, ownCol);
             cur = 1 - cur;
         }
-        if (flags & 2) myMask |= 1u << j;
-        // a pass (other than a first pass) that changes no live cell of the tile is the identity from here on: stop
-        const int any = __syncthreads_or(flags & 1);
-        if (!any && !(isFirst && j == 0)) break;
+        // both flag bits of the pass over the workgroup with ONE barrier: a wave's bits from two ballots, one LDS atomic per wave that has any
+        const unsigned waveBits = (__any(flags & 1) ? 1u : 0u) | (__any(flags & 2) ? 2u : 0u);
+        if (waveBits && (tid & 63) == 0) atomicOr(&s_passFlags[j], waveBits);
+        __syncthreads();
+        const unsigned any = s_passFlags[j];
+        if (any & 2) mask |= 1u << j;
+        if (isFirst && j == 0) {
+            // the state after a layer's first pass is the layer's final state if that pass changed no column of the ZONE (next_phase): kept
+            // in the layer's third plane by the tiles whose own centre it left alone (if it moved one, the zone's mask says so and the plane
+            // is not looked at).  Plane 0 is read-only until the barrier behind the next pass.
+            if (!(any & 2) && tid < 256) st4_dev(work, 4u * (rp.startFirst + centre_offset(tileX, tileZ, tid)), centre_piece(s_s[0], tid));
+        } else if (!(any & 1)) break;      // a pass (other than a first pass) that changes no live cell of the tile is the identity from here on
     }
-    if (myMask) atomicOr(s_mask, myMask);
     // results of the centre
-    if (ownCol) {
-        for (int ez = imax(rowLo, EROSION_K); ez <= imin(rowHi, EROSION_K + 31); ++ez) {
-            const int c = EROSION_EXT * ez + ex, g = (gx0 + ex) + ZS * (gz0 + ez);
-            st_dev(startOut + g, s_s[cur][c]);
-            st_dev(accOut + g, s_acc[c]);
+    if (tid < 256) {
+        const unsigned g = centre_offset(tileX, tileZ, tid);
+        st4_dev(work, 4u * (rp.startOut + g), centre_piece(s_s[cur], tid));
+        if (rp.topFirst) {                 // an unchanged first pass keeps accIn: it has to exist
+            float z = 0.f;
+            asm volatile("" : "+v"(z));          // (made here: as a hoisted constant it occupies four registers for the whole launch)
+            st4_dev(work, 4u * (rp.accIn + g), F4{z, z, z, z});
         }
+    } else if (tid < 512) {
+        st4_dev(work, 4u * (rp.accOut + centre_offset(tileX, tileZ, tid - 256)), centre_piece(s_acc, tid - 256));
     }
-    __syncthreads();
-    if (tid == 0 && *s_mask) atomicOr(zoneMask, *s_mask);
+    return mask;
 }
 
 // The whole relaxation of a batch of zones in ONE launch (the host loop of Chunk::erodeZone chunk.cu:682-705 on the device).  A zone is
-// worked on by `perZone` persistent workgroups; a round = what one launch of the round-3 kernel did (EROSION_K passes of the zone's current
-// layer on each of its 144 tiles, the workgroup's share of them one after the other), then a barrier among the zone's workgroups
-// (release: fence + counter; acquire: spin + fence), then every workgroup derives the next phase from the zone's "changed" mask exactly
-// like the launches did.  Zones do not wait for each other and the host is not involved: no launch gaps, no state read-backs.
+// worked on by `perZone` persistent workgroups; a round = EROSION_K passes of the zone's current layer on each of its 144 tiles, a
+// workgroup's share of them (tiles member, member + perZone, ...: fixed, so the next tile's planes are in flight while the current one is
+// relaxed) one after the other, then a barrier among the zone's workgroups, then every workgroup derives the next phase from the zone's
+// "changed" mask exactly like the host loop does from its flag.  Zones do not wait for each other and the host is not involved.
 // Workgroups take their (zone, member) from a ticket, zone-major: whatever order the dispatcher places workgroups in, the zones with the
-// lowest tickets are complete and make progress, so the barrier cannot deadlock even when the launch does not fit the chip at once.
-__global__ void __launch_bounds__(EROSION_THREADS)
+// lowest tickets are complete and make progress, so the barrier cannot deadlock WITHIN one launch even when it does not fit the chip at
+// once.  What can still starve it (several persistent launches in flight on one device, a faulted workgroup) ends the wait after
+// `timeoutTicks` of the 100 MHz clock: the waiting workgroup raises *err = 0x80000000 | zone << 8 | round, every workgroup of the launch
+// leaves at its next look at that word, and the host reports MMGEN_ERROR_EROSION_STALL instead of hanging.
+__global__ void __launch_bounds__(EROSION_THREADS) __attribute__((amdgpu_waves_per_eu(6, 6)))
 k_erode_zones(const float* __restrict__ gatheredBase, size_t gatheredStride, const float* __restrict__ rawLayers, const float* __restrict__ rawHf,
               const int* __restrict__ zoneChunkIdx /*[zones][576]*/, float* workBase, ErosionState* states, unsigned* ticket, int perZone, int* maxPasses,
-              int* maxPassesAlso)
+              int* maxPassesAlso /*nullable*/, unsigned* err, unsigned* errHost /*host-visible copy of the error word, nullable*/, unsigned long long timeoutTicks)
 {
     __shared__ float s_s[2][EROSION_CELLS_EXT];            // start planes, ping-pong over the passes
     __shared__ float s_t[2][EROSION_CELLS_EXT];            // thickness = end - start of the same states (what the neighbours compare)
     __shared__ float s_end[EROSION_CELLS_EXT];
-    __shared__ float s_acc[EROSION_CELLS_EXT];             // accumulated heights; after the load every cell is touched by its own lane only
-    __shared__ unsigned s_mask;
-    __shared__ unsigned s_ticket, s_tile;
+    __shared__ float s_acc[EROSION_CELLS_EXT];             // accumulated heights; after the commit every cell is touched by its own lane only
+    __shared__ int s_chunk[576];                           // the zone's 24 x 24 chunks (region path): raw pieces are addressed without a dependent global load
+    __shared__ unsigned s_ticket;
+    __shared__ unsigned s_passFlags[EROSION_K];            // per pass of the current tile: bit 0 = a live cell changed, bit 1 = a cell of the centre did
+    __shared__ int s_abort;
     __shared__ ErosionPhase s_ph;
 
     const int tid = threadIdx.x;
-    if (tid == 0) s_ticket = atomicAdd(ticket, 1u);
+    if (tid == 0) { s_ticket = atomicAdd(ticket, 1u); s_abort = 0; }
     __syncthreads();
-    const int zone = (int)(s_ticket / (unsigned)perZone), member = (int)(s_ticket % (unsigned)perZone);
+    const unsigned myTicket = (unsigned)__builtin_amdgcn_readfirstlane((int)s_ticket);
+    const int zone = (int)(myTicket / (unsigned)perZone), member = (int)(myTicket % (unsigned)perZone);
     ErosionState* st = states + zone;
     const RawPlanes raw = {gatheredBase ? gatheredBase + gatheredStride * zone : nullptr, rawLayers, rawHf, zoneChunkIdx ? zoneChunkIdx + 576 * zone : nullptr};
-    float* work = workBase + ZONE_WORK_FLOATS * zone;
+    if (raw.chunkIdx) for (int i = tid; i < 576; i += EROSION_THREADS) s_chunk[i] = raw.chunkIdx[i];      // (visible behind the first round's barrier)
+    const __amdgpu_buffer_rsrc_t work = __builtin_amdgcn_make_buffer_rsrc(workBase + ZONE_WORK_FLOATS * zone, 0, (int)(ZONE_WORK_FLOATS * sizeof(float)), 0x00020000);
 
 #pragma unroll 1
     for (int t = 0;; ++t) {
@@ -283,29 +406,72 @@ k_erode_zones(const float* __restrict__ gatheredBase, size_t gatheredStride, con
                     if (maxPassesAlso) atomicMax(maxPassesAlso, ph.passes);
                 }
                 __hip_atomic_store(&st->changed[(t + 1) & 3], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(&st->tileTicket[(t + 1) & 1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            s_tile = ph.done ? 144u : __hip_atomic_fetch_add(&st->tileTicket[t & 1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         __syncthreads();
         const ErosionPhase ph = s_ph;
         if (ph.done) break;
-        // the zone's 144 tiles are dealt out on demand: a tile costs anything between one pass (nothing moves any more) and EROSION_K
-        unsigned tile = s_tile;
-        while (tile < 144u) {
-            __syncthreads();                                          // everyone has read s_tile
-            if (tid == 0) s_tile = __hip_atomic_fetch_add(&st->tileTicket[t & 1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // the next draw is in flight while this tile is worked on
-            erode_tile(raw, work, ph, (int)(tile % 12u), (int)(tile / 12u), &st->changed[t & 3], s_s, s_t, s_end, s_acc, &s_mask);
-            tile = s_tile;                                            // (erode_tile ends with a workgroup barrier)
+        const RoundPlanes rp = round_planes(ph);
+        unsigned roundMask = 0u;
+        TilePieces piece;
+        int tile = member;
+        if (tile < 144) tile_issue_loads(piece, raw, s_chunk, work, rp, tile % 12, tile / 12);
+#pragma unroll 1
+        while (tile < 144) {
+            const int tileX = tile % 12, tileZ = tile / 12;
+            tile_commit(piece, tileX, tileZ, s_s[0], s_end, s_acc);
+            if (tid < EROSION_K) s_passFlags[tid] = 0u;
+            __syncthreads();
+            tile_derive(rp.isFirst, s_s, s_t, s_end, s_acc);
+            __syncthreads();
+            const int next = tile + perZone;
+            if (next < 144) tile_issue_loads(piece, raw, s_chunk, work, rp, next % 12, next / 12);      // in flight while this tile is relaxed
+            roundMask |= relax_tile(work, rp, tileX, tileZ, s_s, s_t, s_end, s_acc, s_passFlags);
+            __syncthreads();                                          // the centre's pieces have been read: the planes may be overwritten
+            tile = next;
         }
-        // ---- barrier among the zone's workgroups: every store above is a device-scope store this wave has waited for (__syncthreads)
+        // ---- barrier among the zone's workgroups.  Release: every wave waits for its own write-through stores, then the workgroup's barrier,
+        // then ONE lane publishes the mask (and waits for that too) and arrives.  The spin is bounded.
+        MM_DRAIN_VMEM();
         __syncthreads();
         if (tid == 0) {
+            if (roundMask) {
+                __hip_atomic_fetch_or(&st->changed[t & 3], roundMask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                MM_DRAIN_VMEM();
+            }
             __hip_atomic_fetch_add(&st->barrier, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const unsigned want = (unsigned)perZone * (unsigned)(t + 1);
-            while (__hip_atomic_load(&st->barrier, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) __builtin_amdgcn_s_sleep(4);
+            const unsigned long long t0 = wall_clock64();
+            unsigned polls = 0u;
+#ifndef MM_POLL_MODE
+#define MM_POLL_MODE 0
+#endif
+#if MM_POLL_MODE == 1
+#define MM_POLL(p) __hip_atomic_fetch_add((p), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#elif MM_POLL_MODE == 2
+#define MM_POLL(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
+#else
+#define MM_POLL(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#endif
+            while (MM_POLL(&st->barrier) < want) {
+                __builtin_amdgcn_s_sleep(4);
+                if ((++polls & 63u) == 0u) {
+                    unsigned e = __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (e == 0u && (unsigned long long)(wall_clock64() - t0) > timeoutTicks) {
+                        e = 0x80000000u | ((unsigned)zone << 8) | ((unsigned)t & 255u);
+                        if (atomicCAS(err, 0u, e) == 0u) {
+                            if (errHost) __hip_atomic_store(errHost, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                            // what the workgroup that gave up saw (read by the host's report)
+                            err[1] = (unsigned)member; err[2] = MM_POLL(&st->barrier); err[3] = want; err[4] = polls;
+                            err[5] = (unsigned)((wall_clock64() - t0) >> 10);
+                        }
+                    }
+                    if (e != 0u) { s_abort = 1; break; }
+                }
+            }
         }
         __syncthreads();
+        if (s_abort) return;
     }
 }
 
@@ -324,24 +490,21 @@ k_erode_writeback(float* __restrict__ gatheredBase, size_t gatheredStride, const
     if (accOutBase) accOutBase[accStride * zone + c] = work[(size_t)24 * ZN + (size_t)st->accSel * ZN + c];
 }
 
-__global__ void k_erode_init(ErosionState* states, float* workBase, int zones, unsigned* ticket)
+// the zones' state machines and the launch's words (ticket, pass count, error).  The accumulated heights need no clearing
+// (thrust::fill_n of chunk.cu:679-680): a zone's first round takes them as zero without loading them and writes both buffers.
+__global__ void k_erode_init(ErosionState* states, int zones, unsigned* ticket)
 {
-    const int zone = blockIdx.y;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int zone = blockIdx.x * blockDim.x + threadIdx.x;
     if (zone >= zones) return;
-    // zero both accumulator buffers (thrust::fill_n of chunk.cu:679-680)
-    float* acc = workBase + ZONE_WORK_FLOATS * zone + (size_t)24 * ZN;
-    if (i < 2 * ZN) acc[i] = 0.f;
-    if (i == 0) {
-        ErosionPhase s;
-        s.layer = MMGEN_NUM_ERODED_MATERIALS - 1; s.isFirst = 1; s.done = 0; s.passes = 0; s.accSel = 0; s.fresh = 1;
-        s.sel = 0u;
-        states[zone].slot[1] = s;            // launch 0 reads slot[(0 - 1) & 1]
-        states[zone].slot[0] = s;
-        for (int k = 0; k < 4; ++k) states[zone].changed[k] = 0u;
-        states[zone].barrier = 0u; states[zone].tileTicket[0] = 0u; states[zone].tileTicket[1] = 0u;
-        if (zone == 0) { ticket[0] = 0u; ticket[1] = 0u; }
-    }
+    ErosionPhase s;
+    s.layer = MMGEN_NUM_ERODED_MATERIALS - 1; s.isFirst = 1; s.done = 0; s.passes = 0; s.accSel = 0; s.fresh = 1;
+    s.sel = 0u;
+    states[zone].slot[1] = s;            // round 0 reads slot[(0 - 1) & 1]
+    states[zone].slot[0] = s;
+    for (int k = 0; k < 4; ++k) states[zone].changed[k] = 0u;
+    states[zone].barrier = 0u;
+    for (int k = 0; k < 3; ++k) states[zone].reserved[k] = 0u;
+    if (zone == 0) for (int k = 0; k < 8; ++k) ticket[k] = 0u;
 }
 
 // E1: chunk-major raw layers of a chunk grid -> packed zone planes (copyLayers(to) chunk.cu:603-656).
@@ -396,7 +559,8 @@ k_erode_finish(const float* __restrict__ workBase, const ErosionState* __restric
 namespace mmk {
 
 size_t erosion_work_bytes(int zones) { return (size_t)zones * ZONE_WORK_FLOATS * sizeof(float); }
-// the zones' states, then one more record's worth of words: [0] = the launch's ticket counter, [1] = largest pass count of the zones
+// the zones' states, then one more record's worth of words: [0] = the launch's ticket counter, [1] = largest pass count of the zones,
+// [2] = the launch's error word (0, or which zone's barrier gave up in which round)
 size_t erosion_state_bytes(int zones) { return (size_t)(zones + 1) * sizeof(mm::ErosionState); }
 
 // workgroups of k_erode_zones the chip holds at once (LDS-bound: three per CU on gfx950), or `quarterCuCap` / 4 per CU if that is fewer
@@ -416,30 +580,85 @@ static int erosion_resident_workgroups(int quarterCuCap)
     return cap < fit ? (cap > 0 ? cap : 1) : fit;
 }
 
+// How long a zone's workgroups wait for each other before the launch gives up (k_erode_zones): MMGEN_EROSION_TIMEOUT_MS in the
+// environment, 2 000 ms otherwise - three orders of magnitude above the longest healthy wait (a round of one workgroup's tiles).
+static std::atomic<long long> g_timeoutMs{-1};
+static std::atomic<int> g_debugMissing{0};              // test hook: launch this many workgroups too few (mmgen_debug_erosion_stall)
+static unsigned long long erosion_timeout_ticks()
+{
+    long long ms = g_timeoutMs.load(std::memory_order_relaxed);
+    if (ms < 0) {
+        const char* e = getenv("MMGEN_EROSION_TIMEOUT_MS");
+        ms = (e && atoll(e) > 0) ? atoll(e) : 2000;
+        g_timeoutMs.store(ms, std::memory_order_relaxed);
+    }
+    return (unsigned long long)ms * 100000ull;              // wall_clock64(): 100 MHz
+}
+// Persistent relaxations of one device run one after the other, whatever streams they are enqueued on.  Each is sized to be resident as a
+// whole; two of them in flight would share the chip's slots, and a workgroup that has not started cannot take a slot in another XCD than
+// the one the dispatcher has bound it to (workgroup i of a launch goes to XCD i mod 8) - measured: with zone 0 finished and half the chip
+// free, the last workgroups of zone 1 waited for slots of two XCDs that the spinning rest of zone 1 occupied, for as long as they spun.
+// An event chain per device orders the launches without blocking the host; the bounded spin stays as the last line (another process).
+static std::mutex g_chainMu;
+static std::map<int, hipEvent_t> g_chain;
+static int chain_before_launch(hipStream_t s, hipEvent_t* ev)
+{
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return (int)e;
+    auto it = g_chain.find(dev);
+    if (it == g_chain.end()) {
+        hipEvent_t n = nullptr;
+        if ((e = hipEventCreateWithFlags(&n, hipEventDisableTiming)) != hipSuccess) return (int)e;
+        it = g_chain.emplace(dev, n).first;
+    } else if ((e = hipStreamWaitEvent(s, it->second, 0)) != hipSuccess) return (int)e;
+    *ev = it->second;
+    return 0;
+}
+
+void erosion_debug_stall(int missingWorkgroups, int timeoutMs)
+{
+    g_debugMissing.store(missingWorkgroups < 0 ? 0 : missingWorkgroups, std::memory_order_relaxed);
+    g_timeoutMs.store(timeoutMs > 0 ? timeoutMs : -1, std::memory_order_relaxed);
+}
+
 // Enqueues the relaxation of `zones` packed zone buffers (stride in floats) to convergence: ONE persistent launch, then the kernel that
 // moves the final planes out.  Nothing is read back unless the caller asks for the pass count (maxPasses != null: the stream is
-// synchronised, like the reference's erodeZone); maxPassesDev (device, may be null) is raised to the largest pass count with the stream.
+// synchronised, like the reference's erodeZone, and a relaxation that gave up is reported as MMGEN_ERROR_EROSION_STALL); maxPassesDev
+// (device, may be null) is raised to the largest pass count with the stream; errHost (host-visible, may be null) receives the error word
+// of a launch that gave up (written by the device, nothing on success).
 int erode_zones(float* gathered, size_t strideFloats, int zones, float* work, mm::ErosionState* states, float* accOut, size_t accStride,
                 hipStream_t s, int* maxPasses, const int* zoneChunkIdxOut, float* layersOut, int* maxPassesDev, hipEvent_t beforeRelaxation,
                 const float* rawLayers, const float* rawHf, const int* zoneChunkIdx, int workgroupsPer4Cu, const unsigned** startedCounter,
-                unsigned* startedTarget)
+                unsigned* startedTarget, unsigned* errHost)
 {
     if (!gathered && !(rawLayers && rawHf && zoneChunkIdx && layersOut)) return (int)hipErrorInvalidValue;
     if (zones <= 0) return 0;
     unsigned* ticket = (unsigned*)(states + zones);
     int* passesWord = (int*)(ticket + 1);
-    MMK_LAUNCH(KID_ERODE_INIT, mm::k_erode_init, dim3((2 * ZN + 255) / 256, zones), dim3(256), s, states, work, zones, ticket);
-    // as many workgroups per zone as keep the whole launch resident (a zone's 144 tiles are dealt out to them round by round)
+    unsigned* errWord = ticket + 2;
+    MMK_LAUNCH(KID_ERODE_INIT, mm::k_erode_init, dim3((zones + 63) / 64), dim3(64), s, states, zones, ticket);
+    // as many workgroups per zone as keep the whole launch resident (a zone's 144 tiles are shared out among them, the same in every round)
     int perZone = erosion_resident_workgroups(workgroupsPer4Cu) / zones;
     perZone = perZone < 1 ? 1 : (perZone > 144 ? 144 : perZone);
     perZone = (144 + (144 + perZone - 1) / perZone - 1) / ((144 + perZone - 1) / perZone);      // fewest workgroups with the same tiles per round
     if (beforeRelaxation) { hipError_t e = hipEventRecord(beforeRelaxation, s); if (e != hipSuccess) return (int)e; }
     // the launch's ticket counts the workgroups that have STARTED (k_erode_init has just cleared it): a caller that wants them on the chip
     // before it launches something that takes every slot waits for the counter to reach the grid size (launch_caves)
+    int grid = zones * perZone - g_debugMissing.load(std::memory_order_relaxed);
+    if (grid < 1) grid = 1;
     if (startedCounter) *startedCounter = ticket;
-    if (startedTarget) *startedTarget = (unsigned)(zones * perZone);
-    MMK_LAUNCH(KID_ERODE_PASS, mm::k_erode_zones, dim3(zones * perZone), dim3(EROSION_THREADS), s, (const float*)gathered, strideFloats, rawLayers, rawHf,
-               zoneChunkIdx, work, states, ticket, perZone, passesWord, maxPassesDev);
+    if (startedTarget) *startedTarget = (unsigned)grid;
+    {
+        std::lock_guard<std::mutex> lk(g_chainMu);
+        hipEvent_t chain = nullptr;
+        int ce = chain_before_launch(s, &chain);
+        if (ce) return ce;
+        MMK_LAUNCH(KID_ERODE_PASS, mm::k_erode_zones, dim3(grid), dim3(EROSION_THREADS), s, (const float*)gathered, strideFloats, rawLayers, rawHf,
+                   zoneChunkIdx, work, states, ticket, perZone, passesWord, maxPassesDev, errWord, errHost, erosion_timeout_ticks());
+        hipError_t re = hipEventRecord(chain, s);
+        if (re != hipSuccess) return (int)re;
+    }
     if (layersOut) {
         // region path: no in-place contract to honour, the kept chunks' planes go straight to the layers
         MMK_LAUNCH(KID_EROSION_SCATTER, mm::k_erode_finish, dim3(144, 8, zones), dim3(256), s, (const float*)work, (const mm::ErosionState*)states, 0,
@@ -449,10 +668,27 @@ int erode_zones(float* gathered, size_t strideFloats, int zones, float* work, mm
                    accStride, 0);
     }
     if (maxPasses) {
-        hipError_t e = hipMemcpyAsync(maxPasses, passesWord, sizeof(int), hipMemcpyDeviceToHost, s);
+        int words[2] = {0, 0};
+        hipError_t e = hipMemcpyAsync(words, passesWord, 2 * sizeof(int), hipMemcpyDeviceToHost, s);
         if (e != hipSuccess) return (int)e;
         e = hipStreamSynchronize(s);
         if (e != hipSuccess) return (int)e;
+        *maxPasses = words[0];
+        if (words[1] != 0) {
+            fprintf(stderr, "mmgen: the erosion relaxation gave up waiting (zone %d of the launch, round %d; %d zones x %d workgroups)\n",
+                    (int)(((unsigned)words[1] >> 8) & 0x7FFFFFu), words[1] & 255, zones, perZone);
+            // what the zones looked like when the launch ended: started workgroups, and per zone the arrivals and the phase it was in
+            std::vector<mm::ErosionState> h((size_t)zones + 1);
+            if (hipMemcpy(h.data(), states, sizeof(mm::ErosionState) * h.size(), hipMemcpyDeviceToHost) == hipSuccess) {
+                const unsigned* tail = (const unsigned*)&h[zones];
+                fprintf(stderr, "mmgen:   workgroups started: %u of %d; gave up: member %u saw %u arrivals of %u after %u polls, %u x 10.24 us\n", tail[0], grid, tail[3],
+                        tail[4], tail[5], tail[6], tail[7]);
+                for (int z = 0; z < zones && z < 16; ++z)
+                    fprintf(stderr, "mmgen:   zone %d: arrivals %u, layer %d, first %d, done %d, passes %d\n", z, h[z].barrier, h[z].slot[0].layer, h[z].slot[0].isFirst,
+                            h[z].slot[0].done, h[z].slot[0].passes);
+            }
+            return MMGEN_ERROR_EROSION_STALL;
+        }
     }
     return 0;
 }

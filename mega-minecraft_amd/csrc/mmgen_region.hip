@@ -232,7 +232,8 @@ struct mmgen_region {
     // runs beside the caves on sErode; the base fill runs on sFill in z slices, the rasterisers / decorators of slice i follow on sApply
     // beside the fill of slice i + 1.  serial = everything on the caller's stream in the reference's stage order (per-kernel
     // attribution for the roofline; MMGEN_REGION_SERIAL=1 or mmgen_region_set_serial).
-    int* hostMax = nullptr;       // pinned + mapped: largest cave list length beyond MMGEN_CFP_CAP seen by a finish (0 = none)
+    int* hostMax = nullptr;       // pinned + mapped: [0] largest cave list length beyond MMGEN_CFP_CAP seen by a finish (0 = none); [1] the error word
+                                  // of a relaxation that gave up (k_erode_zones; 0 = none, never cleared: MMGEN_ERROR_EROSION_STALL from then on)
     int* hostMaxDev = nullptr;    // its device address
     DevBuf devMax;                // [0] largest cave list length of the finishes since the last query (whatever its size); [1], [2] the longest
                                   // gathered (un-truncated) surface / cave list since the last mmgen_region_max_gathered
@@ -289,8 +290,8 @@ int mmgen_region_create(mmgen_region** out)
     *out = new mmgen_region();
     {
         mmgen_region* r = *out;
-        hipError_t he = hipHostMalloc((void**)&r->hostMax, sizeof(int), hipHostMallocMapped);
-        if (he == hipSuccess) { *r->hostMax = 0; he = hipHostGetDevicePointer((void**)&r->hostMaxDev, r->hostMax, 0); }
+        hipError_t he = hipHostMalloc((void**)&r->hostMax, 2 * sizeof(int), hipHostMallocMapped);
+        if (he == hipSuccess) { r->hostMax[0] = 0; r->hostMax[1] = 0; he = hipHostGetDevicePointer((void**)&r->hostMaxDev, r->hostMax, 0); }
         if (he == hipSuccess && r->devMax.ensure(3 * sizeof(int)) == 0) he = hipMemset(r->devMax.p, 0, 3 * sizeof(int));
         else if (he == hipSuccess) he = hipErrorOutOfMemory;
         if (he == hipSuccess) he = hipHostMalloc((void**)&r->hostPasses, sizeof(int), hipHostMallocDefault);
@@ -469,6 +470,7 @@ int mmgen_region_begin(mmgen_region* r, int cx0, int cz0, int nx, int nz, unsign
     r->earlyBlocks = nullptr;
     if (nx <= 0 || nz <= 0) return (int)hipErrorInvalidValue;
     if (__atomic_load_n(r->hostMax, __ATOMIC_RELAXED) > MMGEN_CFP_CAP) return MMGEN_ERROR_PLACEMENT_OVERFLOW;
+    if (__atomic_load_n(r->hostMax + 1, __ATOMIC_RELAXED) != 0) return MMGEN_ERROR_EROSION_STALL;
     hipStream_t s = (hipStream_t)stream;
     const bool erosion = flags & MMGEN_REGION_EROSION, features = flags & MMGEN_REGION_FEATURES;
     const bool par = !r->serial;
@@ -543,9 +545,9 @@ int mmgen_region_begin(mmgen_region* r, int cx0, int cz0, int nx, int nz, unsign
             const int nb = (Z - z0) < batch ? (Z - z0) : batch;
             // (no E1 copy: the relaxation reads the zones' raw planes through their chunk lists)
             CK(mmk::erode_zones(nullptr, 0, nb, r->erodeWork.as<float>(), r->erodeState.as<mm::ErosionState>(), nullptr, 0, sE, nullptr,
-                                r->zoneIdxOut.as<int>() + (size_t)z0 * 144, layersP, r->devPasses.as<int>(), par ? r->evResident : nullptr,
+                                r->zoneIdxOut.as<int>() + (size_t)z0 * 144, layersP, r->devPasses.as<int>(), (par && z0 == 0) ? r->evResident : nullptr,
                                 r->layersA.as<float>(), r->hfA.as<float>(), r->zoneIdx.as<int>() + (size_t)z0 * 576,
-                                par ? MMGEN_REGION_EROSION_WG_PER_4CU : 0, (par && Z <= batch) ? &startedCounter : nullptr, &startedTarget));
+                                par ? MMGEN_REGION_EROSION_WG_PER_4CU : 0, (par && Z <= batch) ? &startedCounter : nullptr, &startedTarget, (unsigned*)(r->hostMaxDev + 1)));
         }
         // ---- E3 fix-up
         CK(mmk::launch_fix_backward(layersP, np, sE));
@@ -684,6 +686,7 @@ int mmgen_region_finish(mmgen_region* r, uint8_t* d_blocks, float* d_heightfield
     const int* tgt = r->targets.as<int>();
 
     if (__atomic_load_n(r->hostMax, __ATOMIC_RELAXED) > MMGEN_CFP_CAP) return MMGEN_ERROR_PLACEMENT_OVERFLOW;
+    if (__atomic_load_n(r->hostMax + 1, __ATOMIC_RELAXED) != 0) return MMGEN_ERROR_EROSION_STALL;
     if (!r->filled || r->filledInto != d_blocks) CK(mmgen_region_fill(r, d_blocks, stream));
     hipStream_t sA = par ? r->sApply : s;
     if (features) {
@@ -746,6 +749,7 @@ int mmgen_region_last_erosion_passes(const mmgen_region* r)
 {
     if (!r) return -1;
     if (r->passesPending && hipEventSynchronize(r->evPasses) != hipSuccess) return -1;
+    if (__atomic_load_n(r->hostMax + 1, __ATOMIC_RELAXED) != 0) return -1;      // the relaxation gave up (MMGEN_ERROR_EROSION_STALL)
     return *r->hostPasses;
 }
 

@@ -152,14 +152,49 @@ class TileContext:
         self.send_scratch = torch.zeros((3 * len(send) + 1,), dtype=torch.int32, device=device)
         self.recv_scratch = torch.zeros((3 * len(recv) + 1,), dtype=torch.int32, device=device)
         self.overflow = torch.zeros((1,), dtype=torch.int32, device=device)
+        self._torch = torch
+        self._host_overflow = None          # pinned copy of the overflow word of the last step + the event behind that copy (GPU)
+        self._copied = None
+
+    def _raise(self, need):
+        self.overflow.zero_()
+        raise RuntimeError(f"ring message overflow: a peer's cells needed {need} payload words, the budget is {self.words_per_cell} per cell "
+                           f"on average - the tile of that step is INVALID (cells that did not fit arrived empty); rebuild the TileContext "
+                           f"with a larger words_per_cell (7424 can never overflow)")
 
     def check(self):
         """Reads the overflow word (a device read: call it after the step, not inside it).  Raises when a ring message did not fit."""
+        self._copied = None
         need = int(self.overflow.item())
         if need:
-            self.overflow.zero_()
-            raise RuntimeError(f"ring message overflow: a peer's cells needed {need} payload words, the budget is {self.words_per_cell} per cell "
-                               f"on average - rebuild the TileContext with a larger words_per_cell (7424 can never overflow)")
+            self._raise(need)
+
+    def note_step(self):
+        """After a step's region_finish: starts the copy of the overflow word to pinned memory behind everything the step enqueued, without
+        waiting for it (generate_tile calls this; check_previous() looks at it at the start of the next step)."""
+        if self.overflow.is_cuda:
+            t = self._torch
+            if self._host_overflow is None:
+                self._host_overflow = t.zeros((1,), dtype=t.int32).pin_memory()
+            self._host_overflow.copy_(self.overflow, non_blocking=True)
+            self._copied = t.cuda.Event()
+            self._copied.record()
+        else:
+            self._copied = True
+
+    def check_previous(self):
+        """Start of a step: the previous step's overflow word.  On a GPU the wait is for an event recorded behind the previous step -
+        over by the time the caller has consumed that step's tile - so the step itself still makes no device read."""
+        if self._copied is None:
+            return
+        if self._copied is True:
+            need = int(self.overflow[0])
+        else:
+            self._copied.synchronize()
+            need = int(self._host_overflow[0])
+        self._copied = None
+        if need:
+            self._raise(need)
 
 
 def message_layout(seg, words_per_cell):
@@ -211,12 +246,20 @@ def _event(torch):
     return e
 
 
-def generate_tile(backend, layout, rank, flags, dist=None, torch=None, want=(), ctx=None, timing=None):
+def generate_tile(backend, layout, rank, flags, dist=None, torch=None, want=(), ctx=None, timing=None, words_per_cell=2048):
     """Generates this rank's tile of the world through all stages selected by `flags` (MMGEN_REGION_* bits).  Pass a TileContext to
-    keep the per-layout planning out of the step."""
-    if ctx is None:
+    keep the per-layout planning out of the step.
+
+    Ring messages have a fixed budget (module docstring); cells that do not fit arrive EMPTY, which would silently drop features.  It
+    cannot go unnoticed: with a caller-owned context the overflow word of step i is looked at when step i + 1 starts (RuntimeError; no
+    device read inside a step) and by ctx.check() whenever the caller wants certainty - the returned tile is valid once either has passed;
+    without a context (one-off call) the word is read before returning."""
+    own_ctx = ctx is None
+    if own_ctx:
         dev = getattr(backend, "device", "cpu")
-        ctx = TileContext(layout, rank, torch if torch is not None else backend.torch, dev)
+        ctx = TileContext(layout, rank, torch if torch is not None else backend.torch, dev, words_per_cell=words_per_cell)
+    else:
+        ctx.check_previous()
     cx0, cz0, nx, nz = ctx.region
     features = bool(flags & 2)
     exchange = features and ctx.multi
@@ -232,4 +275,9 @@ def generate_tile(backend, layout, rank, flags, dist=None, torch=None, want=(), 
         halo_bytes = exchange_placements(backend, ctx, bufs, dist, torch, overlap=overlap, timing=timing)
     out = backend.region_finish(nx, nz, want)
     out["halo_bytes_received"] = halo_bytes
+    if exchange:
+        if own_ctx:
+            ctx.check()                   # nobody else can: the context dies with this call
+        else:
+            ctx.note_step()
     return out

@@ -109,6 +109,11 @@ class MMGen:
         self._check(self.lib.mmgen_erode_zones(self._p(gathered), zones, self._p(acc), ctypes.byref(mp), self._stream()), "mmgen_erode_zones")
         return (gathered, mp.value, acc) if want_acc else (gathered, mp.value)
 
+    def debug_erosion_stall(self, missing_workgroups, timeout_ms):
+        """Test hook (mmgen_debug_erosion_stall): the next persistent relaxations are launched short; (0, 0) restores the defaults."""
+        self.lib.mmgen_debug_erosion_stall.argtypes = [ctypes.c_int, ctypes.c_int]
+        self._check(self.lib.mmgen_debug_erosion_stall(missing_workgroups, timeout_ms), "mmgen_debug_erosion_stall")
+
     @staticmethod
     def zone_area_coords(zone_cx, zone_cz):
         """The 24x24 chunks a zone gathers for erosion: own 12x12 + 6-chunk padding (terrain.cpp:471-522), z-major."""

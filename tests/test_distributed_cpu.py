@@ -242,3 +242,42 @@ def test_loopback_exchange_restores_the_wiped_ring(oracle):
     assert not np.array_equal(bad["blocks"], ref["blocks"]), "a payload of zeros went unnoticed: the loopback does not test the wire"
     with pytest.raises(ValueError):
         d.TileContext(d.TileLayout(0, 0, 2, 1, 2, 2), 0, torch, "cpu", loopback=True)
+
+
+def test_generate_tile_surfaces_a_ring_message_overflow(oracle):
+    """Cells that do not fit a ring message arrive EMPTY (features silently missing) - generate_tile must not let that pass: with a
+    caller-owned context the NEXT step (or ctx.check()) raises, without a context the call itself does."""
+    import torch
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    d = importlib.import_module("mega-minecraft_amd.distributed")
+    from oracle_binding import OracleBackend
+    lay = d.TileLayout(1487, -1111, 1, 1, 2, 2)
+    ob = OracleBackend(nthreads=oracle.nthreads)
+    ctx = d.TileContext(lay, 0, torch, "cpu", loopback=True, words_per_cell=4)       # a jungle ring cell carries hundreds of words
+    out = d.generate_tile(ob, lay, 0, 7, dist=_SelfLoop(), torch=torch, ctx=ctx)      # the step itself makes no device read ...
+    assert out["halo_bytes_received"] > 0
+    with pytest.raises(RuntimeError, match="ring message overflow"):                   # ... the next one starts with the verdict
+        d.generate_tile(ob, lay, 0, 7, dist=_SelfLoop(), torch=torch, ctx=ctx)
+    d.generate_tile(ob, lay, 0, 7, dist=_SelfLoop(), torch=torch, ctx=ctx)              # (the raise consumed the record; this step overflows again)
+    with pytest.raises(RuntimeError, match="ring message overflow"):
+        ctx.check()
+    ok = d.TileContext(lay, 0, torch, "cpu", loopback=True)
+    d.generate_tile(ob, lay, 0, 7, dist=_SelfLoop(), torch=torch, ctx=ok)
+    ok.check()                                                                         # the default budget fits
+
+
+def test_generate_tile_without_context_checks_before_returning(oracle, monkeypatch):
+    import torch
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    d = importlib.import_module("mega-minecraft_amd.distributed")
+    from oracle_binding import OracleBackend
+    lay = d.TileLayout(1487, -1111, 1, 1, 2, 2)
+    ob = OracleBackend(nthreads=oracle.nthreads)
+    # a one-off call builds its own context; make that one a loopback with a budget that cannot fit
+    real = d.TileContext
+    monkeypatch.setattr(d, "TileContext", lambda layout, rank, t, dev, words_per_cell=2048: real(layout, rank, t, dev, loopback=True, words_per_cell=words_per_cell))
+    with pytest.raises(RuntimeError, match="ring message overflow"):
+        d.generate_tile(ob, lay, 0, 7, dist=_SelfLoop(), torch=torch, words_per_cell=4)
+    out = d.generate_tile(ob, lay, 0, 7, dist=_SelfLoop(), torch=torch)
+    ref = oracle.generate_region(1487, -1111, 2, 2, erosion=True, features=True, decorators=True)
+    assert np.array_equal(out["blocks"], ref["blocks"])

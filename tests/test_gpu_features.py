@@ -240,6 +240,19 @@ def test_config4_world_2x2_tiles_equals_single_region_and_oracle(mmgen_pkg, orac
     assert np.array_equal(got, ref)
 
 
+def test_region_with_more_zones_than_one_relaxation_batch_matches_oracle(gen, oracle):
+    """A 120 x 120-chunk region touches 12 x 12 = 144 erosion zones: two batches of the persistent relaxation (96 + 48, MMGEN_EROSION_ZONE_BATCH)
+    beside one cave launch.  Chunks whose zone is relaxed by the SECOND batch (zone index 116 of the z-major order) == the CPU oracle, and the
+    pass count the region reports covers both batches."""
+    out = gen.generate_region(-60, -60, 120, 120)
+    ref = oracle.generate_region(30, 40, 2, 2, erosion=True, features=True, decorators=True)["blocks"]
+    got = out["blocks"].view(120, 120, 98304)[100:102, 90:92].reshape(4, 98304).cpu().numpy()
+    assert np.array_equal(got, ref)
+    first = oracle.generate_region(-60, -60, 1, 1, erosion=True, features=True, decorators=True)["blocks"]      # ... and one of the first batch
+    assert np.array_equal(out["blocks"][0].cpu().numpy(), first[0])
+    assert gen.lib.mmgen_region_last_erosion_passes(gen._region()) >= 24
+
+
 def test_config5_world_8_tiles_equals_single_region(mmgen_pkg):
     """BASELINE config 5 at full size: the 65 536-chunk world [-128, 128)^2 as 4 x 2 tiles of 64 x 128 chunks (the 8-GPU layout,
     played on one GPU) is block-for-block the world generated as one region: 6.4 GB of block ids compared on the device."""

@@ -309,3 +309,25 @@ def test_stage_calls_on_two_streams_do_not_share_scratch(gen):
     torch.cuda.synchronize()
     for i in range(2):
         assert torch.equal(outs[i], ref[i][2])
+
+
+@pytest.mark.gpu
+def test_starved_relaxation_gives_up_with_an_error_instead_of_hanging(gen):
+    """The relaxation's workgroups wait for each other on the device; a zone whose workgroups never all arrive (here: the launch is one
+    workgroup short, so the last zone's barrier cannot complete) must end the launch after the timeout and surface
+    MMGEN_ERROR_EROSION_STALL - never spin forever (the reference's host loop cannot stall: chunk.cu:682-705)."""
+    import torch
+    pos = gen.positions(gen.zone_area_coords(0, 0))
+    hf, bw, g = gen.generate_heightfields(pos, gathered=True)
+    packed = gen.pack_zone_planes(gen.generate_layers(g, bw, pos), hf)
+    good, passes = gen.erode_zones(packed.clone())
+    gen.debug_erosion_stall(1, 200)
+    try:
+        with pytest.raises(RuntimeError, match="20002"):
+            gen.erode_zones(packed.clone())
+    finally:
+        gen.debug_erosion_stall(0, 0)
+    torch.cuda.synchronize()
+    # the device is fine afterwards: the same call succeeds again with the same result
+    again, p2 = gen.erode_zones(packed.clone())
+    assert p2 == passes and torch.equal(again, good)

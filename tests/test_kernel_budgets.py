@@ -74,3 +74,55 @@ def test_hot_kernels_keep_their_occupancy_budgets():
     # the relaxation: three workgroups per CU alone, one beside four cave workgroups
     m = k("k_erode_zones")
     assert m["scratch"] == 0 and 3 * m["lds"] <= cu_lds and m["lds"] + 4 * k("k_cave_voxels")["lds"] <= cu_lds, m
+
+
+OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+
+
+def kernel_disassembly(prefix):
+    """instruction lines (mnemonic + operands) of the one gfx950 kernel whose mangled name matches mm::<prefix>"""
+    blob = open(LIB, "rb").read()
+    with tempfile.TemporaryDirectory() as d:
+        for i, (triple, co) in enumerate(code_objects(blob)):
+            if "gfx950" not in triple or not co.startswith(b"\x7fELF"):
+                continue
+            path = os.path.join(d, f"co{i}.elf")
+            open(path, "wb").write(co)
+            text = subprocess.run([OBJDUMP, "-d", "--no-show-raw-insn", path], capture_output=True, text=True).stdout
+            m = re.search(r"^[0-9a-f]+ <(_ZN2mm\d+" + prefix + r"E[^>]*)>:\n(.*?)(?=^[0-9a-f]+ <|\Z)", text, re.S | re.M)
+            if m:
+                return [re.sub(r"\s*//.*", "", l).strip() for l in m.group(2).splitlines() if l.strip()]
+    raise AssertionError(prefix + " not found in the shipped code objects")
+
+
+@pytest.mark.skipif(not (os.path.exists(LIB) and os.path.exists(OBJDUMP)), reason="needs the built library and llvm-objdump")
+def test_relaxation_barrier_has_release_ordering_in_the_shipped_isa():
+    """k_erode_zones hands planes, masks and phases from workgroup to workgroup inside one launch with write-through (sc1) stores and a
+    counter.  The counter add must not overtake the stores: every storing wave waits for its own stores (s_waitcnt vmcnt(0)), THEN the
+    workgroup barrier, THEN one lane publishes the mask, waits for that too, and arrives.  A workgroup-scope fence emits no vmcnt wait on
+    gfx950 and s_barrier waits for no counter, so the waits are explicit - this test reads them out of the code object that ships."""
+    ins = kernel_disassembly("k_erode_zones")
+    idx = lambda pred: [i for i, l in enumerate(ins) if pred(l)]
+    # the arrive: the only global atomic add without a returned value (the ticket draw at the top returns one: sc0)
+    arrive = idx(lambda l: l.startswith("global_atomic_add ") and "sc0" not in l)
+    assert len(arrive) == 1, [ins[i] for i in arrive]
+    a = arrive[0]
+    stores = idx(lambda l: re.match(r"(buffer|global)_store_dword", l) is not None and "sc1" in l)
+    payload = [i for i in stores if i < a]
+    assert payload, "no write-through stores ahead of the arrive?"
+    # every plane store is a 16-byte write-through store; the only narrow sc1 stores are the phase / mask words of the zone's first workgroup
+    assert sum(1 for i in payload if ins[i].startswith("buffer_store_dwordx4")) >= 3
+    last = max(payload)
+    drains = idx(lambda l: l.startswith("s_waitcnt") and "vmcnt(0)" in l)
+    barriers = idx(lambda l: l == "s_barrier")
+    d1 = [i for i in drains if last < i < a]
+    assert d1, "no s_waitcnt vmcnt(0) between the last payload store and the arrive"
+    assert any(d1[0] < b < a for b in barriers), "no workgroup barrier between the storing waves' drain and the arrive"
+    ors = [i for i in idx(lambda l: l.startswith("global_atomic_or ")) if last < i < a]
+    assert len(ors) == 1, "the zone's changed mask is published once per round, ahead of the arrive"
+    assert any(ors[0] < i < a for i in drains), "the mask's atomic is not waited for before the arrive"
+    # every load of a handed-off plane is an sc1 load to registers; the spin reads the counter sc1 and sleeps, and consults the clock
+    assert sum(1 for l in ins if l.startswith("buffer_load_dwordx4") and "sc1" in l) >= 3
+    assert not any(l.startswith("flat_load") or l.startswith("flat_store") for l in ins)
+    after = ins[a:]
+    assert any(l.startswith("s_sleep") for l in after) and any(l.startswith("s_memrealtime") for l in after), "unbounded spin?"

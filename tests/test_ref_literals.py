@@ -161,7 +161,12 @@ DEVICE_ALLOW = {
 # the bit-exact stage tests (tests/test_gpu_parity.py: layers, one erosion zone incl. its pass count, fill, gathered lists and bounds).
 DEVICE_NO_OWN_CONSTANTS = {"chunk.cu::kernGenerateHeightfield", "chunk.cu::kernGenerateLayers", "chunk.cu::kernDoErosion.stage", "chunk.cu::kernDoErosion.relax",
                            "chunk.cu::copyLayers", "chunk.cu::fixBackwardStratifiedLayers", "chunk.cu::kernFill", "chunk.cu::heightBoundsMinMax",
-                           "chunk.cu::Chunk.fill.lists"}
+                           "chunk.cu::Chunk.fill.lists",
+                           # the mesh build: the device mesher works on 64-voxel words of bit masks and packed quad records, not on
+                           # the reference's loops - its own constants are mostly layout; the world constants it shares with createVBOs are
+                           # held by test_device_mesher_holds_the_reference_constants below, its bytes by tests/test_mesh.py
+                           "chunk.cu::createVBOs", "chunk.cu::createVBOs.xShapedPosOffset", "chunk.cu::createVBOs.xShapedVertPositions",
+                           "chunk.cu::createVBOs.xShapedFaceNormals", "chunk.cu::createVBOs.directionVertPositions", "chunk.cu::createVBOs.uvOffsets"}
 
 
 def test_device_sections_hold_every_reference_constant():
@@ -221,6 +226,16 @@ def test_device_sections_hold_every_reference_constant():
     assert not problems, "\n".join(problems)
 
 
+def test_device_mesher_holds_the_reference_constants():
+    """Every number Chunk::createVBOs writes (chunk.cu:1778-2003: the 0.4 jitter, the 0.0625 tile size, the half-block centre, 16 / 384 ...)
+    appears in the device mesher, and its X-shaped offset is the correctly rounded 0.5 * sin(45 degrees) of chunk.cu:1753."""
+    ours = set(literals(_read([CS + "mmgen_mesh.hip", CS + "mm_blockdata.cuh"])))
+    missing = sorted(set(REF["chunk.cu::createVBOs"]) - ours)
+    assert not missing, missing
+    assert REF["chunk.cu::createVBOs.xShapedPosOffset"] == [0.5, 45.0]
+    assert float(np.float32(0.5 * np.sin(np.radians(45.0)))) in ours
+
+
 # ---------------------------------------------------------------------------------------------------------------------------------
 # statement skeletons: tests/golden/ref_skeletons.json holds one SHA-256 per reference section (the digest of its normalised token stream,
 # tools/extract_ref_literals.py::skeleton; a digest, not text).  Where the oracle's same-named section has the same digest it IS the
@@ -263,11 +278,11 @@ def test_oracle_sections_are_token_identical_to_the_reference():
     assert not stale, "sections listed as different that are identical now (move them out of SKELETON_DIFFERS): " + ", ".join(stale)
     # what is pinned this way: every function and switch case on the path, and the arithmetic written inline in the kernels / host stages
     # (ANCHORS), kernGenerateCaves included
-    assert len(SKEL) >= 142 and len(identical) == len(SKEL)
+    assert len(SKEL) >= 148 and len(identical) == len(SKEL)
     count = lambda prefix: sum(k.startswith(prefix) for k in identical)
     assert count("biomeFuncs.hpp::getHeight::") == 24
     assert count("featurePlacement.hpp::placeFeature::") == 21 and count("featurePlacement.hpp::placeCaveFeature::") == 10
-    assert count("rng.hpp::") == 24 and count("chunk.cu::") == 24 and count("biomeFuncs.hpp::") == 51 and count("featurePlacement.hpp::") == 43
+    assert count("rng.hpp::") == 24 and count("chunk.cu::") == 30 and count("chunk.cu::createVBOs") == 6 and count("biomeFuncs.hpp::") == 51 and count("featurePlacement.hpp::") == 43
     assert all(SKEL[k]["tokens"] > 0 for k in SKEL)
 
 

@@ -104,12 +104,18 @@ def body_after(text, start):
     raise ValueError("unbalanced braces")
 
 
+STATEMENT = "statement"
+
+
 def sections(text, signature, case_prefixes=(), anchors=None):
     """{section: code}.  `signature` is a regex matching the start of the function definition; with case_prefixes the body is cut at
     `case <prefix>NAME:` labels (consecutive labels share the code that follows; code before the first label is section '').
     anchors = (start regex, end regex or None): only the part of the body from the first match of `start` up to the first match of `end`
     behind it (or the body's end) counts - the arithmetic core of a CUDA kernel without its thread-index preamble and barriers."""
     out = {}
+    if case_prefixes == STATEMENT:                            # a file-scope definition that is one statement: the matches themselves
+        code = " ".join(m.group(0) for m in re.finditer(signature, text))
+        return {"": code} if code else {}
     for m in re.finditer(signature, text):
         try:
             body = body_after(text, m.end() - 1 if text[m.end() - 1] == "{" else m.end())
@@ -151,7 +157,7 @@ RENAME = {"g_smoothstep": "smoothstep", "g_mix": "mix", "g_clamp": "clamp", "g_m
           "mm_fmodf": "fmod", "mm_sqrtf": "sqrt", "mm_sincosf": "sincosf", "sinf": "sin", "cosf": "cos", "acosf": "acos", "atan2f": "atan2",
           "fmodf": "fmod", "fabsf": "abs", "fmaxf": "max", "fminf": "min", "fmax": "max", "fmin": "min", "floorf": "floor", "sqrtf": "sqrt",
           "isInRangeF": "isInRange", "isInRangeI": "isInRange", "g_ceil": "ceil", "ceilf": "ceil", "g_angle": "angle", "g_sin": "sin",
-          "hash_u32": "hash", "Rng": "default_random_engine",
+          "hash_u32": "hash", "Rng": "default_random_engine", "g_radians": "radians",
           # C++ leaves the order of evaluation of call arguments unspecified; where the reference draws from one random stream in several
           # arguments of one vec3(...) the oracle fixes the canonical left-to-right order with a braced list behind this macro (mmo_vec.h)
           "vec3_ltr": "vec3"}
@@ -371,6 +377,15 @@ REFERENCE_SECTIONS = [
     ("terrain/chunk.cu", "kernFill", r"void\s+kernFill\s*\([^{]*\)\s*\{", ()),
     ("terrain/chunk.cu", "heightBoundsMinMax", r"void\s+heightBoundsMinMax\s*\([^{]*\)\s*\{", ()),
     ("terrain/chunk.cu", "Chunk.fill.lists", r"void\s+Chunk::fill\s*\([^{]*\)\s*\{", ()),
+    # SURVEY 8f-2, the mesh build that follows the path: Chunk::createVBOs (plain host C++, whole function) and the static tables in front
+    # of it (chunk.cu:1753-1776; file-scope definitions: a brace initialiser is a body like any other, a one-statement definition is
+    # taken as the statement itself)
+    ("terrain/chunk.cu", "createVBOs", r"void\s+Chunk::createVBOs\s*\(\s*\)\s*\{", ()),
+    ("terrain/chunk.cu", "createVBOs.xShapedPosOffset", r"float\s+xShapedPosOffset\s*=[^;]*;", STATEMENT),
+    ("terrain/chunk.cu", "createVBOs.xShapedVertPositions", r"xShapedVertPositions\s*=\s*\{", ()),
+    ("terrain/chunk.cu", "createVBOs.xShapedFaceNormals", r"vec3\s+xShapedFaceNormal[12]\s*=[^;]*;", STATEMENT),
+    ("terrain/chunk.cu", "createVBOs.directionVertPositions", r"directionVertPositions\s*=\s*\{", ()),
+    ("terrain/chunk.cu", "createVBOs.uvOffsets", r"\buvOffsets\s*=\s*\{", ()),
 ]
 # key -> (start, end): the section is the part of the function body from `start` up to `end` (None = the body's end)
 ANCHORS = {
@@ -403,7 +418,7 @@ def oracle_anchors(key):
 
 # where the oracle restates each reference file
 ORACLE_FILES = {"biomeFuncs.hpp": ["oracle/mmo_biome.h", "oracle/mmo_biome.cpp"], "featurePlacement.hpp": ["oracle/mmo_features.cpp"],
-                "rng.hpp": ["oracle/mmo_noise.h"], "chunk.cu": ["oracle/mmo_stages.cpp"]}
+                "rng.hpp": ["oracle/mmo_noise.h"], "chunk.cu": ["oracle/mmo_stages.cpp", "oracle/mmo_mesh.cpp"]}
 
 # the oracle's spelling of a reference signature (free functions instead of Chunk:: members, its own kernel-less stage names)
 ORACLE_SIGNATURES = {"rng.hpp::hash": r"uint32_t\s+hash_u32\s*\([^)]*\)\s*\{",
