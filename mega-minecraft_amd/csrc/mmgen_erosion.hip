@@ -382,6 +382,12 @@ k_erode_zones(const float* __restrict__ gatheredBase, size_t gatheredStride, con
     __shared__ ErosionPhase s_ph;
 
     const int tid = threadIdx.x;
+#ifndef MM_ERODE_PRIO
+#define MM_ERODE_PRIO 3
+#endif
+    // beside the caves (16 issue-bound waves per CU) this kernel's 8 waves mostly wait: at the highest wave priority they get the issue slot
+    // whenever they can use one, and the workgroup's share of the CU (48.8 KB of LDS = two cave workgroups) is given back sooner
+    __builtin_amdgcn_s_setprio(MM_ERODE_PRIO);
     if (tid == 0) { s_ticket = atomicAdd(ticket, 1u); s_abort = 0; }
     __syncthreads();
     const unsigned myTicket = (unsigned)__builtin_amdgcn_readfirstlane((int)s_ticket);

@@ -1194,6 +1194,9 @@ k_fill_base(const float* __restrict__ hf, const float* __restrict__ bw, const fl
 
 // batchStart[r] = number of 64-voxel batches in the lists of the rows before r (batchStart[nRows] = all of them); rangeRow[g] = the row
 // batch range * g lies in.  One workgroup per 1 024 rows; each sums the counts before its rows itself (a few hundred KB out of L2).
+// (In the stage DAG its 16-wave workgroups find no CU to start on until k_feature_placements has left the chip: 0.17 ms instead of 0.03.
+// That wait is worth having: with four-wave workgroups it is 0.11 ms, k_fill_cave's persistent workgroups then start beside the placement
+// kernel's, the gather takes the slots those free, and the cave fill runs 6.1 ms instead of 5.5 - step 21.5 -> 22.1 ms, profiles/LOG.md r05.)
 __global__ void __launch_bounds__(1024)
 k_fill_scan(const int* __restrict__ rowCounts, int nRows, int range, int* __restrict__ batchStart, int* __restrict__ rangeRow)
 {

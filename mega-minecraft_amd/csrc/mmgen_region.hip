@@ -253,8 +253,14 @@ struct mmgen_region {
         int prLeast = 0, prGreatest = 0;
         if ((e = hipDeviceGetStreamPriorityRange(&prLeast, &prGreatest)) != hipSuccess) return (int)e;
         if ((e = hipStreamCreateWithPriority(&sErode, hipStreamNonBlocking, prGreatest)) != hipSuccess) return (int)e;
-        if ((e = hipStreamCreateWithFlags(&sFill, hipStreamNonBlocking)) != hipSuccess) return (int)e;
-        if ((e = hipStreamCreateWithFlags(&sApply, hipStreamNonBlocking)) != hipSuccess) return (int)e;
+#ifndef MM_FILL_STREAM_HIGH
+#define MM_FILL_STREAM_HIGH 1
+#endif
+        // the fill and the rasterisers are the step's critical path behind the caves; what runs beside them on the caller's stream (cave
+        // biomes, placements, the gather) is not: their queue goes first whenever a slot frees up
+        const int prFill = MM_FILL_STREAM_HIGH ? prGreatest : prLeast;
+        if ((e = hipStreamCreateWithPriority(&sFill, hipStreamNonBlocking, prFill)) != hipSuccess) return (int)e;
+        if ((e = hipStreamCreateWithPriority(&sApply, hipStreamNonBlocking, prFill)) != hipSuccess) return (int)e;
         hipEvent_t* ev[] = {&evK2, &evResident, &evCaveVoxels, &evBegin, &evErosion, &evGather, &evTail, &evEntry};
         for (hipEvent_t* x : ev) if ((e = hipEventCreateWithFlags(x, hipEventDisableTiming)) != hipSuccess) return (int)e;
         for (int i = 0; i < kMaxSlices; ++i)

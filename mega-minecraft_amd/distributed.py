@@ -197,6 +197,30 @@ class TileContext:
             self._raise(need)
 
 
+_K_WORD = -7046029254386353131        # 0x9E3779B97F4A7C15 as int64
+_K_CHUNK = -4417276706812531889       # 0xC2B2AE3D27D4EB4F as int64
+
+
+def tile_checksum(blocks, torch):
+    """64-bit position-dependent checksum of a tile's block ids ([chunks, 98304] uint8, device or host tensor), computed where the tensor
+    lives: sum over chunks c and 8-byte words w of word * (2 w + 1) K1 * (2 c + 1) K2 (mod 2^64).  Linear, so it costs one pass; every
+    multiplier is odd, so a changed, moved or swapped word changes it.  tests/golden/tile_checksums.json holds the values of the bench
+    layouts' tiles as the SINGLE-region pipeline generates them: a multi-GPU run can hold every rank's tile to them (bench.py)."""
+    n = blocks.shape[0]
+    words = blocks.contiguous().view(torch.int64).view(n, -1)
+    mw = (2 * torch.arange(words.shape[1], dtype=torch.int64, device=words.device) + 1) * _K_WORD
+    total = torch.zeros((), dtype=torch.int64, device=words.device)
+    for c0 in range(0, n, 1024):                      # (bounded temporaries: 100 MB per slab)
+        part = (words[c0:c0 + 1024] * mw).sum(1)
+        mc = (2 * torch.arange(c0, c0 + part.shape[0], dtype=torch.int64, device=words.device) + 1) * _K_CHUNK
+        total = total + (part * mc).sum()
+    return int(total.item()) & 0xFFFFFFFFFFFFFFFF
+
+
+def layout_key(layout):
+    return f"{layout.tiles_x}x{layout.tiles_z} tiles of {layout.tile_nx}x{layout.tile_nz} chunks at ({layout.world_cx0},{layout.world_cz0})"
+
+
 def message_layout(seg, words_per_cell):
     """seg: the peers' segment boundaries in a cell list.  Returns (message boundaries in words, flat slots [4 per cell]): slot =
     (word of the cell's two lengths, first payload word of its peer's message, index of the peer's first cell, payload capacity)."""

@@ -5,6 +5,9 @@
 // chunk that is drawable for the player must exist in both with identical blocks, vertices and indices.
 //
 //   mmgen_region_terrain_demo [playerChunkX playerChunkZ]      exit code 0 = identical
+//   mmgen_region_terrain_demo --bench                          the streaming figures as ONE JSON line (bench.py's `streaming` record):
+//       initial load of the radius-16 world and a 32-step walk of one chunk per tick through RegionTerrain - device resident, and with
+//       the packed blocks + meshes copied into the host Chunk objects - beside the action-time mirror's initial load
 #include "terrain.hpp"
 #include "region_terrain.hpp"
 #include <algorithm>
@@ -57,11 +60,71 @@ static int compare(Terrain& a, RegionTerrain& b, ivec2 player)
     return bad;
 }
 
+// one scheduler configuration through the streaming scenario: everything around `home`, then `steps` ticks with the player one chunk
+// further along +x each (a 35 x 1 strip of new drawable chunks + its neighbour ring per tick)
+struct StreamFigures { int loadChunks = 0, loadMeshed = 0; double loadMs = 0; int walkChunks = 0, walkMeshed = 0, ringComputed = 0, ringReused = 0; double walkMs = 0; size_t d2hBytes = 0; };
+static StreamFigures stream_scenario(bool copyToHost, ivec2 home, int steps)
+{
+    StreamFigures f;
+    RegionTerrain t(4096);
+    t.copyToHost = copyToHost;
+    t.packedTransfer = true;
+    t.dropRadius = 24;
+    t.init();
+    t.setCurrentChunkPos(home);
+    auto t0 = Clock::now();
+    do { t.tick(1.f / 60.f); f.loadChunks += t.lastGenerated; f.loadMeshed += t.lastMeshed; f.d2hBytes += t.lastBlockBytesD2H; } while (!t.allQueuesEmpty());
+    HipUtils::checkError("hipDeviceSynchronize", (int)hipDeviceSynchronize());
+    f.loadMs = 1e3 * secondsSince(t0);
+    t0 = Clock::now();
+    for (int k = 1; k <= steps; ++k) {
+        t.setCurrentChunkPos({home.x + k, home.y});
+        do {
+            t.tick(1.f / 60.f);
+            f.walkChunks += t.lastGenerated; f.walkMeshed += t.lastMeshed; f.ringComputed += t.lastRingComputed; f.ringReused += t.lastRingReused;
+        } while (!t.allQueuesEmpty());
+    }
+    HipUtils::checkError("hipDeviceSynchronize", (int)hipDeviceSynchronize());
+    f.walkMs = 1e3 * secondsSince(t0);
+    return f;
+}
+
+static int bench_main()
+{
+    const ivec2 home = {0, 0};
+    const int steps = 32;
+    stream_scenario(false, {100, 100}, 2);                    // warm-up: allocations, first-launch costs
+    const StreamFigures dev = stream_scenario(false, home, steps);
+    const StreamFigures host = stream_scenario(true, home, steps);
+    Terrain stage;
+    stage.init();
+    stage.setCurrentChunkPos(home);
+    const auto t0 = Clock::now();
+    const int ticks = drain(stage, 200000);
+    const double mirrorS = secondsSince(t0);
+    auto rec = [&](const char* name, const StreamFigures& f) {
+        std::printf("\"%s\": {\"initial_load\": {\"chunks\": %d, \"meshed\": %d, \"ms\": %.2f, \"chunks_per_s\": %.0f}, "
+                    "\"walk\": {\"steps\": %d, \"chunks\": %d, \"meshed\": %d, \"ms_per_step\": %.3f, \"chunks_per_s\": %.0f, \"ring_cells_computed\": %d, "
+                    "\"ring_cells_from_cache\": %d}, \"block_bytes_to_host\": %zu}",
+                    name, f.loadChunks, f.loadMeshed, f.loadMs, f.loadChunks / (f.loadMs * 1e-3), steps, f.walkChunks, f.walkMeshed, f.walkMs / steps,
+                    f.walkChunks / (f.walkMs * 1e-3), f.ringComputed, f.ringReused, f.d2hBytes);
+    };
+    std::printf("{\"scenario\": \"RegionTerrain (host/region_terrain.cpp) around chunk (0,0): everything within radius 16 + the mesh neighbour ring, then %d ticks with the "
+                "player one chunk further along +x each; chunks/s = generated chunks incl. their meshing\", ", steps);
+    rec("device_resident", dev);
+    std::printf(", ");
+    rec("host_chunks_packed_d2h", host);
+    std::printf(", \"action_time_mirror\": {\"what\": \"host/terrain.cpp, the reference's scheduler (terrain.cpp:587-960) over the same C ABI, initial load only\", "
+                "\"chunks\": %zu, \"ticks\": %d, \"frame_seconds_at_60fps\": %.1f, \"wall_s\": %.3f}}\n", stage.numChunks(), ticks, ticks / 60.0, mirrorS);
+    return 0;
+}
+
 int main(int argc, char** argv)
 {
     ivec2 player = {argc > 2 ? std::atoi(argv[1]) : 0, argc > 2 ? std::atoi(argv[2]) : 0};
     HipUtils::checkError("hipSetDevice", (int)hipSetDevice(0));
     BiomeUtils::init();
+    if (argc > 1 && std::strcmp(argv[1], "--bench") == 0) return bench_main();
     Terrain stage;
     stage.init();
     RegionTerrain batched;

@@ -9,11 +9,14 @@
 // stated token for token as the reference writes them (tests/golden/ref_skeletons.json holds the reference's digests,
 // tests/test_ref_literals.py compares; tools/extract_ref_literals.py lists what the normaliser treats as equal), over a view struct with
 // the reference's member names; the render DATA is pinned to the reference's block.cpp compiled in place (ref_block_probe.cpp).
-// xShapedPosOffset = 0.5f * sinf(radians(45.f)) is a host-libm value in the reference; here it is the deterministic libm's value, which
-// is the correctly rounded one (0x1.6a09e6p-2f: tests/test_mesh.py).
+// xShapedPosOffset = 0.5f * sinf(radians(45.f)) is a static initialiser the reference evaluates with its HOST libm (MSVC); it is stated the
+// same way here and evaluated by this host's libm.  Any libm that rounds sinf correctly gives 0x1.6a09e6p-2f (the argument lies 0.46 ulp
+// from that value, 0.54 from its neighbour); tests/test_mesh.py holds this oracle and the constant compiled into the device mesher to it.
+// (The path's own deterministic sine, 2 ulp by contract, lands on the neighbour here - it is not what a host initialiser uses.)
 #include <array>
 #include <cstdint>
 #include <cstddef>
+#include <cmath>
 #include <cstring>
 #include <vector>
 #include "mmo_vec.h"
@@ -77,7 +80,7 @@ struct Chunk {
 };
 
 // ---- chunk.cu:1753-1776, as written
-static const float xShapedPosOffset = 0.5f * mm_sinf(g_radians(45.f));
+static const float xShapedPosOffset = 0.5f * sinf(g_radians(45.f));      // (the HOST libm, like the reference: see the header)
 static const std::array<vec3, 8> xShapedVertPositions = {
     vec3(xShapedPosOffset, 0.f, xShapedPosOffset),
     vec3(-xShapedPosOffset, 0.f, -xShapedPosOffset),

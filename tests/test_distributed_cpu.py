@@ -281,3 +281,36 @@ def test_generate_tile_without_context_checks_before_returning(oracle, monkeypat
     out = d.generate_tile(ob, lay, 0, 7, dist=_SelfLoop(), torch=torch)
     ref = oracle.generate_region(1487, -1111, 2, 2, erosion=True, features=True, decorators=True)
     assert np.array_equal(out["blocks"], ref["blocks"])
+
+
+def test_tile_checksum_is_position_dependent_and_goldens_cover_the_bench_layouts():
+    """tile_checksum (bench.py: tiles_bit_exact) changes when a byte changes, when two chunks swap and when two words swap; the committed
+    goldens hold one value per tile of bench.py's layouts at N = 1, 2, 4, 8 and the tiles that are the same rectangle in two layouts
+    (position purity: the middle of the 4 x 2 world is the 2 x 2 world) carry the same value."""
+    import json
+    import torch
+    sys.path.insert(0, ROOT)
+    d = importlib.import_module("mega-minecraft_amd.distributed")
+    g = torch.Generator().manual_seed(3)
+    blocks = torch.randint(0, 200, (5, 98304), dtype=torch.uint8, generator=g)
+    base = d.tile_checksum(blocks, torch)
+    assert base == d.tile_checksum(blocks.clone(), torch) and 0 <= base < 2 ** 64
+    b = blocks.clone(); b[3, 77777] ^= 1
+    assert d.tile_checksum(b, torch) != base
+    b = blocks.clone(); b[[1, 2]] = blocks[[2, 1]]
+    assert d.tile_checksum(b, torch) != base
+    b = blocks.clone(); b[0, 0:8], b[0, 8:16] = blocks[0, 8:16].clone(), blocks[0, 0:8].clone()
+    assert d.tile_checksum(b, torch) != base
+    # slabs of 1 024 chunks: the sum over several slabs equals the one-slab definition
+    many = torch.randint(0, 200, (1030, 64), dtype=torch.uint8, generator=g)
+    words = many.view(torch.int64).view(1030, -1)
+    mw = (2 * torch.arange(8, dtype=torch.int64) + 1) * d._K_WORD
+    mc = (2 * torch.arange(1030, dtype=torch.int64) + 1) * d._K_CHUNK
+    assert d.tile_checksum(many, torch) == int((((words * mw).sum(1)) * mc).sum().item()) & 0xFFFFFFFFFFFFFFFF
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "tile_checksums.json")))
+    tiles = {1: (1, 1), 2: (2, 1), 4: (2, 2), 8: (4, 2)}
+    for n, (tx, tz) in tiles.items():
+        lay = d.TileLayout(-(tx * 64) // 2, -(tz * 128) // 2, tx, tz, 64, 128)
+        assert len(gold[d.layout_key(lay)]) == n and len(set(gold[d.layout_key(lay)])) == n
+    k4, k8 = d.layout_key(d.TileLayout(-64, -128, 2, 2, 64, 128)), d.layout_key(d.TileLayout(-128, -128, 4, 2, 64, 128))
+    assert [gold[k8][i] for i in (1, 2, 5, 6)] == gold[k4]

@@ -265,6 +265,15 @@ def test_config5_world_8_tiles_equals_single_region(mmgen_pkg):
     g = mmgen_pkg.MMGen(0)
     single = g.generate_region(wx0, wz0, W, H)["blocks"]
     assert torch.equal(world, single)
+    # ... and every tile has the checksum the first 8-GPU run will be held to (bench.py: tiles_bit_exact; tools/gen_tile_checksums.py)
+    import json
+    import os
+    golden = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "tile_checksums.json")))[d.layout_key(layout)]
+    w3 = world.view(H, W, 98304)
+    for r in range(8):
+        cx0, cz0, nx, nz = layout.region(r)
+        tile = w3[cz0 - wz0:cz0 - wz0 + nz, cx0 - wx0:cx0 - wx0 + nx].reshape(nx * nz, 98304)
+        assert f"{d.tile_checksum(tile, torch):016x}" == golden[r], (r, golden[r])
     # the product-only capacity (MMGEN_CFP_CAP = 1 024 cave placements per chunk) over the whole 65 536-chunk world: far away
     longest = g.region_max_cave_placements()
     assert 0 < longest < 512, longest

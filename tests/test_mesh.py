@@ -1,7 +1,11 @@
 """Mesh build that follows the generation path (Chunk::createVBOs, chunk.cu:1778-2003): oracle self-checks on CPU, HIP-vs-oracle
 parity on the GPU (vertex and index buffers byte for byte, in the reference's order)."""
+import os
+
 import numpy as np
 import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 AIR, WATER, STONE, GRASS_BLOCK, GRASS_X, BIRCH_LEAVES, ICE = 0, 1, 57, 59, 7, None, None
 
@@ -72,6 +76,18 @@ def test_abi_types_pinned_to_reference_headers(oracle):
         a = np.zeros(256, np.int32)
         m = ctypes.CDLL(live).ref_abi_layout(a.ctypes.data_as(ctypes.c_void_p))
         assert m == n and np.array_equal(a[:m], ref)
+
+
+def test_x_shaped_offset_is_the_correctly_rounded_constant(oracle):
+    """chunk.cu:1753: xShapedPosOffset = 0.5f * sinf(glm::radians(45.f)) runs on the host's libm in the reference.  The oracle states it as
+    written over the deterministic libm; the value it gets is the correctly rounded one, which the device mesher compiles in as a constant."""
+    import ctypes
+    oracle.lib.mmo_x_shaped_pos_offset.restype = ctypes.c_float
+    got = np.float32(oracle.lib.mmo_x_shaped_pos_offset())
+    want = np.float32(0.5) * np.float32(np.sin(np.float64(np.float32(45.0) * np.float32(0.01745329251994329576923690768489))))
+    assert got.view(np.uint32) == np.float32(want).view(np.uint32) == np.uint32(0x3EB504F3), (got, want)
+    text = open(os.path.join(ROOT, "mega-minecraft_amd", "csrc", "mmgen_mesh.hip")).read()
+    assert "0x1.6a09e6p-2f" in text or "0.35355338f" in text or "0.35355339f" in text
 
 
 def test_oracle_mesh_hand_cases(oracle):

@@ -355,6 +355,19 @@ MUTATIONS = [
      "int isThisFilled = shouldGenerateCaveAtBlock(worldPos, shared_maxHeight, shared_oceanAndBeachWeight) ? 1 : 0;", "chunk.cu::kernGenerateCaves.filled"),
     ("oracle/mmo_stages.cpp", "if (y < numOceanAndBeachBiomes)\n    {\n        float biomeWeight = biomeWeights[devBiomeWeightsSize * chunkIdx + 256 * y + idx2d];",
      "if (y <= numOceanAndBeachBiomes)\n    {\n        float biomeWeight = biomeWeights[devBiomeWeightsSize * chunkIdx + 256 * y + idx2d];", "chunk.cu::kernGenerateCaves.weights"),
+    # ---- Chunk::createVBOs and its static tables: the culling rule, the neighbour a face looks at, the uv draw order, a table entry,
+    # and a statement moved out of the block its condition governs
+    ("oracle/mmo_mesh.cpp", "shouldDisplay = neighborBlock == Block::AIR || neighborTrans == TransparencyType::T_SEMI_TRANSPARENT;",
+     "shouldDisplay = neighborBlock == Block::AIR && neighborTrans == TransparencyType::T_SEMI_TRANSPARENT;", "chunk.cu::createVBOs"),
+    ("oracle/mmo_mesh.cpp", "neighborPosChunk = neighbors[3];\n                            neighborPos.x += 16;", "neighborPosChunk = neighbors[1];\n                            neighborPos.x += 16;",
+     "chunk.cu::createVBOs"),
+    ("oracle/mmo_mesh.cpp", "if (sideUv.randRot)\n                        {\n                            uvStartIdx = (int)u04(rng);\n                        }\n                        if (sideUv.randFlip)\n                        {\n                            uvFlipIdx = (int)u04(rng);\n                        }",
+     "if (sideUv.randFlip)\n                        {\n                            uvFlipIdx = (int)u04(rng);\n                        }\n                        if (sideUv.randRot)\n                        {\n                            uvStartIdx = (int)u04(rng);\n                        }", "chunk.cu::createVBOs"),
+    ("oracle/mmo_mesh.cpp", "                            if (uvFlipIdx & 2)\n                            {\n                                uvOffset.y = 1 - uvOffset.y;\n                            }\n                        }\n                        vert.uv = vec2(sideUv.uv + uvOffset) * 0.0625f;",
+     "                            if (uvFlipIdx & 2)\n                            {\n                                uvOffset.y = 1 - uvOffset.y;\n                            }\n                        vert.uv = vec2(sideUv.uv + uvOffset) * 0.0625f;\n                        }", "chunk.cu::createVBOs"),
+    ("oracle/mmo_mesh.cpp", "ivec3(1, 0, 1), ivec3(1, 0, 0), ivec3(1, 1, 0), ivec3(1, 1, 1),", "ivec3(1, 0, 1), ivec3(1, 0, 0), ivec3(1, 1, 1), ivec3(1, 1, 0),",
+     "chunk.cu::createVBOs.directionVertPositions"),
+    ("oracle/mmo_mesh.cpp", "0.5f * sinf(g_radians(45.f))", "0.5f * cosf(g_radians(45.f))", "chunk.cu::createVBOs.xShapedPosOffset"),
 ]
 
 
