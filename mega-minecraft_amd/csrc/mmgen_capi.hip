@@ -69,7 +69,7 @@ int ensure_col_info(Scratch& sc, int n, void* stream)
 {
     if ((size_t)n <= sc.colInfoChunks) return 0;
     sc.colInfoChunks = 0;
-    const int e = regrow(sc.colInfo, (size_t)n * 256 * sizeof(float2), stream);
+    const int e = regrow(sc.colInfo, mmk::cave_scratch_bytes(n), stream);
     if (e) return e;
     sc.colInfoChunks = (size_t)n;
     return 0;
@@ -206,7 +206,7 @@ int mmgen_generate_caves(const float* d_hf, const float* d_bw, const int32_t* d_
     if (!sc) return (int)hipErrorInvalidDevice;
     int e = ensure_col_info(*sc, n, stream);
     if (e) return e;
-    return mmk::launch_caves(d_hf, d_bw, d_pos, n, d_cl, sc->colInfo, nullptr, nullptr, (hipStream_t)stream);
+    return mmk::launch_caves(d_hf, d_bw, d_pos, n, d_cl, sc->colInfo, (int)sc->colInfoChunks, nullptr, nullptr, (hipStream_t)stream);
 }
 
 int mmgen_fill(const float* d_hf, const float* d_bw, const float* d_layers, const mmgen_cave_layer* d_cl, const int32_t* d_pos, int n,

@@ -50,7 +50,10 @@ int erode_zones(float* gathered, size_t strideFloats, int zones, float* work, mm
                 // out (nullable): a device word that counts the persistent launch's workgroups as they start, and the value it reaches
                 const unsigned** startedCounter = nullptr, unsigned* startedTarget = nullptr,
                 // host-visible (mapped) word that receives the error word of a launch that gave up (k_erode_zones); nullable
-                unsigned* errHost = nullptr);
+                unsigned* errHost = nullptr,
+                // region path: clear *maxPassesDev before this batch (the first of a region's batches), and apply
+                // Chunk::fixBackwardStratifiedLayers to the kept chunks in the kernel that writes their eroded planes
+                bool clearPassesDev = false, bool fixBackward = false);
 // test hook: the next persistent launches are `missingWorkgroups` short (a zone's barrier can then never complete) and give up after timeoutMs
 // (0, 0 restores the defaults)
 void erosion_debug_stall(int missingWorkgroups, int timeoutMs);

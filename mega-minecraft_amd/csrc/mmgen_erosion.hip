@@ -498,7 +498,7 @@ k_erode_writeback(float* __restrict__ gatheredBase, size_t gatheredStride, const
 
 // the zones' state machines and the launch's words (ticket, pass count, error).  The accumulated heights need no clearing
 // (thrust::fill_n of chunk.cu:679-680): a zone's first round takes them as zero without loading them and writes both buffers.
-__global__ void k_erode_init(ErosionState* states, int zones, unsigned* ticket)
+__global__ void k_erode_init(ErosionState* states, int zones, unsigned* ticket, int* clearWord /*nullable: the caller's pass-count word, cleared before its first batch*/)
 {
     const int zone = blockIdx.x * blockDim.x + threadIdx.x;
     if (zone >= zones) return;
@@ -510,7 +510,10 @@ __global__ void k_erode_init(ErosionState* states, int zones, unsigned* ticket)
     for (int k = 0; k < 4; ++k) states[zone].changed[k] = 0u;
     states[zone].barrier = 0u;
     for (int k = 0; k < 3; ++k) states[zone].reserved[k] = 0u;
-    if (zone == 0) for (int k = 0; k < 8; ++k) ticket[k] = 0u;
+    if (zone == 0) {
+        for (int k = 0; k < 8; ++k) ticket[k] = 0u;
+        if (clearWord) *clearWord = 0;
+    }
 }
 
 // E1: chunk-major raw layers of a chunk grid -> packed zone planes (copyLayers(to) chunk.cu:603-656).
@@ -544,20 +547,32 @@ k_erosion_scatter(const float* __restrict__ gatheredBase, size_t gatheredStride,
 }
 
 // Region path: the centre 12 x 12 chunks' eroded planes straight from the zones' work planes into the chunk-major layers (what
-// k_erode_writeback + k_erosion_scatter do through the gathered buffer, for the quarter of each zone that is kept).
+// k_erode_writeback + k_erosion_scatter do through the gathered buffer, for the quarter of each zone that is kept), and, with the
+// chunk's eight planes in hand, Chunk::fixBackwardStratifiedLayers for it (chunk.cu:725-749: layers 10 and 11 become start_12 - layer).
+// One workgroup per kept chunk.
 __global__ void __launch_bounds__(256)
 k_erode_finish(const float* __restrict__ workBase, const ErosionState* __restrict__ states, int lastT, const int* __restrict__ zoneChunkIdxOut /*[zones][144], -1 = skip*/,
-               float* __restrict__ layersOut)
+               float* __restrict__ layersOut, int fixBackward)
 {
-    const int zone = blockIdx.z, plane = blockIdx.y, cc = blockIdx.x;
+    const int zone = blockIdx.y, cc = blockIdx.x;
     const int chunk = zoneChunkIdxOut[zone * 144 + cc];
     if (chunk < 0) return;
     const ErosionPhase* st = &states[zone].slot[lastT & 1];      // the phase the last launch ran with: done, all planes final
     const int t = threadIdx.x;
     const int cx = cc % 12 + 6, cz = cc / 12 + 6;
     const int gx = cx * 16 + (t & 15), gz = cz * 16 + (t >> 4);
-    layersOut[(size_t)MMGEN_LAYERS_SIZE * chunk + 256 * (MMGEN_NUM_STRATIFIED_MATERIALS + plane) + t] =
-        workBase[ZONE_WORK_FLOATS * zone + ((size_t)plane * 3 + st->plane(plane)) * ZN + gx + ZS * gz];
+    float* col = layersOut + (size_t)MMGEN_LAYERS_SIZE * chunk + t;
+    float start12 = 0.f;
+#pragma unroll
+    for (int plane = 0; plane < 8; ++plane) {
+        const float v = workBase[ZONE_WORK_FLOATS * zone + ((size_t)plane * 3 + st->plane(plane)) * ZN + gx + ZS * gz];
+        col[256 * (MMGEN_NUM_STRATIFIED_MATERIALS + plane)] = v;
+        if (plane == 0) start12 = v;
+    }
+    if (fixBackward) {
+        col[256 * 10] = start12 - col[256 * 10];
+        col[256 * 11] = start12 - col[256 * 11];
+    }
 }
 
 }  // namespace mm
@@ -636,14 +651,14 @@ void erosion_debug_stall(int missingWorkgroups, int timeoutMs)
 int erode_zones(float* gathered, size_t strideFloats, int zones, float* work, mm::ErosionState* states, float* accOut, size_t accStride,
                 hipStream_t s, int* maxPasses, const int* zoneChunkIdxOut, float* layersOut, int* maxPassesDev, hipEvent_t beforeRelaxation,
                 const float* rawLayers, const float* rawHf, const int* zoneChunkIdx, int workgroupsPer4Cu, const unsigned** startedCounter,
-                unsigned* startedTarget, unsigned* errHost)
+                unsigned* startedTarget, unsigned* errHost, bool clearPassesDev, bool fixBackward)
 {
     if (!gathered && !(rawLayers && rawHf && zoneChunkIdx && layersOut)) return (int)hipErrorInvalidValue;
     if (zones <= 0) return 0;
     unsigned* ticket = (unsigned*)(states + zones);
     int* passesWord = (int*)(ticket + 1);
     unsigned* errWord = ticket + 2;
-    MMK_LAUNCH(KID_ERODE_INIT, mm::k_erode_init, dim3((zones + 63) / 64), dim3(64), s, states, zones, ticket);
+    MMK_LAUNCH(KID_ERODE_INIT, mm::k_erode_init, dim3((zones + 63) / 64), dim3(64), s, states, zones, ticket, clearPassesDev ? maxPassesDev : (int*)nullptr);
     // as many workgroups per zone as keep the whole launch resident (a zone's 144 tiles are shared out among them, the same in every round)
     int perZone = erosion_resident_workgroups(workgroupsPer4Cu) / zones;
     perZone = perZone < 1 ? 1 : (perZone > 144 ? 144 : perZone);
@@ -667,8 +682,8 @@ int erode_zones(float* gathered, size_t strideFloats, int zones, float* work, mm
     }
     if (layersOut) {
         // region path: no in-place contract to honour, the kept chunks' planes go straight to the layers
-        MMK_LAUNCH(KID_EROSION_SCATTER, mm::k_erode_finish, dim3(144, 8, zones), dim3(256), s, (const float*)work, (const mm::ErosionState*)states, 0,
-                   zoneChunkIdxOut, layersOut);
+        MMK_LAUNCH(KID_EROSION_SCATTER, mm::k_erode_finish, dim3(144, zones), dim3(256), s, (const float*)work, (const mm::ErosionState*)states, 0,
+                   zoneChunkIdxOut, layersOut, fixBackward ? 1 : 0);
     } else {
         MMK_LAUNCH(KID_ERODE_WRITEBACK, mm::k_erode_writeback, dim3(ZN / 256, 1, zones), dim3(256), s, gathered, strideFloats, work, states, accOut,
                    accStride, 0);

@@ -384,7 +384,10 @@ k_gather_placements(const mmgen_feature_placement* __restrict__ fp, const mmgen_
                     const int* __restrict__ counts, const int* __restrict__ targetChunk /*[nOut] index into source grid*/,
                     int gridW, int gridH, mmgen_feature_placement* __restrict__ gfp, mmgen_cave_feature_placement* __restrict__ gcfp,
                     int* __restrict__ bounds, const int2* __restrict__ gridPos /*world block origin of every source-grid chunk; null = keep everything*/,
-                    int* maxGathered /*nullable: [0] / [1] raised to the longest un-truncated surface / cave list*/)
+                    int* maxGathered /*nullable: [0] / [1] raised to the longest un-truncated surface / cave list*/,
+                    int* capHost /*nullable: host-visible word raised to a source cell's cave count beyond MMGEN_CFP_CAP*/,
+                    int* capMax /*nullable: raised to the largest cave count of the source cells*/,
+                    unsigned* zeroWords /*nullable*/, int nZeroWords /*words the first workgroup clears: the rasterisers' work counters*/)
 {
     __shared__ int s_offS[50], s_offC[50], s_src[49];
     __shared__ int s_b[4], s_w[4];
@@ -396,7 +399,15 @@ k_gather_placements(const mmgen_feature_placement* __restrict__ fp, const mmgen_
         int nS = 0, nC = 0, n = -1;
         if (t < 49) {
             const int nx = cx + kGatherDX[t], nz = cz + kGatherDZ[t];
-            if (nx >= 0 && nx < gridW && nz >= 0 && nz < gridH) { n = nx + gridW * nz; nS = counts[2 * n]; nC = imin(counts[2 * n + 1], MMGEN_CFP_CAP); }
+            if (nx >= 0 && nx < gridW && nz >= 0 && nz < gridH) {
+                n = nx + gridW * nz; nS = counts[2 * n];
+                const int raw = counts[2 * n + 1];
+                nC = imin(raw, MMGEN_CFP_CAP);
+                // every list length the gather uses, local or received, against the product's one capacity (include/mmgen.h:
+                // MMGEN_ERROR_PLACEMENT_OVERFLOW): a plain look first, the atomics only where they raise something
+                if (capHost && raw > MMGEN_CFP_CAP) __hip_atomic_fetch_max(capHost, raw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                if (capMax && raw > *capMax) atomicMax(capMax, raw);
+            }
             s_src[t] = n;
         }
         int inS = nS, inC = nC;
@@ -409,6 +420,7 @@ k_gather_placements(const mmgen_feature_placement* __restrict__ fp, const mmgen_
         if (t == 48) { s_offS[49] = inS; s_offC[49] = inC; }
         if (t == 0) { s_b[0] = 384; s_b[1] = -1; s_b[2] = 384; s_b[3] = -1; }
     }
+    if (zeroWords && o == 0) for (int i = t; i < nZeroWords; i += 256) zeroWords[i] = 0u;
     __syncthreads();
     const int totS = s_offS[49], totC = s_offC[49];
     // (a plain look first: two atomics per chunk on two addresses serialise in L2 - 0.09 ms for the bench tile - and only a few ever raise the maximum)
@@ -1182,18 +1194,18 @@ int launch_ring_need(const float* bw, const int32_t* pos, const int* chunkList, 
 
 int launch_gather_placements(const mmgen_feature_placement* fp, const mmgen_cave_feature_placement* cfp, const int* counts, const int* target,
                              int nOut, int gridW, int gridH, mmgen_feature_placement* gfp, mmgen_cave_feature_placement* gcfp, int* bounds,
-                             const int32_t* gridPos, hipStream_t s, int* maxGathered)
+                             const int32_t* gridPos, hipStream_t s, int* maxGathered, int* capHost, int* capMax, unsigned* zeroWords, int nZeroWords)
 {
     if (nOut <= 0) return 0;
     LAUNCH(KID_GATHER_PLACEMENTS, mm::k_gather_placements, dim3(nOut), dim3(256), s, fp, cfp, counts, target, gridW, gridH, gfp, gcfp, bounds,
-           (const int2*)gridPos, maxGathered);
+           (const int2*)gridPos, maxGathered, capHost, capMax, zeroWords, nZeroWords);
     return 0;
 }
 
 size_t apply_work_bytes() { return 64 * APPLY_COUNTERS; }
 
 int launch_apply_features(uint8_t* blocks, const int32_t* pos, int n, const mmgen_feature_placement* gfp, const mmgen_cave_feature_placement* gcfp,
-                          const int* bounds, const int* srcIdx, unsigned* workCounter, hipStream_t s)
+                          const int* bounds, const int* srcIdx, unsigned* workCounter, hipStream_t s, bool workCleared)
 {
     if (n <= 0) return 0;
     if (!workCounter) return (int)hipErrorInvalidValue;
@@ -1202,8 +1214,10 @@ int launch_apply_features(uint8_t* blocks, const int32_t* pos, int n, const mmge
     // persistent: MM_APPLY_WAVES waves per SIMD = that many 4-wave workgroups per CU; every wave walks its own units
     const long long units = (long long)n * APPLY_UNITS_PER_CHUNK, groups = (units + APPLY_COLS - 1) / APPLY_COLS, fit = (long long)cus * MM_APPLY_WAVES;
     if (units > 0x7fffffffLL) return (int)hipErrorInvalidValue;
-    const hipError_t e = hipMemsetAsync(workCounter, 0, apply_work_bytes(), s);
-    if (e != hipSuccess) return (int)e;
+    if (!workCleared) {            // (the region's gather kernel clears them on its way)
+        const hipError_t e = hipMemsetAsync(workCounter, 0, apply_work_bytes(), s);
+        if (e != hipSuccess) return (int)e;
+    }
     LAUNCH(KID_APPLY_FEATURES, mm::k_apply_features, dim3((unsigned)(groups < fit ? groups : fit)), dim3(APPLY_THREADS), s, blocks, (const int2*)pos, gfp, gcfp,
            bounds, srcIdx, (int)units, workCounter);
     return 0;

@@ -196,8 +196,10 @@ __global__ void __launch_bounds__(64) k_wait_counter(const unsigned* counter, un
 }
 
 __global__ void __launch_bounds__(256)
-k_cave_columns(const float* __restrict__ bw, const int2* __restrict__ chunkPos, float2* __restrict__ colInfo, const int* __restrict__ chunkList)
+k_cave_columns(const float* __restrict__ bw, const int2* __restrict__ chunkPos, float2* __restrict__ colInfo, const int* __restrict__ chunkList,
+               unsigned* __restrict__ clearWords /*k_cave_biomes' work counters, 16 * CB_COUNTERS words: cleared here, two launches ahead of their use*/)
 {
+    if (blockIdx.x == 0) clearWords[threadIdx.x] = 0u;
     noise_tables_init();
     const int chunk = chunkList ? chunkList[blockIdx.x] : blockIdx.x, t = threadIdx.x;
     const int2 cp = chunkPos[chunk];
@@ -1070,6 +1072,7 @@ MM_DEV void fill_body(const float* __restrict__ hf, const float* __restrict__ bw
                                  // (small launches draw smaller ranges: launch_fill)
 #endif
 #define FILL_COUNTERS 16         // work counters, 64 B apart (one serialises at ~11 ns per draw in L2)
+#define FILL_CLEAR_BYTES (64 * FILL_COUNTERS + 16)      // ... and the 16 bytes behind them: the lush queue's count word (+ three entries that every launch rewrites)
 #define FILLB_THREADS 256
 #define FILLC_THREADS 256
 #define FILLC_DEF_CAP 128        // per wave: CRYSTAL / LUSH voxels waiting for their noise rule
@@ -1240,6 +1243,7 @@ k_fill_cave(const float* __restrict__ hf, const int2* __restrict__ chunkPos, uin
     __shared__ uint2 s_s2[FILLC_THREADS / 64][FILLC_DEF_CAP];      // voxels whose warped height decides nothing: list entry, row of this launch ...
     __shared__ float s_s2py[FILLC_THREADS / 64][FILLC_DEF_CAP];    // ... and that height
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (threadIdx.x == 0) atomicAdd(&work[1], 1u);                 // started workgroups (a word of the first counter's line): launch_fill's startedCounter
     noise_tables_init();                                           // once per (persistent) workgroup; no workgroup barrier after this one
     uint2* def = s_def[wave];
     unsigned* lushBuf = s_lushBuf[wave];
@@ -1514,12 +1518,15 @@ int launch_fix_backward(float* layers, int n, hipStream_t s)
     return 0;
 }
 
-int launch_caves(const float* hf, const float* bw, const int32_t* pos, int n, mmgen_cave_layer* caveLayers, float* colInfoScratch,
+int launch_caves(const float* hf, const float* bw, const int32_t* pos, int n, mmgen_cave_layer* caveLayers, float* colInfoScratch, int colInfoChunks,
                  const int* chunkList, const uint8_t* colNeed, hipStream_t s, hipEvent_t afterVoxels, int biomeWorkgroupsPerCu, hipEvent_t beforeVoxels,
                  const unsigned* waitCounter, unsigned waitTarget)
 {
     if (n <= 0) return 0;
-    LAUNCH(KID_CAVE_COLUMNS, mm::k_cave_columns, dim3(n), dim3(256), s, bw, (const int2*)pos, (float2*)colInfoScratch, chunkList);
+    // (scratch layout: [n chunks][256] float2 per-column info, then k_cave_biomes' work counters - cave_scratch_bytes)
+    unsigned* cbWork = (unsigned*)(colInfoScratch + 2 * 256 * (size_t)colInfoChunks);
+    static_assert(16 * CB_COUNTERS == 256, "k_cave_columns' first workgroup clears one word per thread");
+    LAUNCH(KID_CAVE_COLUMNS, mm::k_cave_columns, dim3(n), dim3(256), s, bw, (const int2*)pos, (float2*)colInfoScratch, chunkList, cbWork);
     // (the per-column pass is small and runs beside whatever the event stands for; the voxel launch is the one that takes the chip)
     if (beforeVoxels) { const hipError_t ew = hipStreamWaitEvent(s, beforeVoxels, 0); if (ew != hipSuccess) return (int)ew; }
     // ... and, where that something is a persistent launch that must be ON THE CHIP first (the relaxation: a few hundred workgroups that
@@ -1529,18 +1536,16 @@ int launch_caves(const float* hf, const float* bw, const int32_t* pos, int n, mm
     LAUNCH(KID_CAVE_VOXELS, mm::k_cave_voxels, dim3(n * 16), dim3(CAVE_THREADS), s, hf, (const float2*)colInfoScratch, (const int2*)pos, caveLayers, chunkList, colNeed);
     // the layers' extents are final here (what the base fill reads); their biomes follow
     if (afterVoxels) { const hipError_t ee = hipEventRecord(afterVoxels, s); if (ee != hipSuccess) return (int)ee; }
-    // k_cave_voxels was the last reader of the per-column info: its first KB becomes k_cave_biomes' work counters
     const int cus = device_cus();
     if (!cus) return (int)hipErrorInvalidDevice;
-    static_assert(64 * CB_COUNTERS <= 256 * sizeof(float2), "the counters fit the per-column info of one chunk");
-    const hipError_t e = hipMemsetAsync(colInfoScratch, 0, 64 * CB_COUNTERS, s);
-    if (e != hipSuccess) return (int)e;
     const long long units = (long long)n * (256 / CB_UNIT_COLS), fit = (long long)cus * (biomeWorkgroupsPerCu > 0 && biomeWorkgroupsPerCu < MM_CB_WAVES ? biomeWorkgroupsPerCu : MM_CB_WAVES);   // persistent: MM_CB_WAVES 4-wave workgroups per CU at most
     if (units >= (1LL << 18) * (256 / CB_UNIT_COLS)) return (int)hipErrorInvalidValue;                  // item ids carry the list index in 18 bits
     LAUNCH(KID_CAVE_BIOMES, mm::k_cave_biomes, dim3((unsigned)(units / 4 + 1 < fit ? units / 4 + 1 : fit)), dim3(CB_THREADS), s, hf, (const int2*)pos, caveLayers, chunkList,
-           (int)units, (unsigned*)colInfoScratch);
+           (int)units, cbWork);
     return 0;
 }
+
+size_t cave_scratch_bytes(int chunks) { return (size_t)chunks * 256 * sizeof(float2) + 64 * CB_COUNTERS; }
 
 // Scratch of one launch_fill call (caller-owned, fill_scratch layout below): the lush queue, the work counters of k_fill_cave, and per
 // sub-batch of kFillSub chunks the row lists with their counts / batch prefix / range index.
@@ -1555,8 +1560,9 @@ FillScratch fill_scratch(char* base, int n)      // base may be null: only `byte
     const size_t nb = (size_t)(n < kFillBatch ? n : kFillBatch), rows = 16 * (size_t)(n < kFillSub ? n : kFillSub);
     FillScratch f;
     size_t o = 0;
+    // the work counters directly in front of the queue's count word: one memset clears both (FILL_CLEAR_BYTES)
+    f.work = (unsigned*)(base + o); o += 64 * FILL_COUNTERS;
     f.lush = (unsigned*)(base + o); f.lushCap = (unsigned)(2048 * nb); o += align256(4 * (2048 * nb + 1));
-    f.work = (unsigned*)(base + o); o += align256(64 * FILL_COUNTERS);
     f.counts = (int*)(base + o); o += align256(4 * rows);
     f.batchStart = (int*)(base + o); o += align256(4 * (rows + 1));
     f.rangeRow = (int*)(base + o); o += align256(4 * (rows * (FILL_VOX / 64) + 1));      // ranges of one batch, every voxel listed: the most there can be
@@ -1572,8 +1578,11 @@ size_t fill_queue_bytes(int n) { return n <= 0 ? 0 : fill_scratch((char*)0x1000,
 void debug_set_lush_queue_cap(int entries) { g_lushCapOverride.store(entries > 0 ? (unsigned)entries : 0u, std::memory_order_relaxed); }
 
 int launch_fill(const float* hf, const float* bw, const float* layers, const mmgen_cave_layer* caveLayers, const int32_t* pos, int n,
-                uint8_t* blocks, const int* srcIdx, unsigned* scratch, size_t scratchBytes, bool allInPruneDomain, hipStream_t s, bool countersCleared)
+                uint8_t* blocks, const int* srcIdx, unsigned* scratch, size_t scratchBytes, bool allInPruneDomain, hipStream_t s, bool countersCleared,
+                const unsigned** startedCounter, unsigned* startedTarget)
 {
+    if (startedCounter) *startedCounter = nullptr;
+    if (startedTarget) *startedTarget = 0u;
     if (n <= 0) return 0;
     if (!scratch || scratchBytes < fill_queue_bytes(n)) return (int)hipErrorInvalidValue;
     const FillScratch f = fill_scratch((char*)scratch, n);
@@ -1591,11 +1600,12 @@ int launch_fill(const float* hf, const float* bw, const float* layers, const mmg
         const float* layB = layers + (size_t)MMGEN_LAYERS_SIZE * in0;
         const mmgen_cave_layer* clB = caveLayers + (size_t)MMGEN_CAVE_LAYERS_SIZE * in0;
         hipError_t e = hipSuccess;
-        if (!(countersCleared && b0 == 0)) e = hipMemsetAsync(f.lush, 0, 4, s);      // the counter; entries are (re)written by every launch
+        // the work counters and the queue's count in one memset (the queue's entries are (re)written by every launch)
+        if (!(countersCleared && b0 == 0)) e = hipMemsetAsync(f.work, 0, FILL_CLEAR_BYTES, s);
         if (e != hipSuccess) return (int)e;
         for (int c0 = 0; c0 < nb; c0 += kFillSub) {
             const int nc = nb - c0 < kFillSub ? nb - c0 : kFillSub, nRows = nc * (256 / FILL_ROW), row0 = c0 * (256 / FILL_ROW);
-            if (!(countersCleared && b0 == 0 && c0 == 0)) e = hipMemsetAsync(f.work, 0, 64 * FILL_COUNTERS, s);
+            if (c0 > 0) e = hipMemsetAsync(f.work, 0, 64 * FILL_COUNTERS, s);          // (a second sub-batch of the same batch: the counters only)
             if (e != hipSuccess) return (int)e;
             LAUNCH(KID_FILL_BASE, mm::k_fill_base, dim3(nRows), dim3(FILLB_THREADS), s, hfB, bwB, layB, clB, p, out, idx, row0, f.lists, f.counts);
             // a row lists ~28 batches; enough ranges for every wave to draw a few (a 256-chunk call would otherwise hand 2 ranges to each)
@@ -1603,8 +1613,12 @@ int launch_fill(const float* hf, const float* bw, const float* layers, const mmg
             const int range = perWave < 1 ? 1 : (perWave > FILL_RANGE ? FILL_RANGE : (int)perWave);
             LAUNCH(KID_FILL_SCAN, mm::k_fill_scan, dim3((nRows + 1023) / 1024), dim3(1024), s, (const int*)f.counts, nRows, range, f.batchStart, f.rangeRow);
             // persistent: MM_FILL_WAVES waves per SIMD
-            LAUNCH(KID_FILL, mm::k_fill_cave, dim3(cus * (4 * MM_FILL_WAVES / (FILLC_THREADS / 64))), dim3(FILLC_THREADS), s, hfB, p, out, idx, row0, (const unsigned*)f.lists, (const int*)f.counts,
+            const unsigned cgrid = (unsigned)(cus * (4 * MM_FILL_WAVES / (FILLC_THREADS / 64)));
+            LAUNCH(KID_FILL, mm::k_fill_cave, dim3(cgrid), dim3(FILLC_THREADS), s, hfB, p, out, idx, row0, (const unsigned*)f.lists, (const int*)f.counts,
                    (const int*)f.batchStart, (const int*)f.rangeRow, nRows, range, f.lush, f.lushCap, f.work);
+            // a caller that wants the cave fill's persistent workgroups on the chip before it starts something beside them watches this
+            // word reach the grid size (one sub-batch only: the next one re-uses the counters)
+            if (n <= kFillSub) { if (startedCounter) *startedCounter = f.work + 1; if (startedTarget) *startedTarget = cgrid; }
         }
         if (!allInPruneDomain)             // rows beyond the pruning domain (k_fill_base leaves them alone)
             LAUNCH(KID_FILL_FAR, mm::k_fill_far, dim3(nb * (256 / FILL_ROW)), dim3(FILL_THREADS), s, hfB, bwB, layB, clB, p, out, idx, f.lush, f.lushCap);
@@ -1620,9 +1634,13 @@ int launch_fill_clear(int n, unsigned* scratch, size_t scratchBytes, hipStream_t
     if (n <= 0) return 0;
     if (!scratch || scratchBytes < fill_queue_bytes(n)) return (int)hipErrorInvalidValue;
     const FillScratch f = fill_scratch((char*)scratch, n);
-    hipError_t e = hipMemsetAsync(f.lush, 0, 4, s);
-    if (e == hipSuccess) e = hipMemsetAsync(f.work, 0, 64 * FILL_COUNTERS, s);
-    return (int)e;
+    return (int)hipMemsetAsync(f.work, 0, FILL_CLEAR_BYTES, s);
+}
+
+int launch_wait_counter(const unsigned* counter, unsigned target, hipStream_t s)
+{
+    LAUNCH(KID_CAVE_COLUMNS, mm::k_wait_counter, dim3(1), dim3(64), s, counter, target);
+    return 0;
 }
 
 int launch_probe(int fn, const float* in, int n, float* out, hipStream_t s)

@@ -62,21 +62,6 @@ k_copy_placements(const mmgen_feature_placement* __restrict__ sfp, const mmgen_c
     if (t < 2) dcnt[2 * d + t] = scnt[2 * s + t];
 }
 
-// largest cave list length of the cells -> a word in host-visible (pinned, mapped) memory; only a list beyond the capacity writes
-__global__ void __launch_bounds__(256) k_caps_check(const int32_t* __restrict__ counts, int n, int* __restrict__ hostMax)
-{
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const int c = counts[2 * i + 1];
-    if (c > MMGEN_CFP_CAP) __hip_atomic_fetch_max(hostMax, c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-
-__global__ void __launch_bounds__(256) k_caps_max(const int32_t* __restrict__ counts, int n, int* __restrict__ devMax)
-{
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < n) atomicMax(devMax, counts[2 * i + 1]);
-}
-
 __global__ void __launch_bounds__(256) k_select(const float* __restrict__ src, const int* __restrict__ idx, float* __restrict__ dst, int floatsPerChunk)
 {
     const int i = blockIdx.x;
@@ -225,6 +210,8 @@ struct mmgen_region {
     unsigned kflags = 0;
     bool kHasMask = false;
     std::vector<uint8_t> kMask;
+    const unsigned* fillStarted = nullptr;      // started-workgroups word of the early fill's k_fill_cave (one slice) and the value it reaches
+    unsigned fillStartedTarget = 0u;
     bool filled = false;          // mmgen_region_fill already ran for the current begin
     uint8_t* filledInto = nullptr;
     uint8_t* earlyBlocks = nullptr;      // mmgen_region_set_output: where the next begin may already put the base blocks
@@ -487,7 +474,7 @@ int mmgen_region_begin(mmgen_region* r, int cx0, int cz0, int nx, int nz, unsign
         CK(r->init_streams());
         CK(hipEventRecord(r->evBegin, s));          // what the caller's stream held when this begin was called
     }
-    r->began = false; r->filled = false; r->filledInto = nullptr;
+    r->began = false; r->filled = false; r->filledInto = nullptr; r->fillStarted = nullptr; r->fillStartedTarget = 0u;
     CK(region_layout(r, cx0, cz0, nx, nz, flags, h_local_mask, s));
     const int np = r->np, na = r->na;
     hipStream_t sE = par ? r->sErode : s;
@@ -497,7 +484,7 @@ int mmgen_region_begin(mmgen_region* r, int cx0, int cz0, int nx, int nz, unsign
     CK(r->gathA.ensure(sizeof(float) * MMGEN_GATHERED_HEIGHTFIELD_SIZE * (size_t)na));
     CK(r->layersA.ensure(sizeof(float) * MMGEN_LAYERS_SIZE * (size_t)na));
     CK(r->caveP.ensure(sizeof(mmgen_cave_layer) * MMGEN_CAVE_LAYERS_SIZE * (size_t)np));
-    CK(r->colInfo.ensure(sizeof(float) * 2 * 256 * (size_t)np));
+    CK(r->colInfo.ensure(mmk::cave_scratch_bytes(np)));
     if (features) {
         CK(r->fp.ensure(sizeof(mmgen_feature_placement) * MMGEN_FP_CAP * (size_t)np));
         CK(r->cfp.ensure(sizeof(mmgen_cave_feature_placement) * MMGEN_CFP_CAP * (size_t)np));
@@ -507,20 +494,28 @@ int mmgen_region_begin(mmgen_region* r, int cx0, int cz0, int nx, int nz, unsign
     // ---- K1 + K2 on the raw area A.  With erosion the P grid's layers exist twice (raw in A for the zones' padding, eroded in P): K2 stores
     // the twelve stratified layers of the P cells - the head of A's order - into both, the eight eroded ones arrive from the relaxation
     if (erosion) CK(r->layersP.ensure(sizeof(float) * MMGEN_LAYERS_SIZE * (size_t)np));
+    // In the stage DAG with erosion the layers (K2) go with the erosion branch: nothing on the caller's stream needs them before that branch
+    // is joined (the caves and their per-column pass read heights and weights only), so the per-column cave pass runs beside K2 instead of
+    // behind it and the caves start 0.1 ms earlier (the relaxation, which K2 feeds, still has to be resident first).
+#ifndef MM_LAYERS_ON_BRANCH
+#define MM_LAYERS_ON_BRANCH 1
+#endif
+    const bool layersOnBranch = MM_LAYERS_ON_BRANCH && erosion && par;
     {
         mmk::StageRange sr("mmgen:heightfield+layers");
         CK(mmk::launch_heightfield(r->posA.as<int32_t>(), na, r->hfA.as<float>(), r->bwA.as<float>(), r->gathA.as<float>(), s));
-        CK(mmk::launch_layers(r->gathA.as<float>(), r->bwA.as<float>(), r->posA.as<int32_t>(), na, r->layersA.as<float>(), s,
+        if (layersOnBranch) { CK(hipEventRecord(r->evK2, s)); CK(hipStreamWaitEvent(sE, r->evK2, 0)); }      // (evK2: "K1 is done" in this schedule)
+        CK(mmk::launch_layers(r->gathA.as<float>(), r->bwA.as<float>(), r->posA.as<int32_t>(), na, r->layersA.as<float>(), layersOnBranch ? sE : s,
                               erosion ? r->layersP.as<float>() : nullptr, erosion ? np : 0));
+        if (erosion && par && !layersOnBranch) { CK(hipEventRecord(r->evK2, s)); CK(hipStreamWaitEvent(sE, r->evK2, 0)); }
     }
 
     float *hfP, *bwP, *layersP;
     int32_t* posP;
     if (erosion) {
         // The P grid's arrays are the first np chunks of A's (region_layout orders A that way); only the layers exist twice: eroded planes
-        // are scattered into layersP, layersA stays raw for the other zones' padding (the copy goes with the erosion branch).
+        // are scattered into layersP, layersA stays raw for the other zones' padding.
         hfP = r->hfA.as<float>(); bwP = r->bwA.as<float>(); layersP = r->layersP.as<float>(); posP = r->posA.as<int32_t>();
-        if (par) { CK(hipEventRecord(r->evK2, s)); CK(hipStreamWaitEvent(sE, r->evK2, 0)); }
     } else {
         hfP = r->hfA.as<float>(); bwP = r->bwA.as<float>(); layersP = r->layersA.as<float>(); posP = r->posA.as<int32_t>();
         CK(mmk::launch_fix_backward(layersP, np, s));
@@ -541,7 +536,6 @@ int mmgen_region_begin(mmgen_region* r, int cx0, int cz0, int nx, int nz, unsign
     // workgroups are on the chip before the caves' launch starts to fill every free slot, and then run beside it
     if (erosion) {
         mmk::StageRange sr("mmgen:erosion");
-        CK(hipMemsetAsync(r->devPasses.p, 0, sizeof(int), sE));
         const int Z = r->nZones;
         const int batch = Z < MMGEN_EROSION_ZONE_BATCH ? Z : MMGEN_EROSION_ZONE_BATCH;
         CK(r->erodeWork.ensure(mmk::erosion_work_bytes(batch)));
@@ -553,10 +547,9 @@ int mmgen_region_begin(mmgen_region* r, int cx0, int cz0, int nx, int nz, unsign
             CK(mmk::erode_zones(nullptr, 0, nb, r->erodeWork.as<float>(), r->erodeState.as<mm::ErosionState>(), nullptr, 0, sE, nullptr,
                                 r->zoneIdxOut.as<int>() + (size_t)z0 * 144, layersP, r->devPasses.as<int>(), (par && z0 == 0) ? r->evResident : nullptr,
                                 r->layersA.as<float>(), r->hfA.as<float>(), r->zoneIdx.as<int>() + (size_t)z0 * 576,
-                                par ? MMGEN_REGION_EROSION_WG_PER_4CU : 0, (par && Z <= batch) ? &startedCounter : nullptr, &startedTarget, (unsigned*)(r->hostMaxDev + 1)));
+                                par ? MMGEN_REGION_EROSION_WG_PER_4CU : 0, (par && Z <= batch) ? &startedCounter : nullptr, &startedTarget, (unsigned*)(r->hostMaxDev + 1),
+                                /*clearPassesDev*/ z0 == 0, /*fixBackward (E3 fix-up of the kept chunks)*/ true));
         }
-        // ---- E3 fix-up
-        CK(mmk::launch_fix_backward(layersP, np, sE));
         CK(hipMemcpyAsync(r->hostPasses, r->devPasses.p, sizeof(int), hipMemcpyDeviceToHost, sE));
         CK(hipEventRecord(r->evPasses, sE));
         r->passesPending = true;
@@ -566,7 +559,7 @@ int mmgen_region_begin(mmgen_region* r, int cx0, int cz0, int nx, int nz, unsign
     // is a few hundred workgroups and must be on the chip before the caves' 150 000 start taking every slot that frees up
     {
         mmk::StageRange sr("mmgen:caves");
-        CK(mmk::launch_caves(hfP, bwP, posP, r->nCompute, r->caveP.as<mmgen_cave_layer>(), r->colInfo.as<float>(), list, colNeed, s,
+        CK(mmk::launch_caves(hfP, bwP, posP, r->nCompute, r->caveP.as<mmgen_cave_layer>(), r->colInfo.as<float>(), np, list, colNeed, s,
                              par ? r->evCaveVoxels : nullptr, (par && early) ? kCaveBiomeWorkgroupsBesideFill : 0,
                              (erosion && par) ? r->evResident : nullptr, startedCounter, startedTarget));
     }
@@ -579,7 +572,8 @@ int mmgen_region_begin(mmgen_region* r, int cx0, int cz0, int nx, int nz, unsign
     // ---- F1 placements (eroded layers + cave layers of every computed cell)
     if (features) {
         mmk::StageRange sr("mmgen:feature_placements");
-        CK(hipMemsetAsync(r->counts.p, 0, sizeof(int) * 2 * np, s));
+        // cells the caller provides (mask 0) read as empty until it has written them; every computed cell's lengths are stored by the kernel
+        if (r->nCompute < np) CK(hipMemsetAsync(r->counts.p, 0, sizeof(int) * 2 * np, s));
         CK(mmk::launch_feature_placements(hfP, bwP, layersP, r->caveP.as<mmgen_cave_layer>(), posP, r->nCompute, r->fp.as<mmgen_feature_placement>(),
                                           r->cfp.as<mmgen_cave_feature_placement>(), r->counts.as<int>(), list, colNeed, s));
     }
@@ -637,7 +631,8 @@ static int region_fill_on(mmgen_region* r, uint8_t* d_blocks, hipEvent_t after0,
     for (int i = 0; i < r->nSlices; ++i) {
         const int c0 = r->sliceRow[i] * r->nx, n = (r->sliceRow[i + 1] - r->sliceRow[i]) * r->nx;
         CK(mmk::launch_fill(hfP, bwP, layersP, r->caveP.as<mmgen_cave_layer>(), posP, n, d_blocks + (size_t)MMGEN_BLOCKS_PER_CHUNK * c0, r->targets.as<int>() + c0,
-                            (unsigned*)((char*)r->fillQueue.p + qb * i), qb, region_in_prune_domain(r), sF, true));
+                            (unsigned*)((char*)r->fillQueue.p + qb * i), qb, region_in_prune_domain(r), sF, true,
+                            r->nSlices == 1 ? &r->fillStarted : nullptr, r->nSlices == 1 ? &r->fillStartedTarget : nullptr));
         CK(hipEventRecord(r->evFill[i], sF));
     }
     r->filled = true; r->filledInto = d_blocks;
@@ -697,16 +692,22 @@ int mmgen_region_finish(mmgen_region* r, uint8_t* d_blocks, float* d_heightfield
     hipStream_t sA = par ? r->sApply : s;
     if (features) {
         mmk::StageRange sr("mmgen:features");
-        // every list length the gather is about to use, local or received (include/mmgen.h: MMGEN_ERROR_PLACEMENT_OVERFLOW)
-        MMK_LAUNCH(mmk::KID_SELECT, k_caps_check, dim3((r->np + 255) / 256), dim3(256), s, r->counts.as<int32_t>(), r->np, r->hostMaxDev);
-        MMK_LAUNCH(mmk::KID_SELECT, k_caps_max, dim3((r->np + 255) / 256), dim3(256), s, r->counts.as<int32_t>(), r->np, r->devMax.as<int>());
+        // (the gather checks every list length it uses, local or received, against MMGEN_CFP_CAP on its way - include/mmgen.h:
+        // MMGEN_ERROR_PLACEMENT_OVERFLOW - and clears the rasterisers' work counters: two launches and a memset less per step)
         CK(r->gfp.ensure(sizeof(mmgen_feature_placement) * MMGEN_MAX_GATHERED_FEATURES_PER_CHUNK * (size_t)nr));
         CK(r->gcfp.ensure(sizeof(mmgen_cave_feature_placement) * MMGEN_MAX_GATHERED_CAVE_FEATURES_PER_CHUNK * (size_t)nr));
         CK(r->bounds.ensure(sizeof(int) * 4 * nr));
         CK(r->applyWork.ensure(mmk::apply_work_bytes() * r->kMaxSlices));      // k_apply_features' work counters, one set per slice
+#ifndef MM_GATHER_WAITS_FOR_FILL
+#define MM_GATHER_WAITS_FOR_FILL 1
+#endif
+        // the gather runs beside the cave fill and must not start before it: the fill's persistent workgroups take the chip first, the gather
+        // the slots they leave (measured: a gather that starts a few microseconds early holds slots the cave fill then never gets)
+        if (MM_GATHER_WAITS_FOR_FILL && par && r->filled && r->fillStarted && r->fillStartedTarget) CK(mmk::launch_wait_counter(r->fillStarted, r->fillStartedTarget, s));
         CK(mmk::launch_gather_placements(r->fp.as<mmgen_feature_placement>(), r->cfp.as<mmgen_cave_feature_placement>(), r->counts.as<int>(), tgt, nr,
                                          r->pnx, r->pnz, r->gfp.as<mmgen_feature_placement>(), r->gcfp.as<mmgen_cave_feature_placement>(),
-                                         r->bounds.as<int>(), posP, s, r->devMax.as<int>() + 1));
+                                         r->bounds.as<int>(), posP, s, r->devMax.as<int>() + 1, r->hostMaxDev, r->devMax.as<int>(),
+                                         (unsigned*)r->applyWork.p, (int)(mmk::apply_work_bytes() * r->kMaxSlices / 4)));
     }
     if (par) { CK(hipEventRecord(r->evGather, s)); CK(hipStreamWaitEvent(sA, r->evGather, 0)); }
     // rasterisers + decorators slice by slice behind that slice's base fill
@@ -718,7 +719,7 @@ int mmgen_region_finish(mmgen_region* r, uint8_t* d_blocks, float* d_heightfield
             mmk::StageRange sr("mmgen:features");
             CK(mmk::launch_apply_features(blk, posP, n, r->gfp.as<mmgen_feature_placement>() + (size_t)MMGEN_MAX_GATHERED_FEATURES_PER_CHUNK * c0,
                                           r->gcfp.as<mmgen_cave_feature_placement>() + (size_t)MMGEN_MAX_GATHERED_CAVE_FEATURES_PER_CHUNK * c0,
-                                          r->bounds.as<int>() + 4 * c0, tgt + c0, (unsigned*)((char*)r->applyWork.p + mmk::apply_work_bytes() * i), sA));
+                                          r->bounds.as<int>() + 4 * c0, tgt + c0, (unsigned*)((char*)r->applyWork.p + mmk::apply_work_bytes() * i), sA, true));
         }
         if (decor) {
             mmk::StageRange sr("mmgen:decorators");
