@@ -184,6 +184,15 @@ int mmgen_region_max_cave_placements(mmgen_region* region, int* out_max, void* s
  * serial = 1: every kernel on the caller's stream in the reference's stage order (what per-kernel timing and the counters want); also
  * selected by MMGEN_REGION_SERIAL=1 in the environment.  Results are identical. */
 int mmgen_region_set_serial(mmgen_region* region, int serial, int slices);
+/* Streaming callers (host/region_terrain.cpp): keep the eroded layers of up to max_zones whole zones (1.18 MB each, device memory of the
+ * region) across calls; 0 = off (the default) and frees them.  A region call then relaxes only the covering zones it has not seen, and
+ * runs K1 / K2 on their gathered areas only - a thin strip of new chunks touches up to ten zones, each a 24 x 24-chunk gather and a full
+ * relaxation in the reference (terrain.cpp:471-522, chunk.cu:658-723).  Results are identical: with the canonical raw padding (DESIGN.md
+ * section 4) a zone's eroded layers are a pure function of its position.  Least recently used zones make room.  Synchronises the device.
+ * Not for throughput measurements of a fixed rectangle (every call after the first would skip the erosion).
+ * mmgen_region_zone_cache_stats: zones served from the cache / relaxed since the last set_zone_cache. */
+int mmgen_region_set_zone_cache(mmgen_region* region, int max_zones);
+int mmgen_region_zone_cache_stats(const mmgen_region* region, long long* hits, long long* misses);
 /* Copies the placement lists of n whole cells between two placement grids with the per-cell layout of mmgen_region_placement_buffers
  * (fp [cells][MMGEN_FP_CAP], cfp [cells][MMGEN_CFP_CAP], counts [cells][2]): cell d_dst_idx[i] of dst <- cell d_src_idx[i] of src.  A streaming
  * caller keeps the lists of chunks it has generated in its own grid and feeds them back as ring cells of later regions (mask 0 in

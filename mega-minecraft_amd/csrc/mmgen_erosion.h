@@ -53,7 +53,10 @@ int erode_zones(float* gathered, size_t strideFloats, int zones, float* work, mm
                 unsigned* errHost = nullptr,
                 // region path: clear *maxPassesDev before this batch (the first of a region's batches), and apply
                 // Chunk::fixBackwardStratifiedLayers to the kept chunks in the kernel that writes their eroded planes
-                bool clearPassesDev = false, bool fixBackward = false);
+                bool clearPassesDev = false, bool fixBackward = false,
+                // region path, zone cache: the 144 kept chunks' planes of zone z also go to zoneCache + zoneCacheSlot[z] * 144 * 8 * 256 floats
+                // (slot -1 = not kept)
+                float* zoneCache = nullptr, const int* zoneCacheSlot = nullptr);
 // test hook: the next persistent launches are `missingWorkgroups` short (a zone's barrier can then never complete) and give up after timeoutMs
 // (0, 0 restores the defaults)
 void erosion_debug_stall(int missingWorkgroups, int timeoutMs);

@@ -552,24 +552,27 @@ k_erosion_scatter(const float* __restrict__ gatheredBase, size_t gatheredStride,
 // One workgroup per kept chunk.
 __global__ void __launch_bounds__(256)
 k_erode_finish(const float* __restrict__ workBase, const ErosionState* __restrict__ states, int lastT, const int* __restrict__ zoneChunkIdxOut /*[zones][144], -1 = skip*/,
-               float* __restrict__ layersOut, int fixBackward)
+               float* __restrict__ layersOut, int fixBackward, float* __restrict__ zoneCache /*nullable*/, const int* __restrict__ cacheSlot /*[zones], -1 = not kept*/)
 {
     const int zone = blockIdx.y, cc = blockIdx.x;
     const int chunk = zoneChunkIdxOut[zone * 144 + cc];
-    if (chunk < 0) return;
+    // zone cache (mmgen_region_set_zone_cache): ALL 144 kept chunks of the zone go into its slot, inside the region's grid or not
+    float* keep = (zoneCache && cacheSlot[zone] >= 0) ? zoneCache + (size_t)cacheSlot[zone] * 144 * 8 * 256 + (size_t)cc * 8 * 256 + threadIdx.x : nullptr;
+    if (chunk < 0 && !keep) return;
     const ErosionPhase* st = &states[zone].slot[lastT & 1];      // the phase the last launch ran with: done, all planes final
     const int t = threadIdx.x;
     const int cx = cc % 12 + 6, cz = cc / 12 + 6;
     const int gx = cx * 16 + (t & 15), gz = cz * 16 + (t >> 4);
-    float* col = layersOut + (size_t)MMGEN_LAYERS_SIZE * chunk + t;
+    float* col = layersOut + (size_t)MMGEN_LAYERS_SIZE * (chunk < 0 ? 0 : chunk) + t;
     float start12 = 0.f;
 #pragma unroll
     for (int plane = 0; plane < 8; ++plane) {
         const float v = workBase[ZONE_WORK_FLOATS * zone + ((size_t)plane * 3 + st->plane(plane)) * ZN + gx + ZS * gz];
-        col[256 * (MMGEN_NUM_STRATIFIED_MATERIALS + plane)] = v;
+        if (keep) keep[256 * plane] = v;
+        if (chunk >= 0) col[256 * (MMGEN_NUM_STRATIFIED_MATERIALS + plane)] = v;
         if (plane == 0) start12 = v;
     }
-    if (fixBackward) {
+    if (fixBackward && chunk >= 0) {
         col[256 * 10] = start12 - col[256 * 10];
         col[256 * 11] = start12 - col[256 * 11];
     }
@@ -651,7 +654,7 @@ void erosion_debug_stall(int missingWorkgroups, int timeoutMs)
 int erode_zones(float* gathered, size_t strideFloats, int zones, float* work, mm::ErosionState* states, float* accOut, size_t accStride,
                 hipStream_t s, int* maxPasses, const int* zoneChunkIdxOut, float* layersOut, int* maxPassesDev, hipEvent_t beforeRelaxation,
                 const float* rawLayers, const float* rawHf, const int* zoneChunkIdx, int workgroupsPer4Cu, const unsigned** startedCounter,
-                unsigned* startedTarget, unsigned* errHost, bool clearPassesDev, bool fixBackward)
+                unsigned* startedTarget, unsigned* errHost, bool clearPassesDev, bool fixBackward, float* zoneCache, const int* zoneCacheSlot)
 {
     if (!gathered && !(rawLayers && rawHf && zoneChunkIdx && layersOut)) return (int)hipErrorInvalidValue;
     if (zones <= 0) return 0;
@@ -683,7 +686,7 @@ int erode_zones(float* gathered, size_t strideFloats, int zones, float* work, mm
     if (layersOut) {
         // region path: no in-place contract to honour, the kept chunks' planes go straight to the layers
         MMK_LAUNCH(KID_EROSION_SCATTER, mm::k_erode_finish, dim3(144, zones), dim3(256), s, (const float*)work, (const mm::ErosionState*)states, 0,
-                   zoneChunkIdxOut, layersOut, fixBackward ? 1 : 0);
+                   zoneChunkIdxOut, layersOut, fixBackward ? 1 : 0, zoneCache, zoneCacheSlot);
     } else {
         MMK_LAUNCH(KID_ERODE_WRITEBACK, mm::k_erode_writeback, dim3(ZN / 256, 1, zones), dim3(256), s, gathered, strideFloats, work, states, accOut,
                    accStride, 0);

@@ -13,6 +13,7 @@
 //   caves + placements are generated on P (or on the caller-selected subset when ring cells arrive from another GPU),
 //   gather / fill / features / decorators on R.
 #include <hip/hip_runtime.h>
+#include <map>
 #include <vector>
 #include <cstdio>
 #include <cstring>
@@ -24,6 +25,7 @@
 #include "mmgen_prof.h"
 
 namespace {
+constexpr size_t mmgen_region_zone_floats = (size_t)144 * 8 * 256;
 
 struct DevBuf {
     void* p = nullptr;
@@ -60,6 +62,27 @@ k_copy_placements(const mmgen_feature_placement* __restrict__ sfp, const mmgen_c
     uint4* e = (uint4*)(dcfp + (size_t)MMGEN_CFP_CAP * d);
     for (int i = t; i < nC; i += 256) e[i] = c[i];
     if (t < 2) dcnt[2 * d + t] = scnt[2 * s + t];
+}
+
+// zone cache, hit: the kept chunks' eroded planes from the cache slot into the chunk-major layers of P, then
+// Chunk::fixBackwardStratifiedLayers for the chunk (chunk.cu:725-749), like k_erode_finish does for a zone that was relaxed
+__global__ void __launch_bounds__(256) k_zone_cache_read(const float* __restrict__ cache, const int* __restrict__ slots, const int* __restrict__ idxOut /*[zones][144], -1 = skip*/,
+                                                          float* __restrict__ layersOut)
+{
+    const int zone = blockIdx.y, cc = blockIdx.x, t = threadIdx.x;
+    const int chunk = idxOut[zone * 144 + cc];
+    if (chunk < 0) return;
+    const float* src = cache + (size_t)slots[zone] * mmgen_region_zone_floats + (size_t)cc * 8 * 256 + t;
+    float* col = layersOut + (size_t)MMGEN_LAYERS_SIZE * chunk + t;
+    float start12 = 0.f;
+#pragma unroll
+    for (int plane = 0; plane < 8; ++plane) {
+        const float v = src[256 * plane];
+        col[256 * (MMGEN_NUM_STRATIFIED_MATERIALS + plane)] = v;
+        if (plane == 0) start12 = v;
+    }
+    col[256 * 10] = start12 - col[256 * 10];
+    col[256 * 11] = start12 - col[256 * 11];
 }
 
 __global__ void __launch_bounds__(256) k_select(const float* __restrict__ src, const int* __restrict__ idx, float* __restrict__ dst, int floatsPerChunk)
@@ -210,6 +233,21 @@ struct mmgen_region {
     unsigned kflags = 0;
     bool kHasMask = false;
     std::vector<uint8_t> kMask;
+    // ---- zone cache (mmgen_region_set_zone_cache): the eroded planes of whole zones (12 x 12 kept chunks x 8 planes), kept across region calls.
+    // A streaming caller generates thin strips; every strip touches up to ten zones, each of which costs 576 chunks of K1 / K2 and a full
+    // relaxation for a few dozen new chunks.  Erosion is a pure function of the zone's position (canonical raw padding),
+    // so a zone relaxed once serves every later region that touches it.
+    static constexpr size_t kZoneCacheFloats = (size_t)144 * 8 * 256;
+    int zoneCacheCap = 0;
+    DevBuf zoneCache;                                   // [cap][144 chunks][8 planes][256]
+    std::map<std::pair<int, int>, int> zoneSlotOf;      // zone (chunk coordinates of its first kept chunk) -> slot
+    std::vector<std::pair<int, int>> slotZone;          // slot -> zone (valid if slotUsed)
+    std::vector<char> slotUsed;
+    std::vector<long long> slotStamp;                   // last use
+    long long zoneStamp = 0;
+    int nHitZones = 0, nMissZones = 0;
+    long long zoneHits = 0, zoneMisses = 0;             // since the cache was (re)sized
+    DevBuf hitSlots, hitIdxOut, missSlots;              // device: [nHit] slot, [nHit][144] P index or -1; [nMiss] slot or -1
     const unsigned* fillStarted = nullptr;      // started-workgroups word of the early fill's k_fill_cave (one slice) and the value it reaches
     unsigned fillStartedTarget = 0u;
     bool filled = false;          // mmgen_region_fill already ran for the current begin
@@ -268,7 +306,8 @@ struct mmgen_region {
             for (int i = 0; i < kMaxSlices; ++i) if (evFill[i]) (void)hipEventDestroy(evFill[i]);
         }
         DevBuf* all[] = {&posA, &hfA, &bwA, &gathA, &layersA, &layersP, &caveP, &colInfo, &fp, &cfp, &counts, &zoneIdx,
-                         &zoneIdxOut, &erodeWork, &erodeState, &computeList, &targets, &gfp, &gcfp, &bounds, &fillQueue, &cellLazy, &colNeed, &applyWork};
+                         &zoneIdxOut, &erodeWork, &erodeState, &computeList, &targets, &gfp, &gcfp, &bounds, &fillQueue, &cellLazy, &colNeed, &applyWork,
+                         &zoneCache, &hitSlots, &hitIdxOut, &missSlots};
         for (DevBuf* b : all) b->release();
     }
 };
@@ -299,6 +338,30 @@ int mmgen_region_create(mmgen_region** out)
     return 0;
 }
 
+int mmgen_region_set_zone_cache(mmgen_region* r, int max_zones)
+{
+    if (!r || max_zones < 0) return (int)hipErrorInvalidValue;
+    if (r->sErode) { CK(hipStreamSynchronize(r->sErode)); CK(hipStreamSynchronize(r->sFill)); CK(hipStreamSynchronize(r->sApply)); }
+    CK(hipDeviceSynchronize());                        // (a resize frees planes a queued kernel may still read)
+    r->zoneSlotOf.clear();
+    r->slotZone.assign(max_zones, {0, 0}); r->slotUsed.assign(max_zones, 0); r->slotStamp.assign(max_zones, 0);
+    r->zoneHits = r->zoneMisses = 0;
+    r->zoneCacheCap = 0;
+    r->layoutValid = false;
+    if (max_zones == 0) { r->zoneCache.release(); return 0; }
+    CK(r->zoneCache.ensure(sizeof(float) * mmgen_region::kZoneCacheFloats * (size_t)max_zones));
+    r->zoneCacheCap = max_zones;
+    return 0;
+}
+
+int mmgen_region_zone_cache_stats(const mmgen_region* r, long long* hits, long long* misses)
+{
+    if (!r) return (int)hipErrorInvalidValue;
+    if (hits) *hits = r->zoneHits;
+    if (misses) *misses = r->zoneMisses;
+    return 0;
+}
+
 int mmgen_region_set_serial(mmgen_region* r, int serial, int slices)
 {
     if (!r || slices < 0 || slices > mmgen_region::kMaxSlices) return (int)hipErrorInvalidValue;
@@ -322,7 +385,7 @@ static int region_layout(mmgen_region* r, int cx0, int cz0, int nx, int nz, unsi
     const bool same = r->layoutValid && r->kcx0 == cx0 && r->kcz0 == cz0 && r->knx == nx && r->knz == nz && r->kflags == flags &&
                       r->kHasMask == (h_local_mask != nullptr) &&
                       (!h_local_mask || (r->kMask.size() == maskBytes && std::memcmp(r->kMask.data(), h_local_mask, maskBytes) == 0));
-    if (same) return 0;
+    if (same && r->zoneCacheCap == 0) return 0;      // (with the zone cache the layout depends on what is cached: rebuilt every call)
     r->layoutValid = false;
 
     r->cx0 = cx0; r->cz0 = cz0; r->nx = nx; r->nz = nz; r->flags = flags;
@@ -330,25 +393,75 @@ static int region_layout(mmgen_region* r, int cx0, int cz0, int nx, int nz, unsi
     r->px0 = cx0 - ring; r->pz0 = cz0 - ring; r->pnx = nx + 2 * ring; r->pnz = nz + 2 * ring; r->np = r->pnx * r->pnz;
     const int np = r->np;
 
-    std::vector<int> zonesX, zonesZ;
+    std::vector<int> zonesX, zonesZ, hitX, hitZ, hitSlot, missSlot;
+    const bool zoneCaching = erosion && r->zoneCacheCap > 0;
     if (erosion) {
         const int zx0 = floordiv(r->px0, MMGEN_ZONE_SIZE) * MMGEN_ZONE_SIZE, zz0 = floordiv(r->pz0, MMGEN_ZONE_SIZE) * MMGEN_ZONE_SIZE;
         const int zx1 = floordiv(r->px0 + r->pnx - 1, MMGEN_ZONE_SIZE) * MMGEN_ZONE_SIZE, zz1 = floordiv(r->pz0 + r->pnz - 1, MMGEN_ZONE_SIZE) * MMGEN_ZONE_SIZE;
         r->ax0 = zx0 - 6; r->az0 = zz0 - 6; r->anx = (zx1 - zx0) + 24; r->anz = (zz1 - zz0) + 24;
-        for (int zz = zz0; zz <= zz1; zz += MMGEN_ZONE_SIZE) for (int zx = zx0; zx <= zx1; zx += MMGEN_ZONE_SIZE) { zonesX.push_back(zx); zonesZ.push_back(zz); }
+        ++r->zoneStamp;
+        for (int zz = zz0; zz <= zz1; zz += MMGEN_ZONE_SIZE) for (int zx = zx0; zx <= zx1; zx += MMGEN_ZONE_SIZE) {
+            if (zoneCaching) {
+                auto it = r->zoneSlotOf.find({zx, zz});
+                if (it != r->zoneSlotOf.end()) { hitX.push_back(zx); hitZ.push_back(zz); hitSlot.push_back(it->second); r->slotStamp[it->second] = r->zoneStamp; ++r->zoneHits; continue; }
+                ++r->zoneMisses;
+            }
+            zonesX.push_back(zx); zonesZ.push_back(zz);
+        }
+        if (zoneCaching) {
+            // a slot for every zone that is relaxed now: a free one, else the least recently used one that this call does not read
+            for (size_t z = 0; z < zonesX.size(); ++z) {
+                int best = -1;
+                for (int k = 0; k < r->zoneCacheCap; ++k) {
+                    if (!r->slotUsed[k]) { best = k; break; }
+                    if (r->slotStamp[k] < r->zoneStamp && (best < 0 || r->slotStamp[k] < r->slotStamp[best])) best = k;
+                }
+                if (best >= 0) {
+                    if (r->slotUsed[best]) r->zoneSlotOf.erase(r->slotZone[best]);
+                    r->slotUsed[best] = 1; r->slotZone[best] = {zonesX[z], zonesZ[z]}; r->slotStamp[best] = r->zoneStamp;
+                    r->zoneSlotOf[{zonesX[z], zonesZ[z]}] = best;
+                }
+                missSlot.push_back(best);                   // -1: relaxed, used, not kept (more zones in one call than the cache holds)
+            }
+        }
     } else {
         r->ax0 = r->px0; r->az0 = r->pz0; r->anx = r->pnx; r->anz = r->pnz;
     }
-    r->na = r->anx * r->anz;
+    r->nHitZones = (int)hitX.size(); r->nMissZones = (int)zonesX.size();
+    // The raw area A: every cell K1 / K2 run on.  Without the zone cache it is the rectangle of the covering zones' gathered areas; with it,
+    // the cells of P plus the gathered areas of the zones that are relaxed in this call only (none when every zone is cached).
+    std::vector<std::pair<int, int>> areaCells;             // (x, z) relative to (ax0, az0), in A's order BEHIND the cells of P
+    std::vector<int> areaIndex;                             // [anx * anz] A index or -1
+    if (zoneCaching) {
+        areaIndex.assign((size_t)r->anx * r->anz, -1);
+        int next = r->np;
+        for (int z = 0; z < r->pnz; ++z) for (int x = 0; x < r->pnx; ++x) areaIndex[(r->px0 + x - r->ax0) + (size_t)r->anx * (r->pz0 + z - r->az0)] = x + r->pnx * z;
+        for (size_t zi = 0; zi < zonesX.size(); ++zi)
+            for (int cz = 0; cz < 24; ++cz) for (int cx = 0; cx < 24; ++cx) {
+                const int x = zonesX[zi] - 6 + cx - r->ax0, z = zonesZ[zi] - 6 + cz - r->az0;
+                int& a = areaIndex[x + (size_t)r->anx * z];
+                if (a < 0) { a = next++; areaCells.push_back({x, z}); }
+            }
+        r->na = next;
+    } else {
+        r->na = r->anx * r->anz;
+    }
     r->nZones = (int)zonesX.size();
     const int na = r->na, nr = nx * nz, Z = r->nZones;
 
     // Order of the raw area A: the cells of the placement grid P first, in P's order, then the padding cells.  Every per-chunk array of
     // A (positions, heights, biome weights) then starts with the array of P - no copies - and only the layers exist twice (raw in A for
     // the zones' padding, eroded in P).
-    std::vector<int32_t> posA(2 * (size_t)na), aIndex((size_t)na), computeList, targets(nr);
+    std::vector<int32_t> posA(2 * (size_t)na), aIndex, computeList, targets(nr);
     std::vector<uint8_t> lazy(np, 0);
-    {
+    if (zoneCaching) {
+        aIndex.assign(areaIndex.begin(), areaIndex.end());
+        for (int i = 0; i < np; ++i) { posA[2 * (size_t)i] = (r->px0 + i % r->pnx) * 16; posA[2 * (size_t)i + 1] = (r->pz0 + i / r->pnx) * 16; }
+        for (size_t k = 0; k < areaCells.size(); ++k) {
+            posA[2 * ((size_t)np + k)] = (r->ax0 + areaCells[k].first) * 16; posA[2 * ((size_t)np + k) + 1] = (r->az0 + areaCells[k].second) * 16;
+        }
+    } else {
+        aIndex.resize((size_t)r->anx * r->anz);
         int next = np;
         for (int z = 0; z < r->anz; ++z) for (int x = 0; x < r->anx; ++x) {
             const int gx = r->ax0 + x - r->px0, gz = r->az0 + z - r->pz0;
@@ -388,6 +501,14 @@ static int region_layout(mmgen_region* r, int cx0, int cz0, int nx, int nz, unsi
         }
     }
 
+    // cached zones: where their kept chunks lie in P
+    std::vector<int> ho((size_t)r->nHitZones * 144);
+    for (int z = 0; z < r->nHitZones; ++z)
+        for (int cz = 0; cz < 12; ++cz) for (int cx = 0; cx < 12; ++cx) {
+            const int gx = hitX[z] + cx - r->px0, gz = hitZ[z] + cz - r->pz0;
+            ho[(size_t)z * 144 + cx + 12 * cz] = (gx >= 0 && gx < r->pnx && gz >= 0 && gz < r->pnz) ? gx + r->pnx * gz : -1;
+        }
+
     CK(r->posA.ensure(sizeof(int32_t) * 2 * na));
     CK(r->computeList.ensure(sizeof(int) * np));
     CK(r->targets.ensure(sizeof(int) * nr));
@@ -404,6 +525,16 @@ static int region_layout(mmgen_region* r, int cx0, int cz0, int nx, int nz, unsi
         CK(r->zoneIdxOut.ensure(sizeof(int) * zo.size()));
         CK(hipMemcpyAsync(r->zoneIdx.p, zi.data(), sizeof(int) * zi.size(), hipMemcpyHostToDevice, s));
         CK(hipMemcpyAsync(r->zoneIdxOut.p, zo.data(), sizeof(int) * zo.size(), hipMemcpyHostToDevice, s));
+    }
+    if (r->nHitZones) {
+        CK(r->hitSlots.ensure(sizeof(int) * hitSlot.size()));
+        CK(r->hitIdxOut.ensure(sizeof(int) * ho.size()));
+        CK(hipMemcpyAsync(r->hitSlots.p, hitSlot.data(), sizeof(int) * hitSlot.size(), hipMemcpyHostToDevice, s));
+        CK(hipMemcpyAsync(r->hitIdxOut.p, ho.data(), sizeof(int) * ho.size(), hipMemcpyHostToDevice, s));
+    }
+    if (zoneCaching && Z) {
+        CK(r->missSlots.ensure(sizeof(int) * missSlot.size()));
+        CK(hipMemcpyAsync(r->missSlots.p, missSlot.data(), sizeof(int) * missSlot.size(), hipMemcpyHostToDevice, s));
     }
     CK(hipStreamSynchronize(s));     // host vectors go out of scope
 
@@ -537,7 +668,7 @@ int mmgen_region_begin(mmgen_region* r, int cx0, int cz0, int nx, int nz, unsign
     if (erosion) {
         mmk::StageRange sr("mmgen:erosion");
         const int Z = r->nZones;
-        const int batch = Z < MMGEN_EROSION_ZONE_BATCH ? Z : MMGEN_EROSION_ZONE_BATCH;
+        const int batch = Z < MMGEN_EROSION_ZONE_BATCH ? (Z > 0 ? Z : 1) : MMGEN_EROSION_ZONE_BATCH;
         CK(r->erodeWork.ensure(mmk::erosion_work_bytes(batch)));
         CK(r->erodeState.ensure(mmk::erosion_state_bytes(batch)));
         startedCounter = nullptr; startedTarget = 0u;
@@ -548,8 +679,14 @@ int mmgen_region_begin(mmgen_region* r, int cx0, int cz0, int nx, int nz, unsign
                                 r->zoneIdxOut.as<int>() + (size_t)z0 * 144, layersP, r->devPasses.as<int>(), (par && z0 == 0) ? r->evResident : nullptr,
                                 r->layersA.as<float>(), r->hfA.as<float>(), r->zoneIdx.as<int>() + (size_t)z0 * 576,
                                 par ? MMGEN_REGION_EROSION_WG_PER_4CU : 0, (par && Z <= batch) ? &startedCounter : nullptr, &startedTarget, (unsigned*)(r->hostMaxDev + 1),
-                                /*clearPassesDev*/ z0 == 0, /*fixBackward (E3 fix-up of the kept chunks)*/ true));
+                                /*clearPassesDev*/ z0 == 0, /*fixBackward (E3 fix-up of the kept chunks)*/ true,
+                                r->zoneCacheCap > 0 ? r->zoneCache.as<float>() : nullptr, r->zoneCacheCap > 0 ? r->missSlots.as<int>() + z0 : nullptr));
         }
+        if (Z == 0) CK(hipMemsetAsync(r->devPasses.p, 0, sizeof(int), sE));      // (every zone came out of the cache: no relaxation, no passes)
+        // zones that were relaxed by an earlier call: their kept chunks' planes out of the cache
+        if (r->nHitZones)
+            MMK_LAUNCH(mmk::KID_EROSION_SCATTER, k_zone_cache_read, dim3(144, r->nHitZones), dim3(256), sE, (const float*)r->zoneCache.as<float>(),
+                       (const int*)r->hitSlots.as<int>(), (const int*)r->hitIdxOut.as<int>(), layersP);
         CK(hipMemcpyAsync(r->hostPasses, r->devPasses.p, sizeof(int), hipMemcpyDeviceToHost, sE));
         CK(hipEventRecord(r->evPasses, sE));
         r->passesPending = true;

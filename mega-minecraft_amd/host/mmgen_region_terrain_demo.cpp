@@ -62,11 +62,13 @@ static int compare(Terrain& a, RegionTerrain& b, ivec2 player)
 
 // one scheduler configuration through the streaming scenario: everything around `home`, then `steps` ticks with the player one chunk
 // further along +x each (a 35 x 1 strip of new drawable chunks + its neighbour ring per tick)
-struct StreamFigures { int loadChunks = 0, loadMeshed = 0; double loadMs = 0; int walkChunks = 0, walkMeshed = 0, ringComputed = 0, ringReused = 0; double walkMs = 0; size_t d2hBytes = 0; };
-static StreamFigures stream_scenario(bool copyToHost, ivec2 home, int steps)
+struct StreamFigures { int loadChunks = 0, loadMeshed = 0; double loadMs = 0; int walkChunks = 0, walkMeshed = 0, ringComputed = 0, ringReused = 0; double walkMs = 0; size_t d2hBytes = 0;
+                       long long zoneHits = 0, zoneMisses = 0; };
+static StreamFigures stream_scenario(bool copyToHost, ivec2 home, int steps, int zoneCacheZones = 128)
 {
     StreamFigures f;
     RegionTerrain t(4096);
+    t.zoneCacheZones = zoneCacheZones;
     t.copyToHost = copyToHost;
     t.packedTransfer = true;
     t.dropRadius = 24;
@@ -86,6 +88,7 @@ static StreamFigures stream_scenario(bool copyToHost, ivec2 home, int steps)
     }
     HipUtils::checkError("hipDeviceSynchronize", (int)hipDeviceSynchronize());
     f.walkMs = 1e3 * secondsSince(t0);
+    t.zoneCacheStats(f.zoneHits, f.zoneMisses);
     return f;
 }
 
@@ -95,6 +98,7 @@ static int bench_main()
     const int steps = 32;
     stream_scenario(false, {100, 100}, 2);                    // warm-up: allocations, first-launch costs
     const StreamFigures dev = stream_scenario(false, home, steps);
+    const StreamFigures devNoZones = stream_scenario(false, home, steps, 0);      // what the zone cache is worth: the same walk relaxing every zone it grazes
     const StreamFigures host = stream_scenario(true, home, steps);
     Terrain stage;
     stage.init();
@@ -105,13 +109,15 @@ static int bench_main()
     auto rec = [&](const char* name, const StreamFigures& f) {
         std::printf("\"%s\": {\"initial_load\": {\"chunks\": %d, \"meshed\": %d, \"ms\": %.2f, \"chunks_per_s\": %.0f}, "
                     "\"walk\": {\"steps\": %d, \"chunks\": %d, \"meshed\": %d, \"ms_per_step\": %.3f, \"chunks_per_s\": %.0f, \"ring_cells_computed\": %d, "
-                    "\"ring_cells_from_cache\": %d}, \"block_bytes_to_host\": %zu}",
+                    "\"ring_cells_from_cache\": %d}, \"zones_from_cache\": %lld, \"zones_relaxed\": %lld, \"block_bytes_to_host\": %zu}",
                     name, f.loadChunks, f.loadMeshed, f.loadMs, f.loadChunks / (f.loadMs * 1e-3), steps, f.walkChunks, f.walkMeshed, f.walkMs / steps,
-                    f.walkChunks / (f.walkMs * 1e-3), f.ringComputed, f.ringReused, f.d2hBytes);
+                    f.walkChunks / (f.walkMs * 1e-3), f.ringComputed, f.ringReused, f.zoneHits, f.zoneMisses, f.d2hBytes);
     };
     std::printf("{\"scenario\": \"RegionTerrain (host/region_terrain.cpp) around chunk (0,0): everything within radius 16 + the mesh neighbour ring, then %d ticks with the "
                 "player one chunk further along +x each; chunks/s = generated chunks incl. their meshing\", ", steps);
     rec("device_resident", dev);
+    std::printf(", ");
+    rec("device_resident_without_zone_cache", devNoZones);
     std::printf(", ");
     rec("host_chunks_packed_d2h", host);
     std::printf(", \"action_time_mirror\": {\"what\": \"host/terrain.cpp, the reference's scheduler (terrain.cpp:587-960) over the same C ABI, initial load only\", "

@@ -29,6 +29,9 @@ RegionTerrain::~RegionTerrain()
 void RegionTerrain::init()
 {
     RT_CALL(mmgen_region_create(&region), "mmgen_region_create failed");
+    // the eroded layers of the zones the walk has touched stay on the device: a strip of new chunks then costs its own chunks, not a
+    // relaxation of every zone it grazes (include/mmgen.h mmgen_region_set_zone_cache)
+    if (zoneCacheZones > 0) RT_CALL(mmgen_region_set_zone_cache(region, zoneCacheZones), "mmgen_region_set_zone_cache failed");
     RT_CALL(hipMalloc((void**)&d_pool, poolChunks * (size_t)devBlocksSize), "hipMalloc (chunk pool) failed");
     freeSlots.resize(poolChunks);
     for (size_t i = 0; i < poolChunks; ++i) freeSlots[i] = (int)(poolChunks - 1 - i);

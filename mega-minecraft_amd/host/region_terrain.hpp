@@ -42,6 +42,8 @@ public:
     int maxChunksPerTick = 4096;          // generation budget of one tick, in chunks
     int dropRadius = 40;                  // chunks farther than this (Chebyshev) from the player are destroyed; = chunkMaxGenRadius of the reference
     bool copyToHost = true;               // false: blocks and meshes stay on the device (renderer interop), Chunk::blocks / verts stay empty
+    int zoneCacheZones = 128;             // eroded zones kept on the device (151 MB; set before init(); 0 = relax every covering zone of every region anew)
+    void zoneCacheStats(long long& hits, long long& misses) const { mmgen_region_zone_cache_stats(region, &hits, &misses); }
     bool cachePlacements = true;          // keep the placement lists of generated chunks and feed them back as ring cells of later regions
     bool packedTransfer = true;           // blocks cross PCIe in the run-length wire format (mmgen_pack_*, ~10 KB instead of 96 KB per chunk)
     size_t lastBlockBytesD2H = 0;         // bytes of block data copied to the host by the last tick

@@ -264,6 +264,17 @@ class MMGen:
             self.lib.mmgen_region_last_erosion_passes.argtypes = [vp]
         return self._region_handle
 
+    def region_set_zone_cache(self, max_zones):
+        """Keep the eroded layers of up to max_zones zones across region calls (include/mmgen.h mmgen_region_set_zone_cache; 0 = off)."""
+        self.lib.mmgen_region_set_zone_cache.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        self._check(self.lib.mmgen_region_set_zone_cache(self._region(), max_zones), "mmgen_region_set_zone_cache")
+
+    def region_zone_cache_stats(self):
+        h, m = ctypes.c_longlong(0), ctypes.c_longlong(0)
+        self.lib.mmgen_region_zone_cache_stats.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_longlong), ctypes.POINTER(ctypes.c_longlong)]
+        self._check(self.lib.mmgen_region_zone_cache_stats(self._region(), ctypes.byref(h), ctypes.byref(m)), "mmgen_region_zone_cache_stats")
+        return h.value, m.value
+
     def region_set_serial(self, serial, slices=0):
         """serial=True: every kernel of the region path on one stream (per-kernel attribution); False: the stage DAG (include/mmgen.h)."""
         self.lib.mmgen_region_set_serial.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]

@@ -253,6 +253,31 @@ def test_region_with_more_zones_than_one_relaxation_batch_matches_oracle(gen, or
     assert gen.lib.mmgen_region_last_erosion_passes(gen._region()) >= 24
 
 
+def test_zone_cache_gives_the_same_regions(mmgen_pkg, gen, oracle):
+    """mmgen_region_set_zone_cache (the streaming scheduler's: eroded zones kept across calls, K1 / K2 only on the gathered areas of the
+    zones that are new): a walk of thin strips - the regime it exists for - with a cache too small for the walk (evictions), in the DAG and
+    in the serial schedule, gives block for block, layer for layer what a region without the cache gives; one strip == the CPU oracle."""
+    import torch
+    walker = mmgen_pkg.MMGen(0)
+    walker.region_set_zone_cache(5)
+    strips = [(1480 + k, -1120, 1, 35) for k in range(8)] + [(1470, -1100 + 3 * k, 35, 2) for k in range(4)] + [(1480, -1120, 1, 35), (-3, -3, 7, 7), (1487, -1120, 1, 35)]
+    for i, (cx0, cz0, nx, nz) in enumerate(strips):
+        walker.region_set_serial(i % 5 == 4)
+        got = walker.generate_region(cx0, cz0, nx, nz, want=("layers", "cave"))
+        ref = gen.generate_region(cx0, cz0, nx, nz, want=("layers", "cave"))
+        for k in ("blocks", "hf", "layers", "cave"):
+            assert torch.equal(got[k], ref[k]), (i, k, (cx0, cz0, nx, nz))
+    hits, misses = walker.region_zone_cache_stats()
+    assert hits > 20 and misses >= 5, (hits, misses)
+    cx0, cz0, nx, nz = strips[3]
+    want = oracle.generate_region(cx0, cz0, nx, 3, erosion=True, features=True, decorators=True)["blocks"]
+    got = walker.generate_region(cx0, cz0, nx, 3)
+    assert np.array_equal(got["blocks"].cpu().numpy(), want)
+    walker.region_set_zone_cache(0)                            # off again: everything is relaxed anew, same result
+    again = walker.generate_region(cx0, cz0, nx, 3)
+    assert torch.equal(again["blocks"], got["blocks"]) and walker.region_zone_cache_stats() == (0, 0)
+
+
 def test_config5_world_8_tiles_equals_single_region(mmgen_pkg):
     """BASELINE config 5 at full size: the 65 536-chunk world [-128, 128)^2 as 4 x 2 tiles of 64 x 128 chunks (the 8-GPU layout,
     played on one GPU) is block-for-block the world generated as one region: 6.4 GB of block ids compared on the device."""
