@@ -311,6 +311,24 @@ def test_stage_calls_on_two_streams_do_not_share_scratch(gen):
         assert torch.equal(outs[i], ref[i][2])
 
 
+def test_erosion_launch_that_fills_the_chip_exactly(gen):
+    """16 zones in one call: 48 workgroups per zone = 768 = every slot the occupancy query promises (three per CU).  If the chip held fewer,
+    the workgroups that cannot start would wait for slots of the XCD the dispatcher has bound them to while spinning workgroups hold them
+    (profiles/LOG.md, round 5) - the call would end with MMGEN_ERROR_EROSION_STALL.  It must simply work, and give each zone what a
+    single-zone call gives it."""
+    import torch
+    zones = [(12 * (i % 4), 12 * (i // 4)) for i in range(16)]
+    packs = []
+    for z in zones:
+        pos = gen.positions(gen.zone_area_coords(*z))
+        hf, bw, g = gen.generate_heightfields(pos, gathered=True)
+        packs.append(gen.pack_zone_planes(gen.generate_layers(g, bw, pos), hf))
+    batched, passes = gen.erode_zones(torch.cat(packs, dim=0).contiguous())
+    for i in (0, 7, 15):
+        single, p1 = gen.erode_zones(packs[i].clone())
+        assert torch.equal(batched[i], single[0]) and p1 <= passes
+
+
 @pytest.mark.gpu
 def test_starved_relaxation_gives_up_with_an_error_instead_of_hanging(gen):
     """The relaxation's workgroups wait for each other on the device; a zone whose workgroups never all arrive (here: the launch is one
