@@ -409,7 +409,7 @@ k_erode_zones(const float* __restrict__ gatheredBase, size_t gatheredStride, con
                 if (ph.done) {                                       // both slots final: the finish kernels read slot[0]
                     store_phase(&st->slot[(t + 1) & 1], ph);
                     atomicMax(maxPasses, ph.passes);
-                    if (maxPassesAlso) atomicMax(maxPassesAlso, ph.passes);
+                    if (maxPassesAlso) __hip_atomic_fetch_max(maxPassesAlso, ph.passes, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);      // (may be host memory)
                 }
                 __hip_atomic_store(&st->changed[(t + 1) & 3], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }

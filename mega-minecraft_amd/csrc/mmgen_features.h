@@ -16,7 +16,9 @@ int launch_gather_placements(const mmgen_feature_placement* fp, const mmgen_cave
                              const int32_t* gridPos, hipStream_t s, int* maxGathered = nullptr,
                              // the region folds three small launches into this one: the capacity check of every source cell's cave list
                              // (capHost: host-visible word, capMax: device word) and the clearing of the rasterisers' work counters
-                             int* capHost = nullptr, int* capMax = nullptr, unsigned* zeroWords = nullptr, int nZeroWords = 0);
+                             int* capHost = nullptr, int* capMax = nullptr, unsigned* zeroWords = nullptr, int nZeroWords = 0,
+                             // ... and the copy of the targets' heightfields out of the grid (hfGrid [grid][256] -> hfOut [nOut][256])
+                             const float* hfGrid = nullptr, float* hfOut = nullptr);
 // workCounter: apply_work_bytes() of device scratch that nothing else uses while the kernel runs (the waves draw their work from it)
 size_t apply_work_bytes();
 int launch_apply_features(uint8_t* blocks, const int32_t* pos, int n, const mmgen_feature_placement* gfp, const mmgen_cave_feature_placement* gcfp,

@@ -387,7 +387,8 @@ k_gather_placements(const mmgen_feature_placement* __restrict__ fp, const mmgen_
                     int* maxGathered /*nullable: [0] / [1] raised to the longest un-truncated surface / cave list*/,
                     int* capHost /*nullable: host-visible word raised to a source cell's cave count beyond MMGEN_CFP_CAP*/,
                     int* capMax /*nullable: raised to the largest cave count of the source cells*/,
-                    unsigned* zeroWords /*nullable*/, int nZeroWords /*words the first workgroup clears: the rasterisers' work counters*/)
+                    unsigned* zeroWords /*nullable*/, int nZeroWords /*words the first workgroup clears: the rasterisers' work counters*/,
+                    const float* __restrict__ hfGrid /*nullable*/, float* __restrict__ hfOut /*the targets' heightfields, dense (what k_select did)*/)
 {
     __shared__ int s_offS[50], s_offC[50], s_src[49];
     __shared__ int s_b[4], s_w[4];
@@ -421,6 +422,7 @@ k_gather_placements(const mmgen_feature_placement* __restrict__ fp, const mmgen_
         if (t == 0) { s_b[0] = 384; s_b[1] = -1; s_b[2] = 384; s_b[3] = -1; }
     }
     if (zeroWords && o == 0) for (int i = t; i < nZeroWords; i += 256) zeroWords[i] = 0u;
+    if (hfOut) hfOut[(size_t)256 * o + t] = hfGrid[(size_t)256 * c + t];
     __syncthreads();
     const int totS = s_offS[49], totC = s_offC[49];
     // (a plain look first: two atomics per chunk on two addresses serialise in L2 - 0.09 ms for the bench tile - and only a few ever raise the maximum)
@@ -1194,11 +1196,12 @@ int launch_ring_need(const float* bw, const int32_t* pos, const int* chunkList, 
 
 int launch_gather_placements(const mmgen_feature_placement* fp, const mmgen_cave_feature_placement* cfp, const int* counts, const int* target,
                              int nOut, int gridW, int gridH, mmgen_feature_placement* gfp, mmgen_cave_feature_placement* gcfp, int* bounds,
-                             const int32_t* gridPos, hipStream_t s, int* maxGathered, int* capHost, int* capMax, unsigned* zeroWords, int nZeroWords)
+                             const int32_t* gridPos, hipStream_t s, int* maxGathered, int* capHost, int* capMax, unsigned* zeroWords, int nZeroWords,
+                             const float* hfGrid, float* hfOut)
 {
     if (nOut <= 0) return 0;
     LAUNCH(KID_GATHER_PLACEMENTS, mm::k_gather_placements, dim3(nOut), dim3(256), s, fp, cfp, counts, target, gridW, gridH, gfp, gcfp, bounds,
-           (const int2*)gridPos, maxGathered, capHost, capMax, zeroWords, nZeroWords);
+           (const int2*)gridPos, maxGathered, capHost, capMax, zeroWords, nZeroWords, hfGrid, hfOut);
     return 0;
 }
 

@@ -222,9 +222,7 @@ struct mmgen_region {
     DevBuf layersP, caveP, colInfo, fp, cfp, counts;
     DevBuf zoneIdx, zoneIdxOut, erodeWork, erodeState, computeList, targets, gfp, gcfp, bounds, fillQueue, cellLazy, colNeed, applyWork;
     bool passesPending = false;
-    int* hostPasses = nullptr;    // pinned: largest erosion pass count of the last begin, valid once evPasses has fired
-    DevBuf devPasses;
-    hipEvent_t evPasses = nullptr;
+    hipEvent_t evPasses = nullptr;      // behind the erosion branch of the last begin: hostMax[2] (its largest pass count) is valid once it has fired
     // layout cache: the host-built index tables (positions, A->P selection, compute list, zone gather / scatter lists, fill targets)
     // depend only on (rectangle, flags, mask); a caller that regenerates the same layout (bench loop, fixed tiles) re-uses the
     // device copies and region_begin / region_finish issue no host rebuild, no H2D copy and no stream synchronisation.
@@ -257,7 +255,8 @@ struct mmgen_region {
     // runs beside the caves on sErode; the base fill runs on sFill in z slices, the rasterisers / decorators of slice i follow on sApply
     // beside the fill of slice i + 1.  serial = everything on the caller's stream in the reference's stage order (per-kernel
     // attribution for the roofline; MMGEN_REGION_SERIAL=1 or mmgen_region_set_serial).
-    int* hostMax = nullptr;       // pinned + mapped: [0] largest cave list length beyond MMGEN_CFP_CAP seen by a finish (0 = none); [1] the error word
+    int* hostMax = nullptr;       // pinned + mapped: [2] largest erosion pass count of the last begin (written by the relaxation itself, no copy);
+                                  // [0] largest cave list length beyond MMGEN_CFP_CAP seen by a finish (0 = none); [1] the error word
                                   // of a relaxation that gave up (k_erode_zones; 0 = none, never cleared: MMGEN_ERROR_EROSION_STALL from then on)
     int* hostMaxDev = nullptr;    // its device address
     DevBuf devMax;                // [0] largest cave list length of the finishes since the last query (whatever its size); [1], [2] the longest
@@ -295,9 +294,8 @@ struct mmgen_region {
     ~mmgen_region()
     {
         if (hostMax) (void)hipHostFree(hostMax);
-        if (hostPasses) (void)hipHostFree(hostPasses);
         if (evPasses) (void)hipEventDestroy(evPasses);
-        devMax.release(); devPasses.release();
+        devMax.release();
         if (sErode) {
             (void)hipStreamSynchronize(sErode); (void)hipStreamSynchronize(sFill); (void)hipStreamSynchronize(sApply);
             (void)hipStreamDestroy(sErode); (void)hipStreamDestroy(sFill); (void)hipStreamDestroy(sApply);
@@ -322,13 +320,11 @@ int mmgen_region_create(mmgen_region** out)
     *out = new mmgen_region();
     {
         mmgen_region* r = *out;
-        hipError_t he = hipHostMalloc((void**)&r->hostMax, 2 * sizeof(int), hipHostMallocMapped);
-        if (he == hipSuccess) { r->hostMax[0] = 0; r->hostMax[1] = 0; he = hipHostGetDevicePointer((void**)&r->hostMaxDev, r->hostMax, 0); }
+        hipError_t he = hipHostMalloc((void**)&r->hostMax, 4 * sizeof(int), hipHostMallocMapped);
+        if (he == hipSuccess) { r->hostMax[0] = r->hostMax[1] = r->hostMax[2] = r->hostMax[3] = 0; he = hipHostGetDevicePointer((void**)&r->hostMaxDev, r->hostMax, 0); }
         if (he == hipSuccess && r->devMax.ensure(3 * sizeof(int)) == 0) he = hipMemset(r->devMax.p, 0, 3 * sizeof(int));
         else if (he == hipSuccess) he = hipErrorOutOfMemory;
-        if (he == hipSuccess) he = hipHostMalloc((void**)&r->hostPasses, sizeof(int), hipHostMallocDefault);
-        if (he == hipSuccess) { *r->hostPasses = 0; he = hipEventCreateWithFlags(&r->evPasses, hipEventDisableTiming); }
-        if (he == hipSuccess && r->devPasses.ensure(sizeof(int)) != 0) he = hipErrorOutOfMemory;
+        if (he == hipSuccess) he = hipEventCreateWithFlags(&r->evPasses, hipEventDisableTiming);
         if (he != hipSuccess) { delete r; *out = nullptr; return (int)he; }
     }
     const char* e = getenv("MMGEN_REGION_SERIAL");
@@ -676,18 +672,17 @@ int mmgen_region_begin(mmgen_region* r, int cx0, int cz0, int nx, int nz, unsign
             const int nb = (Z - z0) < batch ? (Z - z0) : batch;
             // (no E1 copy: the relaxation reads the zones' raw planes through their chunk lists)
             CK(mmk::erode_zones(nullptr, 0, nb, r->erodeWork.as<float>(), r->erodeState.as<mm::ErosionState>(), nullptr, 0, sE, nullptr,
-                                r->zoneIdxOut.as<int>() + (size_t)z0 * 144, layersP, r->devPasses.as<int>(), (par && z0 == 0) ? r->evResident : nullptr,
+                                r->zoneIdxOut.as<int>() + (size_t)z0 * 144, layersP, r->hostMaxDev + 2, (par && z0 == 0) ? r->evResident : nullptr,
                                 r->layersA.as<float>(), r->hfA.as<float>(), r->zoneIdx.as<int>() + (size_t)z0 * 576,
                                 par ? MMGEN_REGION_EROSION_WG_PER_4CU : 0, (par && Z <= batch) ? &startedCounter : nullptr, &startedTarget, (unsigned*)(r->hostMaxDev + 1),
                                 /*clearPassesDev*/ z0 == 0, /*fixBackward (E3 fix-up of the kept chunks)*/ true,
                                 r->zoneCacheCap > 0 ? r->zoneCache.as<float>() : nullptr, r->zoneCacheCap > 0 ? r->missSlots.as<int>() + z0 : nullptr));
         }
-        if (Z == 0) CK(hipMemsetAsync(r->devPasses.p, 0, sizeof(int), sE));      // (every zone came out of the cache: no relaxation, no passes)
+        if (Z == 0) CK(hipMemsetAsync(r->hostMaxDev + 2, 0, sizeof(int), sE));      // (every zone came out of the cache: no relaxation, no passes)
         // zones that were relaxed by an earlier call: their kept chunks' planes out of the cache
         if (r->nHitZones)
             MMK_LAUNCH(mmk::KID_EROSION_SCATTER, k_zone_cache_read, dim3(144, r->nHitZones), dim3(256), sE, (const float*)r->zoneCache.as<float>(),
                        (const int*)r->hitSlots.as<int>(), (const int*)r->hitIdxOut.as<int>(), layersP);
-        CK(hipMemcpyAsync(r->hostPasses, r->devPasses.p, sizeof(int), hipMemcpyDeviceToHost, sE));
         CK(hipEventRecord(r->evPasses, sE));
         r->passesPending = true;
     }
@@ -844,7 +839,8 @@ int mmgen_region_finish(mmgen_region* r, uint8_t* d_blocks, float* d_heightfield
         CK(mmk::launch_gather_placements(r->fp.as<mmgen_feature_placement>(), r->cfp.as<mmgen_cave_feature_placement>(), r->counts.as<int>(), tgt, nr,
                                          r->pnx, r->pnz, r->gfp.as<mmgen_feature_placement>(), r->gcfp.as<mmgen_cave_feature_placement>(),
                                          r->bounds.as<int>(), posP, s, r->devMax.as<int>() + 1, r->hostMaxDev, r->devMax.as<int>(),
-                                         (unsigned*)r->applyWork.p, (int)(mmk::apply_work_bytes() * r->kMaxSlices / 4)));
+                                         (unsigned*)r->applyWork.p, (int)(mmk::apply_work_bytes() * r->kMaxSlices / 4), hfP, d_heightfields));
+        d_heightfields = nullptr;                       // (copied by the gather)
     }
     if (par) { CK(hipEventRecord(r->evGather, s)); CK(hipStreamWaitEvent(sA, r->evGather, 0)); }
     // rasterisers + decorators slice by slice behind that slice's base fill
@@ -894,7 +890,7 @@ int mmgen_region_last_erosion_passes(const mmgen_region* r)
     if (!r) return -1;
     if (r->passesPending && hipEventSynchronize(r->evPasses) != hipSuccess) return -1;
     if (__atomic_load_n(r->hostMax + 1, __ATOMIC_RELAXED) != 0) return -1;      // the relaxation gave up (MMGEN_ERROR_EROSION_STALL)
-    return *r->hostPasses;
+    return __atomic_load_n(r->hostMax + 2, __ATOMIC_RELAXED);
 }
 
 int mmgen_copy_placements(const mmgen_feature_placement* d_src_fp, const mmgen_cave_feature_placement* d_src_cfp, const int32_t* d_src_counts,
