@@ -274,8 +274,8 @@ int mmgen_debug_probe(int fn, const float* d_in, int n, float* d_out, void* stre
 /* Test-only: caps the queue of deferred clay / moss voxels of mmgen_fill / the region path at `entries` (0 = the library's own size, 2 048 per
  * chunk), so that a test can drive the path that evaluates them in place when a reservation does not fit.  Process-wide. */
 int mmgen_debug_set_lush_queue_cap(int entries);
-/* Test-only: the following persistent relaxation launches are `missing_workgroups` short, so that a zone's barrier can never complete, and
- * give up after timeout_ms: drives the MMGEN_ERROR_EROSION_STALL path.  (0, 0) restores the defaults.  Process-wide. */
+/* Test-only: the following persistent relaxation launches wait for `missing_workgroups` more workgroups than they have, so that the wait
+ * can never complete, and give up after timeout_ms: drives the MMGEN_ERROR_EROSION_STALL path.  (0, 0) restores the defaults.  Process-wide. */
 int mmgen_debug_erosion_stall(int missing_workgroups, int timeout_ms);
 /* Test-only: the library's constant rule tables (BiomeUtils::init, biomeFuncs.hpp:725-1256) as floats in the layout of
  * tools/extract_ref_tables.py, so that a test can hold them to the reference's literals.  d_out == NULL: returns the number of floats. */

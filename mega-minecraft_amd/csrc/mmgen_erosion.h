@@ -57,7 +57,7 @@ int erode_zones(float* gathered, size_t strideFloats, int zones, float* work, mm
                 // region path, zone cache: the 144 kept chunks' planes of zone z also go to zoneCache + zoneCacheSlot[z] * 144 * 8 * 256 floats
                 // (slot -1 = not kept)
                 float* zoneCache = nullptr, const int* zoneCacheSlot = nullptr);
-// test hook: the next persistent launches are `missingWorkgroups` short (a zone's barrier can then never complete) and give up after timeoutMs
+// test hook: the next persistent launches wait for `missingWorkgroups` more workgroups than they have (the wait can then never complete) and give up after timeoutMs
 // (0, 0 restores the defaults)
 void erosion_debug_stall(int missingWorkgroups, int timeoutMs);
 int erosion_gather(const float* layers, const float* hf, const int* zoneChunkIdx, int zones, float* gathered, size_t strideFloats, hipStream_t s);

@@ -88,10 +88,17 @@ MM_DEV F4 ld4_dev(__amdgpu_buffer_rsrc_t rs, unsigned byteOff)
     const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)byteOff, 0, MM_AUX_SC1);
     return F4{__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
 }
+// A zone is relaxed by workgroups of ONE XCD (k_erode_zones reads HW_REG_XCC_ID and forms its groups per XCD): its planes travel through
+// that XCD's L2, which every CU of the XCD shares.  The stores are therefore plain (the line stays in the L2: the guide's "plain / sc0 / nt
+// KEEP the line in the XCD's L2, sc1 DROPs it"), the loads keep sc1 (past the per-CU L1, served by the L2).  MM_ERODE_STORE_AUX=16 restores
+// the write-through stores (then any placement of a zone's workgroups is coherent, and every round's planes cross the fabric).
+#ifndef MM_ERODE_STORE_AUX
+#define MM_ERODE_STORE_AUX 0
+#endif
 MM_DEV void st4_dev(__amdgpu_buffer_rsrc_t rs, unsigned byteOff, const F4& f)
 {
     const u32x4 v = {__float_as_uint(f.x), __float_as_uint(f.y), __float_as_uint(f.z), __float_as_uint(f.w)};
-    __builtin_amdgcn_raw_buffer_store_b128(v, rs, (int)byteOff, 0, MM_AUX_SC1);
+    __builtin_amdgcn_raw_buffer_store_b128(v, rs, (int)byteOff, 0, MM_ERODE_STORE_AUX);
 }
 
 // Geometry of a tile's traffic.  Loads: the rows of the extended tile as aligned 16-byte pieces (columns [gx0 - PAD, gx0 - PAD + 4 SEGS) of
@@ -356,45 +363,143 @@ MM_DEV unsigned relax_tile(__amdgpu_buffer_rsrc_t work, const RoundPlanes& rp, i
     return mask;
 }
 
-// The whole relaxation of a batch of zones in ONE launch (the host loop of Chunk::erodeZone chunk.cu:682-705 on the device).  A zone is
-// worked on by `perZone` persistent workgroups; a round = EROSION_K passes of the zone's current layer on each of its 144 tiles, a
-// workgroup's share of them (tiles member, member + perZone, ...: fixed, so the next tile's planes are in flight while the current one is
-// relaxed) one after the other, then a barrier among the zone's workgroups, then every workgroup derives the next phase from the zone's
-// "changed" mask exactly like the host loop does from its flag.  Zones do not wait for each other and the host is not involved.
-// Workgroups take their (zone, member) from a ticket, zone-major: whatever order the dispatcher places workgroups in, the zones with the
-// lowest tickets are complete and make progress, so the barrier cannot deadlock WITHIN one launch even when it does not fit the chip at
-// once.  What can still starve it (several persistent launches in flight on one device, a faulted workgroup) ends the wait after
-// `timeoutTicks` of the 100 MHz clock: the waiting workgroup raises *err = 0x80000000 | zone << 8 | round, every workgroup of the launch
-// leaves at its next look at that word, and the host reports MMGEN_ERROR_EROSION_STALL instead of hanging.
+// The whole relaxation of a batch of zones in ONE launch (the host loop of Chunk::erodeZone chunk.cu:682-705 on the device).
+// GROUPS PER XCD.  A workgroup reads the XCD it runs on (HW_REG_XCC_ID) and takes a number there; numbers g * groupSize .. (g + 1) *
+// groupSize - 1 of an XCD form its group g.  A group that is complete draws zones from a launch-wide counter, one after the other, until
+// none is left.  A zone's planes therefore never leave one XCD's L2 between its rounds (plain stores, sc1 loads: st4_dev), and which XCD
+// a workgroup landed on decides only WHO works on a zone, never whether the result is right.  Nothing assumes that the launch is resident
+// as a whole: the groups that exist do the work, workgroups that start late form later groups (and usually find no zone left), members
+// of a group that can never become complete (the launch's last workgroups on an XCD) leave once every workgroup has started.  The host
+// still sizes the launch so that it fits the chip: that is speed, not correctness.
+// A round = EROSION_K passes of the zone's current layer on each of its 144 tiles, a group member's share of them (tiles member,
+// member + groupSize, ...: fixed, so the next tile's planes are in flight while the current one is relaxed) one after the other, then a
+// barrier among the group, then every member derives the next phase from the zone's "changed" mask exactly like the host loop does from
+// its flag.  Zones do not wait for each other and the host is not involved.
+// No wait is unbounded: after `timeoutTicks` of the 100 MHz clock the waiting workgroup raises *err = 0x80000000 | zone << 8 | round
+// (zone 0x7fffff: waiting for the group to form or for its next zone), every workgroup of the launch leaves at its next look at that
+// word, and the host reports MMGEN_ERROR_EROSION_STALL instead of hanging.  (Round 4's kernel took (zone, member) from one launch-wide
+// ticket and could starve for good: workgroups that cannot start are bound to an XCD by the dispatcher, and their XCD's slots were held
+// by spinning members of the very zone they belonged to - profiles/LOG.md.  Here a group only ever waits for workgroups of its own XCD
+// with LOWER numbers than the ones still to come, i.e. for workgroups that have started.)
+#define EROSION_WORD_REGISTERED 0      // the launch's words (behind the zones' states): workgroups that have started
+#define EROSION_WORD_PASSES 1
+#define EROSION_WORD_ERR 2             // ... [2..7] the error word and what the workgroup that gave up saw
+#define EROSION_WORD_XCD 8             // ... [8..15] workgroups started per XCD
+#define EROSION_WORD_ZONE_NEXT 16      // ... the next zone to hand out
+#define EROSION_WORD_GROUPS 32         // ... then two words per group (XCD * 32 + group of the XCD): draws so far, the zone drawn last (-1: none left)
+#define EROSION_GROUPS_PER_XCD 32
+#define EROSION_LAUNCH_WORDS (EROSION_WORD_GROUPS + 2 * 8 * EROSION_GROUPS_PER_XCD)
+// spins until *word >= want; false = gave up (the error word is set) or another workgroup did
+MM_DEV bool erosion_spin(const unsigned* word, unsigned want, unsigned* err, unsigned* errHost, unsigned code, unsigned long long timeoutTicks)
+{
+    const unsigned long long t0 = wall_clock64();
+    unsigned polls = 0u;
+    // (one lane polls: the loaded value goes to a scalar register, so that `want` and the loop's other operands stay scalar too)
+    while ((unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < want) {
+        __builtin_amdgcn_s_sleep(4);
+        if ((++polls & 63u) == 0u) {
+            unsigned e = __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (e == 0u && (unsigned long long)(wall_clock64() - t0) > timeoutTicks) {
+                e = code;
+                if (atomicCAS(err, 0u, e) == 0u) {
+                    if (errHost) __hip_atomic_store(errHost, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    // what the workgroup that gave up saw (read by the host's report)
+                    err[2] = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); err[3] = want; err[4] = polls;
+                    err[5] = (unsigned)((wall_clock64() - t0) >> 10);
+                }
+            }
+            if (e != 0u) return false;
+        }
+    }
+    return true;
+}
+
 __global__ void __launch_bounds__(EROSION_THREADS) __attribute__((amdgpu_waves_per_eu(6, 6)))
 k_erode_zones(const float* __restrict__ gatheredBase, size_t gatheredStride, const float* __restrict__ rawLayers, const float* __restrict__ rawHf,
-              const int* __restrict__ zoneChunkIdx /*[zones][576]*/, float* workBase, ErosionState* states, unsigned* ticket, int perZone, int* maxPasses,
-              int* maxPassesAlso /*nullable*/, unsigned* err, unsigned* errHost /*host-visible copy of the error word, nullable*/, unsigned long long timeoutTicks)
+              const int* __restrict__ zoneChunkIdx /*[zones][576]*/, float* workBase, ErosionState* states, unsigned* words, int zones, int groupSize,
+              int groupWait /*workgroups a group waits for: groupSize (more only in the test of the give-up path)*/, int* maxPassesAlso /*nullable*/,
+              unsigned* errHost /*host-visible copy of the error word, nullable*/, unsigned long long timeoutTicks)
 {
     __shared__ float s_s[2][EROSION_CELLS_EXT];            // start planes, ping-pong over the passes
     __shared__ float s_t[2][EROSION_CELLS_EXT];            // thickness = end - start of the same states (what the neighbours compare)
     __shared__ float s_end[EROSION_CELLS_EXT];
     __shared__ float s_acc[EROSION_CELLS_EXT];             // accumulated heights; after the commit every cell is touched by its own lane only
     __shared__ int s_chunk[576];                           // the zone's 24 x 24 chunks (region path): raw pieces are addressed without a dependent global load
-    __shared__ unsigned s_ticket;
     __shared__ unsigned s_passFlags[EROSION_K];            // per pass of the current tile: bit 0 = a live cell changed, bit 1 = a cell of the centre did
+    __shared__ int s_group[2];                             // the group's slot (XCD * 32 + group of the XCD) and this workgroup's member index (< 0: leave)
+    __shared__ int s_zone;
     __shared__ int s_abort;
     __shared__ ErosionPhase s_ph;
 
     const int tid = threadIdx.x;
-#ifndef MM_ERODE_PRIO
-#define MM_ERODE_PRIO 3
-#endif
-    // beside the caves (16 issue-bound waves per CU) this kernel's 8 waves mostly wait: at the highest wave priority they get the issue slot
-    // whenever they can use one, and the workgroup's share of the CU (48.8 KB of LDS = two cave workgroups) is given back sooner
-    __builtin_amdgcn_s_setprio(MM_ERODE_PRIO);
-    if (tid == 0) { s_ticket = atomicAdd(ticket, 1u); s_abort = 0; }
+    unsigned* err = words + EROSION_WORD_ERR;
+    const unsigned giveUpCode = 0x80000000u | (0x7fffffu << 8);
+    if (tid == 0) {
+        s_abort = 0;
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        xcc &= 7u;
+        const unsigned mine = __hip_atomic_fetch_add(&words[EROSION_WORD_XCD + xcc], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (the XCD's count is in before the launch-wide one says "started")
+        __hip_atomic_fetch_add(&words[EROSION_WORD_REGISTERED], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int g = (int)mine / groupSize;
+        int member = (int)mine % groupSize;
+        if (g >= EROSION_GROUPS_PER_XCD) member = -2;
+        else {
+            // the group is complete once the XCD has handed out the numbers of all its members; it never will be if every workgroup of the
+            // launch has started and the XCD's count is still short (the last, partial group of an XCD: nothing to do)
+            const unsigned need = (unsigned)(g * groupSize + groupWait);
+            const unsigned long long t0 = wall_clock64();
+            for (unsigned polls = 1u;; ++polls) {
+                if (__hip_atomic_load(&words[EROSION_WORD_XCD + xcc], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= need) break;
+                if (__hip_atomic_load(&words[EROSION_WORD_REGISTERED], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= gridDim.x && groupWait == groupSize) {
+                    if (__hip_atomic_load(&words[EROSION_WORD_XCD + xcc], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) member = -2;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(4);
+                if ((polls & 63u) == 0u) {
+                    unsigned e = __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (e == 0u && (unsigned long long)(wall_clock64() - t0) > timeoutTicks) {
+                        e = giveUpCode;
+                        if (atomicCAS(err, 0u, e) == 0u && errHost) __hip_atomic_store(errHost, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    }
+                    if (e != 0u) { member = -1; break; }
+                }
+            }
+        }
+        s_group[0] = (int)xcc * EROSION_GROUPS_PER_XCD + g; s_group[1] = member;
+    }
     __syncthreads();
-    const unsigned myTicket = (unsigned)__builtin_amdgcn_readfirstlane((int)s_ticket);
-    const int zone = (int)(myTicket / (unsigned)perZone), member = (int)(myTicket % (unsigned)perZone);
+    const int member = __builtin_amdgcn_readfirstlane(s_group[1]), perZone = groupSize;      // (workgroup-uniform: scalar registers)
+    if (member < 0) return;
+    unsigned* groupWords = words + EROSION_WORD_GROUPS + 2 * __builtin_amdgcn_readfirstlane(s_group[0]);
+    // beside the caves (16 issue-bound waves per CU) this kernel's 8 waves mostly wait: at the highest wave priority they get the issue slot
+    // whenever they can use one
+    __builtin_amdgcn_s_setprio(3);
+
+#pragma unroll 1
+  for (unsigned draw = 1u;; ++draw) {
+    // the group's next zone: its first member draws it and tells the others (who cannot be a zone behind: every zone has rounds, every
+    // round a barrier among the group)
+    if (tid == 0) {
+        int z = -1;
+        if (member == 0) {
+            const unsigned d = __hip_atomic_fetch_add(&words[EROSION_WORD_ZONE_NEXT], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            z = d < (unsigned)zones ? (int)d : -1;
+            __hip_atomic_store(&groupWords[1], (unsigned)z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(&groupWords[0], draw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else if (erosion_spin(&groupWords[0], draw, err, errHost, giveUpCode, timeoutTicks)) {
+            z = (int)__hip_atomic_load(&groupWords[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        s_zone = z;
+    }
+    __syncthreads();
+    const int zone = __builtin_amdgcn_readfirstlane(s_zone);
+    if (zone < 0) return;
     ErosionState* st = states + zone;
     const RawPlanes raw = {gatheredBase ? gatheredBase + gatheredStride * zone : nullptr, rawLayers, rawHf, zoneChunkIdx ? zoneChunkIdx + 576 * zone : nullptr};
-    if (raw.chunkIdx) for (int i = tid; i < 576; i += EROSION_THREADS) s_chunk[i] = raw.chunkIdx[i];      // (visible behind the first round's barrier)
+    if (raw.chunkIdx) for (int i = opaque_tid(); i < 576; i += EROSION_THREADS) s_chunk[i] = raw.chunkIdx[i];      // (visible behind the first round's barrier)
     const __amdgpu_buffer_rsrc_t work = __builtin_amdgcn_make_buffer_rsrc(workBase + ZONE_WORK_FLOATS * zone, 0, (int)(ZONE_WORK_FLOATS * sizeof(float)), 0x00020000);
 
 #pragma unroll 1
@@ -408,7 +513,7 @@ k_erode_zones(const float* __restrict__ gatheredBase, size_t gatheredStride, con
                 store_phase(&st->slot[t & 1], ph);
                 if (ph.done) {                                       // both slots final: the finish kernels read slot[0]
                     store_phase(&st->slot[(t + 1) & 1], ph);
-                    atomicMax(maxPasses, ph.passes);
+                    atomicMax((int*)&words[EROSION_WORD_PASSES], ph.passes);
                     if (maxPassesAlso) __hip_atomic_fetch_max(maxPassesAlso, ph.passes, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);      // (may be host memory)
                 }
                 __hip_atomic_store(&st->changed[(t + 1) & 3], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -436,8 +541,8 @@ k_erode_zones(const float* __restrict__ gatheredBase, size_t gatheredStride, con
             __syncthreads();                                          // the centre's pieces have been read: the planes may be overwritten
             tile = next;
         }
-        // ---- barrier among the zone's workgroups.  Release: every wave waits for its own write-through stores, then the workgroup's barrier,
-        // then ONE lane publishes the mask (and waits for that too) and arrives.  The spin is bounded.
+        // ---- barrier among the zone's group.  Release: every wave waits for its own stores (they are in the XCD's L2 then), then the
+        // workgroup's barrier, then ONE lane publishes the mask (and waits for that too) and arrives.  The spin is bounded.
         MM_DRAIN_VMEM();
         __syncthreads();
         if (tid == 0) {
@@ -446,39 +551,14 @@ k_erode_zones(const float* __restrict__ gatheredBase, size_t gatheredStride, con
                 MM_DRAIN_VMEM();
             }
             __hip_atomic_fetch_add(&st->barrier, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const unsigned want = (unsigned)perZone * (unsigned)(t + 1);
-            const unsigned long long t0 = wall_clock64();
-            unsigned polls = 0u;
-#ifndef MM_POLL_MODE
-#define MM_POLL_MODE 0
-#endif
-#if MM_POLL_MODE == 1
-#define MM_POLL(p) __hip_atomic_fetch_add((p), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-#elif MM_POLL_MODE == 2
-#define MM_POLL(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
-#else
-#define MM_POLL(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-#endif
-            while (MM_POLL(&st->barrier) < want) {
-                __builtin_amdgcn_s_sleep(4);
-                if ((++polls & 63u) == 0u) {
-                    unsigned e = __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (e == 0u && (unsigned long long)(wall_clock64() - t0) > timeoutTicks) {
-                        e = 0x80000000u | ((unsigned)zone << 8) | ((unsigned)t & 255u);
-                        if (atomicCAS(err, 0u, e) == 0u) {
-                            if (errHost) __hip_atomic_store(errHost, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                            // what the workgroup that gave up saw (read by the host's report)
-                            err[1] = (unsigned)member; err[2] = MM_POLL(&st->barrier); err[3] = want; err[4] = polls;
-                            err[5] = (unsigned)((wall_clock64() - t0) >> 10);
-                        }
-                    }
-                    if (e != 0u) { s_abort = 1; break; }
-                }
-            }
+            if (!erosion_spin(&st->barrier, (unsigned)perZone * (unsigned)(t + 1), err, errHost, 0x80000000u | ((unsigned)zone << 8) | ((unsigned)t & 255u), timeoutTicks))
+                s_abort = 1;
         }
         __syncthreads();
         if (s_abort) return;
     }
+    __syncthreads();                                                  // (s_chunk, s_ph and s_zone are rewritten for the next zone)
+  }
 }
 
 // final planes back into the caller's gathered-layers buffer (in-place contract of Chunk::erodeZone) and the accumulated heights
@@ -511,7 +591,7 @@ __global__ void k_erode_init(ErosionState* states, int zones, unsigned* ticket, 
     states[zone].barrier = 0u;
     for (int k = 0; k < 3; ++k) states[zone].reserved[k] = 0u;
     if (zone == 0) {
-        for (int k = 0; k < 8; ++k) ticket[k] = 0u;
+        for (int k = 0; k < EROSION_LAUNCH_WORDS; ++k) ticket[k] = 0u;
         if (clearWord) *clearWord = 0;
     }
 }
@@ -585,7 +665,7 @@ namespace mmk {
 size_t erosion_work_bytes(int zones) { return (size_t)zones * ZONE_WORK_FLOATS * sizeof(float); }
 // the zones' states, then one more record's worth of words: [0] = the launch's ticket counter, [1] = largest pass count of the zones,
 // [2] = the launch's error word (0, or which zone's barrier gave up in which round)
-size_t erosion_state_bytes(int zones) { return (size_t)(zones + 1) * sizeof(mm::ErosionState); }
+size_t erosion_state_bytes(int zones) { return (size_t)zones * sizeof(mm::ErosionState) + sizeof(unsigned) * EROSION_LAUNCH_WORDS; }
 
 // workgroups of k_erode_zones the chip holds at once (LDS-bound: three per CU on gfx950), or `quarterCuCap` / 4 per CU if that is fewer
 static int erosion_resident_workgroups(int quarterCuCap)
@@ -658,31 +738,46 @@ int erode_zones(float* gathered, size_t strideFloats, int zones, float* work, mm
 {
     if (!gathered && !(rawLayers && rawHf && zoneChunkIdx && layersOut)) return (int)hipErrorInvalidValue;
     if (zones <= 0) return 0;
-    unsigned* ticket = (unsigned*)(states + zones);
-    int* passesWord = (int*)(ticket + 1);
-    unsigned* errWord = ticket + 2;
-    MMK_LAUNCH(KID_ERODE_INIT, mm::k_erode_init, dim3((zones + 63) / 64), dim3(64), s, states, zones, ticket, clearPassesDev ? maxPassesDev : (int*)nullptr);
-    // as many workgroups per zone as keep the whole launch resident (a zone's 144 tiles are shared out among them, the same in every round)
-    int perZone = erosion_resident_workgroups(workgroupsPer4Cu) / zones;
-    perZone = perZone < 1 ? 1 : (perZone > 144 ? 144 : perZone);
-    perZone = (144 + (144 + perZone - 1) / perZone - 1) / ((144 + perZone - 1) / perZone);      // fewest workgroups with the same tiles per round
+    unsigned* words = (unsigned*)(states + zones);        // the launch's words (EROSION_WORD_*)
+    int* passesWord = (int*)(words + EROSION_WORD_PASSES);
+    MMK_LAUNCH(KID_ERODE_INIT, mm::k_erode_init, dim3((zones + 63) / 64), dim3(64), s, states, zones, words, clearPassesDev ? maxPassesDev : (int*)nullptr);
+    // The launch is resident as a whole: at most what the chip holds (or the caller's cap), a multiple of the XCD count so that the
+    // dispatcher's round-robin gives every XCD the same share.  Groups: with few zones every XCD's workgroups form one group (all of them
+    // on one zone); with many, groups of 32 - measured on the 72-zone bench tile alone on the chip (96 workgroups per XCD): groups of 32 /
+    // 48 / 96 -> 1.65 / 1.87 / 2.77 ms, 2.1 / 2.3 / 2.0 GB of traffic; beside the caves an XCD has 32 workgroups anyway (16: 21.9 ms per
+    // step instead of 21.6).
+    const int cus = device_cus();
+    const int nXcd = cus >= 64 ? cus / 32 : 1;
+    int grid = erosion_resident_workgroups(workgroupsPer4Cu);
+    if (grid > nXcd) grid -= grid % nXcd;
+    const int perXcd = grid / nXcd > 0 ? grid / nXcd : 1;
+    int groupSize = perXcd;
+    if (zones > nXcd && perXcd >= 64) groupSize = 32;
+    {
+        static const int forced = [] { const char* e = getenv("MMGEN_EROSION_GROUP"); return e ? atoi(e) : 0; }();      // (experiments: workgroups per zone)
+        if (forced > 0 && forced <= perXcd) groupSize = forced;
+    }
+    if (groupSize > 144) groupSize = 144;
+    // (fewer zones than groups: the surplus groups find nothing to do; launching fewer workgroups than the XCDs' shares would only unbalance them)
+    const int groupWait = groupSize + g_debugMissing.load(std::memory_order_relaxed);      // (test hook: groups that can never become complete)
     if (beforeRelaxation) { hipError_t e = hipEventRecord(beforeRelaxation, s); if (e != hipSuccess) return (int)e; }
-    // the launch's ticket counts the workgroups that have STARTED (k_erode_init has just cleared it): a caller that wants them on the chip
+    // the launch counts the workgroups that have STARTED (k_erode_init has just cleared the word): a caller that wants them on the chip
     // before it launches something that takes every slot waits for the counter to reach the grid size (launch_caves)
-    int grid = zones * perZone - g_debugMissing.load(std::memory_order_relaxed);
-    if (grid < 1) grid = 1;
-    if (startedCounter) *startedCounter = ticket;
+    if (startedCounter) *startedCounter = words + EROSION_WORD_REGISTERED;
     if (startedTarget) *startedTarget = (unsigned)grid;
+    unsigned* errWord = words + EROSION_WORD_ERR;
+    (void)errWord;
     {
         std::lock_guard<std::mutex> lk(g_chainMu);
         hipEvent_t chain = nullptr;
         int ce = chain_before_launch(s, &chain);
         if (ce) return ce;
         MMK_LAUNCH(KID_ERODE_PASS, mm::k_erode_zones, dim3(grid), dim3(EROSION_THREADS), s, (const float*)gathered, strideFloats, rawLayers, rawHf,
-                   zoneChunkIdx, work, states, ticket, perZone, passesWord, maxPassesDev, errWord, errHost, erosion_timeout_ticks());
+                   zoneChunkIdx, work, states, words, zones, groupSize, groupWait, maxPassesDev, errHost, erosion_timeout_ticks());
         hipError_t re = hipEventRecord(chain, s);
         if (re != hipSuccess) return (int)re;
     }
+    const int perZone = groupSize;
     if (layersOut) {
         // region path: no in-place contract to honour, the kept chunks' planes go straight to the layers
         MMK_LAUNCH(KID_EROSION_SCATTER, mm::k_erode_finish, dim3(144, zones), dim3(256), s, (const float*)work, (const mm::ErosionState*)states, 0,
@@ -699,14 +794,14 @@ int erode_zones(float* gathered, size_t strideFloats, int zones, float* work, mm
         if (e != hipSuccess) return (int)e;
         *maxPasses = words[0];
         if (words[1] != 0) {
-            fprintf(stderr, "mmgen: the erosion relaxation gave up waiting (zone %d of the launch, round %d; %d zones x %d workgroups)\n",
+            fprintf(stderr, "mmgen: the erosion relaxation gave up waiting (zone %d of the launch - 8388607 = the registration -, round %d; %d zones, groups of %d workgroups)\n",
                     (int)(((unsigned)words[1] >> 8) & 0x7FFFFFu), words[1] & 255, zones, perZone);
             // what the zones looked like when the launch ended: started workgroups, and per zone the arrivals and the phase it was in
             std::vector<mm::ErosionState> h((size_t)zones + 1);
             if (hipMemcpy(h.data(), states, sizeof(mm::ErosionState) * h.size(), hipMemcpyDeviceToHost) == hipSuccess) {
                 const unsigned* tail = (const unsigned*)&h[zones];
-                fprintf(stderr, "mmgen:   workgroups started: %u of %d; gave up: member %u saw %u arrivals of %u after %u polls, %u x 10.24 us\n", tail[0], grid, tail[3],
-                        tail[4], tail[5], tail[6], tail[7]);
+                fprintf(stderr, "mmgen:   workgroups started: %u of %d; gave up at %u arrivals of %u after %u polls, %u x 10.24 us; per XCD: %u %u %u %u %u %u %u %u\n",
+                        tail[0], grid, tail[4], tail[5], tail[6], tail[7], tail[8], tail[9], tail[10], tail[11], tail[12], tail[13], tail[14], tail[15]);
                 for (int z = 0; z < zones && z < 16; ++z)
                     fprintf(stderr, "mmgen:   zone %d: arrivals %u, layer %d, first %d, done %d, passes %d\n", z, h[z].barrier, h[z].slot[0].layer, h[z].slot[0].isFirst,
                             h[z].slot[0].done, h[z].slot[0].passes);
