@@ -748,7 +748,8 @@ int erode_zones(float* gathered, size_t strideFloats, int zones, float* work, mm
     // step instead of 21.6).
     const int cus = device_cus();
     const int nXcd = cus >= 64 ? cus / 32 : 1;
-    int grid = erosion_resident_workgroups(workgroupsPer4Cu);
+    static const int forcedCap = [] { const char* e = getenv("MMGEN_EROSION_WG_PER_4CU"); return e ? atoi(e) : 0; }();      // (measurements: the DAG's share of the chip in a serial run)
+    int grid = erosion_resident_workgroups(forcedCap > 0 ? forcedCap : workgroupsPer4Cu);
     if (grid > nXcd) grid -= grid % nXcd;
     const int perXcd = grid / nXcd > 0 ? grid / nXcd : 1;
     int groupSize = perXcd;
