@@ -23,7 +23,7 @@ int launch_fill(const float* hf, const float* bw, const float* layers, const mmg
                 unsigned* lushQueue /*nullable device scratch: deferred clay / moss voxels*/, size_t lushQueueBytes, bool allInPruneDomain /* every chunk within MM_PRUNE_DOMAIN blocks of the origin: k_fill_far is not launched */, hipStream_t s,
                 bool countersCleared = false /* launch_fill_clear already ran on this scratch */,
                 // out (nullable): a device word that counts k_fill_cave's persistent workgroups as they start, and the value it reaches
-                const unsigned** startedCounter = nullptr, unsigned* startedTarget = nullptr);
+                const unsigned** startedCounter = nullptr, unsigned* startedTarget = nullptr, hipEvent_t beforeCave = nullptr);
 // one lane waits (bounded: ~3 ms) until *counter >= target: orders a launch behind the START of a persistent one on another stream
 int launch_wait_counter(const unsigned* counter, unsigned target, hipStream_t s);
 int launch_fill_clear(int n, unsigned* lushQueue, size_t lushQueueBytes, hipStream_t s);

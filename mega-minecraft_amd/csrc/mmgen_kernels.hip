@@ -185,12 +185,22 @@ __global__ void __launch_bounds__(256) k_fix_backward(float* __restrict__ layers
 //                    reachable 8x8x7 cell box staged in LDS; solid/air bits → LDS bit words → popcount ranks → (start,end) runs
 //   k_cave_biomes  : the occupied layer slots' (bottom, top) cave-biome evaluations, streamed by persistent waves 64 at a time
 // =========================================================================================================
+#ifndef MM_WAIT_RMW
+#define MM_WAIT_RMW 0
+#endif
+#ifndef MM_WAIT_SLACK
+#define MM_WAIT_SLACK 0u
+#endif
 // one wave, one lane working: returns when *counter >= target or after ~3 ms (the wait is an optimisation, never a condition)
 __global__ void __launch_bounds__(64) k_wait_counter(const unsigned* counter, unsigned target)
 {
     if (threadIdx.x != 0) return;
     for (int i = 0; i < 4096; ++i) {
-        if (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) return;
+#if MM_WAIT_RMW
+        if (__hip_atomic_fetch_or(const_cast<unsigned*>(counter), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + MM_WAIT_SLACK >= target) return;
+#else
+        if (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + MM_WAIT_SLACK >= target) return;
+#endif
         __builtin_amdgcn_s_sleep(32);
     }
 }
@@ -1579,7 +1589,7 @@ void debug_set_lush_queue_cap(int entries) { g_lushCapOverride.store(entries > 0
 
 int launch_fill(const float* hf, const float* bw, const float* layers, const mmgen_cave_layer* caveLayers, const int32_t* pos, int n,
                 uint8_t* blocks, const int* srcIdx, unsigned* scratch, size_t scratchBytes, bool allInPruneDomain, hipStream_t s, bool countersCleared,
-                const unsigned** startedCounter, unsigned* startedTarget)
+                const unsigned** startedCounter, unsigned* startedTarget, hipEvent_t beforeCave)
 {
     if (startedCounter) *startedCounter = nullptr;
     if (startedTarget) *startedTarget = 0u;
@@ -1611,6 +1621,7 @@ int launch_fill(const float* hf, const float* bw, const float* layers, const mmg
             // a row lists ~28 batches; enough ranges for every wave to draw a few (a 256-chunk call would otherwise hand 2 ranges to each)
             const long long perWave = 28LL * nRows / ((long long)cus * 4 * MM_FILL_WAVES * 6);
             const int range = perWave < 1 ? 1 : (perWave > FILL_RANGE ? FILL_RANGE : (int)perWave);
+            if (beforeCave && b0 == 0 && c0 == 0) { e = hipStreamWaitEvent(s, beforeCave, 0); if (e != hipSuccess) return (int)e; }
             LAUNCH(KID_FILL_SCAN, mm::k_fill_scan, dim3((nRows + 1023) / 1024), dim3(1024), s, (const int*)f.counts, nRows, range, f.batchStart, f.rangeRow);
             // persistent: MM_FILL_WAVES waves per SIMD
             const unsigned cgrid = (unsigned)(cus * (4 * MM_FILL_WAVES / (FILLC_THREADS / 64)));

@@ -265,7 +265,7 @@ struct mmgen_region {
     int wantSlices = 0;           // 0 = automatic
     hipStream_t sErode = nullptr, sFill = nullptr, sApply = nullptr;
     static constexpr int kMaxSlices = 16;
-    hipEvent_t evK2 = nullptr, evResident = nullptr, evCaveVoxels = nullptr, evBegin = nullptr, evErosion = nullptr, evGather = nullptr, evTail = nullptr, evFill[kMaxSlices] = {}, evEntry = nullptr;
+    hipEvent_t evK2 = nullptr, evResident = nullptr, evCaveVoxels = nullptr, evBegin = nullptr, evErosion = nullptr, evGather = nullptr, evF1 = nullptr, evTail = nullptr, evFill[kMaxSlices] = {}, evEntry = nullptr;
     int nSlices = 1;
     int sliceRow[kMaxSlices + 1] = {};        // rows of R per slice: [sliceRow[i], sliceRow[i + 1])
     int init_streams()
@@ -276,16 +276,21 @@ struct mmgen_region {
         // priority only helps its short tail kernels (finish, fix-up) to a free slot beside the caves
         int prLeast = 0, prGreatest = 0;
         if ((e = hipDeviceGetStreamPriorityRange(&prLeast, &prGreatest)) != hipSuccess) return (int)e;
-        if ((e = hipStreamCreateWithPriority(&sErode, hipStreamNonBlocking, prGreatest)) != hipSuccess) return (int)e;
-#ifndef MM_FILL_STREAM_HIGH
-#define MM_FILL_STREAM_HIGH 1
+#ifndef MM_ERODE_STREAM_HIGH
+#define MM_ERODE_STREAM_HIGH 1
 #endif
-        // the fill and the rasterisers are the step's critical path behind the caves; what runs beside them on the caller's stream (cave
-        // biomes, placements, the gather) is not: their queue goes first whenever a slot frees up
-        const int prFill = MM_FILL_STREAM_HIGH ? prGreatest : prLeast;
+        if ((e = hipStreamCreateWithPriority(&sErode, hipStreamNonBlocking, MM_ERODE_STREAM_HIGH ? prGreatest : 0)) != hipSuccess) return (int)e;
+#ifndef MM_FILL_STREAM_HIGH
+#define MM_FILL_STREAM_HIGH 2
+#endif
+        // the fill and the rasterisers at NORMAL priority.  At the highest (tried in round 5: they are the step's critical path behind the
+        // caves) a Python host sees no difference, but a host that enqueues many steps ahead (mmgen_tiled_demo) loses 0.8 ms per step: every
+        // hand-over between the caller's queue and a high-priority one then costs 0.05 - 0.16 ms instead of 0.01 - 0.02
+        // (profiles/LOG.md, r05z C++ host)
+        const int prFill = MM_FILL_STREAM_HIGH == 1 ? prGreatest : MM_FILL_STREAM_HIGH == 2 ? 0 /*normal*/ : prLeast;
         if ((e = hipStreamCreateWithPriority(&sFill, hipStreamNonBlocking, prFill)) != hipSuccess) return (int)e;
         if ((e = hipStreamCreateWithPriority(&sApply, hipStreamNonBlocking, prFill)) != hipSuccess) return (int)e;
-        hipEvent_t* ev[] = {&evK2, &evResident, &evCaveVoxels, &evBegin, &evErosion, &evGather, &evTail, &evEntry};
+        hipEvent_t* ev[] = {&evK2, &evResident, &evCaveVoxels, &evBegin, &evErosion, &evGather, &evF1, &evTail, &evEntry};
         for (hipEvent_t* x : ev) if ((e = hipEventCreateWithFlags(x, hipEventDisableTiming)) != hipSuccess) return (int)e;
         for (int i = 0; i < kMaxSlices; ++i)
             if ((e = hipEventCreateWithFlags(&evFill[i], hipEventDisableTiming)) != hipSuccess) return (int)e;
@@ -299,7 +304,7 @@ struct mmgen_region {
         if (sErode) {
             (void)hipStreamSynchronize(sErode); (void)hipStreamSynchronize(sFill); (void)hipStreamSynchronize(sApply);
             (void)hipStreamDestroy(sErode); (void)hipStreamDestroy(sFill); (void)hipStreamDestroy(sApply);
-            hipEvent_t ev[] = {evK2, evResident, evCaveVoxels, evBegin, evErosion, evGather, evTail, evEntry};
+            hipEvent_t ev[] = {evK2, evResident, evCaveVoxels, evBegin, evErosion, evGather, evF1, evTail, evEntry};
             for (hipEvent_t x : ev) if (x) (void)hipEventDestroy(x);
             for (int i = 0; i < kMaxSlices; ++i) if (evFill[i]) (void)hipEventDestroy(evFill[i]);
         }
@@ -558,6 +563,9 @@ int mmgen_region_max_cave_placements(mmgen_region* r, int* out_max, void* stream
 }
 
 static int region_fill_on(mmgen_region* r, uint8_t* d_blocks, hipEvent_t after0, hipEvent_t after1, hipEvent_t after2);
+#ifndef MM_FILL_CAVE_AFTER_F1
+#define MM_FILL_CAVE_AFTER_F1 1
+#endif
 // with the base fill starting the moment the caves' extents exist, the cave biomes (which only the placement stages wait for) leave it
 // most of every CU: persistent workgroups per CU of k_cave_biomes then
 // Workgroups of the relaxation per four CUs when it runs beside the caves (46.7 KB of LDS, 8 waves each): ONE per CU.  It waits more than it
@@ -697,10 +705,6 @@ int mmgen_region_begin(mmgen_region* r, int cx0, int cz0, int nx, int nz, unsign
     }
     if (erosion && par) { CK(hipEventRecord(r->evErosion, sE)); CK(hipStreamWaitEvent(s, r->evErosion, 0)); }
     r->began = true;
-    // ---- the base fill as soon as its inputs exist (the caves' extents, the eroded layers), beside the cave biomes and the placement
-    // stages that only the rasterisers wait for (mmgen_region_set_output)
-    if (par && early) CK(region_fill_on(r, early, /*after*/ r->evBegin, r->evCaveVoxels, erosion ? r->evErosion : nullptr));
-
     // ---- F1 placements (eroded layers + cave layers of every computed cell)
     if (features) {
         mmk::StageRange sr("mmgen:feature_placements");
@@ -708,7 +712,12 @@ int mmgen_region_begin(mmgen_region* r, int cx0, int cz0, int nx, int nz, unsign
         if (r->nCompute < np) CK(hipMemsetAsync(r->counts.p, 0, sizeof(int) * 2 * np, s));
         CK(mmk::launch_feature_placements(hfP, bwP, layersP, r->caveP.as<mmgen_cave_layer>(), posP, r->nCompute, r->fp.as<mmgen_feature_placement>(),
                                           r->cfp.as<mmgen_cave_feature_placement>(), r->counts.as<int>(), list, colNeed, s));
+        if (par) CK(hipEventRecord(r->evF1, s));
     }
+    // ---- the base fill as soon as its inputs exist (the caves' extents, the eroded layers), beside the cave biomes and the placement
+    // stages that only the rasterisers wait for (mmgen_region_set_output).  Enqueued after F1 so that its cave part can wait for F1's end
+    // (region_fill_on)
+    if (par && early) CK(region_fill_on(r, early, /*after*/ r->evBegin, r->evCaveVoxels, erosion ? r->evErosion : nullptr));
     return 0;
 }
 
@@ -760,11 +769,17 @@ static int region_fill_on(mmgen_region* r, uint8_t* d_blocks, hipEvent_t after0,
         CK(mmk::launch_fill_clear((r->sliceRow[i + 1] - r->sliceRow[i]) * r->nx, (unsigned*)((char*)r->fillQueue.p + qb * i), qb, sF));
     hipEvent_t after[3] = {after0, after1, after2};
     for (hipEvent_t e : after) if (e) CK(hipStreamWaitEvent(sF, e, 0));
+    // The cave fill's persistent workgroups (six per CU, 26.3 KB of LDS each) must find the chip EMPTY: started while workgroups of
+    // k_feature_placements or k_cave_biomes are resident, the sixth one of many CUs has no contiguous LDS left and starts only when a
+    // neighbour exits - k_fill_cave then takes 6.1 ms instead of 5.4 and F1 beside it 2.1 ms instead of 1.0 (profiles/LOG.md, r05z C++
+    // host trace).  So the scan + cave part waits for F1's end; k_fill_base still runs beside F1.
+    const bool features = r->flags & MMGEN_REGION_FEATURES;
+    hipEvent_t beforeCave = (features && MM_FILL_CAVE_AFTER_F1) ? r->evF1 : nullptr;
     for (int i = 0; i < r->nSlices; ++i) {
         const int c0 = r->sliceRow[i] * r->nx, n = (r->sliceRow[i + 1] - r->sliceRow[i]) * r->nx;
         CK(mmk::launch_fill(hfP, bwP, layersP, r->caveP.as<mmgen_cave_layer>(), posP, n, d_blocks + (size_t)MMGEN_BLOCKS_PER_CHUNK * c0, r->targets.as<int>() + c0,
                             (unsigned*)((char*)r->fillQueue.p + qb * i), qb, region_in_prune_domain(r), sF, true,
-                            r->nSlices == 1 ? &r->fillStarted : nullptr, r->nSlices == 1 ? &r->fillStartedTarget : nullptr));
+                            r->nSlices == 1 ? &r->fillStarted : nullptr, r->nSlices == 1 ? &r->fillStartedTarget : nullptr, beforeCave));
         CK(hipEventRecord(r->evFill[i], sF));
     }
     r->filled = true; r->filledInto = d_blocks;
