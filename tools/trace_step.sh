@@ -7,5 +7,7 @@ cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --output-format csv -d $out/${tag}_trace -- python3 $root/bench.py --steps 3 --warmup 1 --cpu-side 0 --no-kernel-events --no-cpp-host --no-streaming "$@" > $out/${tag}_trace.log 2>&1
 # (--no-cpp-host: bench.py would otherwise run mmgen_tiled_demo as a child, which the profiler traces too; the largest trace is the bench's own)
 f=$(ls -S $out/${tag}_trace/*/*kernel_trace.csv | head -1)
-python3 $root/tools/trace_overlap.py $f $n > $out/${tag}_trace.txt
+# one steady-state step (between two k_heightfield launches; the checksum kernels behind the last step are torch's and not shown)
+python3 $root/tools/trace_one_step.py $f 2 > $out/${tag}_trace.txt
+python3 $root/tools/trace_overlap.py $f $n | tail -2 >> $out/${tag}_trace.txt
 cat $out/${tag}_trace.txt
