@@ -44,6 +44,48 @@ struct DevBuf {
     template <class T> T* as() const { return (T*)p; }
 };
 
+// Host side of the layout's index tables: two pinned slots used alternately.  A layout's tables are written into one slot and copied
+// from there by asynchronous copies on the caller's stream; the slot is not written again before the event behind those copies has
+// fired (two layouts later: long over).  From pageable vectors every copy staged through the runtime and the call ended with a stream
+// synchronisation - per tick of a streaming host (a new strip every tick) that was a tenth of the step.
+struct HostStage {
+    char* slot[2] = {nullptr, nullptr};
+    size_t cap = 0, used = 0;
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    int cur = 0;
+    int begin(size_t bytes)                       // picks the other slot, waits until its last copies are over, makes room
+    {
+        cur ^= 1;
+        hipError_t e;
+        if (!ev[0]) for (int i = 0; i < 2; ++i) if ((e = hipEventCreateWithFlags(&ev[i], hipEventDisableTiming)) != hipSuccess) return (int)e;
+        if ((e = hipEventSynchronize(ev[cur])) != hipSuccess) return (int)e;
+        if (bytes > cap) {
+            if ((e = hipEventSynchronize(ev[cur ^ 1])) != hipSuccess) return (int)e;
+            for (int i = 0; i < 2; ++i) { if (slot[i]) (void)hipHostFree(slot[i]); slot[i] = nullptr; }
+            cap = bytes + bytes / 4;
+            for (int i = 0; i < 2; ++i) if ((e = hipHostMalloc((void**)&slot[i], cap, hipHostMallocDefault)) != hipSuccess) { cap = 0; return (int)e; }
+        }
+        used = 0;
+        return 0;
+    }
+    static size_t padded(size_t bytes) { return (bytes + 255) / 256 * 256; }
+    int upload(DevBuf& dst, const void* src, size_t bytes, hipStream_t s)
+    {
+        if (!bytes) return 0;
+        if (used + padded(bytes) > cap) return (int)hipErrorInvalidValue;
+        char* h = slot[cur] + used;
+        used += padded(bytes);
+        std::memcpy(h, src, bytes);
+        return (int)hipMemcpyAsync(dst.p, h, bytes, hipMemcpyHostToDevice, s);
+    }
+    int end(hipStream_t s) { return (int)hipEventRecord(ev[cur], s); }
+    void release()
+    {
+        for (int i = 0; i < 2; ++i) { if (ev[i]) { (void)hipEventSynchronize(ev[i]); (void)hipEventDestroy(ev[i]); ev[i] = nullptr; } if (slot[i]) (void)hipHostFree(slot[i]); slot[i] = nullptr; }
+        cap = 0;
+    }
+};
+
 inline int floordiv(int a, int b) { int q = a / b; return (a % b != 0 && ((a < 0) != (b < 0))) ? q - 1 : q; }
 
 // placement lists of whole cells from one placement grid (region buffers or a caller-owned cache) to another
@@ -245,6 +287,7 @@ struct mmgen_region {
     long long zoneStamp = 0;
     int nHitZones = 0, nMissZones = 0;
     long long zoneHits = 0, zoneMisses = 0;             // since the cache was (re)sized
+    HostStage stage;                                    // pinned host side of the layout's tables
     DevBuf hitSlots, hitIdxOut, missSlots;              // device: [nHit] slot, [nHit][144] P index or -1; [nMiss] slot or -1
     const unsigned* fillStarted = nullptr;      // started-workgroups word of the early fill's k_fill_cave (one slice) and the value it reaches
     unsigned fillStartedTarget = 0u;
@@ -298,6 +341,7 @@ struct mmgen_region {
     }
     ~mmgen_region()
     {
+        stage.release();
         if (hostMax) (void)hipHostFree(hostMax);
         if (evPasses) (void)hipEventDestroy(evPasses);
         devMax.release();
@@ -513,31 +557,38 @@ static int region_layout(mmgen_region* r, int cx0, int cz0, int nx, int nz, unsi
     CK(r->posA.ensure(sizeof(int32_t) * 2 * na));
     CK(r->computeList.ensure(sizeof(int) * np));
     CK(r->targets.ensure(sizeof(int) * nr));
-    CK(hipMemcpyAsync(r->posA.p, posA.data(), sizeof(int32_t) * 2 * na, hipMemcpyHostToDevice, s));
-    CK(hipMemcpyAsync(r->computeList.p, computeList.data(), sizeof(int) * r->nCompute, hipMemcpyHostToDevice, s));
-    CK(hipMemcpyAsync(r->targets.p, targets.data(), sizeof(int) * nr, hipMemcpyHostToDevice, s));
+    {
+        using HS = HostStage;
+        const size_t total = HS::padded(sizeof(int32_t) * 2 * na) + HS::padded(sizeof(int) * r->nCompute) + HS::padded(sizeof(int) * nr) + HS::padded(np) +
+                             HS::padded(sizeof(int) * zi.size()) + HS::padded(sizeof(int) * zo.size()) + HS::padded(sizeof(int) * hitSlot.size()) +
+                             HS::padded(sizeof(int) * ho.size()) + HS::padded(sizeof(int) * missSlot.size());
+        CK(r->stage.begin(total));
+    }
+    CK(r->stage.upload(r->posA, posA.data(), sizeof(int32_t) * 2 * na, s));
+    CK(r->stage.upload(r->computeList, computeList.data(), sizeof(int) * r->nCompute, s));
+    CK(r->stage.upload(r->targets, targets.data(), sizeof(int) * nr, s));
     if (r->nLazy) {
         CK(r->cellLazy.ensure(np));
         CK(r->colNeed.ensure((size_t)256 * np));
-        CK(hipMemcpyAsync(r->cellLazy.p, lazy.data(), np, hipMemcpyHostToDevice, s));
+        CK(r->stage.upload(r->cellLazy, lazy.data(), np, s));
     }
     if (Z) {
         CK(r->zoneIdx.ensure(sizeof(int) * zi.size()));
         CK(r->zoneIdxOut.ensure(sizeof(int) * zo.size()));
-        CK(hipMemcpyAsync(r->zoneIdx.p, zi.data(), sizeof(int) * zi.size(), hipMemcpyHostToDevice, s));
-        CK(hipMemcpyAsync(r->zoneIdxOut.p, zo.data(), sizeof(int) * zo.size(), hipMemcpyHostToDevice, s));
+        CK(r->stage.upload(r->zoneIdx, zi.data(), sizeof(int) * zi.size(), s));
+        CK(r->stage.upload(r->zoneIdxOut, zo.data(), sizeof(int) * zo.size(), s));
     }
     if (r->nHitZones) {
         CK(r->hitSlots.ensure(sizeof(int) * hitSlot.size()));
         CK(r->hitIdxOut.ensure(sizeof(int) * ho.size()));
-        CK(hipMemcpyAsync(r->hitSlots.p, hitSlot.data(), sizeof(int) * hitSlot.size(), hipMemcpyHostToDevice, s));
-        CK(hipMemcpyAsync(r->hitIdxOut.p, ho.data(), sizeof(int) * ho.size(), hipMemcpyHostToDevice, s));
+        CK(r->stage.upload(r->hitSlots, hitSlot.data(), sizeof(int) * hitSlot.size(), s));
+        CK(r->stage.upload(r->hitIdxOut, ho.data(), sizeof(int) * ho.size(), s));
     }
     if (zoneCaching && Z) {
         CK(r->missSlots.ensure(sizeof(int) * missSlot.size()));
-        CK(hipMemcpyAsync(r->missSlots.p, missSlot.data(), sizeof(int) * missSlot.size(), hipMemcpyHostToDevice, s));
+        CK(r->stage.upload(r->missSlots, missSlot.data(), sizeof(int) * missSlot.size(), s));
     }
-    CK(hipStreamSynchronize(s));     // host vectors go out of scope
+    CK(r->stage.end(s));             // (no synchronisation: the host side of the tables is the pinned slot, not these vectors)
 
     r->kcx0 = cx0; r->kcz0 = cz0; r->knx = nx; r->knz = nz; r->kflags = flags; r->kHasMask = h_local_mask != nullptr;
     if (h_local_mask) r->kMask.assign(h_local_mask, h_local_mask + maskBytes); else r->kMask.clear();
@@ -564,19 +615,19 @@ int mmgen_region_max_cave_placements(mmgen_region* r, int* out_max, void* stream
 
 static int region_fill_on(mmgen_region* r, uint8_t* d_blocks, hipEvent_t after0, hipEvent_t after1, hipEvent_t after2);
 #ifndef MM_FILL_CAVE_AFTER_F1
-#define MM_FILL_CAVE_AFTER_F1 1
+#define MM_FILL_CAVE_AFTER_F1 1      // the scan + cave part of the fill waits for the placement pass to leave the chip (region_fill_on)
 #endif
-// with the base fill starting the moment the caves' extents exist, the cave biomes (which only the placement stages wait for) leave it
-// most of every CU: persistent workgroups per CU of k_cave_biomes then
 // Workgroups of the relaxation per four CUs when it runs beside the caves (46.7 KB of LDS, 8 waves each): ONE per CU.  It waits more than it
-// issues (4.5 ms alone at one per CU, 2.2 at two, 1.7 at three), the caves take the rest of every CU (four of their workgroups fit beside
-// one of these, two beside two, none beside three), and what the relaxation costs the caves is its occupancy-time, which is smallest
-// here: with every workgroup of it on the chip before the caves start (launch_caves' counter watch) 3 / 4 / 5 / 6 per four CUs give
-// 24.18 / 24.11 / 24.17 / 24.45 ms per step (profiles/README.md r04)
+// issues (3.2 ms at one per CU, 1.7 alone on the chip), the caves take the rest of every CU (four of their workgroups fit beside one of
+// these, two beside two, none beside three), and what the relaxation costs the caves is its occupancy-time, which is smallest here: with
+// every workgroup of it on the chip before the caves start (launch_caves' counter watch) 2 / 3 / 4 / 6 / 8 / 12 per four CUs give
+// 21.56 / 21.60 / 21.65 and (another box) 4 / 6 / 8 / 12 -> 21.28 / 21.46 / 21.64 / 21.96 ms per step (profiles/LOG.md, round 5)
 #ifndef MMGEN_REGION_EROSION_WG_PER_4CU
 #define MMGEN_REGION_EROSION_WG_PER_4CU 4
 #endif
-static constexpr int kCaveBiomeWorkgroupsBesideFill = 1;      // (1 / 2 / 3 / 6 per CU: 24.60 / 24.73 / 24.77 / 24.81 ms per step, profiles/README.md r04)
+// with the base fill starting the moment the caves' extents exist, the cave biomes (which only the placement stages wait for) leave it
+// most of every CU: persistent workgroups per CU of k_cave_biomes then (1 / 2 / 3 / 6: 24.60 / 24.73 / 24.77 / 24.81 ms per step, LOG round 4)
+static constexpr int kCaveBiomeWorkgroupsBesideFill = 1;
 
 int mmgen_region_max_gathered(mmgen_region* r, int* out_surface, int* out_cave, void* stream)
 {

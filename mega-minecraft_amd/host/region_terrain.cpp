@@ -68,10 +68,29 @@ void RegionTerrain::generateRect(int cx0, int cz0, int nx, int nz)
 {
     const size_t n = (size_t)nx * nz;
     if (freeSlots.size() < n) HipUtils::checkError("RegionTerrain: chunk pool exhausted (raise poolChunks or lower dropRadius)", 2, __LINE__);
+    // n consecutive free slots if the pool has such a run anywhere (lowest first; the list is sorted descending, so a run of ascending
+    // slots is a stretch of the vector read backwards): the region then writes its blocks straight into the pool.  Only a pool without
+    // one is served from the lowest free slots through the staging buffer (one device copy per run of consecutive slots below).
     std::vector<int> slots(n);
-    for (size_t i = 0; i < n; ++i) { slots[i] = freeSlots.back(); freeSlots.pop_back(); }
-    bool contiguous = true;
-    for (size_t i = 1; i < n && contiguous; ++i) contiguous = slots[i] == slots[i - 1] + 1;
+    bool contiguous = false;
+    {
+        const size_t m = freeSlots.size();
+        size_t run = 1, endAt = m;                     // freeSlots[endAt - 1 .. endAt - 1 + n) is the run, lowest slot at the highest index
+        for (size_t i = m; i-- > 0;) {
+            run = (i + 1 < m && freeSlots[i] == freeSlots[i + 1] + 1) ? run + 1 : 1;
+            if (run == n) { endAt = i + 1; break; }
+        }
+        if (endAt != m || n == 1) {
+            const size_t lo = (n == 1) ? m - 1 : endAt - 1;
+            for (size_t i = 0; i < n; ++i) slots[i] = freeSlots[lo + n - 1 - i];
+            freeSlots.erase(freeSlots.begin() + lo, freeSlots.begin() + lo + n);
+            contiguous = true;
+        } else {
+            for (size_t i = 0; i < n; ++i) { slots[i] = freeSlots.back(); freeSlots.pop_back(); }
+            contiguous = true;
+            for (size_t i = 1; i < n && contiguous; ++i) contiguous = slots[i] == slots[i - 1] + 1;
+        }
+    }
     uint8_t* dst = d_pool + (size_t)slots[0] * devBlocksSize;
     if (!contiguous) {
         if (stageChunks < n) {
@@ -109,16 +128,15 @@ void RegionTerrain::generateRect(int cx0, int cz0, int nx, int nz)
         RT_CALL(mmgen_region_placement_buffers(region, &gfp, &gcfp, &gcnt, &gx0, &gz0, &w, &h), "mmgen_region_placement_buffers failed");
         const size_t ni = impSrc.size(), ne = expSrc.size();
         int32_t* wk = (int32_t*)ensure(d_idxWork, idxWorkCap, (2 * ni + 2 * ne + 4) * sizeof(int32_t));
-        if (ni) {
-            RT_CALL(hipMemcpy(wk, impSrc.data(), ni * 4, hipMemcpyHostToDevice), "H2D failed");
-            RT_CALL(hipMemcpy(wk + ni, impDst.data(), ni * 4, hipMemcpyHostToDevice), "H2D failed");
-            RT_CALL(mmgen_copy_placements(d_cacheFp, d_cacheCfp, d_cacheCnt, wk, gfp, gcfp, gcnt, wk + ni, (int)ni, nullptr), "mmgen_copy_placements failed");
+        if (ni + ne) {                                          // the four index lists in one copy
+            std::vector<int32_t> lists;
+            lists.reserve(2 * (ni + ne));
+            lists.insert(lists.end(), impSrc.begin(), impSrc.end()); lists.insert(lists.end(), impDst.begin(), impDst.end());
+            lists.insert(lists.end(), expSrc.begin(), expSrc.end()); lists.insert(lists.end(), expDst.begin(), expDst.end());
+            RT_CALL(hipMemcpy(wk, lists.data(), lists.size() * 4, hipMemcpyHostToDevice), "H2D failed");
         }
-        if (ne) {
-            RT_CALL(hipMemcpy(wk + 2 * ni, expSrc.data(), ne * 4, hipMemcpyHostToDevice), "H2D failed");
-            RT_CALL(hipMemcpy(wk + 2 * ni + ne, expDst.data(), ne * 4, hipMemcpyHostToDevice), "H2D failed");
-            RT_CALL(mmgen_copy_placements(gfp, gcfp, gcnt, wk + 2 * ni, d_cacheFp, d_cacheCfp, d_cacheCnt, wk + 2 * ni + ne, (int)ne, nullptr), "mmgen_copy_placements failed");
-        }
+        if (ni) RT_CALL(mmgen_copy_placements(d_cacheFp, d_cacheCfp, d_cacheCnt, wk, gfp, gcfp, gcnt, wk + ni, (int)ni, nullptr), "mmgen_copy_placements failed");
+        if (ne) RT_CALL(mmgen_copy_placements(gfp, gcfp, gcnt, wk + 2 * ni, d_cacheFp, d_cacheCfp, d_cacheCnt, wk + 2 * ni + ne, (int)ne, nullptr), "mmgen_copy_placements failed");
         RT_CALL(mmgen_region_finish(region, dst, nullptr, nullptr, nullptr, nullptr), "mmgen_region_finish failed");
     }
     if (!contiguous)
@@ -240,15 +258,16 @@ void RegionTerrain::meshReady()
     const size_t oIdx = 0, oNb = oIdx + (size_t)n * 4, oPos = oNb + (size_t)n * 16, oCol = oPos + (size_t)n * 8, oCnt = oCol + (size_t)n * 1024,
                  oOff = (oCnt + (size_t)n * 4 + 7) / 8 * 8, total = oOff + (size_t)n * 8;
     char* w = (char*)ensure(d_meshWork, meshWorkCap, total);
-    std::vector<int32_t> hIdx(n), hNb((size_t)n * 4), hPos((size_t)n * 2);
+    // the three input arrays are adjacent in the work area: one copy (a blocking copy from pageable memory is 20 - 30 us of a 1.5 ms tick)
+    std::vector<int32_t> hIn((size_t)n * 7);
+    int32_t *hIdx = hIn.data(), *hNb = hIdx + n, *hPos = hNb + (size_t)n * 4;
     for (int i = 0; i < n; ++i) {
         hIdx[i] = meta[7 * i];
         for (int k = 0; k < 4; ++k) hNb[4 * i + k] = meta[7 * i + 1 + k];
         hPos[2 * i] = meta[7 * i + 5]; hPos[2 * i + 1] = meta[7 * i + 6];
     }
-    RT_CALL(hipMemcpy(w + oIdx, hIdx.data(), (size_t)n * 4, hipMemcpyHostToDevice), "H2D failed");
-    RT_CALL(hipMemcpy(w + oNb, hNb.data(), (size_t)n * 16, hipMemcpyHostToDevice), "H2D failed");
-    RT_CALL(hipMemcpy(w + oPos, hPos.data(), (size_t)n * 8, hipMemcpyHostToDevice), "H2D failed");
+    static_assert(sizeof(int32_t) == 4, "layout of the work area");
+    RT_CALL(hipMemcpy(w + oIdx, hIn.data(), (size_t)n * 28, hipMemcpyHostToDevice), "H2D failed");
     RT_CALL(mmgen_mesh_count(d_pool, (int32_t*)(w + oIdx), (int32_t*)(w + oNb), n, (uint32_t*)(w + oCol), (uint32_t*)(w + oCnt), nullptr), "mmgen_mesh_count failed");
     std::vector<uint32_t> cnt(n);
     RT_CALL(hipMemcpy(cnt.data(), w + oCnt, (size_t)n * 4, hipMemcpyDeviceToHost), "D2H failed");
