@@ -171,6 +171,28 @@ def test_mesh_matches_oracle_on_generated_terrain(gen, oracle):
 
 
 @pytest.mark.gpu
+def test_mesh_is_the_same_however_many_workgroups_share_a_chunk(gen):
+    """mmgen_mesh_fill gives every chunk of a small launch to several workgroups (8 below 33 chunks, 4 / 2 up to 256: a streaming strip is
+    33 chunks) and one workgroup per chunk to a large one.  The oracle comparisons above all run with 8; here the same 324 chunks are
+    meshed in one launch (1 per chunk) and in slices of 20, 100 and 204 chunks (8, 4, 2 per chunk): every chunk's bytes are the same."""
+    blocks = gen.generate_region(1488, -1110, 18, 18)["blocks"]
+    pos = gen.positions([(1488 + x, -1110 + z) for z in range(18) for x in range(18)])
+    whole = gen.create_vbos(blocks, pos)                       # every chunk alone: the neighbourhood does not depend on the slicing
+    wv = whole["verts"].cpu().numpy().view(np.uint8).reshape(-1, 40)
+    wi = whole["idx"].cpu().numpy().view(np.uint32)
+    woff = whole["vert_offset"].cpu().numpy(); wcnt = whole["chunk_verts"].cpu().numpy()
+    assert wcnt.sum() == len(wv) and len(wv) > 10 ** 6
+    for lo, hi in ((0, 20), (20, 120), (120, 324)):
+        part = gen.create_vbos(blocks[lo:hi].contiguous(), pos[lo:hi].contiguous())
+        pv = part["verts"].cpu().numpy().view(np.uint8).reshape(-1, 40)
+        pi = part["idx"].cpu().numpy().view(np.uint32)
+        assert np.array_equal(part["chunk_verts"].cpu().numpy(), wcnt[lo:hi])
+        assert np.array_equal(pv, wv[woff[lo]:woff[lo] + len(pv)]), (lo, hi)
+        # indices are chunk-local vertex numbers: the same in any batch
+        assert np.array_equal(pi, wi[woff[lo] * 3 // 2:woff[lo] * 3 // 2 + len(pi)]), (lo, hi)
+
+
+@pytest.mark.gpu
 def test_mesh_edge_cases(gen, oracle):
     """Empty batch, all-AIR chunk, lone chunks (no neighbours: NULL index array), explicit neighbour indices, full stone chunk."""
     import torch
