@@ -176,7 +176,10 @@ void RegionTerrain::generateRect(int cx0, int cz0, int nx, int nz)
         }
         lastBlockBytesD2H += hostStage.size();
     } else {
-        RT_CALL(hipDeviceSynchronize(), "region generation failed");
+        // device resident: nothing on the host reads these blocks.  The mesher's calls come behind the region's on the same (null)
+        // stream and end with a synchronisation; a tick without meshing synchronises at its end (tick): errors surface there, and the
+        // 33 Chunk objects of a strip are made while the GPU generates their blocks instead of after it
+        generationOutstanding = true;
     }
     for (int z = 0; z < nz; ++z)
         for (int x = 0; x < nx; ++x) {
@@ -287,6 +290,7 @@ void RegionTerrain::meshReady()
     } else {
         RT_CALL(hipDeviceSynchronize(), "mesh build failed");
     }
+    generationOutstanding = false;      // (either branch waited for everything the null stream held)
     for (int i = 0; i < n; ++i) {
         Chunk* c = work[i]->chunk.get();
         if (copyToHost) {
@@ -338,6 +342,7 @@ void RegionTerrain::tick(float)
             budget -= nx * nz;
         }
     meshReady();
+    if (generationOutstanding) { RT_CALL(hipDeviceSynchronize(), "region generation failed"); generationOutstanding = false; }
     pending = numMissing > 0;
 }
 

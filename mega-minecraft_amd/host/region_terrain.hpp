@@ -63,6 +63,7 @@ private:
     mmgen_region* region = nullptr;
     uint8_t* d_pool = nullptr;            // [poolChunks][98304]
     size_t poolChunks;
+    bool generationOutstanding = false;   // a device-resident region call whose completion nothing has waited for yet
     std::vector<int> freeSlots;           // sorted descending: slots are handed out in ascending order, so fresh pools fill contiguously
     uint8_t* d_stage = nullptr; size_t stageChunks = 0;      // region output when the free slots are not one contiguous run
     void* d_meshOut = nullptr; size_t meshOutCap = 0;
