@@ -627,7 +627,10 @@ static int region_fill_on(mmgen_region* r, uint8_t* d_blocks, hipEvent_t after0,
 #endif
 // with the base fill starting the moment the caves' extents exist, the cave biomes (which only the placement stages wait for) leave it
 // most of every CU: persistent workgroups per CU of k_cave_biomes then (1 / 2 / 3 / 6: 24.60 / 24.73 / 24.77 / 24.81 ms per step, LOG round 4)
-static constexpr int kCaveBiomeWorkgroupsBesideFill = 1;
+#ifndef MM_CAVE_BIOME_WG_BESIDE_FILL
+#define MM_CAVE_BIOME_WG_BESIDE_FILL 1
+#endif
+static constexpr int kCaveBiomeWorkgroupsBesideFill = MM_CAVE_BIOME_WG_BESIDE_FILL;
 
 int mmgen_region_max_gathered(mmgen_region* r, int* out_surface, int* out_cave, void* stream)
 {
