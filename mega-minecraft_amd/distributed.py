@@ -201,20 +201,49 @@ _K_WORD = -7046029254386353131        # 0x9E3779B97F4A7C15 as int64
 _K_CHUNK = -4417276706812531889       # 0xC2B2AE3D27D4EB4F as int64
 
 
-def tile_checksum(blocks, torch):
-    """64-bit position-dependent checksum of a tile's block ids ([chunks, 98304] uint8, device or host tensor), computed where the tensor
-    lives: sum over chunks c and 8-byte words w of word * (2 w + 1) K1 * (2 c + 1) K2 (mod 2^64).  Linear, so it costs one pass; every
-    multiplier is odd, so a changed, moved or swapped word changes it.  tests/golden/tile_checksums.json holds the values of the bench
-    layouts' tiles as the SINGLE-region pipeline generates them: a multi-GPU run can hold every rank's tile to them (bench.py)."""
+def chunk_digests(blocks, torch):
+    """One 64-bit digest per chunk of block ids ([chunks, 98304] uint8, device or host tensor) as int64 [chunks], computed where the tensor
+    lives: sum over the chunk's 8-byte words w of word * (2 w + 1) K1 (mod 2^64).  Every multiplier is odd, so a changed, moved or swapped
+    word changes it.  tests/golden/world_digests.npz holds these for every chunk of the [-128, 128)^2 world as the CPU ORACLE generates it
+    (tools/gen_world_digests.py): BASELINE configs 4 and 5 at full size and every tile of bench.py's layouts are compared chunk by chunk."""
     n = blocks.shape[0]
     words = blocks.contiguous().view(torch.int64).view(n, -1)
     mw = (2 * torch.arange(words.shape[1], dtype=torch.int64, device=words.device) + 1) * _K_WORD
-    total = torch.zeros((), dtype=torch.int64, device=words.device)
+    out = torch.empty(n, dtype=torch.int64, device=words.device)
     for c0 in range(0, n, 1024):                      # (bounded temporaries: 100 MB per slab)
-        part = (words[c0:c0 + 1024] * mw).sum(1)
-        mc = (2 * torch.arange(c0, c0 + part.shape[0], dtype=torch.int64, device=words.device) + 1) * _K_CHUNK
-        total = total + (part * mc).sum()
-    return int(total.item()) & 0xFFFFFFFFFFFFFFFF
+        out[c0:c0 + 1024] = (words[c0:c0 + 1024] * mw).sum(1)
+    return out
+
+
+def checksum_of_digests(digests, torch):
+    """A tile's checksum from its chunks' digests in the tile's z-major order: sum over chunks c of digest_c * (2 c + 1) K2 (mod 2^64)."""
+    digests = torch.as_tensor(digests).reshape(-1)
+    mc = (2 * torch.arange(digests.shape[0], dtype=torch.int64, device=digests.device) + 1) * _K_CHUNK
+    return int((digests * mc).sum().item()) & 0xFFFFFFFFFFFFFFFF
+
+
+def tile_checksum(blocks, torch):
+    """64-bit position-dependent checksum of a tile's block ids: checksum_of_digests(chunk_digests(blocks)) - linear, one pass."""
+    return checksum_of_digests(chunk_digests(blocks, torch), torch)
+
+
+def load_world_digests(path):
+    """tests/golden/world_digests.npz -> (cx0, cz0, int64 array [nz, nx]): the ORACLE's digest of chunk (cx0 + x, cz0 + z) at [z, x]."""
+    import numpy as np
+    f = np.load(path)
+    cx0, cz0, nx, nz = (int(v) for v in f["world"])
+    d = f["digests"]
+    assert d.shape == (nz, nx) and d.dtype == np.int64
+    return cx0, cz0, d
+
+
+def golden_tile_digests(world, cx0, cz0, nx, nz):
+    """The digests of the rectangle [cx0, cx0 + nx) x [cz0, cz0 + nz) in a region's z-major chunk order, or None where the golden world
+    (load_world_digests) does not cover it."""
+    wx0, wz0, d = world
+    if cx0 < wx0 or cz0 < wz0 or cx0 + nx > wx0 + d.shape[1] or cz0 + nz > wz0 + d.shape[0]:
+        return None
+    return d[cz0 - wz0:cz0 - wz0 + nz, cx0 - wx0:cx0 - wx0 + nx].reshape(-1).copy()
 
 
 def layout_key(layout):

@@ -2,13 +2,26 @@
 // Behavioural spec: src/terrain/chunk.cu (host orchestrators :187-229, :231-302, :417-469, :603-749, :939-993, :1147-1196,
 // :1518-1632, :1679-1747).  Each static stage keeps the reference's contract: pack into the caller's pinned staging slice →
 // H2D → device stage → D2H → unpack into the Chunk members → stream synchronise → error check (print + exit).
+#ifdef MMHOST_REFERENCE_TREE
+#include "terrain/terrain.hpp"     // the reference's own (Zone, dev*Size); it includes "chunk.hpp" = this tree's header first, like terrain.cpp does
+#endif
 #include "chunk.hpp"
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
 
-namespace mmhost {
+MMHOST_NS_BEGIN
+
+// the host-side vocabulary (the reference's own structs in MMHOST_REFERENCE_TREE builds) is layout-identical to the C ABI's PODs
+static_assert(sizeof(Block) == 1 && sizeof(CaveLayer) == sizeof(mmgen_cave_layer) && sizeof(Vertex) == sizeof(mmgen_vertex), "ABI layout");
+static_assert(sizeof(FeaturePlacement) == sizeof(mmgen_feature_placement) && sizeof(CaveFeaturePlacement) == sizeof(mmgen_cave_feature_placement), "ABI layout");
+static_assert(sizeof(ivec2) == 8 && sizeof(ivec3) == 12 && sizeof(GLuint) == 4, "ABI layout");
+static inline const mmgen_feature_placement& abi(const FeaturePlacement& p) { return reinterpret_cast<const mmgen_feature_placement&>(p); }
+static inline const mmgen_cave_feature_placement& abi(const CaveFeaturePlacement& p) { return reinterpret_cast<const mmgen_cave_feature_placement&>(p); }
+#define ABI_CL(p) ((mmgen_cave_layer*)(p))
+#define ABI_FP(p) ((mmgen_feature_placement*)(p))
+#define ABI_CFP(p) ((mmgen_cave_feature_placement*)(p))
 
 // ---------------------------------------------------------------------------------------------------------
 // error convention (src/cuda/cuda_utils.cpp:5-17): message to stderr, exit(EXIT_FAILURE)
@@ -23,7 +36,7 @@ void HipUtils::checkError(const char* msg, int code, int line)
 }
 #define MM_CALL(expr, what) HipUtils::checkError(what, (int)(expr), __LINE__)
 
-void BiomeUtils::init()
+void BiomeUtils::init()      // biomeFuncs.hpp:725 (declared by biome.hpp:299-305)
 {
     int dev = 0;
     MM_CALL(hipGetDevice(&dev), "hipGetDevice");
@@ -48,7 +61,7 @@ struct Scratch {
 Scratch g_bounds, g_single;
 }  // namespace
 
-Chunk::Chunk(ivec2 worldChunkPos) : worldChunkPos(worldChunkPos), worldBlockPos{worldChunkPos.x * 16, 0, worldChunkPos.y * 16} {}
+Chunk::Chunk(ivec2 worldChunkPos) : worldChunkPos(worldChunkPos), worldBlockPos(worldChunkPos.x * 16, 0, worldChunkPos.y * 16) {}
 
 ChunkState Chunk::getState() const { return state; }
 void Chunk::setState(ChunkState newState) { state = newState; readyForQueue = true; }
@@ -111,10 +124,10 @@ void Chunk::floodFillAndIterateNeighbors(ChunkState currentState, ChunkState nex
 // heightfield (chunk.cu:187-229) + gathered 18x18 ring (chunk.cu:231-302)
 // ---------------------------------------------------------------------------------------------------------
 void Chunk::generateHeightfields(std::vector<Chunk*>& chunks, ivec2* host_pos, ivec2* dev_pos, float* host_hf, float* dev_hf, float* host_bw,
-                                 float* dev_bw, hipStream_t stream)
+                                 float* dev_bw, mmhostStream stream)
 {
     const int n = (int)chunks.size();
-    for (int i = 0; i < n; ++i) host_pos[i] = {chunks[i]->worldBlockPos.x, chunks[i]->worldBlockPos.z};
+    for (int i = 0; i < n; ++i) host_pos[i] = ivec2(chunks[i]->worldBlockPos.x, chunks[i]->worldBlockPos.z);
     MM_CALL(hipMemcpyAsync(dev_pos, host_pos, n * sizeof(ivec2), hipMemcpyHostToDevice, stream), "H2D positions");
     MM_CALL(mmgen_generate_heightfields((const int32_t*)dev_pos, n, dev_hf, dev_bw, stream), "Chunk::generateHeightfield() failed");
     MM_CALL(hipMemcpyAsync(host_hf, dev_hf, (size_t)n * 256 * sizeof(float), hipMemcpyDeviceToHost, stream), "D2H heightfields");
@@ -148,7 +161,7 @@ void Chunk::gatherHeightfield()
 // layers (chunk.cu:417-469)
 // ---------------------------------------------------------------------------------------------------------
 void Chunk::generateLayers(std::vector<Chunk*>& chunks, float* host_hf, float* dev_hf, float* host_bw, float* dev_bw, ivec2* host_pos, ivec2* dev_pos,
-                           float* host_layers, float* dev_layers, hipStream_t stream)
+                           float* host_layers, float* dev_layers, mmhostStream stream)
 {
     const int n = (int)chunks.size();
     for (int i = 0; i < n; ++i) {
@@ -156,7 +169,7 @@ void Chunk::generateLayers(std::vector<Chunk*>& chunks, float* host_hf, float* d
         std::memcpy(host_hf + (size_t)i * devHeightfieldSize, c->gatheredHeightfield.data(), devHeightfieldSize * sizeof(float));
         c->gatheredHeightfield.clear();
         std::memcpy(host_bw + (size_t)i * devBiomeWeightsSize, c->biomeWeights.data(), devBiomeWeightsSize * sizeof(float));
-        host_pos[i] = {c->worldBlockPos.x, c->worldBlockPos.z};
+        host_pos[i] = ivec2(c->worldBlockPos.x, c->worldBlockPos.z);
     }
     MM_CALL(hipMemcpyAsync(dev_hf, host_hf, (size_t)n * devHeightfieldSize * sizeof(float), hipMemcpyHostToDevice, stream), "H2D gathered heightfields");
     MM_CALL(hipMemcpyAsync(dev_bw, host_bw, (size_t)n * devBiomeWeightsSize * sizeof(float), hipMemcpyHostToDevice, stream), "H2D biome weights");
@@ -195,7 +208,7 @@ static void copyLayers(Zone* zone, float* packed, bool toPacked)
     }
 }
 
-void Chunk::erodeZone(Zone* zone, float* host_gathered, float* dev_gathered, float* dev_acc, hipStream_t stream)
+void Chunk::erodeZone(Zone* zone, float* host_gathered, float* dev_gathered, float* dev_acc, mmhostStream stream)
 {
     copyLayers(zone, host_gathered, true);
     zone->gatheredChunks.clear();
@@ -220,19 +233,19 @@ void Chunk::fixBackwardStratifiedLayers()
 // caves (chunk.cu:939-993)
 // ---------------------------------------------------------------------------------------------------------
 void Chunk::generateCaves(std::vector<Chunk*>& chunks, float* host_hf, float* dev_hf, float* host_bw, float* dev_bw, ivec2* host_pos, ivec2* dev_pos,
-                          CaveLayer* host_cl, CaveLayer* dev_cl, hipStream_t stream)
+                          CaveLayer* host_cl, CaveLayer* dev_cl, mmhostStream stream)
 {
     const int n = (int)chunks.size();
     for (int i = 0; i < n; ++i) {
         Chunk* c = chunks[i];
         std::memcpy(host_hf + (size_t)i * 256, c->heightfield.data(), 256 * sizeof(float));
         std::memcpy(host_bw + (size_t)i * devBiomeWeightsSize, c->biomeWeights.data(), devBiomeWeightsSize * sizeof(float));
-        host_pos[i] = {c->worldBlockPos.x, c->worldBlockPos.z};
+        host_pos[i] = ivec2(c->worldBlockPos.x, c->worldBlockPos.z);
     }
     MM_CALL(hipMemcpyAsync(dev_hf, host_hf, (size_t)n * 256 * sizeof(float), hipMemcpyHostToDevice, stream), "H2D heightfields");
     MM_CALL(hipMemcpyAsync(dev_bw, host_bw, (size_t)n * devBiomeWeightsSize * sizeof(float), hipMemcpyHostToDevice, stream), "H2D biome weights");
     MM_CALL(hipMemcpyAsync(dev_pos, host_pos, n * sizeof(ivec2), hipMemcpyHostToDevice, stream), "H2D positions");
-    MM_CALL(mmgen_generate_caves(dev_hf, dev_bw, (const int32_t*)dev_pos, n, dev_cl, stream), "Chunk::generateCaves() failed");
+    MM_CALL(mmgen_generate_caves(dev_hf, dev_bw, (const int32_t*)dev_pos, n, ABI_CL(dev_cl), stream), "Chunk::generateCaves() failed");
     MM_CALL(hipMemcpyAsync(host_cl, dev_cl, (size_t)n * devCaveLayersSize * sizeof(CaveLayer), hipMemcpyDeviceToHost, stream), "D2H cave layers");
     MM_CALL(hipStreamSynchronize(stream), "Chunk::generateCaves() failed");
     for (int i = 0; i < n; ++i) std::memcpy(chunks[i]->caveLayers.data(), host_cl + (size_t)i * devCaveLayersSize, devCaveLayersSize * sizeof(CaveLayer));
@@ -254,8 +267,8 @@ void Chunk::generateFeaturePlacements()
     MM_CALL(hipMemcpy(d + oL, layers.data(), devLayersSize * 4, hipMemcpyHostToDevice), "H2D");
     MM_CALL(hipMemcpy(d + oCl, caveLayers.data(), devCaveLayersSize * sizeof(CaveLayer), hipMemcpyHostToDevice), "H2D");
     MM_CALL(hipMemcpy(d + oPos, pos, 8, hipMemcpyHostToDevice), "H2D");
-    MM_CALL(mmgen_generate_feature_placements((float*)(d + oHf), (float*)(d + oBw), (float*)(d + oL), (CaveLayer*)(d + oCl), (int32_t*)(d + oPos), 1,
-                                              (FeaturePlacement*)(d + oFp), (CaveFeaturePlacement*)(d + oCfp), (int32_t*)(d + oCnt), nullptr),
+    MM_CALL(mmgen_generate_feature_placements((float*)(d + oHf), (float*)(d + oBw), (float*)(d + oL), ABI_CL(d + oCl), (int32_t*)(d + oPos), 1,
+                                              ABI_FP(d + oFp), ABI_CFP(d + oCfp), (int32_t*)(d + oCnt), nullptr),
             "Chunk::generateFeaturePlacements() failed");
     int32_t counts[2];
     MM_CALL(hipMemcpy(counts, d + oCnt, 8, hipMemcpyDeviceToHost), "D2H");
@@ -266,7 +279,7 @@ void Chunk::generateFeaturePlacements()
         MM_CALL(hipMemcpy(caveFeaturePlacements.data(), d + oCfp, caveFeaturePlacements.size() * sizeof(CaveFeaturePlacement), hipMemcpyDeviceToHost), "D2H");
 }
 
-static const ivec2 kGatherOffsets[49] = {      // chunk.cu:1158-1167 — the order is observable (first match wins in fill)
+static const struct { int x, y; } kGatherOffsets[49] = {      // chunk.cu:1158-1167 — the order is observable (first match wins in fill)
     {0, 0}, {0, 1}, {1, 1}, {1, 0}, {1, -1}, {0, -1}, {-1, -1}, {-1, 0}, {-1, 1}, {2, 0}, {2, 1}, {2, 2}, {1, 2}, {0, 2}, {-1, 2}, {-2, 2},
     {-2, 1}, {-2, 0}, {-2, -1}, {-2, -2}, {-1, -2}, {0, -2}, {1, -2}, {2, -2}, {2, -1}, {-3, -3}, {-2, -3}, {-1, -3}, {0, -3}, {1, -3}, {2, -3},
     {3, -3}, {3, -2}, {3, -1}, {3, 0}, {3, 1}, {3, 2}, {3, 3}, {2, 3}, {1, 3}, {0, 3}, {-1, 3}, {-2, 3}, {-3, 3}, {-3, 2}, {-3, 1}, {-3, 0},
@@ -275,7 +288,7 @@ static const ivec2 kGatherOffsets[49] = {      // chunk.cu:1158-1167 — the ord
 void Chunk::otherChunkGatherFeaturePlacements(Chunk* c, Chunk* const (&grid)[13][13], int cx, int cz)
 {
     c->gatheredFeaturePlacements.clear();
-    for (const ivec2& o : kGatherOffsets) {
+    for (const auto& o : kGatherOffsets) {
         const Chunk* n = grid[cz + o.y][cx + o.x];
         c->gatheredFeaturePlacements.insert(c->gatheredFeaturePlacements.end(), n->featurePlacements.begin(), n->featurePlacements.end());
         c->gatheredCaveFeaturePlacements.insert(c->gatheredCaveFeaturePlacements.end(), n->caveFeaturePlacements.begin(), n->caveFeaturePlacements.end());
@@ -297,7 +310,7 @@ static const int kCaveFeatureBounds[MMGEN_NUM_CAVE_FEATURES][2] = {{0, 0}, {-3, 
 
 void Chunk::fill(std::vector<Chunk*>& chunks, float* host_hf, float* dev_hf, float* host_bw, float* dev_bw, float* host_layers, float* dev_layers,
                  CaveLayer* host_cl, CaveLayer* dev_cl, FeaturePlacement* dev_fp, CaveFeaturePlacement* dev_cfp, Block* host_blocks, Block* dev_blocks,
-                 hipStream_t stream)
+                 mmhostStream stream)
 {
     const int n = (int)chunks.size();
     std::vector<int32_t> pos(2 * (size_t)n), bounds(4 * (size_t)n);
@@ -317,10 +330,12 @@ void Chunk::fill(std::vector<Chunk*>& chunks, float* host_hf, float* dev_hf, flo
     for (int i = 0; i < n; ++i) {
         Chunk* c = chunks[i];
         int lo0 = 384, hi0 = -1, lo1 = 384, hi1 = -1;     // unions over the un-truncated lists (chunk.cu:1555-1570)
-        for (const auto& p : c->gatheredFeaturePlacements) {
+        for (const auto& e : c->gatheredFeaturePlacements) {
+            const mmgen_feature_placement& p = abi(e);
             lo0 = std::min(lo0, p.pos[1] + kFeatureBounds[p.feature][0]); hi0 = std::max(hi0, p.pos[1] + kFeatureBounds[p.feature][1]);
         }
-        for (const auto& p : c->gatheredCaveFeaturePlacements) {
+        for (const auto& e : c->gatheredCaveFeaturePlacements) {
+            const mmgen_cave_feature_placement& p = abi(e);
             lo1 = std::min(lo1, p.pos[1] + kCaveFeatureBounds[p.feature][0]);
             hi1 = std::max(hi1, p.pos[1] + p.layer_height + kCaveFeatureBounds[p.feature][1]);
         }
@@ -343,8 +358,8 @@ void Chunk::fill(std::vector<Chunk*>& chunks, float* host_hf, float* dev_hf, flo
     int32_t* dev_pos = (int32_t*)(d + (size_t)n * 16);
     MM_CALL(hipMemcpyAsync(dev_bounds, bounds.data(), (size_t)n * 16, hipMemcpyHostToDevice, stream), "H2D bounds");
     MM_CALL(hipMemcpyAsync(dev_pos, pos.data(), (size_t)n * 8, hipMemcpyHostToDevice, stream), "H2D positions");
-    MM_CALL(mmgen_fill(dev_hf, dev_bw, dev_layers, dev_cl, dev_pos, n, dev_fp, dev_cfp, dev_bounds, dev_blocks, stream), "Chunk::fill() failed");
-    MM_CALL(mmgen_place_decorators(dev_blocks, dev_hf, dev_bw, dev_cl, dev_pos, n, stream), "Chunk::fill() failed");
+    MM_CALL(mmgen_fill(dev_hf, dev_bw, dev_layers, ABI_CL(dev_cl), dev_pos, n, ABI_FP(dev_fp), ABI_CFP(dev_cfp), dev_bounds, (uint8_t*)dev_blocks, stream), "Chunk::fill() failed");
+    MM_CALL(mmgen_place_decorators((uint8_t*)dev_blocks, dev_hf, dev_bw, ABI_CL(dev_cl), dev_pos, n, stream), "Chunk::fill() failed");
     MM_CALL(hipMemcpyAsync(host_blocks, dev_blocks, (size_t)n * devBlocksSize, hipMemcpyDeviceToHost, stream), "D2H blocks");
     MM_CALL(hipStreamSynchronize(stream), "Chunk::fill() failed");
     for (int i = 0; i < n; ++i) std::memcpy(chunks[i]->blocks.data(), host_blocks + (size_t)i * devBlocksSize, devBlocksSize);
@@ -361,7 +376,7 @@ void Chunk::placeDecorators()
     MM_CALL(hipMemcpy(d + oBw, biomeWeights.data(), devBiomeWeightsSize * 4, hipMemcpyHostToDevice), "H2D");
     MM_CALL(hipMemcpy(d + oCl, caveLayers.data(), devCaveLayersSize * sizeof(CaveLayer), hipMemcpyHostToDevice), "H2D");
     MM_CALL(hipMemcpy(d + oPos, pos, 8, hipMemcpyHostToDevice), "H2D");
-    MM_CALL(mmgen_place_decorators((uint8_t*)(d + oB), (float*)(d + oHf), (float*)(d + oBw), (CaveLayer*)(d + oCl), (int32_t*)(d + oPos), 1, nullptr),
+    MM_CALL(mmgen_place_decorators((uint8_t*)(d + oB), (float*)(d + oHf), (float*)(d + oBw), ABI_CL(d + oCl), (int32_t*)(d + oPos), 1, nullptr),
             "Chunk::placeDecorators() failed");
     MM_CALL(hipMemcpy(blocks.data(), d + oB, devBlocksSize, hipMemcpyDeviceToHost), "D2H");
 }
@@ -395,7 +410,7 @@ void Chunk::createVBOs()
     static Scratch out;
     const size_t vb = (size_t)nv * sizeof(Vertex), ib = (size_t)nv / 4 * 6 * sizeof(unsigned int);
     char* o = (char*)out.get(vb + ib);
-    MM_CALL(mmgen_mesh_fill((uint8_t*)(d + oB), nullptr, (int32_t*)(d + oN), (int32_t*)(d + oPos), 1, (uint32_t*)(d + oCol), (uint64_t*)(d + oOff), (Vertex*)o,
+    MM_CALL(mmgen_mesh_fill((uint8_t*)(d + oB), nullptr, (int32_t*)(d + oN), (int32_t*)(d + oPos), 1, (uint32_t*)(d + oCol), (uint64_t*)(d + oOff), (mmgen_vertex*)o,
                             (uint32_t*)(o + vb), nullptr),
             "Chunk::createVBOs() fill failed");
     verts.resize(nv);
@@ -405,4 +420,4 @@ void Chunk::createVBOs()
     idxCount = (int)idx.size();
 }
 
-}  // namespace mmhost
+MMHOST_NS_END

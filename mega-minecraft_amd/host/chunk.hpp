@@ -8,6 +8,7 @@
 //   * renderer coupling is dropped: no `Drawable` base and no GL buffers (bufferVBOs, chunk.cu:2005-2021); createVBOs() keeps its
 //     name, its `verts` / `idx` outputs and their exact contents, but is built on the GPU (mmgen_mesh_count / mmgen_mesh_fill);
 //   * stream type is hipStream_t; glm's ivec2/ivec3 are replaced by layout-identical PODs (glm is not a dependency);
+//     with -DMMHOST_REFERENCE_TREE the header is instead built inside the reference's tree on the reference's own types (below);
 //   * generateFeaturePlacements() and placeDecorators() keep their member signatures but run as device kernels.
 #pragma once
 #include <array>
@@ -17,13 +18,39 @@
 #include <hip/hip_runtime.h>
 #include "../../include/mmgen.h"
 
-namespace mmhost {
+#ifdef MMHOST_REFERENCE_TREE
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Built INSIDE the reference's source tree in place of its chunk.hpp (tests/refdrop/ builds the reference's own
+// unmodified terrain.cpp against this header and runs its Terrain::tick on the MI355X).  The vocabulary is the reference's own:
+// glm vectors, `Block` / `CaveLayer` / `FeaturePlacement` / `Vertex` from its block.hpp / biome.hpp / rendering/structs.hpp, `Zone` and
+// the dev*Size constants from its terrain.hpp, `Drawable` as the base class, cudaStream_t (= hipStream_t through the name map), the
+// global namespace.  Their layouts equal the C ABI's PODs (pinned by oracle/ref_block_probe.cpp -> tests/golden/block_data.npz and
+// static_asserts in chunk.cpp), so the ABI calls reinterpret the pointers.
+// ---------------------------------------------------------------------------------------------------------------------------------
+#include <glm/glm.hpp>
+#include "block.hpp"
+#include "rendering/drawable.hpp"
+#include "rendering/structs.hpp"
+#include "biome.hpp"
+#include "cuda/cudaUtils.hpp"
+#define MMHOST_NS_BEGIN
+#define MMHOST_NS_END
+using namespace glm;
+typedef cudaStream_t mmhostStream;
+struct Zone;                                 // terrain.hpp:26-37 (the reference's own definition is used)
+namespace HipUtils { void checkError(const char* msg, int code = 0, int line = -1); }
+#else
+#define MMHOST_NS_BEGIN namespace mmhost {
+#define MMHOST_NS_END }
+MMHOST_NS_BEGIN
 
-struct ivec2 { int x, y; };
-struct ivec3 { int x, y, z; };
+struct ivec2 { int x, y; ivec2() = default; constexpr ivec2(int x, int y) : x(x), y(y) {} };
+struct ivec3 { int x, y, z; ivec3() = default; constexpr ivec3(int x, int y, int z) : x(x), y(y), z(z) {} };
 inline ivec2 operator+(ivec2 a, ivec2 b) { return {a.x + b.x, a.y + b.y}; }
 inline ivec2 operator-(ivec2 a, ivec2 b) { return {a.x - b.x, a.y - b.y}; }
 inline bool operator==(ivec2 a, ivec2 b) { return a.x == b.x && a.y == b.y; }
+typedef hipStream_t mmhostStream;
+typedef unsigned int GLuint;
 
 using Block = uint8_t;                       // enum Block : unsigned char (block.hpp:5-154), ids MMB_*
 using CaveLayer = mmgen_cave_layer;          // biome.hpp:106-115
@@ -34,6 +61,7 @@ using Vertex = mmgen_vertex;                 // rendering/structs.hpp:25-31
 constexpr int numMaterials = MMGEN_NUM_MATERIALS, numBiomes = MMGEN_NUM_BIOMES;
 constexpr int numStratifiedMaterials = MMGEN_NUM_STRATIFIED_MATERIALS, numForwardMaterials = MMGEN_NUM_FORWARD_MATERIALS;
 constexpr int numErodedMaterials = MMGEN_NUM_ERODED_MATERIALS;
+#define MAX_CAVE_LAYERS_PER_COLUMN MMGEN_MAX_CAVE_LAYERS_PER_COLUMN
 #define ZONE_SIZE MMGEN_ZONE_SIZE
 #define EROSION_GRID_SIDE_LENGTH_BLOCKS MMGEN_EROSION_GRID_SIDE
 #define EROSION_GRID_NUM_COLS MMGEN_EROSION_GRID_NUM_COLS
@@ -49,6 +77,10 @@ constexpr int devAccumulatedHeightsSize = MMGEN_EROSION_GRID_NUM_COLS;
 
 namespace BiomeUtils { void init(); }        // biome.hpp:299-305 → mmgen_init(current device)
 namespace HipUtils { void checkError(const char* msg, int code = 0, int line = -1); }   // CudaUtils::checkCUDAError
+MMHOST_NS_END
+#endif
+
+MMHOST_NS_BEGIN
 
 enum class ChunkState : unsigned char {      // chunk.hpp:18-32
     EMPTY, HAS_HEIGHTFIELD, NEEDS_LAYERS, HAS_LAYERS, NEEDS_EROSION, NEEDS_CAVES, NEEDS_FEATURE_PLACEMENTS,
@@ -57,6 +89,7 @@ enum class ChunkState : unsigned char {      // chunk.hpp:18-32
 
 class Chunk;
 
+#ifndef MMHOST_REFERENCE_TREE
 struct Zone {                                // terrain.hpp:26-37
     explicit Zone(ivec2 worldChunkPos) : worldChunkPos(worldChunkPos) {}
     ivec2 worldChunkPos;
@@ -65,8 +98,13 @@ struct Zone {                                // terrain.hpp:26-37
     std::vector<Chunk*> gatheredChunks;      // 24 x 24, filled by the scheduler (isZoneReadyForErosion, terrain.cpp:471-522)
     bool hasBeenQueuedForErosion{false};
 };
+#endif
 
+#ifdef MMHOST_REFERENCE_TREE
+class Chunk : public Drawable {
+#else
 class Chunk {
+#endif
     template <std::size_t diameter>
     using ChunkProcessorFunc = std::function<void(Chunk* chunkPtr, Chunk* const (&neighborChunks)[diameter][diameter], int centerX, int centerZ)>;
 
@@ -91,11 +129,11 @@ public:
     // chunk's eroded result (canonical raw-padding semantics; the reference reads `layers`, chunk.cu:638, and is
     // therefore dependent on the order in which the player's movement erodes zones)
     std::array<float, 256 * numErodedMaterials> rawErodedLayers;
-    std::array<CaveLayer, 256 * MMGEN_MAX_CAVE_LAYERS_PER_COLUMN> caveLayers;   // z, x, y
+    std::array<CaveLayer, 256 * MAX_CAVE_LAYERS_PER_COLUMN> caveLayers;   // z, x, y
     std::array<float, 256 * numBiomes> biomeWeights;                      // y, z, x
     std::array<Block, 98304> blocks;                                      // z, x, y
 
-    explicit Chunk(ivec2 worldChunkPos);
+    Chunk(ivec2 worldChunkPos);
 
     ChunkState getState() const;
     void setState(ChunkState newState);
@@ -116,32 +154,37 @@ private:
 public:
     static void generateHeightfields(std::vector<Chunk*>& chunks, ivec2* host_chunkWorldBlockPositions, ivec2* dev_chunkWorldBlockPositions,
                                      float* host_heightfields, float* dev_heightfields, float* host_biomeWeights, float* dev_biomeWeights,
-                                     hipStream_t stream);
+                                     mmhostStream stream);
     void gatherHeightfield();
     static void generateLayers(std::vector<Chunk*>& chunks, float* host_heightfields, float* dev_heightfields, float* host_biomeWeights,
                                float* dev_biomeWeights, ivec2* host_chunkWorldBlockPositions, ivec2* dev_chunkWorldBlockPositions,
-                               float* host_layers, float* dev_layers, hipStream_t stream);
-    static void erodeZone(Zone* zonePtr, float* host_gatheredLayers, float* dev_gatheredLayers, float* dev_accumulatedHeights, hipStream_t stream);
+                               float* host_layers, float* dev_layers, mmhostStream stream);
+    static void erodeZone(Zone* zonePtr, float* host_gatheredLayers, float* dev_gatheredLayers, float* dev_accumulatedHeights, mmhostStream stream);
     static void generateCaves(std::vector<Chunk*>& chunks, float* host_heightfields, float* dev_heightfields, float* host_biomeWeights,
                               float* dev_biomeWeights, ivec2* host_chunkWorldBlockPositions, ivec2* dev_chunkWorldBlockPositions,
-                              CaveLayer* host_caveLayers, CaveLayer* dev_caveLayers, hipStream_t stream);
+                              CaveLayer* host_caveLayers, CaveLayer* dev_caveLayers, mmhostStream stream);
     void generateFeaturePlacements();
     void gatherFeaturePlacements();
     static void fill(std::vector<Chunk*>& chunks, float* host_heightfields, float* dev_heightfields, float* host_biomeWeights, float* dev_biomeWeights,
                      float* host_layers, float* dev_layers, CaveLayer* host_caveLayers, CaveLayer* dev_caveLayers,
                      FeaturePlacement* dev_featurePlacements, CaveFeaturePlacement* dev_caveFeaturePlacements, Block* host_blocks, Block* dev_blocks,
-                     hipStream_t stream);
+                     mmhostStream stream);
     void placeDecorators();
 
     // Drawable's buffers (rendering/drawable.hpp) as filled by createVBOs (chunk.cu:1778-2003): same order, same bytes
+    std::vector<GLuint> idx;
     std::vector<Vertex> verts;
-    std::vector<unsigned int> idx;
+#ifdef MMHOST_REFERENCE_TREE
+    void createVBOs();
+    void bufferVBOs() override;              // chunk.cu:2005-2021: the renderer's GL upload stays the reference's (not on the generation path)
+#else
     int idxCount{0};
     void createVBOs();
+#endif
 
     // test hooks
     const std::vector<FeaturePlacement>& getFeaturePlacements() const { return featurePlacements; }
     const std::vector<CaveFeaturePlacement>& getCaveFeaturePlacements() const { return caveFeaturePlacements; }
 };
 
-}  // namespace mmhost
+MMHOST_NS_END

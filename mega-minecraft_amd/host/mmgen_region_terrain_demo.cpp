@@ -4,12 +4,15 @@
 // Both stream the world around a player position, then around a second position 13 / -5 chunks away (new strips only).  Every
 // chunk that is drawable for the player must exist in both with identical blocks, vertices and indices.
 //
-//   mmgen_region_terrain_demo [playerChunkX playerChunkZ]      exit code 0 = identical
+//   mmgen_region_terrain_demo [playerChunkX playerChunkZ [digests.txt]]      exit code 0 = identical
+//       digests.txt: one line per chunk RegionTerrain holds drawable after the second leg (chunk_digest.hpp) - the tests hold them to
+//       the CPU oracle's chunks
 //   mmgen_region_terrain_demo --bench                          the streaming figures as ONE JSON line (bench.py's `streaming` record):
 //       initial load of the radius-16 world and a 32-step walk of one chunk per tick through RegionTerrain - device resident, and with
 //       the packed blocks + meshes copied into the host Chunk objects - beside the action-time mirror's initial load
 #include "terrain.hpp"
 #include "region_terrain.hpp"
+#include "chunk_digest.hpp"
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
@@ -160,6 +163,12 @@ int main(int argc, char** argv)
         std::printf("  block data copied to the host: %.1f MB (%s, %.1f KB per chunk)\n", blockBytes / 1e6, batched.packedTransfer ? "wire format" : "raw",
                     generated ? blockBytes / 1e3 / generated : 0.0);
         bad += compare(stage, batched, player);
+    }
+    if (argc > 3) {
+        FILE* f = std::fopen(argv[3], "w");
+        if (!f) return 2;
+        for (Chunk* c : batched.getDrawableChunks()) mmhostWriteChunkDigest(f, c);
+        std::fclose(f);
     }
     {   // the same two legs with everything left on the device (renderer interop): what the GPU path itself costs
         RegionTerrain resident;

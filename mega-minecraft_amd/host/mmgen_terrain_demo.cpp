@@ -2,8 +2,10 @@
 // `Terrain`, ticks it at a fixed dt until every generation queue has drained (the reference's DEBUG_TIME_CHUNK_FILL measurement,
 // terrain.cpp:939-959), then checks chunks produced by the streaming scheduler against the device-resident region path.
 //
-//   mmgen_terrain_demo [playerChunkX playerChunkZ]      exit code 0 = all sampled chunks identical
+//   mmgen_terrain_demo [playerChunkX playerChunkZ [digests.txt]]      exit code 0 = all sampled chunks identical
+// digests.txt: one line per drawable chunk (chunk_digest.hpp) - the tests hold them to the CPU oracle's chunks
 #include "terrain.hpp"
+#include "chunk_digest.hpp"
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -56,6 +58,12 @@ int main(int argc, char** argv)
         }
     }
     mmgen_region_destroy(region);
+    if (argc > 3) {
+        FILE* f = std::fopen(argv[3], "w");
+        if (!f) return 2;
+        for (Chunk* c : terrain.getDrawableChunks()) mmhostWriteChunkDigest(f, c);
+        std::fclose(f);
+    }
     size_t totalVerts = 0;
     for (Chunk* c : terrain.getDrawableChunks()) totalVerts += c->verts.size();
     std::printf("mmgen_terrain_demo: %zu mesh vertices over the drawable chunks (%.0f per chunk)\n", totalVerts, drawable ? (double)totalVerts / drawable : 0.0);

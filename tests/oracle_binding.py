@@ -68,12 +68,13 @@ class Oracle:
         self.lib.mmo_fill(n, _p(pos), _p(hf), _p(bw), _p(layers), _p(cave), None, None, None, None, _p(blocks), int(decorators), self.nthreads)
         return blocks
 
-    def generate_region(self, cx0, cz0, nx, nz, erosion=False, features=False, decorators=False, want=("blocks", "hf")):
+    def generate_region(self, cx0, cz0, nx, nz, erosion=False, features=False, decorators=False, want=("blocks", "hf"), lean=False):
+        """lean: only the block ids are returned (no heightfield / layer / cave-layer copies: 117 KB per chunk less)."""
         n = nx * nz
         blocks = np.zeros((n, 98304), np.uint8)
-        hf = np.zeros((n, 256), np.float32)
-        layers = np.zeros((n, 20, 256), np.float32)
-        cave = np.zeros((n, 256, 32, 3), np.int32)
+        hf = None if lean else np.zeros((n, 256), np.float32)
+        layers = None if lean else np.zeros((n, 20, 256), np.float32)
+        cave = None if lean else np.zeros((n, 256, 32, 3), np.int32)
         flags = (1 if erosion else 0) | (2 if features else 0) | (4 if decorators else 0)
         self.lib.mmo_generate_region(cx0, cz0, nx, nz, flags, _p(blocks), _p(hf), _p(layers), _p(cave), self.nthreads, None)
         return dict(blocks=blocks, hf=hf, layers=layers, cave=cave)
