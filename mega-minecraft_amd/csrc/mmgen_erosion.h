@@ -60,6 +60,9 @@ int erode_zones(float* gathered, size_t strideFloats, int zones, float* work, mm
 // test hook: the next persistent launches wait for `missingWorkgroups` more workgroups than they have (the wait can then never complete) and give up after timeoutMs
 // (0, 0 restores the defaults)
 void erosion_debug_stall(int missingWorkgroups, int timeoutMs);
+// process-wide: persistent relaxations that gave up (as far as the host has learnt of them) and zones the rescue pass relaxed (synchronous calls only)
+void erosion_rescue_counts(long long* stalls, long long* zonesRescued);
+void erosion_note_stall();
 int erosion_gather(const float* layers, const float* hf, const int* zoneChunkIdx, int zones, float* gathered, size_t strideFloats, hipStream_t s);
 int erosion_scatter(const float* gathered, size_t strideFloats, const int* zoneChunkIdxOut, int zones, float* layersOut, hipStream_t s);
 }  // namespace mmk

@@ -386,6 +386,7 @@ MM_DEV unsigned relax_tile(__amdgpu_buffer_rsrc_t work, const RoundPlanes& rp, i
 #define EROSION_WORD_ERR 2             // ... [2..7] the error word and what the workgroup that gave up saw
 #define EROSION_WORD_XCD 8             // ... [8..15] workgroups started per XCD
 #define EROSION_WORD_ZONE_NEXT 16      // ... the next zone to hand out
+#define EROSION_WORD_RESCUED 17        // ... zones the rescue pass had to relax (0 in a healthy launch)
 #define EROSION_WORD_GROUPS 32         // ... then two words per group (XCD * 32 + group of the XCD): draws so far, the zone drawn last (-1: none left)
 #define EROSION_GROUPS_PER_XCD 32
 #define EROSION_LAUNCH_WORDS (EROSION_WORD_GROUPS + 2 * 8 * EROSION_GROUPS_PER_XCD)
@@ -418,7 +419,10 @@ __global__ void __launch_bounds__(EROSION_THREADS) __attribute__((amdgpu_waves_p
 k_erode_zones(const float* __restrict__ gatheredBase, size_t gatheredStride, const float* __restrict__ rawLayers, const float* __restrict__ rawHf,
               const int* __restrict__ zoneChunkIdx /*[zones][576]*/, float* workBase, ErosionState* states, unsigned* words, int zones, int groupSize,
               int groupWait /*workgroups a group waits for: groupSize (more only in the test of the give-up path)*/, int* maxPassesAlso /*nullable*/,
-              unsigned* errHost /*host-visible copy of the error word, nullable*/, unsigned long long timeoutTicks)
+              unsigned* errHost /*host-visible copy of the error word, nullable*/, unsigned long long timeoutTicks,
+              int rescue /*0: the persistent launch.  1: the pass behind it - workgroup i looks at zones i, i + gridDim.x, ... and relaxes every zone
+                           that is NOT done (never drawn, or abandoned by a launch that gave up) from its raw planes, on its own: a group of one
+                           waits for nobody, so this pass cannot stall and needs no residency*/)
 {
     __shared__ float s_s[2][EROSION_CELLS_EXT];            // start planes, ping-pong over the passes
     __shared__ float s_t[2][EROSION_CELLS_EXT];            // thickness = end - start of the same states (what the neighbours compare)
@@ -434,7 +438,9 @@ k_erode_zones(const float* __restrict__ gatheredBase, size_t gatheredStride, con
     const int tid = threadIdx.x;
     unsigned* err = words + EROSION_WORD_ERR;
     const unsigned giveUpCode = 0x80000000u | (0x7fffffu << 8);
-    if (tid == 0) {
+    if (rescue) {
+        if (tid == 0) { s_abort = 0; s_group[0] = 0; s_group[1] = 0; }
+    } else if (tid == 0) {
         s_abort = 0;
         unsigned xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
@@ -470,7 +476,7 @@ k_erode_zones(const float* __restrict__ gatheredBase, size_t gatheredStride, con
         s_group[0] = (int)xcc * EROSION_GROUPS_PER_XCD + g; s_group[1] = member;
     }
     __syncthreads();
-    const int member = __builtin_amdgcn_readfirstlane(s_group[1]), perZone = groupSize;      // (workgroup-uniform: scalar registers)
+    const int member = __builtin_amdgcn_readfirstlane(s_group[1]), perZone = rescue ? 1 : groupSize;      // (workgroup-uniform: scalar registers)
     if (member < 0) return;
     unsigned* groupWords = words + EROSION_WORD_GROUPS + 2 * __builtin_amdgcn_readfirstlane(s_group[0]);
     // beside the caves (16 issue-bound waves per CU) this kernel's 8 waves mostly wait: at the highest wave priority they get the issue slot
@@ -481,7 +487,23 @@ k_erode_zones(const float* __restrict__ gatheredBase, size_t gatheredStride, con
   for (unsigned draw = 1u;; ++draw) {
     // the group's next zone: its first member draws it and tells the others (who cannot be a zone behind: every zone has rounds, every
     // round a barrier among the group)
-    if (tid == 0) {
+    if (rescue) {
+        if (tid == 0) {
+            int z = (int)blockIdx.x + (int)(draw - 1u) * (int)gridDim.x;
+            while (z < zones && states[z].slot[0].done) z += (int)gridDim.x;      // (done: both slots final, see below)
+            if (z < zones) {
+                // the zone starts over from its raw planes (read-only inputs of the relaxation): the state k_erode_init gives it
+                ErosionPhase f;
+                f.layer = MMGEN_NUM_ERODED_MATERIALS - 1; f.isFirst = 1; f.done = 0; f.passes = 0; f.accSel = 0; f.fresh = 1; f.sel = 0u;
+                store_phase(&states[z].slot[0], f); store_phase(&states[z].slot[1], f);
+                for (int k = 0; k < 4; ++k) __hip_atomic_store(&states[z].changed[k], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&states[z].barrier, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_fetch_add(&words[EROSION_WORD_RESCUED], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            s_zone = z < zones ? z : -1;
+        }
+    } else if (tid == 0) {
         int z = -1;
         if (member == 0) {
             const unsigned d = __hip_atomic_fetch_add(&words[EROSION_WORD_ZONE_NEXT], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -667,6 +689,23 @@ size_t erosion_work_bytes(int zones) { return (size_t)zones * ZONE_WORK_FLOATS *
 // [2] = the launch's error word (0, or which zone's barrier gave up in which round)
 size_t erosion_state_bytes(int zones) { return (size_t)zones * sizeof(mm::ErosionState) + sizeof(unsigned) * EROSION_LAUNCH_WORDS; }
 
+// XCDs of the current device as the runtime reports them (hipDeviceAttributeNumberOfXccs); only where that fails, the gfx950 layout of 32
+// CUs per XCD.  A wrong count only costs speed (groups that never fill leave, their zones go to the rescue pass), never a result.
+static int device_xcds(int cus)
+{
+    static std::atomic<int> cached{0};
+    int n = cached.load(std::memory_order_relaxed);
+    if (!n) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeNumberOfXccs, dev) != hipSuccess || v < 1 || v > 8) v = cus >= 64 ? cus / 32 : 1;
+        if (v > 8) v = 8;
+        if (v < 1) v = 1;
+        n = v;
+        cached.store(n, std::memory_order_relaxed);
+    }
+    return n;
+}
+
 // workgroups of k_erode_zones the chip holds at once (LDS-bound: three per CU on gfx950), or `quarterCuCap` / 4 per CU if that is fewer
 static int erosion_resident_workgroups(int quarterCuCap)
 {
@@ -720,6 +759,14 @@ static int chain_before_launch(hipStream_t s, hipEvent_t* ev)
     return 0;
 }
 
+static std::atomic<long long> g_stalls{0}, g_rescued{0};
+void erosion_rescue_counts(long long* stalls, long long* zonesRescued)
+{
+    if (stalls) *stalls = g_stalls.load(std::memory_order_relaxed);
+    if (zonesRescued) *zonesRescued = g_rescued.load(std::memory_order_relaxed);
+}
+void erosion_note_stall() { g_stalls.fetch_add(1, std::memory_order_relaxed); }
+
 void erosion_debug_stall(int missingWorkgroups, int timeoutMs)
 {
     g_debugMissing.store(missingWorkgroups < 0 ? 0 : missingWorkgroups, std::memory_order_relaxed);
@@ -747,7 +794,7 @@ int erode_zones(float* gathered, size_t strideFloats, int zones, float* work, mm
     // 48 / 96 -> 1.65 / 1.87 / 2.77 ms, 2.1 / 2.3 / 2.0 GB of traffic; beside the caves an XCD has 32 workgroups anyway (16: 21.9 ms per
     // step instead of 21.6).
     const int cus = device_cus();
-    const int nXcd = cus >= 64 ? cus / 32 : 1;
+    const int nXcd = device_xcds(cus);
     static const int forcedCap = [] { const char* e = getenv("MMGEN_EROSION_WG_PER_4CU"); return e ? atoi(e) : 0; }();      // (measurements: the DAG's share of the chip in a serial run)
     int grid = erosion_resident_workgroups(forcedCap > 0 ? forcedCap : workgroupsPer4Cu);
     if (grid > nXcd) grid -= grid % nXcd;
@@ -766,17 +813,25 @@ int erode_zones(float* gathered, size_t strideFloats, int zones, float* work, mm
     // before it launches something that takes every slot waits for the counter to reach the grid size (launch_caves)
     if (startedCounter) *startedCounter = words + EROSION_WORD_REGISTERED;
     if (startedTarget) *startedTarget = (unsigned)grid;
-    unsigned* errWord = words + EROSION_WORD_ERR;
-    (void)errWord;
     {
         std::lock_guard<std::mutex> lk(g_chainMu);
         hipEvent_t chain = nullptr;
         int ce = chain_before_launch(s, &chain);
         if (ce) return ce;
         MMK_LAUNCH(KID_ERODE_PASS, mm::k_erode_zones, dim3(grid), dim3(EROSION_THREADS), s, (const float*)gathered, strideFloats, rawLayers, rawHf,
-                   zoneChunkIdx, work, states, words, zones, groupSize, groupWait, maxPassesDev, errHost, erosion_timeout_ticks());
+                   zoneChunkIdx, work, states, words, zones, groupSize, groupWait, maxPassesDev, errHost, erosion_timeout_ticks(), 0);
         hipError_t re = hipEventRecord(chain, s);
         if (re != hipSuccess) return (int)re;
+    }
+    // The rescue pass: whatever the persistent launch left undone - a zone nobody drew (fewer complete groups than the host assumed: a
+    // device whose XCDs the dispatcher fills unevenly, a CU mask), the zones of a launch that gave up (starved by another process'
+    // persistent kernel) - is relaxed here by single workgroups that wait for nobody.  In a healthy step every workgroup finds its zones
+    // done and leaves: one launch of a few workgroups.  The reference's host loop cannot stall (chunk.cu:682-705); with this pass neither can
+    // ours, it can only be slow.
+    {
+        const int rescueGrid = zones < 64 ? zones : 64;
+        MMK_LAUNCH(KID_ERODE_PASS, mm::k_erode_zones, dim3(rescueGrid), dim3(EROSION_THREADS), s, (const float*)gathered, strideFloats, rawLayers, rawHf,
+                   zoneChunkIdx, work, states, words, zones, 1, 1, maxPassesDev, (unsigned*)nullptr, erosion_timeout_ticks(), 1);
     }
     const int perZone = groupSize;
     if (layersOut) {
@@ -788,27 +843,28 @@ int erode_zones(float* gathered, size_t strideFloats, int zones, float* work, mm
                    accStride, 0);
     }
     if (maxPasses) {
-        int words[2] = {0, 0};
-        hipError_t e = hipMemcpyAsync(words, passesWord, 2 * sizeof(int), hipMemcpyDeviceToHost, s);
+        static_assert(EROSION_WORD_ERR == EROSION_WORD_PASSES + 1, "the pass count and the error word are read with one copy");
+        int hw[3] = {0, 0, 0};                             // largest pass count, error word of the persistent launch, zones the rescue pass relaxed
+        hipError_t e = hipMemcpyAsync(hw, passesWord, 2 * sizeof(int), hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipMemcpyAsync(hw + 2, words + EROSION_WORD_RESCUED, sizeof(int), hipMemcpyDeviceToHost, s);
         if (e != hipSuccess) return (int)e;
         e = hipStreamSynchronize(s);
         if (e != hipSuccess) return (int)e;
-        *maxPasses = words[0];
-        if (words[1] != 0) {
-            fprintf(stderr, "mmgen: the erosion relaxation gave up waiting (zone %d of the launch - 8388607 = the registration -, round %d; %d zones, groups of %d workgroups)\n",
-                    (int)(((unsigned)words[1] >> 8) & 0x7FFFFFu), words[1] & 255, zones, perZone);
-            // what the zones looked like when the launch ended: started workgroups, and per zone the arrivals and the phase it was in
-            std::vector<mm::ErosionState> h((size_t)zones + 1);
-            if (hipMemcpy(h.data(), states, sizeof(mm::ErosionState) * h.size(), hipMemcpyDeviceToHost) == hipSuccess) {
-                const unsigned* tail = (const unsigned*)&h[zones];
-                fprintf(stderr, "mmgen:   workgroups started: %u of %d; gave up at %u arrivals of %u after %u polls, %u x 10.24 us; per XCD: %u %u %u %u %u %u %u %u\n",
-                        tail[0], grid, tail[4], tail[5], tail[6], tail[7], tail[8], tail[9], tail[10], tail[11], tail[12], tail[13], tail[14], tail[15]);
-                for (int z = 0; z < zones && z < 16; ++z)
-                    fprintf(stderr, "mmgen:   zone %d: arrivals %u, layer %d, first %d, done %d, passes %d\n", z, h[z].barrier, h[z].slot[0].layer, h[z].slot[0].isFirst,
-                            h[z].slot[0].done, h[z].slot[0].passes);
-            }
-            return MMGEN_ERROR_EROSION_STALL;
+        *maxPasses = hw[0];
+        if (hw[1] != 0) {
+            // the persistent launch gave up; its zones were relaxed by the rescue pass (same planes, same pass counts): report, do not fail
+            unsigned tail[EROSION_LAUNCH_WORDS] = {0};
+            (void)hipMemcpy(tail, words, sizeof(tail), hipMemcpyDeviceToHost);
+            g_stalls.fetch_add(1, std::memory_order_relaxed);
+            fprintf(stderr, "mmgen: the erosion relaxation gave up waiting (zone %d of the launch - 8388607 = the registration -, round %d; %d zones, groups of %d workgroups); "
+                            "%u zones were relaxed by the rescue pass\n",
+                    (int)(((unsigned)hw[1] >> 8) & 0x7FFFFFu), hw[1] & 255, zones, perZone, tail[EROSION_WORD_RESCUED]);
+            fprintf(stderr, "mmgen:   workgroups started: %u of %d; gave up at %u arrivals of %u after %u polls, %u x 10.24 us; per XCD: %u %u %u %u %u %u %u %u\n",
+                    tail[EROSION_WORD_REGISTERED], grid, tail[EROSION_WORD_ERR + 2], tail[EROSION_WORD_ERR + 3], tail[EROSION_WORD_ERR + 4], tail[EROSION_WORD_ERR + 5],
+                    tail[EROSION_WORD_XCD], tail[EROSION_WORD_XCD + 1], tail[EROSION_WORD_XCD + 2], tail[EROSION_WORD_XCD + 3], tail[EROSION_WORD_XCD + 4],
+                    tail[EROSION_WORD_XCD + 5], tail[EROSION_WORD_XCD + 6], tail[EROSION_WORD_XCD + 7]);
         }
+        if (hw[2] != 0) g_rescued.fetch_add(hw[2], std::memory_order_relaxed);
     }
     return 0;
 }

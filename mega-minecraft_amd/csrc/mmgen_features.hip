@@ -530,9 +530,10 @@ MM_DEV bool surface_extent(int feat, int fy, int dx, int dz, uint32_t fstate, bo
         const float hd = len2(px, pz);
         if (!(hd > 8.f)) return true;
         // beyond radius 8: pos.y >= height - 12 and |pos - top| <= 35, or the rasteriser returns false
-        const float rest = 35.f * 35.f - hd * hd;
-        if (rest < 0.f) return false;
-        const float vr = __builtin_sqrtf(rest);
+        // (the rasteriser's |pos - top| is a rounded root of a sum that is monotone in dy^2 and equals hd's at dy = 0: the column is out iff
+        // hd itself is beyond 35 - not iff fl(hd^2) > 35^2, which can hold for a kept voxel; see the stormlight spheres in cave_extent)
+        if (hd > 35.f) return false;
+        const float vr = __builtin_sqrtf(__builtin_fmaxf(35.f * 35.f - hd * hd, 0.f));
         dlo = imax(dlo, (int)((height - gmin(12.f, vr)) / sc) - 1);             // height - 12 >= 13
         dhi = imin(dhi, (int)((height + vr) / sc) + 2);
         if (!(hd > 11.6f)) return true;
@@ -713,9 +714,13 @@ MM_DEV bool cave_extent(int feat, int lh, int dx, int dz, uint32_t fstate, bool 
     if (feat == MMCF_STORMLIGHT_SPHERE || feat == MMCF_CEILING_STORMLIGHT_SPHERE) {
         MinStd frng; frng.x = fstate;
         const float radius = 3.5f + 4.f * frng.u01();
-        const float rest = radius * radius - (float)d2;
-        if (rest < 0.f) return false;
-        const int m = (int)__builtin_sqrtf(rest) + 1;
+        // The rasteriser keeps a voxel iff fl(sqrt(fl(d2 + dy^2))) <= radius.  The column's nearest voxel (dy = 0) is therefore tested with the
+        // SAME rounded root, not with radius^2 >= d2: for radius == fl(sqrt(d2)) rounded down, fl(radius^2) < d2 although the voxel is kept
+        // (chunks (-93,-80) / (-93,-79) of the seed-0 world: a ceiling sphere of radius fl(sqrt(34)) lost its eight rim voxels; found by
+        // the full-world diff against the oracle's digests, round 6).  sqrt is monotone, so a column whose dy = 0 voxel fails has none.
+        if (__builtin_sqrtf((float)d2) > radius) return false;
+        const float rest = __builtin_fmaxf(radius * radius - (float)d2, 0.f);
+        const int m = (int)__builtin_sqrtf(rest) + 1;              // |dy| <= sqrt(radius^2 (1 + 2^-22) - d2) < sqrt(rest) + 1
         const int c = feat == MMCF_STORMLIGHT_SPHERE ? 0 : lh;
         dlo = imax(dlo, c - m); dhi = imin(dhi, c + m);
         return true;

@@ -285,9 +285,7 @@ def test_generate_tile_without_context_checks_before_returning(oracle, monkeypat
 
 def test_tile_checksum_is_position_dependent_and_goldens_cover_the_bench_layouts():
     """tile_checksum (bench.py: tiles_bit_exact) changes when a byte changes, when two chunks swap and when two words swap; the committed
-    goldens hold one value per tile of bench.py's layouts at N = 1, 2, 4, 8 and the tiles that are the same rectangle in two layouts
-    (position purity: the middle of the 4 x 2 world is the 2 x 2 world) carry the same value."""
-    import json
+    golden world digests (the CPU oracle's, one per chunk of [-128, 128)^2) cover every tile of bench.py's layouts at N = 1, 2, 4, 8."""
     import torch
     sys.path.insert(0, ROOT)
     d = importlib.import_module("mega-minecraft_amd.distributed")
@@ -307,10 +305,20 @@ def test_tile_checksum_is_position_dependent_and_goldens_cover_the_bench_layouts
     mw = (2 * torch.arange(8, dtype=torch.int64) + 1) * d._K_WORD
     mc = (2 * torch.arange(1030, dtype=torch.int64) + 1) * d._K_CHUNK
     assert d.tile_checksum(many, torch) == int((((words * mw).sum(1)) * mc).sum().item()) & 0xFFFFFFFFFFFFFFFF
-    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "tile_checksums.json")))
+    # per-chunk digests: tile_checksum is checksum_of_digests(chunk_digests); the numpy statement tools/gen_world_digests.py uses agrees
+    dig = d.chunk_digests(blocks, torch)
+    assert d.checksum_of_digests(dig, torch) == base
+    wnp = blocks.numpy().view(np.int64).reshape(5, -1)
+    with np.errstate(over="ignore"):
+        assert np.array_equal(dig.numpy(), (wnp * ((2 * np.arange(wnp.shape[1], dtype=np.int64) + 1) * np.int64(d._K_WORD))).sum(1, dtype=np.int64))
+    # the golden world (tests/golden/world_digests.npz: the ORACLE's digest of every chunk of [-128, 128)^2) covers every tile of bench.py's
+    # layouts at N = 1, 2, 4, 8 and BASELINE config 4's world; rectangles outside it have no golden
+    world = d.load_world_digests(os.path.join(ROOT, "tests", "golden", "world_digests.npz"))
+    assert (world[0], world[1], world[2].shape) == (-128, -128, (256, 256)) and len(np.unique(world[2])) == 65536
     tiles = {1: (1, 1), 2: (2, 1), 4: (2, 2), 8: (4, 2)}
     for n, (tx, tz) in tiles.items():
         lay = d.TileLayout(-(tx * 64) // 2, -(tz * 128) // 2, tx, tz, 64, 128)
-        assert len(gold[d.layout_key(lay)]) == n and len(set(gold[d.layout_key(lay)])) == n
-    k4, k8 = d.layout_key(d.TileLayout(-64, -128, 2, 2, 64, 128)), d.layout_key(d.TileLayout(-128, -128, 4, 2, 64, 128))
-    assert [gold[k8][i] for i in (1, 2, 5, 6)] == gold[k4]
+        for r in range(n):
+            g = d.golden_tile_digests(world, *lay.region(r))
+            assert g is not None and g.shape == (64 * 128,)
+    assert d.golden_tile_digests(world, -32, -32, 64, 64) is not None and d.golden_tile_digests(world, 100, 100, 64, 64) is None

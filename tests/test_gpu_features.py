@@ -224,10 +224,25 @@ def _tiled_world_on_one_gpu(mmgen_pkg, layout):
     return world.view(H * W, 98304), (wx0, wz0, W, H)
 
 
+def _world_digests(d):
+    import os
+    return d.load_world_digests(os.path.join(os.path.dirname(__file__), "golden", "world_digests.npz"))
+
+
+def _assert_chunks_equal_oracle_digests(d, torch, blocks, cx0, cz0, nx, nz, what):
+    """Every chunk of the rectangle against the ORACLE's digest of that chunk (tests/golden/world_digests.npz, tools/gen_world_digests.py:
+    the CPU oracle over the whole [-128, 128)^2 world, no HIP code involved)."""
+    gold = d.golden_tile_digests(_world_digests(d), cx0, cz0, nx, nz)
+    assert gold is not None
+    got = d.chunk_digests(blocks, torch).cpu().numpy()
+    bad = np.nonzero(got != gold)[0]
+    assert bad.size == 0, f"{what}: {bad.size} of {nx * nz} chunks differ from the oracle, first {[(cx0 + int(i) % nx, cz0 + int(i) // nx) for i in bad[:8]]}"
+
+
 def test_config4_world_2x2_tiles_equals_single_region_and_oracle(mmgen_pkg, oracle):
     """BASELINE config 4 at full size: the 4 096-chunk world [-32, 32)^2, all stages, as 2 x 2 tiles of 32 x 32 chunks with the
-    placement-ring exchange == the same world generated as ONE region (tiling invariance, every block of 4 096 chunks), and the
-    2 x 2 chunks around the four-tile corner == the CPU oracle."""
+    placement-ring exchange == the same world generated as ONE region (tiling invariance, every block of 4 096 chunks), EVERY chunk ==
+    the CPU oracle's chunk by digest (the golden world), and the 2 x 2 chunks around the four-tile corner == the oracle run live."""
     import importlib
     import torch
     d = importlib.import_module("mega-minecraft_amd.distributed")
@@ -235,6 +250,7 @@ def test_config4_world_2x2_tiles_equals_single_region_and_oracle(mmgen_pkg, orac
     world, (wx0, wz0, W, H) = _tiled_world_on_one_gpu(mmgen_pkg, layout)
     single = mmgen_pkg.MMGen(0).generate_region(wx0, wz0, W, H)["blocks"]
     assert torch.equal(world, single)
+    _assert_chunks_equal_oracle_digests(d, torch, world, wx0, wz0, W, H, "config 4 world")
     ref = oracle.generate_region(-1, -1, 2, 2, erosion=True, features=True, decorators=True)["blocks"]
     got = world.view(H, W, 98304)[31:33, 31:33].reshape(4, 98304).cpu().numpy()
     assert np.array_equal(got, ref)
@@ -280,7 +296,8 @@ def test_zone_cache_gives_the_same_regions(mmgen_pkg, gen, oracle):
 
 def test_config5_world_8_tiles_equals_single_region(mmgen_pkg):
     """BASELINE config 5 at full size: the 65 536-chunk world [-128, 128)^2 as 4 x 2 tiles of 64 x 128 chunks (the 8-GPU layout,
-    played on one GPU) is block-for-block the world generated as one region: 6.4 GB of block ids compared on the device."""
+    played on one GPU) is block-for-block the world generated as one region (6.4 GB of block ids compared on the device), and every chunk
+    of it equals the CPU oracle's chunk by digest."""
     import importlib
     import torch
     d = importlib.import_module("mega-minecraft_amd.distributed")
@@ -290,15 +307,15 @@ def test_config5_world_8_tiles_equals_single_region(mmgen_pkg):
     g = mmgen_pkg.MMGen(0)
     single = g.generate_region(wx0, wz0, W, H)["blocks"]
     assert torch.equal(world, single)
-    # ... and every tile has the checksum the first 8-GPU run will be held to (bench.py: tiles_bit_exact; tools/gen_tile_checksums.py)
-    import json
-    import os
-    golden = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "tile_checksums.json")))[d.layout_key(layout)]
+    # ... and EVERY one of the 65 536 chunks is the CPU oracle's chunk (digest for digest: the bit-exact block-id diff of the north star at
+    # full size), hence every tile has the checksum bench.py derives from the same digests for the first 8-GPU run (tiles_bit_exact)
+    _assert_chunks_equal_oracle_digests(d, torch, world, wx0, wz0, W, H, "config 5 world")
     w3 = world.view(H, W, 98304)
+    gold_world = _world_digests(d)
     for r in range(8):
         cx0, cz0, nx, nz = layout.region(r)
         tile = w3[cz0 - wz0:cz0 - wz0 + nz, cx0 - wx0:cx0 - wx0 + nx].reshape(nx * nz, 98304)
-        assert f"{d.tile_checksum(tile, torch):016x}" == golden[r], (r, golden[r])
+        assert d.tile_checksum(tile, torch) == d.checksum_of_digests(torch.from_numpy(d.golden_tile_digests(gold_world, cx0, cz0, nx, nz)), torch), r
     # the product-only capacity (MMGEN_CFP_CAP = 1 024 cave placements per chunk) over the whole 65 536-chunk world: far away
     longest = g.region_max_cave_placements()
     assert 0 < longest < 512, longest
@@ -725,6 +742,19 @@ def test_tight_extents_lose_nothing(gen, oracle, case):
         plain = oracle.generate_region(cx0, cz0, 1, 1, erosion=True, features=True, decorators=True)["blocks"]
         total_diff_from_plain += int((ref != plain).sum())
     assert total_diff_from_plain > 1000                                       # the synthetic placements really claim voxels
+
+
+@pytest.mark.gpu
+def test_sphere_whose_radius_is_the_rounded_root_of_its_rim_distance(gen, oracle):
+    """Found by the first diff of the full 65 536-chunk world against the oracle's digests (round 6; random sweeps of 4 x 65 536 other chunks
+    had not met the case): the ceiling stormlight sphere at block (-1478, 53, -1267), layer height 11, draws radius == fl(sqrt(34)), so its
+    eight rim voxels (+-3, 0, +-5), (+-5, 0, +-3) pass the rasteriser's `dist > radius` test (featurePlacement.hpp:1202-1208) exactly at
+    equality - and cave_extent had dropped their columns because fl(radius^2) < 34.  Chunks (-93, -80) and (-93, -79), all stages."""
+    ref = oracle.generate_region(-93, -80, 1, 2, erosion=True, features=True, decorators=True)["blocks"]
+    got = np_(gen.generate_region(-93, -80, 1, 2)["blocks"])
+    assert int((ref == 93).sum()) > 100                                        # the sphere's cyan crystal is there ...
+    assert ref[0, 384 * (7 + 16 * 8) + 64] == 93                               # ... including the rim voxel at (-1481, 64, -1272)
+    assert np.array_equal(got, ref), f"{int((got != ref).sum())} block ids differ"
 
 
 @pytest.mark.gpu

@@ -1,0 +1,25 @@
+"""tests/golden/world_digests.npz - the CPU oracle's digest of every chunk of the 65 536-chunk world [-128, 128)^2 (BASELINE config 5; it
+contains config 4's world and every tile of bench.py's layouts), written by tools/gen_world_digests.py on the GPU box's 256 host threads
+with no HIP code involved (log: profiles/r06_world_digests_oracle_gen.log).  Here: the file is what it says - the oracle, run again on this
+machine on sampled chunks as 1 x 1 regions (a different piece size than the 64 x 64 pieces it was made from), reproduces the digests."""
+import importlib
+import os
+import sys
+
+import numpy as np
+
+from conftest import ROOT, GOLDEN
+
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+
+def test_golden_world_digests_are_the_oracles(oracle):
+    d = importlib.import_module("mega-minecraft_amd.distributed")
+    gen = importlib.import_module("gen_world_digests")
+    cx0, cz0, dig = d.load_world_digests(os.path.join(GOLDEN, "world_digests.npz"))
+    rng = np.random.default_rng(20261003)
+    # two random chunks, a world corner, and the chunk the first full-world diff of the device against these digests found wrong (round 6)
+    samples = [tuple(int(v) for v in rng.integers(-128, 128, 2)) for _ in range(2)] + [(-128, 127), (-93, -80)]
+    for cx, cz in samples:
+        blocks = oracle.generate_region(cx, cz, 1, 1, erosion=True, features=True, decorators=True, lean=True)["blocks"]
+        assert int(gen.chunk_digests_np(blocks)[0]) == int(dig[cz - cz0, cx - cx0]), (cx, cz)

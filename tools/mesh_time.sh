@@ -4,7 +4,7 @@ root=${GRAFT_REPO_ROOT:-$PWD}
 cd /tmp && export TMPDIR=/tmp
 for lib in "$@"; do
   export MMGEN_LIB=$root/$lib
-  rm -rf /tmp/ms; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ms -- python3 $root/bench.py --steps 2 --warmup 1 --cpu-side 0 --extras --tile-nx 36 --tile-nz 36 > /tmp/b.log 2>&1
+  rm -rf /tmp/ms; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ms -- python3 $root/bench.py --no-cpp-host --no-streaming --steps 2 --warmup 1 --cpu-side 0 --extras --tile-nx 36 --tile-nz 36 > /tmp/b.log 2>&1
   python3 - <<PY
 import csv,glob
 print("== $lib")
