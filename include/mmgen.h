@@ -66,9 +66,11 @@ int mmgen_fix_backward_layers(float* d_layers, int num_chunks, void* stream);
 int mmgen_erode_zone(float* d_gathered_layers, float* d_accumulated_heights, void* stream);
 /* The relaxation loop runs on the device as one persistent launch whose workgroups wait for each other; no wait is unbounded.  If a zone's
  * workgroups do not meet within MMGEN_EROSION_TIMEOUT_MS (environment; default 2 000 ms, a thousand times the longest healthy wait) the
- * launch ends itself and the call that synchronises with it returns this code instead of hanging the GPU (the reference's loop cannot
- * stall: the host launches every pass, chunk.cu:682-705).  Starvation is the realistic cause: several persistent relaxations in flight on
- * one device (regions on several streams, concurrent mmgen_erode_zones calls, several processes) can hold each other's slots. */
+ * launch ends itself - starvation is the realistic cause: persistent kernels of other processes, or of this one on other streams, holding
+ * its slots - and the RESCUE PASS enqueued right behind it relaxes every zone that is not done (abandoned, or never drawn because the
+ * device handed the launch's workgroups to its XCDs differently than assumed) with single workgroups that wait for nobody: same planes,
+ * same pass counts, only slower.  Like the reference's host loop (chunk.cu:682-705) the relaxation therefore cannot fail; a launch that
+ * gave up is reported on stderr and counted (mmgen_erosion_stalls).  The code below is kept for ABI stability; no call returns it. */
 #define MMGEN_ERROR_EROSION_STALL 20002
 /* Batched form: num_zones buffers of MMGEN_GATHERED_LAYERS_SIZE floats back to back (ONE persistent launch relaxes all zones to
  * convergence: the host loop of chunk.cu:682-705 runs on the device, a zone's workgroups meet at a barrier after every block of passes);
@@ -155,8 +157,7 @@ int mmgen_region_fill(mmgen_region* region, uint8_t* d_blocks, void* stream);
 int mmgen_region_set_output(mmgen_region* region, uint8_t* d_blocks);
 int mmgen_region_finish(mmgen_region* region, uint8_t* d_blocks, float* d_heightfields /*nullable*/, float* d_layers /*[n][20][256], nullable*/,
                         mmgen_cave_layer* d_cave_layers /*[n][256][32], nullable*/, void* stream);
-/* waits for the erosion branch of the last begin; -1 if it failed (a relaxation that gave up: from then on mmgen_region_begin / _finish
- * return MMGEN_ERROR_EROSION_STALL - the planes of that step are not to be trusted and the region is to be destroyed) */
+/* waits for the erosion branch of the last begin and returns the largest pass count of its zones (-1: the wait itself failed) */
 int mmgen_region_last_erosion_passes(const mmgen_region* region);
 /* The longest gathered (un-truncated) surface / cave placement list any chunk had in the finishes since the last call (synchronises the
  * stream; clears the record).  With a full ring (mask 1 or peer-provided lists) these are the lengths the reference's Chunk::fill truncates
@@ -275,8 +276,11 @@ int mmgen_debug_probe(int fn, const float* d_in, int n, float* d_out, void* stre
  * chunk), so that a test can drive the path that evaluates them in place when a reservation does not fit.  Process-wide. */
 int mmgen_debug_set_lush_queue_cap(int entries);
 /* Test-only: the following persistent relaxation launches wait for `missing_workgroups` more workgroups than they have, so that the wait
- * can never complete, and give up after timeout_ms: drives the MMGEN_ERROR_EROSION_STALL path.  (0, 0) restores the defaults.  Process-wide. */
+ * can never complete, and give up after timeout_ms: drives the give-up + rescue path.  (0, 0) restores the defaults.  Process-wide. */
 int mmgen_debug_erosion_stall(int missing_workgroups, int timeout_ms);
+/* process-wide counters (either pointer may be NULL): persistent relaxations that gave up, as far as the host has learnt of them (the
+ * synchronous per-stage calls at once, a region at its next call), and zones the rescue pass had to relax (synchronous calls only) */
+int mmgen_erosion_stalls(long long* stalls, long long* zones_rescued);
 /* Test-only: the library's constant rule tables (BiomeUtils::init, biomeFuncs.hpp:725-1256) as floats in the layout of
  * tools/extract_ref_tables.py, so that a test can hold them to the reference's literals.  d_out == NULL: returns the number of floats. */
 int mmgen_debug_tables(float* d_out, int capacity_floats, void* stream);

@@ -102,7 +102,7 @@ const char* mmgen_error_string(int code)
     if (code == MMGEN_ERROR_PLACEMENT_OVERFLOW)
         return "a chunk's cave placement list exceeded MMGEN_CFP_CAP and lost entries (mmgen_region_max_cave_placements acknowledges)";
     if (code == MMGEN_ERROR_EROSION_STALL)
-        return "the erosion relaxation gave up: a zone's workgroups did not meet within MMGEN_EROSION_TIMEOUT_MS (starved persistent launch?)";
+        return "the erosion relaxation gave up: a zone's workgroups did not meet within MMGEN_EROSION_TIMEOUT_MS (since round 6 the rescue pass finishes such zones; no call returns this any more)";
     return hipGetErrorString((hipError_t)code);
 }
 
@@ -191,6 +191,12 @@ int mmgen_erode_zones(float* d_gathered, int num_zones, float* d_acc, int* max_p
 }
 
 int mmgen_erode_zone(float* d_gathered, float* d_acc, void* stream) { return mmgen_erode_zones(d_gathered, 1, d_acc, nullptr, stream); }
+
+int mmgen_erosion_stalls(long long* stalls, long long* zones_rescued)
+{
+    mmk::erosion_rescue_counts(stalls, zones_rescued);
+    return 0;
+}
 
 int mmgen_debug_erosion_stall(int missing_workgroups, int timeout_ms)
 {

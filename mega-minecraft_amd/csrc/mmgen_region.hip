@@ -300,7 +300,8 @@ struct mmgen_region {
     // attribution for the roofline; MMGEN_REGION_SERIAL=1 or mmgen_region_set_serial).
     int* hostMax = nullptr;       // pinned + mapped: [2] largest erosion pass count of the last begin (written by the relaxation itself, no copy);
                                   // [0] largest cave list length beyond MMGEN_CFP_CAP seen by a finish (0 = none); [1] the error word
-                                  // of a relaxation that gave up (k_erode_zones; 0 = none, never cleared: MMGEN_ERROR_EROSION_STALL from then on)
+                                  // of a relaxation that gave up (k_erode_zones; 0 = none).  Its zones are relaxed by the rescue pass of
+                                  // the same enqueue, so this is bookkeeping: the next call counts it (mmgen_erosion_stalls) and clears it
     int* hostMaxDev = nullptr;    // its device address
     DevBuf devMax;                // [0] largest cave list length of the finishes since the last query (whatever its size); [1], [2] the longest
                                   // gathered (un-truncated) surface / cave list since the last mmgen_region_max_gathered
@@ -308,7 +309,7 @@ struct mmgen_region {
     int wantSlices = 0;           // 0 = automatic
     hipStream_t sErode = nullptr, sFill = nullptr, sApply = nullptr;
     static constexpr int kMaxSlices = 16;
-    hipEvent_t evK2 = nullptr, evResident = nullptr, evCaveVoxels = nullptr, evBegin = nullptr, evErosion = nullptr, evGather = nullptr, evF1 = nullptr, evTail = nullptr, evFill[kMaxSlices] = {}, evEntry = nullptr;
+    hipEvent_t evK2 = nullptr, evResident = nullptr, evCaveVoxels = nullptr, evBegin = nullptr, evErosion = nullptr, evGather = nullptr, evF1 = nullptr, evTail = nullptr, evFill[kMaxSlices] = {}, evEntry = nullptr, evFillCleared = nullptr;
     int nSlices = 1;
     int sliceRow[kMaxSlices + 1] = {};        // rows of R per slice: [sliceRow[i], sliceRow[i + 1])
     int init_streams()
@@ -333,7 +334,7 @@ struct mmgen_region {
         const int prFill = MM_FILL_STREAM_HIGH == 1 ? prGreatest : MM_FILL_STREAM_HIGH == 2 ? 0 /*normal*/ : prLeast;
         if ((e = hipStreamCreateWithPriority(&sFill, hipStreamNonBlocking, prFill)) != hipSuccess) return (int)e;
         if ((e = hipStreamCreateWithPriority(&sApply, hipStreamNonBlocking, prFill)) != hipSuccess) return (int)e;
-        hipEvent_t* ev[] = {&evK2, &evResident, &evCaveVoxels, &evBegin, &evErosion, &evGather, &evF1, &evTail, &evEntry};
+        hipEvent_t* ev[] = {&evK2, &evResident, &evCaveVoxels, &evBegin, &evErosion, &evGather, &evF1, &evTail, &evEntry, &evFillCleared};
         for (hipEvent_t* x : ev) if ((e = hipEventCreateWithFlags(x, hipEventDisableTiming)) != hipSuccess) return (int)e;
         for (int i = 0; i < kMaxSlices; ++i)
             if ((e = hipEventCreateWithFlags(&evFill[i], hipEventDisableTiming)) != hipSuccess) return (int)e;
@@ -348,7 +349,7 @@ struct mmgen_region {
         if (sErode) {
             (void)hipStreamSynchronize(sErode); (void)hipStreamSynchronize(sFill); (void)hipStreamSynchronize(sApply);
             (void)hipStreamDestroy(sErode); (void)hipStreamDestroy(sFill); (void)hipStreamDestroy(sApply);
-            hipEvent_t ev[] = {evK2, evResident, evCaveVoxels, evBegin, evErosion, evGather, evF1, evTail, evEntry};
+            hipEvent_t ev[] = {evK2, evResident, evCaveVoxels, evBegin, evErosion, evGather, evF1, evTail, evEntry, evFillCleared};
             for (hipEvent_t x : ev) if (x) (void)hipEventDestroy(x);
             for (int i = 0; i < kMaxSlices; ++i) if (evFill[i]) (void)hipEventDestroy(evFill[i]);
         }
@@ -652,7 +653,8 @@ int mmgen_region_begin(mmgen_region* r, int cx0, int cz0, int nx, int nz, unsign
     r->earlyBlocks = nullptr;
     if (nx <= 0 || nz <= 0) return (int)hipErrorInvalidValue;
     if (__atomic_load_n(r->hostMax, __ATOMIC_RELAXED) > MMGEN_CFP_CAP) return MMGEN_ERROR_PLACEMENT_OVERFLOW;
-    if (__atomic_load_n(r->hostMax + 1, __ATOMIC_RELAXED) != 0) return MMGEN_ERROR_EROSION_STALL;
+    // a relaxation of an earlier step that gave up: its zones were relaxed by the rescue pass (same planes); counted, not an error
+    if (__atomic_load_n(r->hostMax + 1, __ATOMIC_RELAXED) != 0) { __atomic_store_n(r->hostMax + 1, 0, __ATOMIC_RELAXED); mmk::erosion_note_stall(); }
     hipStream_t s = (hipStream_t)stream;
     const bool erosion = flags & MMGEN_REGION_EROSION, features = flags & MMGEN_REGION_FEATURES;
     const bool par = !r->serial;
@@ -664,6 +666,13 @@ int mmgen_region_begin(mmgen_region* r, int cx0, int cz0, int nx, int nz, unsign
         CK(hipEventRecord(r->evBegin, s));          // what the caller's stream held when this begin was called
     }
     r->began = false; r->filled = false; r->filledInto = nullptr; r->fillStarted = nullptr; r->fillStartedTarget = 0u;
+    // zone cache: region_layout registers the zones this begin is going to relax in the cache map BEFORE anything is enqueued.  If the begin
+    // fails after that (an allocation, an upload, the relaxation's enqueue) their slots were never written, and the next begin would take
+    // cache hits on them: an error return drops every cached zone (slots and map; the layout is rebuilt).
+    struct CacheGuard {
+        mmgen_region* r; bool ok = false;
+        ~CacheGuard() { if (!ok && r->zoneCacheCap) { r->zoneSlotOf.clear(); std::fill(r->slotUsed.begin(), r->slotUsed.end(), 0); r->layoutValid = false; } }
+    } cacheGuard{r};
     CK(region_layout(r, cx0, cz0, nx, nz, flags, h_local_mask, s));
     const int np = r->np, na = r->na;
     hipStream_t sE = par ? r->sErode : s;
@@ -772,6 +781,7 @@ int mmgen_region_begin(mmgen_region* r, int cx0, int cz0, int nx, int nz, unsign
     // stages that only the rasterisers wait for (mmgen_region_set_output).  Enqueued after F1 so that its cave part can wait for F1's end
     // (region_fill_on)
     if (par && early) CK(region_fill_on(r, early, /*after*/ r->evBegin, r->evCaveVoxels, erosion ? r->evErosion : nullptr));
+    cacheGuard.ok = true;
     return 0;
 }
 
@@ -821,6 +831,7 @@ static int region_fill_on(mmgen_region* r, uint8_t* d_blocks, hipEvent_t after0,
     // thing in the queue is k_fill_base, not a memset that has to find a free slot beside whatever is running then
     for (int i = 0; i < r->nSlices; ++i)
         CK(mmk::launch_fill_clear((r->sliceRow[i + 1] - r->sliceRow[i]) * r->nx, (unsigned*)((char*)r->fillQueue.p + qb * i), qb, sF));
+    CK(hipEventRecord(r->evFillCleared, sF));       // (the gather's watch of the cave fill's started-workgroups word must not see the previous step's count)
     hipEvent_t after[3] = {after0, after1, after2};
     for (hipEvent_t e : after) if (e) CK(hipStreamWaitEvent(sF, e, 0));
     // The cave fill's persistent workgroups (six per CU, 26.3 KB of LDS each) must find the chip EMPTY: started while workgroups of
@@ -888,7 +899,8 @@ int mmgen_region_finish(mmgen_region* r, uint8_t* d_blocks, float* d_heightfield
     const int* tgt = r->targets.as<int>();
 
     if (__atomic_load_n(r->hostMax, __ATOMIC_RELAXED) > MMGEN_CFP_CAP) return MMGEN_ERROR_PLACEMENT_OVERFLOW;
-    if (__atomic_load_n(r->hostMax + 1, __ATOMIC_RELAXED) != 0) return MMGEN_ERROR_EROSION_STALL;
+    // a relaxation of an earlier step that gave up: its zones were relaxed by the rescue pass (same planes); counted, not an error
+    if (__atomic_load_n(r->hostMax + 1, __ATOMIC_RELAXED) != 0) { __atomic_store_n(r->hostMax + 1, 0, __ATOMIC_RELAXED); mmk::erosion_note_stall(); }
     if (!r->filled || r->filledInto != d_blocks) CK(mmgen_region_fill(r, d_blocks, stream));
     hipStream_t sA = par ? r->sApply : s;
     if (features) {
@@ -904,7 +916,10 @@ int mmgen_region_finish(mmgen_region* r, uint8_t* d_blocks, float* d_heightfield
 #endif
         // the gather runs beside the cave fill and must not start before it: the fill's persistent workgroups take the chip first, the gather
         // the slots they leave (measured: a gather that starts a few microseconds early holds slots the cave fill then never gets)
-        if (MM_GATHER_WAITS_FOR_FILL && par && r->filled && r->fillStarted && r->fillStartedTarget) CK(mmk::launch_wait_counter(r->fillStarted, r->fillStartedTarget, s));
+        if (MM_GATHER_WAITS_FOR_FILL && par && r->filled && r->fillStarted && r->fillStartedTarget) {
+            CK(hipStreamWaitEvent(s, r->evFillCleared, 0));      // the word was cleared on the fill stream (long ago: region_fill_on's first enqueue)
+            CK(mmk::launch_wait_counter(r->fillStarted, r->fillStartedTarget, s));
+        }
         CK(mmk::launch_gather_placements(r->fp.as<mmgen_feature_placement>(), r->cfp.as<mmgen_cave_feature_placement>(), r->counts.as<int>(), tgt, nr,
                                          r->pnx, r->pnz, r->gfp.as<mmgen_feature_placement>(), r->gcfp.as<mmgen_cave_feature_placement>(),
                                          r->bounds.as<int>(), posP, s, r->devMax.as<int>() + 1, r->hostMaxDev, r->devMax.as<int>(),
@@ -958,7 +973,8 @@ int mmgen_region_last_erosion_passes(const mmgen_region* r)
 {
     if (!r) return -1;
     if (r->passesPending && hipEventSynchronize(r->evPasses) != hipSuccess) return -1;
-    if (__atomic_load_n(r->hostMax + 1, __ATOMIC_RELAXED) != 0) return -1;      // the relaxation gave up (MMGEN_ERROR_EROSION_STALL)
+    // a relaxation of an earlier step that gave up: its zones were relaxed by the rescue pass (same planes); counted, not an error
+    if (__atomic_load_n(r->hostMax + 1, __ATOMIC_RELAXED) != 0) { __atomic_store_n(r->hostMax + 1, 0, __ATOMIC_RELAXED); mmk::erosion_note_stall(); }
     return __atomic_load_n(r->hostMax + 2, __ATOMIC_RELAXED);
 }
 

@@ -162,33 +162,47 @@ class TileContext:
                            f"on average - the tile of that step is INVALID (cells that did not fit arrived empty); rebuild the TileContext "
                            f"with a larger words_per_cell (7424 can never overflow)")
 
-    def check(self):
-        """Reads the overflow word (a device read: call it after the step, not inside it).  Raises when a ring message did not fit."""
+    def _verdict(self, dist):
+        """The overflow word every rank will see: the MAXIMUM over the ranks.  An oversized message is only noticed by its sender and its
+        receiver; if only those two raised, every other rank would walk into the next exchange with peers that have left the step and hang
+        until the communicator's timeout.  One 4-byte all-reduce per step, enqueued behind the step (nccl: stream-ordered, the host does
+        not wait; gloo: a CPU tensor) - bookkeeping, not data path.  Stand-in `dist` objects of one-process tests have no all_reduce."""
+        if dist is None or self.loopback or not hasattr(dist, "all_reduce") or not hasattr(dist, "get_world_size") or dist.get_world_size() <= 1:
+            return self.overflow
+        v = self.overflow.clone()
+        dist.all_reduce(v, op=dist.ReduceOp.MAX)
+        return v
+
+    def check(self, dist=None):
+        """Reads the overflow word (a device read: call it after the step, not inside it).  Raises - on EVERY rank when `dist` is the
+        process group - when a ring message did not fit.  Collective: all ranks call it, or none."""
         self._copied = None
-        need = int(self.overflow.item())
+        need = int(self._verdict(dist).item())
         if need:
             self._raise(need)
 
-    def note_step(self):
-        """After a step's region_finish: starts the copy of the overflow word to pinned memory behind everything the step enqueued, without
-        waiting for it (generate_tile calls this; check_previous() looks at it at the start of the next step)."""
+    def note_step(self, dist=None):
+        """After a step's region_finish: agrees on the step's overflow word with the other ranks (_verdict) and starts its copy to pinned
+        memory behind everything the step enqueued, without waiting for it (generate_tile calls this; check_previous() looks at it at the
+        start of the next step, on every rank in the same step)."""
+        v = self._verdict(dist)
         if self.overflow.is_cuda:
             t = self._torch
             if self._host_overflow is None:
                 self._host_overflow = t.zeros((1,), dtype=t.int32).pin_memory()
-            self._host_overflow.copy_(self.overflow, non_blocking=True)
+            self._host_overflow.copy_(v, non_blocking=True)
             self._copied = t.cuda.Event()
             self._copied.record()
         else:
-            self._copied = True
+            self._copied = int(v[0]) + 1              # (CPU backends: the agreed value itself, + 1 so that 0 still means "a step was noted")
 
     def check_previous(self):
-        """Start of a step: the previous step's overflow word.  On a GPU the wait is for an event recorded behind the previous step -
+        """Start of a step: the previous step's agreed overflow word.  On a GPU the wait is for an event recorded behind the previous step -
         over by the time the caller has consumed that step's tile - so the step itself still makes no device read."""
         if self._copied is None:
             return
-        if self._copied is True:
-            need = int(self.overflow[0])
+        if isinstance(self._copied, int):
+            need = self._copied - 1
         else:
             self._copied.synchronize()
             need = int(self._host_overflow[0])
@@ -304,9 +318,10 @@ def generate_tile(backend, layout, rank, flags, dist=None, torch=None, want=(), 
     keep the per-layout planning out of the step.
 
     Ring messages have a fixed budget (module docstring); cells that do not fit arrive EMPTY, which would silently drop features.  It
-    cannot go unnoticed: with a caller-owned context the overflow word of step i is looked at when step i + 1 starts (RuntimeError; no
-    device read inside a step) and by ctx.check() whenever the caller wants certainty - the returned tile is valid once either has passed;
-    without a context (one-off call) the word is read before returning."""
+    cannot go unnoticed: with a caller-owned context the overflow word of step i - the maximum over ALL ranks, so that every rank raises
+    in the same step instead of leaving its peers in the next exchange - is looked at when step i + 1 starts (RuntimeError; no device read
+    inside a step) and by ctx.check(dist) whenever the caller wants certainty - the returned tile is valid once either has passed; without a
+    context (one-off call) the word is read before returning."""
     own_ctx = ctx is None
     if own_ctx:
         dev = getattr(backend, "device", "cpu")
@@ -330,7 +345,7 @@ def generate_tile(backend, layout, rank, flags, dist=None, torch=None, want=(), 
     out["halo_bytes_received"] = halo_bytes
     if exchange:
         if own_ctx:
-            ctx.check()                   # nobody else can: the context dies with this call
+            ctx.check(dist)               # nobody else can: the context dies with this call
         else:
-            ctx.note_step()
+            ctx.note_step(dist)
     return out

@@ -125,6 +125,12 @@ int TiledWorld::generateAsync(unsigned flags, uint8_t* d_blocks, float* d_height
 int TiledWorld::finishStep()
 {
     int32_t need = 0;
+    // the verdict is the MAXIMUM over the ranks: an oversized message is only seen by its sender and its receiver, and a rank that returned
+    // kRingOverflow alone would leave the others waiting in their next exchange (collective: every rank calls finishStep, or none)
+    if (comm && layout.worldSize() > 1 && !loopback) {
+        const ncclResult_t nr = ncclAllReduce(d_overflow, d_overflow, 1, ncclInt32, ncclMax, comm, sMain);
+        if (nr != ncclSuccess) return 1000 + (int)nr;
+    }
     TW_HIP(hipMemcpyAsync(&need, d_overflow, 4, hipMemcpyDeviceToHost, sMain));
     TW_HIP(hipStreamSynchronize(sMain));
     if (need) {

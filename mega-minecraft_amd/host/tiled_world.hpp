@@ -36,7 +36,8 @@ public:
     // kRingOverflow when a ring message did not fit its budget (the tile is then incomplete: construct with a larger wordsPerCell).
     int generate(unsigned flags, uint8_t* d_blocks, float* d_heightfields);
     // the same without the final synchronisation and overflow check: everything is enqueued on stream() and the caller pipelines steps;
-    // call finishStep() before trusting (or re-using) the outputs
+    // call finishStep() before trusting (or re-using) the outputs.  finishStep is collective over the communicator (the ring-overflow verdict
+    // is agreed with one 4-byte all-reduce, so that every rank returns kRingOverflow in the same call): all ranks call it the same number of times
     int generateAsync(unsigned flags, uint8_t* d_blocks, float* d_heightfields);
     int finishStep();
     hipStream_t stream() const { return sMain; }

@@ -109,6 +109,13 @@ class MMGen:
         self._check(self.lib.mmgen_erode_zones(self._p(gathered), zones, self._p(acc), ctypes.byref(mp), self._stream()), "mmgen_erode_zones")
         return (gathered, mp.value, acc) if want_acc else (gathered, mp.value)
 
+    def erosion_stalls(self):
+        """(persistent relaxations that gave up, zones the rescue pass relaxed) - process-wide counters (mmgen_erosion_stalls)."""
+        a, b = ctypes.c_longlong(0), ctypes.c_longlong(0)
+        self.lib.mmgen_erosion_stalls.argtypes = [ctypes.POINTER(ctypes.c_longlong), ctypes.POINTER(ctypes.c_longlong)]
+        self._check(self.lib.mmgen_erosion_stalls(ctypes.byref(a), ctypes.byref(b)), "mmgen_erosion_stalls")
+        return a.value, b.value
+
     def debug_erosion_stall(self, missing_workgroups, timeout_ms):
         """Test hook (mmgen_debug_erosion_stall): the next persistent relaxations are launched short; (0, 0) restores the defaults."""
         self.lib.mmgen_debug_erosion_stall.argtypes = [ctypes.c_int, ctypes.c_int]

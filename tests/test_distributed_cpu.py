@@ -322,3 +322,42 @@ def test_tile_checksum_is_position_dependent_and_goldens_cover_the_bench_layouts
             g = d.golden_tile_digests(world, *lay.region(r))
             assert g is not None and g.shape == (64 * 128,)
     assert d.golden_tile_digests(world, -32, -32, 64, 64) is not None and d.golden_tile_digests(world, 100, 100, 64, 64) is None
+
+
+def _verdict_worker(rank, world, port, outdir):
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    d = importlib.import_module("mega-minecraft_amd.distributed")
+    ctx = d.TileContext(d.TileLayout(0, 0, world, 1, 2, 2), rank, torch, "cpu")
+    raised = []
+    for step in range(3):
+        try:
+            ctx.check_previous()
+            raised.append(0)
+        except RuntimeError as e:
+            raised.append(1 if "ring message overflow" in str(e) else -1)
+        if rank == 1 and step == 1:
+            ctx.overflow[0] = 4242                 # what ring_pack / ring_unpack_messages leave on the two ranks of an oversized message
+        ctx.note_step(dist)
+    try:
+        ctx.check(dist)                            # (the synchronous form agrees too: nothing is pending after step 2's clean verdict)
+        raised.append(0)
+    except RuntimeError:
+        raised.append(1)
+    with open(os.path.join(outdir, f"verdict_{rank}.txt"), "w") as f:
+        f.write(" ".join(str(v) for v in raised))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_every_rank_raises_a_ring_overflow_in_the_same_step(tmp_path):
+    """world_size 3 in a row (gloo): only rank 1 sees an oversized message in step 1 - rank 2 is neither its sender nor its receiver.  The
+    step's overflow word is agreed over all ranks (TileContext._verdict: one MAX all-reduce behind the step), so ALL THREE raise at the
+    start of step 2 - nobody is left waiting in the next exchange for peers that have gone - and are clean again afterwards."""
+    import torch.multiprocessing as mp
+    mp.spawn(_verdict_worker, args=(3, _free_port(), str(tmp_path)), nprocs=3, join=True)
+    for r in range(3):
+        assert open(tmp_path / f"verdict_{r}.txt").read().split() == ["0", "0", "1", "0"], r      # (the raise clears the word on the rank that held it)

@@ -330,22 +330,34 @@ def test_erosion_launch_that_fills_the_chip_exactly(gen):
 
 
 @pytest.mark.gpu
-def test_starved_relaxation_gives_up_with_an_error_instead_of_hanging(gen):
-    """The relaxation's workgroups wait for each other on the device; a zone whose workgroups never all arrive (here: the launch is one
-    workgroup short, so the last zone's barrier cannot complete) must end the launch after the timeout and surface
-    MMGEN_ERROR_EROSION_STALL - never spin forever (the reference's host loop cannot stall: chunk.cu:682-705)."""
+def test_starved_relaxation_gives_up_and_the_rescue_pass_finishes_its_zones(gen, oracle):
+    """The relaxation's workgroups wait for each other on the device; a launch whose groups can never become complete (here: every group
+    waits for one workgroup more than it has) must end itself after the timeout - never spin forever - and the rescue pass enqueued behind
+    it must then relax the zones it abandoned: same planes, same pass count as a healthy launch, no error (the reference's host loop cannot
+    stall either: chunk.cu:682-705).  Per-stage ABI (one zone, two zones) and the region path (a stall inside mmgen_region_generate)."""
     import torch
     pos = gen.positions(gen.zone_area_coords(0, 0))
     hf, bw, g = gen.generate_heightfields(pos, gathered=True)
     packed = gen.pack_zone_planes(gen.generate_layers(g, bw, pos), hf)
     good, passes = gen.erode_zones(packed.clone())
+    region_good = gen.generate_region(3, 5, 2, 2)["blocks"].clone()
+    stalls0, rescued0 = gen.erosion_stalls()
     gen.debug_erosion_stall(1, 200)
     try:
-        with pytest.raises(RuntimeError, match="20002"):
-            gen.erode_zones(packed.clone())
+        again, p2 = gen.erode_zones(packed.clone())
+        two, p3 = gen.erode_zones(torch.cat([packed, packed], dim=0).contiguous())
+        region_again = gen.generate_region(3, 5, 2, 2)["blocks"].clone()
+        torch.cuda.synchronize()
     finally:
         gen.debug_erosion_stall(0, 0)
-    torch.cuda.synchronize()
-    # the device is fine afterwards: the same call succeeds again with the same result
-    again, p2 = gen.erode_zones(packed.clone())
     assert p2 == passes and torch.equal(again, good)
+    assert p3 == passes and torch.equal(two[0], good[0]) and torch.equal(two[1], good[0])
+    assert torch.equal(region_again, region_good)
+    ref = oracle.generate_region(3, 5, 2, 2, erosion=True, features=True, decorators=True)["blocks"]
+    assert np.array_equal(region_again.cpu().numpy(), ref)
+    gen.generate_region(3, 5, 1, 1)                      # (a region learns of its stall at its next call)
+    stalls1, rescued1 = gen.erosion_stalls()
+    assert stalls1 >= stalls0 + 3 and rescued1 >= rescued0 + 3, ((stalls0, rescued0), (stalls1, rescued1))
+    # healthy again afterwards, and a healthy launch rescues nothing
+    once, p4 = gen.erode_zones(packed.clone())
+    assert p4 == passes and torch.equal(once, good) and gen.erosion_stalls() == (stalls1, rescued1)
