@@ -18,6 +18,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <string>
+#include <vector>
 
 using namespace mmhost;
 using Clock = std::chrono::steady_clock;
@@ -188,6 +190,54 @@ int main(int argc, char** argv)
             std::printf("device-resident leg %d: %d chunks generated, %d meshed in %.1f ms (%.0f generated chunks/s incl. meshing); ring cells: %d computed, %d from the placement cache\n",
                         leg, generated, meshed, 1e3 * s, generated / s, computed, reused);
         }
+    }
+    {   // several lanes ("multi-GPU streaming"): one lane per GPU of the box, or two handles on the one GPU there is.  The
+        // same two legs as above; every drawable chunk must equal the mirror's (blocks, vertices, indices - across the lanes' borders too,
+        // where a mesh looks at a neighbour that another lane generated), then the same again device-resident against lane-free digests
+        int nDev = 0;
+        HipUtils::checkError("hipGetDeviceCount", (int)hipGetDeviceCount(&nDev));
+        std::vector<int> devices;
+        if (nDev >= 2) for (int d = 0; d < nDev && d < 8; ++d) devices.push_back(d); else devices = {0, 0};
+        const ivec2 first = {player.x - 13, player.y + 5};
+        RegionTerrain lanes2(4096, devices);
+        lanes2.init();
+        std::vector<int> share(devices.size(), 0);
+        for (int leg = 0; leg < 2; ++leg) {
+            lanes2.setCurrentChunkPos(leg == 0 ? first : player);
+            const auto t0 = Clock::now();
+            int generated = 0;
+            do { lanes2.tick(1.f / 60.f); generated += lanes2.lastGenerated; for (size_t l = 0; l < devices.size(); ++l) share[l] += lanes2.lastGeneratedOnLane((int)l); } while (!lanes2.allQueuesEmpty());
+            std::printf("%zu lanes (%s), leg %d: %d chunks generated in %.1f ms\n", devices.size(), nDev >= 2 ? "one per GPU" : "two handles on one GPU", leg, generated, 1e3 * secondsSince(t0));
+            bad += compare(stage, lanes2, leg == 0 ? first : player);
+        }
+        std::printf("  chunks per lane:");
+        for (size_t l = 0; l < devices.size(); ++l) { std::printf(" %d", share[l]); if (share[l] == 0) ++bad; }
+        std::printf("\n");
+        if (argc > 3) {
+            const std::string path = std::string(argv[3]) + ".lanes";
+            FILE* f = std::fopen(path.c_str(), "w");
+            if (!f) return 2;
+            for (Chunk* c : lanes2.getDrawableChunks()) mmhostWriteChunkDigest(f, c);
+            std::fclose(f);
+        }
+        RegionTerrain residentLanes(4096, devices), residentOne;
+        residentLanes.copyToHost = false; residentOne.copyToHost = false;
+        residentLanes.init(); residentOne.init();
+        residentLanes.setCurrentChunkPos(player); residentOne.setCurrentChunkPos(player);
+        do residentLanes.tick(1.f / 60.f); while (!residentLanes.allQueuesEmpty());
+        do residentOne.tick(1.f / 60.f); while (!residentOne.allQueuesEmpty());
+        int differ = 0;
+        const int r = Terrain::chunkVbosGenRadius;
+        for (int dz = -r; dz <= r; ++dz)
+            for (int dx = -r; dx <= r; ++dx) {
+                const ivec2 c = {player.x + dx, player.y + dz};
+                Chunk *a = residentLanes.findChunk(c), *b = residentOne.findChunk(c), *m = stage.findChunk(c);
+                if (!a || !b || !m || a->getState() != ChunkState::DRAWABLE || b->getState() != ChunkState::DRAWABLE) { ++differ; continue; }
+                const uint64_t da = residentLanes.deviceBlocksDigest(c), db = residentOne.deviceBlocksDigest(c);
+                if (da != db || da != mmhostDigest(m->blocks.data(), m->blocks.size()) || a->idxCount != b->idxCount || a->idxCount != m->idxCount) ++differ;
+            }
+        std::printf("device-resident, %zu lanes vs one lane vs the mirror: %d of %d drawable chunks differ (pool digests, index counts)\n", devices.size(), differ, (2 * r + 1) * (2 * r + 1));
+        bad += differ;
     }
     {   // chunk lifetime: a pool of 2 600 slots serves a 2 x 16-step walk (each step regenerates a strip, far chunks are destroyed and
         // their slots recycled); back at the first position everything was dropped and regenerated, and must equal the mirror's chunks

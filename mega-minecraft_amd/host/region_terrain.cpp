@@ -1,5 +1,6 @@
 // mmgen host side — region-batched streaming scheduler (see region_terrain.hpp).
 #include "region_terrain.hpp"
+#include "chunk_digest.hpp"
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
@@ -11,37 +12,93 @@ const ivec2 kDir4[4] = {{0, 1}, {1, 0}, {0, -1}, {-1, 0}};      // N (+z), E (+x
 #define RT_CALL(expr, msg) HipUtils::checkError(msg, (int)(expr), __LINE__)
 }  // namespace
 
-RegionTerrain::RegionTerrain(size_t poolChunks) : poolChunks(poolChunks) {}
+RegionTerrain::RegionTerrain(size_t poolChunks, std::vector<int> devices) : poolChunks(poolChunks)
+{
+    if (devices.empty()) {
+        int dev = 0;
+        RT_CALL(hipGetDevice(&dev), "hipGetDevice failed");
+        devices.push_back(dev);
+    }
+    lanes.resize(devices.size());
+    for (size_t i = 0; i < devices.size(); ++i) lanes[i].device = devices[i];
+}
+
+void RegionTerrain::use(const Lane& L) { RT_CALL(hipSetDevice(L.device), "hipSetDevice failed"); }
+
+// a blocking copy on the lane's stream (one lane: the null stream, like the hipMemcpy it replaces)
+void RegionTerrain::copySync(const Lane& L, void* dst, const void* src, size_t bytes, hipMemcpyKind kind, const char* what)
+{
+    RT_CALL(hipMemcpyAsync(dst, src, bytes, kind, L.stream), what);
+    RT_CALL(hipStreamSynchronize(L.stream), what);
+}
 
 RegionTerrain::~RegionTerrain()
 {
-    if (region) mmgen_region_destroy(region);
-    if (d_pool) (void)hipFree(d_pool);
-    if (d_stage) (void)hipFree(d_stage);
-    if (d_cacheFp) (void)hipFree(d_cacheFp);
-    if (d_cacheCfp) (void)hipFree(d_cacheCfp);
-    if (d_cacheCnt) (void)hipFree(d_cacheCnt);
-    if (d_idxWork) (void)hipFree(d_idxWork);
-    if (d_meshOut) (void)hipFree(d_meshOut);
-    if (d_meshWork) (void)hipFree(d_meshWork);
+    for (Lane& L : lanes) {
+        (void)hipSetDevice(L.device);
+        if (L.region) mmgen_region_destroy(L.region);
+        if (L.d_pool) (void)hipFree(L.d_pool);
+        if (L.d_stage) (void)hipFree(L.d_stage);
+        if (L.d_cacheFp) (void)hipFree(L.d_cacheFp);
+        if (L.d_cacheCfp) (void)hipFree(L.d_cacheCfp);
+        if (L.d_cacheCnt) (void)hipFree(L.d_cacheCnt);
+        if (L.d_idxWork) (void)hipFree(L.d_idxWork);
+        if (L.d_meshOut) (void)hipFree(L.d_meshOut);
+        if (L.d_meshWork) (void)hipFree(L.d_meshWork);
+        if (L.stream) (void)hipStreamDestroy(L.stream);
+    }
+    if (!lanes.empty()) (void)hipSetDevice(lanes[0].device);
 }
 
 void RegionTerrain::init()
 {
-    RT_CALL(mmgen_region_create(&region), "mmgen_region_create failed");
-    // the eroded layers of the zones the walk has touched stay on the device: a strip of new chunks then costs its own chunks, not a
-    // relaxation of every zone it grazes (include/mmgen.h mmgen_region_set_zone_cache)
-    if (zoneCacheZones > 0) RT_CALL(mmgen_region_set_zone_cache(region, zoneCacheZones), "mmgen_region_set_zone_cache failed");
-    RT_CALL(hipMalloc((void**)&d_pool, poolChunks * (size_t)devBlocksSize), "hipMalloc (chunk pool) failed");
-    freeSlots.resize(poolChunks);
-    for (size_t i = 0; i < poolChunks; ++i) freeSlots[i] = (int)(poolChunks - 1 - i);
-    // the cache also holds ring chunks that were computed for a region but never generated themselves: 2 x the pool is ample
-    cacheCells = 2 * poolChunks;
-    RT_CALL(hipMalloc((void**)&d_cacheFp, cacheCells * MMGEN_FP_CAP * sizeof(FeaturePlacement)), "hipMalloc (placement cache) failed");
-    RT_CALL(hipMalloc((void**)&d_cacheCfp, cacheCells * MMGEN_CFP_CAP * sizeof(CaveFeaturePlacement)), "hipMalloc (placement cache) failed");
-    RT_CALL(hipMalloc((void**)&d_cacheCnt, cacheCells * 2 * sizeof(int32_t)), "hipMalloc (placement cache) failed");
-    freePlacementSlots.resize(cacheCells);
-    for (size_t i = 0; i < cacheCells; ++i) freePlacementSlots[i] = (int)(cacheCells - 1 - i);
+    for (Lane& L : lanes) {
+        use(L);
+        RT_CALL(mmgen_init(L.device), "mmgen_init failed");
+        // one lane keeps the caller's null stream (the single-GPU scheduler as it always ran); several lanes get a stream each, so that two
+        // handles on ONE device overlap too
+        if (lanes.size() > 1) RT_CALL(hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking), "hipStreamCreate failed");
+        RT_CALL(mmgen_region_create(&L.region), "mmgen_region_create failed");
+        // the eroded layers of the zones the walk has touched stay on the device: a strip of new chunks then costs its own chunks, not a
+        // relaxation of every zone it grazes (include/mmgen.h mmgen_region_set_zone_cache)
+        if (zoneCacheZones > 0) RT_CALL(mmgen_region_set_zone_cache(L.region, zoneCacheZones), "mmgen_region_set_zone_cache failed");
+        RT_CALL(hipMalloc((void**)&L.d_pool, (poolChunks + (lanes.size() > 1 ? kGhostSlots : 0)) * (size_t)devBlocksSize), "hipMalloc (chunk pool) failed");
+        L.freeSlots.resize(poolChunks);
+        for (size_t i = 0; i < poolChunks; ++i) L.freeSlots[i] = (int)(poolChunks - 1 - i);
+        // the cache also holds ring chunks that were computed for a region but never generated themselves: 2 x the pool is ample
+        L.cacheCells = 2 * poolChunks;
+        RT_CALL(hipMalloc((void**)&L.d_cacheFp, L.cacheCells * MMGEN_FP_CAP * sizeof(FeaturePlacement)), "hipMalloc (placement cache) failed");
+        RT_CALL(hipMalloc((void**)&L.d_cacheCfp, L.cacheCells * MMGEN_CFP_CAP * sizeof(CaveFeaturePlacement)), "hipMalloc (placement cache) failed");
+        RT_CALL(hipMalloc((void**)&L.d_cacheCnt, L.cacheCells * 2 * sizeof(int32_t)), "hipMalloc (placement cache) failed");
+        L.freePlacementSlots.resize(L.cacheCells);
+        for (size_t i = 0; i < L.cacheCells; ++i) L.freePlacementSlots[i] = (int)(L.cacheCells - 1 - i);
+    }
+    use(lanes[0]);
+}
+
+void RegionTerrain::zoneCacheStats(long long& hits, long long& misses) const
+{
+    hits = misses = 0;
+    for (const Lane& L : lanes) { long long h = 0, m = 0; mmgen_region_zone_cache_stats(L.region, &h, &m); hits += h; misses += m; }
+}
+
+size_t RegionTerrain::poolInUse() const
+{
+    size_t n = 0;
+    for (const Lane& L : lanes) n += poolChunks - L.freeSlots.size();
+    return n;
+}
+
+uint64_t RegionTerrain::deviceBlocksDigest(ivec2 c)
+{
+    auto it = cells.find({c.x, c.y});
+    if (it == cells.end()) return 0;
+    Lane& L = lanes[it->second.lane];
+    use(L);
+    std::vector<uint8_t> h(devBlocksSize);
+    copySync(L, h.data(), L.d_pool + (size_t)it->second.slot * devBlocksSize, devBlocksSize, hipMemcpyDeviceToHost, "D2H (digest) failed");
+    use(lanes[0]);
+    return mmhostDigest(h.data(), h.size());
 }
 
 void* RegionTerrain::ensure(void*& p, size_t& cap, size_t bytes)
@@ -64,45 +121,48 @@ std::unordered_set<Chunk*> RegionTerrain::getDrawableChunks() { return drawable;
 
 // one region call: all stages for the rectangle; blocks go straight into pool slots when the next free slots are one contiguous run
 // (always, until something has been dropped), else through a staging buffer and one device copy per run of consecutive slots
-void RegionTerrain::generateRect(int cx0, int cz0, int nx, int nz)
+void RegionTerrain::generateRect(int lane, int cx0, int cz0, int nx, int nz)
 {
+    Lane& L = lanes[lane];
+    use(L);
+    hipStream_t st = L.stream;
     const size_t n = (size_t)nx * nz;
-    if (freeSlots.size() < n) HipUtils::checkError("RegionTerrain: chunk pool exhausted (raise poolChunks or lower dropRadius)", 2, __LINE__);
+    if (L.freeSlots.size() < n) HipUtils::checkError("RegionTerrain: chunk pool exhausted (raise poolChunks or lower dropRadius)", 2, __LINE__);
     // n consecutive free slots if the pool has such a run anywhere (lowest first; the list is sorted descending, so a run of ascending
     // slots is a stretch of the vector read backwards): the region then writes its blocks straight into the pool.  Only a pool without
     // one is served from the lowest free slots through the staging buffer (one device copy per run of consecutive slots below).
     std::vector<int> slots(n);
     bool contiguous = false;
     {
-        const size_t m = freeSlots.size();
-        size_t run = 1, endAt = m;                     // freeSlots[endAt - 1 .. endAt - 1 + n) is the run, lowest slot at the highest index
+        const size_t m = L.freeSlots.size();
+        size_t run = 1, endAt = m;                     // L.freeSlots[endAt - 1 .. endAt - 1 + n) is the run, lowest slot at the highest index
         for (size_t i = m; i-- > 0;) {
-            run = (i + 1 < m && freeSlots[i] == freeSlots[i + 1] + 1) ? run + 1 : 1;
+            run = (i + 1 < m && L.freeSlots[i] == L.freeSlots[i + 1] + 1) ? run + 1 : 1;
             if (run == n) { endAt = i + 1; break; }
         }
         if (endAt != m || n == 1) {
             const size_t lo = (n == 1) ? m - 1 : endAt - 1;
-            for (size_t i = 0; i < n; ++i) slots[i] = freeSlots[lo + n - 1 - i];
-            freeSlots.erase(freeSlots.begin() + lo, freeSlots.begin() + lo + n);
+            for (size_t i = 0; i < n; ++i) slots[i] = L.freeSlots[lo + n - 1 - i];
+            L.freeSlots.erase(L.freeSlots.begin() + lo, L.freeSlots.begin() + lo + n);
             contiguous = true;
         } else {
-            for (size_t i = 0; i < n; ++i) { slots[i] = freeSlots.back(); freeSlots.pop_back(); }
+            for (size_t i = 0; i < n; ++i) { slots[i] = L.freeSlots.back(); L.freeSlots.pop_back(); }
             contiguous = true;
             for (size_t i = 1; i < n && contiguous; ++i) contiguous = slots[i] == slots[i - 1] + 1;
         }
     }
-    uint8_t* dst = d_pool + (size_t)slots[0] * devBlocksSize;
+    uint8_t* dst = L.d_pool + (size_t)slots[0] * devBlocksSize;
     if (!contiguous) {
-        if (stageChunks < n) {
-            if (d_stage) RT_CALL(hipFree(d_stage), "hipFree failed");
-            RT_CALL(hipMalloc((void**)&d_stage, n * (size_t)devBlocksSize), "hipMalloc (stage) failed");
-            stageChunks = n;
+        if (L.stageChunks < n) {
+            if (L.d_stage) RT_CALL(hipFree(L.d_stage), "hipFree failed");
+            RT_CALL(hipMalloc((void**)&L.d_stage, n * (size_t)devBlocksSize), "hipMalloc (stage) failed");
+            L.stageChunks = n;
         }
-        dst = d_stage;
+        dst = L.d_stage;
     }
     const unsigned flags = MMGEN_REGION_EROSION | MMGEN_REGION_FEATURES | MMGEN_REGION_DECORATORS;
     if (!cachePlacements) {
-        RT_CALL(mmgen_region_generate(region, cx0, cz0, nx, nz, flags, dst, nullptr, nullptr), "mmgen_region_generate failed");
+        RT_CALL(mmgen_region_generate(L.region, cx0, cz0, nx, nz, flags, dst, nullptr, st), "mmgen_region_generate failed");
     } else {
         // two-phase region: ring cells whose placement lists are cached are masked out of the compute list (no caves, no placements
         // for them) and their lists are copied in; everything this region computed goes into the cache for the regions to come
@@ -113,37 +173,37 @@ void RegionTerrain::generateRect(int cx0, int cz0, int nx, int nz)
             for (int x = 0; x < gw; ++x) {
                 const int cell = x + gw * z;
                 const bool inR = x >= 3 && x < nx + 3 && z >= 3 && z < nz + 3;
-                auto it = placementSlot.find({cx0 - 3 + x, cz0 - 3 + z});
-                if (it != placementSlot.end() && !inR) { mask[cell] = 0; impSrc.push_back(it->second); impDst.push_back(cell); ++lastRingReused; }
-                else if (it == placementSlot.end()) {
-                    if (freePlacementSlots.empty()) continue;              // cache full: this cell is simply recomputed next time
-                    const int slot = freePlacementSlots.back(); freePlacementSlots.pop_back();
-                    placementSlot[{cx0 - 3 + x, cz0 - 3 + z}] = slot;
+                auto it = L.placementSlot.find({cx0 - 3 + x, cz0 - 3 + z});
+                if (it != L.placementSlot.end() && !inR) { mask[cell] = 0; impSrc.push_back(it->second); impDst.push_back(cell); ++lastRingReused; }
+                else if (it == L.placementSlot.end()) {
+                    if (L.freePlacementSlots.empty()) continue;              // cache full: this cell is simply recomputed next time
+                    const int slot = L.freePlacementSlots.back(); L.freePlacementSlots.pop_back();
+                    L.placementSlot[{cx0 - 3 + x, cz0 - 3 + z}] = slot;
                     expSrc.push_back(cell); expDst.push_back(slot);
                     if (!inR) ++lastRingComputed;
                 }
             }
-        RT_CALL(mmgen_region_begin(region, cx0, cz0, nx, nz, flags, mask.data(), nullptr), "mmgen_region_begin failed");
+        RT_CALL(mmgen_region_begin(L.region, cx0, cz0, nx, nz, flags, mask.data(), st), "mmgen_region_begin failed");
         FeaturePlacement* gfp; CaveFeaturePlacement* gcfp; int32_t* gcnt; int gx0, gz0, w, h;
-        RT_CALL(mmgen_region_placement_buffers(region, &gfp, &gcfp, &gcnt, &gx0, &gz0, &w, &h), "mmgen_region_placement_buffers failed");
+        RT_CALL(mmgen_region_placement_buffers(L.region, &gfp, &gcfp, &gcnt, &gx0, &gz0, &w, &h), "mmgen_region_placement_buffers failed");
         const size_t ni = impSrc.size(), ne = expSrc.size();
-        int32_t* wk = (int32_t*)ensure(d_idxWork, idxWorkCap, (2 * ni + 2 * ne + 4) * sizeof(int32_t));
+        int32_t* wk = (int32_t*)ensure(L.d_idxWork, L.idxWorkCap, (2 * ni + 2 * ne + 4) * sizeof(int32_t));
         if (ni + ne) {                                          // the four index lists in one copy
             std::vector<int32_t> lists;
             lists.reserve(2 * (ni + ne));
             lists.insert(lists.end(), impSrc.begin(), impSrc.end()); lists.insert(lists.end(), impDst.begin(), impDst.end());
             lists.insert(lists.end(), expSrc.begin(), expSrc.end()); lists.insert(lists.end(), expDst.begin(), expDst.end());
-            RT_CALL(hipMemcpy(wk, lists.data(), lists.size() * 4, hipMemcpyHostToDevice), "H2D failed");
+            copySync(L, wk, lists.data(), lists.size() * 4, hipMemcpyHostToDevice, "H2D failed");
         }
-        if (ni) RT_CALL(mmgen_copy_placements(d_cacheFp, d_cacheCfp, d_cacheCnt, wk, gfp, gcfp, gcnt, wk + ni, (int)ni, nullptr), "mmgen_copy_placements failed");
-        if (ne) RT_CALL(mmgen_copy_placements(gfp, gcfp, gcnt, wk + 2 * ni, d_cacheFp, d_cacheCfp, d_cacheCnt, wk + 2 * ni + ne, (int)ne, nullptr), "mmgen_copy_placements failed");
-        RT_CALL(mmgen_region_finish(region, dst, nullptr, nullptr, nullptr, nullptr), "mmgen_region_finish failed");
+        if (ni) RT_CALL(mmgen_copy_placements(L.d_cacheFp, L.d_cacheCfp, L.d_cacheCnt, wk, gfp, gcfp, gcnt, wk + ni, (int)ni, st), "mmgen_copy_placements failed");
+        if (ne) RT_CALL(mmgen_copy_placements(gfp, gcfp, gcnt, wk + 2 * ni, L.d_cacheFp, L.d_cacheCfp, L.d_cacheCnt, wk + 2 * ni + ne, (int)ne, st), "mmgen_copy_placements failed");
+        RT_CALL(mmgen_region_finish(L.region, dst, nullptr, nullptr, nullptr, st), "mmgen_region_finish failed");
     }
     if (!contiguous)
         for (size_t i = 0; i < n;) {
             size_t j = i + 1;
             while (j < n && slots[j] == slots[j - 1] + 1) ++j;
-            RT_CALL(hipMemcpyAsync(d_pool + (size_t)slots[i] * devBlocksSize, d_stage + i * (size_t)devBlocksSize, (j - i) * (size_t)devBlocksSize, hipMemcpyDeviceToDevice, nullptr),
+            RT_CALL(hipMemcpyAsync(L.d_pool + (size_t)slots[i] * devBlocksSize, L.d_stage + i * (size_t)devBlocksSize, (j - i) * (size_t)devBlocksSize, hipMemcpyDeviceToDevice, st),
                     "D2D into pool slots failed");
             i = j;
         }
@@ -152,34 +212,34 @@ void RegionTerrain::generateRect(int cx0, int cz0, int nx, int nz)
     if (copyToHost && packedTransfer) {
         // wire format: count, prefix on the host, fill, one copy of ~10 KB per chunk, decode into the Chunk objects below
         const size_t oSlots = 0, oRuns = oSlots + n * 4, oBytes = oRuns + n * 512, oOff = (oBytes + n * 4 + 7) / 8 * 8, total = oOff + n * 8;
-        char* w = (char*)ensure(d_meshWork, meshWorkCap, total);
-        RT_CALL(hipMemcpy(w + oSlots, slots.data(), n * 4, hipMemcpyHostToDevice), "H2D failed");
-        RT_CALL(mmgen_pack_count(d_pool, (int32_t*)(w + oSlots), (int)n, (uint16_t*)(w + oRuns), (uint32_t*)(w + oBytes), nullptr), "mmgen_pack_count failed");
+        char* w = (char*)ensure(L.d_meshWork, L.meshWorkCap, total);
+        copySync(L, w + oSlots, slots.data(), n * 4, hipMemcpyHostToDevice, "H2D failed");
+        RT_CALL(mmgen_pack_count(L.d_pool, (int32_t*)(w + oSlots), (int)n, (uint16_t*)(w + oRuns), (uint32_t*)(w + oBytes), st), "mmgen_pack_count failed");
         packBytes.resize(n); packOff.resize(n);
-        RT_CALL(hipMemcpy(packBytes.data(), w + oBytes, n * 4, hipMemcpyDeviceToHost), "D2H failed");
+        copySync(L, packBytes.data(), w + oBytes, n * 4, hipMemcpyDeviceToHost, "D2H failed");
         uint64_t totalBytes = 0;
         for (size_t i = 0; i < n; ++i) { packOff[i] = totalBytes; totalBytes += packBytes[i]; }
-        RT_CALL(hipMemcpy(w + oOff, packOff.data(), n * 8, hipMemcpyHostToDevice), "H2D failed");
-        char* o = (char*)ensure(d_meshOut, meshOutCap, totalBytes + 64);
-        RT_CALL(mmgen_pack_fill(d_pool, (int32_t*)(w + oSlots), (int)n, (uint16_t*)(w + oRuns), (uint64_t*)(w + oOff), (uint8_t*)o, nullptr), "mmgen_pack_fill failed");
-        hostStage.resize(totalBytes);
-        RT_CALL(hipMemcpy(hostStage.data(), o, totalBytes, hipMemcpyDeviceToHost), "D2H packed blocks failed");
+        copySync(L, w + oOff, packOff.data(), n * 8, hipMemcpyHostToDevice, "H2D failed");
+        char* o = (char*)ensure(L.d_meshOut, L.meshOutCap, totalBytes + 64);
+        RT_CALL(mmgen_pack_fill(L.d_pool, (int32_t*)(w + oSlots), (int)n, (uint16_t*)(w + oRuns), (uint64_t*)(w + oOff), (uint8_t*)o, st), "mmgen_pack_fill failed");
+        L.hostStage.resize(totalBytes);
+        copySync(L, L.hostStage.data(), o, totalBytes, hipMemcpyDeviceToHost, "D2H packed blocks failed");
         lastBlockBytesD2H += totalBytes;
     } else if (copyToHost) {
-        hostStage.resize(n * (size_t)devBlocksSize);
+        L.hostStage.resize(n * (size_t)devBlocksSize);
         for (size_t i = 0; i < n;) {
             size_t j = i + 1;
             while (j < n && slots[j] == slots[j - 1] + 1) ++j;
-            RT_CALL(hipMemcpy(hostStage.data() + i * (size_t)devBlocksSize, d_pool + (size_t)slots[i] * devBlocksSize, (j - i) * (size_t)devBlocksSize, hipMemcpyDeviceToHost),
-                    "D2H blocks failed");
+            copySync(L, L.hostStage.data() + i * (size_t)devBlocksSize, L.d_pool + (size_t)slots[i] * devBlocksSize, (j - i) * (size_t)devBlocksSize, hipMemcpyDeviceToHost,
+                     "D2H blocks failed");
             i = j;
         }
-        lastBlockBytesD2H += hostStage.size();
+        lastBlockBytesD2H += L.hostStage.size();
     } else {
         // device resident: nothing on the host reads these blocks.  The mesher's calls come behind the region's on the same (null)
         // stream and end with a synchronisation; a tick without meshing synchronises at its end (tick): errors surface there, and the
         // 33 Chunk objects of a strip are made while the GPU generates their blocks instead of after it
-        generationOutstanding = true;
+        L.generationOutstanding = true;
     }
     for (int z = 0; z < nz; ++z)
         for (int x = 0; x < nx; ++x) {
@@ -189,11 +249,12 @@ void RegionTerrain::generateRect(int cx0, int cz0, int nx, int nz)
             cell.chunk = std::make_unique<Chunk>(c);
             cell.slot = slots[i];
             cell.meshed = false;
+            cell.lane = lane;
             if (copyToHost && packedTransfer) {
-                if (mmgen_unpack_chunk_host(hostStage.data() + packOff[i], packBytes[i], cell.chunk->blocks.data()) != 0)
+                if (mmgen_unpack_chunk_host(L.hostStage.data() + packOff[i], packBytes[i], cell.chunk->blocks.data()) != 0)
                     HipUtils::checkError("RegionTerrain: malformed packed chunk", 2, __LINE__);
             } else if (copyToHost) {
-                std::memcpy(cell.chunk->blocks.data(), hostStage.data() + i * devBlocksSize, devBlocksSize);
+                std::memcpy(cell.chunk->blocks.data(), L.hostStage.data() + i * devBlocksSize, devBlocksSize);
             }
             cell.chunk->setState(ChunkState::FILLED);
             Chunk* cp = cell.chunk.get();
@@ -206,6 +267,8 @@ void RegionTerrain::generateRect(int cx0, int cz0, int nx, int nz)
             }
         }
     lastGenerated += (int)n;
+    L.lastGenerated += (int)n;
+    L.totalGenerated += (long long)n;
     lastRegions += 1;
 }
 
@@ -219,34 +282,63 @@ void RegionTerrain::dropFarChunks()
         for (int k = 0; k < 4; ++k)
             if (c->neighbors[k]) c->neighbors[k]->neighbors[(k + 2) % 4] = nullptr;
         drawable.erase(c);
-        freeSlots.push_back(it->second.slot);
+        lanes[it->second.lane].freeSlots.push_back(it->second.slot);
         it = cells.erase(it);
         ++lastDropped;
     }
-    if (lastDropped) std::sort(freeSlots.begin(), freeSlots.end(), [](int a, int b) { return a > b; });
-    for (auto it = placementSlot.begin(); it != placementSlot.end();) {
-        const int dx = it->first.first - plannedFor.x, dz = it->first.second - plannedFor.y;
-        if (std::max(std::abs(dx), std::abs(dz)) <= dropRadius + 3) { ++it; continue; }
-        freePlacementSlots.push_back(it->second);
-        it = placementSlot.erase(it);
+    for (Lane& L : lanes) {
+        if (lastDropped) std::sort(L.freeSlots.begin(), L.freeSlots.end(), [](int a, int b) { return a > b; });
+        for (auto it = L.placementSlot.begin(); it != L.placementSlot.end();) {
+            const int dx = it->first.first - plannedFor.x, dz = it->first.second - plannedFor.y;
+            if (std::max(std::abs(dx), std::abs(dz)) <= dropRadius + 3) { ++it; continue; }
+            L.freePlacementSlots.push_back(it->second);
+            it = L.placementSlot.erase(it);
+        }
     }
 }
 
-// every unmeshed chunk of the drawable square whose four neighbours exist: one count + fill pair over the pool
+// every unmeshed chunk of the drawable square whose four neighbours exist: one count + fill pair over each lane's pool
 void RegionTerrain::meshReady()
 {
+    if (lanes.size() > 1) {
+        // a lane's meshes look at neighbours that another lane may have generated in this very tick: all generation first
+        for (Lane& L : lanes) { use(L); RT_CALL(hipStreamSynchronize(L.stream), "region generation failed"); L.generationOutstanding = false; }
+    }
+    for (int l = 0; l < (int)lanes.size(); ++l) meshLane(l);
+    use(lanes[0]);
+}
+
+void RegionTerrain::meshLane(int lane)
+{
+    Lane& L = lanes[lane];
+    use(L);
+    hipStream_t st = L.stream;
     std::vector<Cell*> work;
     std::vector<int32_t> meta;          // per chunk: slot, 4 neighbour slots, world block x, z
+    std::map<std::pair<int, int>, int> ghostOf;      // a foreign neighbour's position -> its ghost slot in this lane's pool (this tick)
     const int r = chunkVbosGenRadius;
     for (int dz = -r; dz <= r; ++dz)
         for (int dx = -r; dx <= r; ++dx) {
             auto it = cells.find({plannedFor.x + dx, plannedFor.y + dz});
-            if (it == cells.end() || it->second.meshed) continue;
+            if (it == cells.end() || it->second.meshed || it->second.lane != lane) continue;
             int32_t nb[4];
             bool all = true;
             for (int k = 0; k < 4 && all; ++k) {
-                auto n = cells.find({plannedFor.x + dx + kDir4[k].x, plannedFor.y + dz + kDir4[k].y});
-                if (n == cells.end()) all = false; else nb[k] = n->second.slot;
+                const std::pair<int, int> np = {plannedFor.x + dx + kDir4[k].x, plannedFor.y + dz + kDir4[k].y};
+                auto n = cells.find(np);
+                if (n == cells.end()) { all = false; break; }
+                if (n->second.lane == lane) { nb[k] = n->second.slot; continue; }
+                // the one-chunk overlap between lanes: the neighbour's blocks, device to device, into a ghost slot behind this lane's pool
+                auto g = ghostOf.find(np);
+                if (g == ghostOf.end()) {
+                    if (ghostOf.size() >= kGhostSlots) { all = false; break; }      // (more foreign neighbours than ghost slots in one tick: next tick)
+                    const int gs = (int)(poolChunks + ghostOf.size());
+                    const Lane& O = lanes[n->second.lane];
+                    RT_CALL(hipMemcpyPeerAsync(L.d_pool + (size_t)gs * devBlocksSize, L.device, O.d_pool + (size_t)n->second.slot * devBlocksSize, O.device,
+                                               devBlocksSize, st), "peer copy of a neighbour chunk failed");
+                    g = ghostOf.emplace(np, gs).first;
+                }
+                nb[k] = g->second;
             }
             if (!all) continue;         // terrain.cpp:569-585: VBOs only once all four neighbours are filled
             work.push_back(&it->second);
@@ -260,7 +352,7 @@ void RegionTerrain::meshReady()
     // device work area: chunk idx [n], neighbour idx [n][4], positions [n][2], column counts [n][256], chunk counts [n], offsets [n] (u64)
     const size_t oIdx = 0, oNb = oIdx + (size_t)n * 4, oPos = oNb + (size_t)n * 16, oCol = oPos + (size_t)n * 8, oCnt = oCol + (size_t)n * 1024,
                  oOff = (oCnt + (size_t)n * 4 + 7) / 8 * 8, total = oOff + (size_t)n * 8;
-    char* w = (char*)ensure(d_meshWork, meshWorkCap, total);
+    char* w = (char*)ensure(L.d_meshWork, L.meshWorkCap, total);
     // the three input arrays are adjacent in the work area: one copy (a blocking copy from pageable memory is 20 - 30 us of a 1.5 ms tick)
     std::vector<int32_t> hIn((size_t)n * 7);
     int32_t *hIdx = hIn.data(), *hNb = hIdx + n, *hPos = hNb + (size_t)n * 4;
@@ -270,32 +362,34 @@ void RegionTerrain::meshReady()
         hPos[2 * i] = meta[7 * i + 5]; hPos[2 * i + 1] = meta[7 * i + 6];
     }
     static_assert(sizeof(int32_t) == 4, "layout of the work area");
-    RT_CALL(hipMemcpy(w + oIdx, hIn.data(), (size_t)n * 28, hipMemcpyHostToDevice), "H2D failed");
-    RT_CALL(mmgen_mesh_count(d_pool, (int32_t*)(w + oIdx), (int32_t*)(w + oNb), n, (uint32_t*)(w + oCol), (uint32_t*)(w + oCnt), nullptr), "mmgen_mesh_count failed");
+    copySync(L, w + oIdx, hIn.data(), (size_t)n * 28, hipMemcpyHostToDevice, "H2D failed");
+    RT_CALL(mmgen_mesh_count(L.d_pool, (int32_t*)(w + oIdx), (int32_t*)(w + oNb), n, (uint32_t*)(w + oCol), (uint32_t*)(w + oCnt), st), "mmgen_mesh_count failed");
     std::vector<uint32_t> cnt(n);
-    RT_CALL(hipMemcpy(cnt.data(), w + oCnt, (size_t)n * 4, hipMemcpyDeviceToHost), "D2H failed");
+    copySync(L, cnt.data(), w + oCnt, (size_t)n * 4, hipMemcpyDeviceToHost, "D2H failed");
     std::vector<uint64_t> off(n);
     uint64_t totalVerts = 0;
     for (int i = 0; i < n; ++i) { off[i] = totalVerts; totalVerts += cnt[i]; }
-    RT_CALL(hipMemcpy(w + oOff, off.data(), (size_t)n * 8, hipMemcpyHostToDevice), "H2D failed");
+    copySync(L, w + oOff, off.data(), (size_t)n * 8, hipMemcpyHostToDevice, "H2D failed");
     const size_t vb = (size_t)totalVerts * sizeof(Vertex), ib = (size_t)totalVerts / 4 * 6 * sizeof(unsigned int);
-    char* o = (char*)ensure(d_meshOut, meshOutCap, vb + ib + 64);
+    char* o = (char*)ensure(L.d_meshOut, L.meshOutCap, vb + ib + 64);
     if (totalVerts)
-        RT_CALL(mmgen_mesh_fill(d_pool, (int32_t*)(w + oIdx), (int32_t*)(w + oNb), (int32_t*)(w + oPos), n, (uint32_t*)(w + oCol), (uint64_t*)(w + oOff),
-                                (Vertex*)o, (uint32_t*)(o + vb), nullptr),
+        RT_CALL(mmgen_mesh_fill(L.d_pool, (int32_t*)(w + oIdx), (int32_t*)(w + oNb), (int32_t*)(w + oPos), n, (uint32_t*)(w + oCol), (uint64_t*)(w + oOff),
+                                (Vertex*)o, (uint32_t*)(o + vb), st),
                 "mmgen_mesh_fill failed");
     if (copyToHost && totalVerts) {
-        hostStage.resize(vb + ib);
-        RT_CALL(hipMemcpy(hostStage.data(), o, vb + ib, hipMemcpyDeviceToHost), "D2H mesh failed");
+        L.hostStage.resize(vb + ib);
+        copySync(L, L.hostStage.data(), o, vb + ib, hipMemcpyDeviceToHost, "D2H mesh failed");
+    } else if (L.stream) {
+        RT_CALL(hipStreamSynchronize(L.stream), "mesh build failed");
     } else {
         RT_CALL(hipDeviceSynchronize(), "mesh build failed");
     }
-    generationOutstanding = false;      // (either branch waited for everything the null stream held)
+    L.generationOutstanding = false;    // (either branch waited for everything the lane's stream held)
     for (int i = 0; i < n; ++i) {
         Chunk* c = work[i]->chunk.get();
         if (copyToHost) {
-            const Vertex* v = (const Vertex*)hostStage.data() + off[i];
-            const unsigned int* ix = (const unsigned int*)(hostStage.data() + vb) + off[i] / 4 * 6;
+            const Vertex* v = (const Vertex*)L.hostStage.data() + off[i];
+            const unsigned int* ix = (const unsigned int*)(L.hostStage.data() + vb) + off[i] / 4 * 6;
             c->verts.assign(v, v + cnt[i]);
             c->idx.assign(ix, ix + (size_t)cnt[i] / 4 * 6);
         }
@@ -311,6 +405,7 @@ void RegionTerrain::tick(float)
 {
     lastGenerated = lastMeshed = lastRegions = lastDropped = lastRingReused = lastRingComputed = 0;
     lastBlockBytesD2H = 0;
+    for (Lane& L : lanes) L.lastGenerated = 0;
     if (!planned || !(plannedFor == currentChunkPos)) { plannedFor = currentChunkPos; planned = true; pending = true; dropFarChunks(); }
     if (!pending) return;
 
@@ -336,13 +431,29 @@ void RegionTerrain::tick(float)
                 if (!full) break;
             }
             if (nx * nz > budget) { nz = std::max(1, budget / nx); if (nx * nz > budget) nx = budget; }
-            generateRect(plannedFor.x - R + x, plannedFor.y - R + z, nx, nz);
+            // deal the rectangle to the lanes: a large one is cut into one z-strip per lane (every strip a region call of its own: it builds
+            // the placement ring and the erosion padding it needs itself), a small one goes to the lane with the least work this tick
+            const int nl = (int)lanes.size();
+            const int strips = (nl > 1 && nz >= nl && nx * nz >= 64 * nl) ? nl : 1;
+            for (int k = 0; k < strips; ++k) {
+                const int z0 = (int)((long long)nz * k / strips), z1 = (int)((long long)nz * (k + 1) / strips);
+                int lane = 0;
+                for (int l = 1; l < nl; ++l)
+                    if (lanes[l].lastGenerated < lanes[lane].lastGenerated || (lanes[l].lastGenerated == lanes[lane].lastGenerated && lanes[l].totalGenerated < lanes[lane].totalGenerated)) lane = l;
+                generateRect(lane, plannedFor.x - R + x, plannedFor.y - R + z + z0, nx, z1 - z0);
+            }
             for (int j = 0; j < nz; ++j) for (int i = 0; i < nx; ++i) missing[(size_t)(x + i) + (size_t)S * (z + j)] = 0;
             numMissing -= nx * nz;
             budget -= nx * nz;
         }
     meshReady();
-    if (generationOutstanding) { RT_CALL(hipDeviceSynchronize(), "region generation failed"); generationOutstanding = false; }
+    for (Lane& L : lanes)
+        if (L.generationOutstanding) {
+            use(L);
+            if (L.stream) RT_CALL(hipStreamSynchronize(L.stream), "region generation failed"); else RT_CALL(hipDeviceSynchronize(), "region generation failed");
+            L.generationOutstanding = false;
+        }
+    use(lanes[0]);
     pending = numMissing > 0;
 }
 

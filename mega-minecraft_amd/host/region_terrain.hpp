@@ -14,6 +14,13 @@
 // Chunk lifetime (the reference never frees, terrain.cpp:63 DESTROY_ZONES is off): chunks farther than
 // `dropRadius` from the player are destroyed and their pool slots recycled, so a bounded pool serves an unbounded walk; a chunk that
 // is needed again is simply regenerated (generation is a pure function of position, so it comes back identical).
+// SEVERAL GPUs ("multi-GPU streaming"): `RegionTerrain(pool, devices)` keeps one LANE per listed device - its own region
+// handle (zone cache, placement ring), chunk pool, placement cache and stream.  A tick deals its rectangles to the lanes (large ones are
+// cut into one z-strip per lane first); a region call builds the 3-chunk placement ring and the erosion padding it needs itself, so lanes
+// exchange nothing while they generate.  Meshing looks one chunk across: a chunk is meshed by the lane that owns it, and neighbours owned
+// by another lane are copied device-to-device (hipMemcpyPeerAsync) into ghost slots behind that lane's pool first.  Which lane made a
+// chunk can never show in it (a chunk is a function of its position): mmgen_region_terrain_demo holds a two-lane run - two handles on one
+// GPU where there is only one - to the single-lane run and to the oracle's digests.
 #pragma once
 #include <map>
 #include <memory>
@@ -26,7 +33,8 @@ namespace mmhost {
 class RegionTerrain {
 public:
     static constexpr int chunkVbosGenRadius = 16;                 // terrain.cpp:65
-    explicit RegionTerrain(size_t poolChunks = 8192);
+    // devices: one lane per entry (HIP device ordinals; an ordinal may repeat: several handles on one GPU).  Empty = the current device.
+    explicit RegionTerrain(size_t poolChunks = 8192, std::vector<int> devices = {});
     ~RegionTerrain();
     void init();
     void tick(float deltaTime);
@@ -43,44 +51,58 @@ public:
     int dropRadius = 40;                  // chunks farther than this (Chebyshev) from the player are destroyed; = chunkMaxGenRadius of the reference
     bool copyToHost = true;               // false: blocks and meshes stay on the device (renderer interop), Chunk::blocks / verts stay empty
     int zoneCacheZones = 128;             // eroded zones kept on the device (151 MB; set before init(); 0 = relax every covering zone of every region anew)
-    void zoneCacheStats(long long& hits, long long& misses) const { mmgen_region_zone_cache_stats(region, &hits, &misses); }
+    void zoneCacheStats(long long& hits, long long& misses) const;
     bool cachePlacements = true;          // keep the placement lists of generated chunks and feed them back as ring cells of later regions
     bool packedTransfer = true;           // blocks cross PCIe in the run-length wire format (mmgen_pack_*, ~10 KB instead of 96 KB per chunk)
     size_t lastBlockBytesD2H = 0;         // bytes of block data copied to the host by the last tick
     // last tick's accounting
     int lastGenerated = 0, lastMeshed = 0, lastRegions = 0, lastDropped = 0, lastRingReused = 0, lastRingComputed = 0;
-    size_t poolInUse() const { return poolChunks - freeSlots.size(); }
-    // device-side results of the last mesh pass (valid until the next tick)
-    const Vertex* deviceVerts() const { return (const Vertex*)d_meshOut; }
+    size_t poolInUse() const;
+    int numLanes() const { return (int)lanes.size(); }
+    int lastGeneratedOnLane(int lane) const { return lanes[lane].lastGenerated; }
+    // device-side results of lane 0's last mesh pass (valid until the next tick)
+    const Vertex* deviceVerts() const { return (const Vertex*)lanes[0].d_meshOut; }
+    // test hook: digest (host/chunk_digest.hpp) of a chunk's blocks as they lie in its lane's pool - what a device-resident consumer would read
+    uint64_t deviceBlocksDigest(ivec2 worldChunkPos);
 
 private:
-    struct Cell { std::unique_ptr<Chunk> chunk; int slot; bool meshed; };
+    struct Cell { std::unique_ptr<Chunk> chunk; int slot; bool meshed; int lane; };
     std::map<std::pair<int, int>, Cell> cells;
     std::unordered_set<Chunk*> drawable;
     ivec2 currentChunkPos{0, 0}, plannedFor{0, 0};
     bool planned = false, pending = true;
+    size_t poolChunks;                    // per lane
+    static constexpr size_t kGhostSlots = 512;      // per lane, behind the pool: other lanes' chunks that this lane's meshes look at in one tick
 
-    mmgen_region* region = nullptr;
-    uint8_t* d_pool = nullptr;            // [poolChunks][98304]
-    size_t poolChunks;
-    bool generationOutstanding = false;   // a device-resident region call whose completion nothing has waited for yet
-    std::vector<int> freeSlots;           // sorted descending: slots are handed out in ascending order, so fresh pools fill contiguously
-    uint8_t* d_stage = nullptr; size_t stageChunks = 0;      // region output when the free slots are not one contiguous run
-    void* d_meshOut = nullptr; size_t meshOutCap = 0;
-    void* d_meshWork = nullptr; size_t meshWorkCap = 0;
-    std::vector<uint8_t> hostStage;
-
-    // placement-list cache (device): one slot per chunk whose lists are known, same per-cell layout as the region's placement grid
-    std::map<std::pair<int, int>, int> placementSlot;
-    std::vector<int> freePlacementSlots;
-    FeaturePlacement* d_cacheFp = nullptr;
-    CaveFeaturePlacement* d_cacheCfp = nullptr;
-    int32_t* d_cacheCnt = nullptr;
-    size_t cacheCells = 0;
-    void* d_idxWork = nullptr; size_t idxWorkCap = 0;
-    void generateRect(int cx0, int cz0, int nx, int nz);
+    struct Lane {
+        int device = 0;
+        hipStream_t stream = nullptr;
+        mmgen_region* region = nullptr;
+        uint8_t* d_pool = nullptr;            // [poolChunks + kGhostSlots][98304]
+        bool generationOutstanding = false;   // a device-resident region call whose completion nothing has waited for yet
+        std::vector<int> freeSlots;           // sorted descending: slots are handed out in ascending order, so fresh pools fill contiguously
+        uint8_t* d_stage = nullptr; size_t stageChunks = 0;      // region output when the free slots are not one contiguous run
+        void* d_meshOut = nullptr; size_t meshOutCap = 0;
+        void* d_meshWork = nullptr; size_t meshWorkCap = 0;
+        std::vector<uint8_t> hostStage;
+        // placement-list cache (device): one slot per chunk whose lists this lane knows, same per-cell layout as the region's placement grid
+        std::map<std::pair<int, int>, int> placementSlot;
+        std::vector<int> freePlacementSlots;
+        FeaturePlacement* d_cacheFp = nullptr;
+        CaveFeaturePlacement* d_cacheCfp = nullptr;
+        int32_t* d_cacheCnt = nullptr;
+        size_t cacheCells = 0;
+        void* d_idxWork = nullptr; size_t idxWorkCap = 0;
+        int lastGenerated = 0;
+        long long totalGenerated = 0;
+    };
+    std::vector<Lane> lanes;
+    void use(const Lane& L);
+    void copySync(const Lane& L, void* dst, const void* src, size_t bytes, hipMemcpyKind kind, const char* what);
+    void generateRect(int lane, int cx0, int cz0, int nx, int nz);
     void dropFarChunks();
     void meshReady();
+    void meshLane(int lane);
     void* ensure(void*& p, size_t& cap, size_t bytes);
 };
 

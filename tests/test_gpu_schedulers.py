@@ -99,9 +99,14 @@ def test_action_time_mirror_chunks_equal_oracle(mmgen_pkg, world, oracle_meshes,
 
 
 def test_region_terrain_chunks_equal_oracle(mmgen_pkg, world, oracle_meshes, tmp_path):
-    """RegionTerrain after its two legs (player (-13, 5), then (0, 0)): everything drawable around the second position."""
+    """RegionTerrain after its two legs (player (-13, 5), then (0, 0)): everything drawable around the second position - with one lane and
+    with several (streaming over several GPUs; rehearsed with two handles on one GPU where there is only one)."""
     exe = os.path.join(os.path.dirname(mmgen_pkg.LIB_PATH), "mmgen_region_terrain_demo")
     out = tmp_path / "region.txt"
     r = subprocess.run([exe, "-13", "5", str(out)], capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0 and "IDENTICAL" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
     check_against_oracle(read_digests(out), world, oracle_meshes, (0, 0), "host/region_terrain.cpp")
+    # ... and of the same scheduler with several lanes (one per GPU, or two region handles on the one GPU of this box): the strips the lanes
+    # generated and the meshes across their borders carry the oracle's blocks and mesh bytes too
+    assert " lanes (" in r.stdout and "chunks per lane:" in r.stdout
+    check_against_oracle(read_digests(str(out) + ".lanes"), world, oracle_meshes, (0, 0), "host/region_terrain.cpp with lanes")
