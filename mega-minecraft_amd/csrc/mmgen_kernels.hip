@@ -1074,7 +1074,9 @@ MM_DEV void fill_body(const float* __restrict__ hf, const float* __restrict__ bw
 #define FILL_COUNTERS 16         // work counters, 64 B apart (one serialises at ~11 ns per draw in L2)
 #define FILL_CLEAR_BYTES (64 * FILL_COUNTERS + 16)      // ... and the 16 bytes behind them: the lush queue's count word (+ three entries that every launch rewrites)
 #define FILLB_THREADS 256
-#define FILLC_THREADS 256
+#ifndef FILLC_THREADS
+#define FILLC_THREADS 256       // waves per persistent workgroup x 64 (the waves of a workgroup share the noise tables and nothing else)
+#endif
 #define FILLC_DEF_CAP 128        // per wave: CRYSTAL / LUSH voxels waiting for their noise rule
 #define FILLC_LUSH_CAP 128       // per wave: lush voxels waiting for a queue reservation
 
