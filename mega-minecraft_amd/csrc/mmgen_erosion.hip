@@ -415,15 +415,17 @@ MM_DEV bool erosion_spin(const unsigned* word, unsigned want, unsigned* err, uns
     return true;
 }
 
-__global__ void __launch_bounds__(EROSION_THREADS) __attribute__((amdgpu_waves_per_eu(6, 6)))
-k_erode_zones(const float* __restrict__ gatheredBase, size_t gatheredStride, const float* __restrict__ rawLayers, const float* __restrict__ rawHf,
+template <bool RESCUE>
+MM_DEV void erode_zones_body(const float* __restrict__ gatheredBase, size_t gatheredStride, const float* __restrict__ rawLayers, const float* __restrict__ rawHf,
               const int* __restrict__ zoneChunkIdx /*[zones][576]*/, float* workBase, ErosionState* states, unsigned* words, int zones, int groupSize,
               int groupWait /*workgroups a group waits for: groupSize (more only in the test of the give-up path)*/, int* maxPassesAlso /*nullable*/,
-              unsigned* errHost /*host-visible copy of the error word, nullable*/, unsigned long long timeoutTicks,
-              int rescue /*0: the persistent launch.  1: the pass behind it - workgroup i looks at zones i, i + gridDim.x, ... and relaxes every zone
-                           that is NOT done (never drawn, or abandoned by a launch that gave up) from its raw planes, on its own: a group of one
-                           waits for nobody, so this pass cannot stall and needs no residency*/)
+              unsigned* errHost /*host-visible copy of the error word, nullable*/, unsigned long long timeoutTicks)
 {
+    // RESCUE = false: the persistent launch.  RESCUE = true (k_erode_rescue): the pass behind it - workgroup i looks at zones i, i + gridDim.x,
+    // ... and relaxes every zone that is NOT done (never drawn, or abandoned by a launch that gave up) from its raw planes, on its own: a
+    // group of one waits for nobody, so this pass cannot stall and needs no residency.  A template parameter, not an argument: as an
+    // argument it cost the persistent kernel 20 B of scratch and 0.1 ms (80 VGPRs is what six waves per SIMD allow).
+    constexpr bool rescue = RESCUE;
     __shared__ float s_s[2][EROSION_CELLS_EXT];            // start planes, ping-pong over the passes
     __shared__ float s_t[2][EROSION_CELLS_EXT];            // thickness = end - start of the same states (what the neighbours compare)
     __shared__ float s_end[EROSION_CELLS_EXT];
@@ -438,7 +440,7 @@ k_erode_zones(const float* __restrict__ gatheredBase, size_t gatheredStride, con
     const int tid = threadIdx.x;
     unsigned* err = words + EROSION_WORD_ERR;
     const unsigned giveUpCode = 0x80000000u | (0x7fffffu << 8);
-    if (rescue) {
+    if constexpr (rescue) {
         if (tid == 0) { s_abort = 0; s_group[0] = 0; s_group[1] = 0; }
     } else if (tid == 0) {
         s_abort = 0;
@@ -487,7 +489,7 @@ k_erode_zones(const float* __restrict__ gatheredBase, size_t gatheredStride, con
   for (unsigned draw = 1u;; ++draw) {
     // the group's next zone: its first member draws it and tells the others (who cannot be a zone behind: every zone has rounds, every
     // round a barrier among the group)
-    if (rescue) {
+    if constexpr (rescue) {
         if (tid == 0) {
             int z = (int)blockIdx.x + (int)(draw - 1u) * (int)gridDim.x;
             while (z < zones && states[z].slot[0].done) z += (int)gridDim.x;      // (done: both slots final, see below)
@@ -581,6 +583,21 @@ k_erode_zones(const float* __restrict__ gatheredBase, size_t gatheredStride, con
     }
     __syncthreads();                                                  // (s_chunk, s_ph and s_zone are rewritten for the next zone)
   }
+}
+
+__global__ void __launch_bounds__(EROSION_THREADS) __attribute__((amdgpu_waves_per_eu(6, 6)))
+k_erode_zones(const float* __restrict__ gatheredBase, size_t gatheredStride, const float* __restrict__ rawLayers, const float* __restrict__ rawHf,
+              const int* __restrict__ zoneChunkIdx, float* workBase, ErosionState* states, unsigned* words, int zones, int groupSize, int groupWait,
+              int* maxPassesAlso, unsigned* errHost, unsigned long long timeoutTicks)
+{
+    erode_zones_body<false>(gatheredBase, gatheredStride, rawLayers, rawHf, zoneChunkIdx, workBase, states, words, zones, groupSize, groupWait, maxPassesAlso, errHost, timeoutTicks);
+}
+
+__global__ void __launch_bounds__(EROSION_THREADS) __attribute__((amdgpu_waves_per_eu(6, 6)))
+k_erode_rescue(const float* __restrict__ gatheredBase, size_t gatheredStride, const float* __restrict__ rawLayers, const float* __restrict__ rawHf,
+               const int* __restrict__ zoneChunkIdx, float* workBase, ErosionState* states, unsigned* words, int zones, int* maxPassesAlso, unsigned long long timeoutTicks)
+{
+    erode_zones_body<true>(gatheredBase, gatheredStride, rawLayers, rawHf, zoneChunkIdx, workBase, states, words, zones, 1, 1, maxPassesAlso, nullptr, timeoutTicks);
 }
 
 // final planes back into the caller's gathered-layers buffer (in-place contract of Chunk::erodeZone) and the accumulated heights
@@ -819,7 +836,7 @@ int erode_zones(float* gathered, size_t strideFloats, int zones, float* work, mm
         int ce = chain_before_launch(s, &chain);
         if (ce) return ce;
         MMK_LAUNCH(KID_ERODE_PASS, mm::k_erode_zones, dim3(grid), dim3(EROSION_THREADS), s, (const float*)gathered, strideFloats, rawLayers, rawHf,
-                   zoneChunkIdx, work, states, words, zones, groupSize, groupWait, maxPassesDev, errHost, erosion_timeout_ticks(), 0);
+                   zoneChunkIdx, work, states, words, zones, groupSize, groupWait, maxPassesDev, errHost, erosion_timeout_ticks());
         hipError_t re = hipEventRecord(chain, s);
         if (re != hipSuccess) return (int)re;
     }
@@ -830,8 +847,8 @@ int erode_zones(float* gathered, size_t strideFloats, int zones, float* work, mm
     // ours, it can only be slow.
     {
         const int rescueGrid = zones < 64 ? zones : 64;
-        MMK_LAUNCH(KID_ERODE_PASS, mm::k_erode_zones, dim3(rescueGrid), dim3(EROSION_THREADS), s, (const float*)gathered, strideFloats, rawLayers, rawHf,
-                   zoneChunkIdx, work, states, words, zones, 1, 1, maxPassesDev, (unsigned*)nullptr, erosion_timeout_ticks(), 1);
+        MMK_LAUNCH(KID_ERODE_RESCUE, mm::k_erode_rescue, dim3(rescueGrid), dim3(EROSION_THREADS), s, (const float*)gathered, strideFloats, rawLayers, rawHf,
+                   zoneChunkIdx, work, states, words, zones, maxPassesDev, erosion_timeout_ticks());
     }
     const int perZone = groupSize;
     if (layersOut) {

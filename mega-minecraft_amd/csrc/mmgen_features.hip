@@ -826,13 +826,20 @@ k_apply_features(uint8_t* __restrict__ blocks, const int2* __restrict__ chunkPos
     // for the 131 072 units of the bench tile, whatever else the kernel did): APPLY_COUNTERS of them, a cache line apart, counter p
     // hands out the units u = p (mod APPLY_COUNTERS); a wave moves on to the next counter when its own has run dry.
     int part = (APPLY_COLS * blockIdx.x + wave) % APPLY_COUNTERS, dry = 0;
+    (void)dry;
     unsigned drawn = 0u;
     if (lane == 0) drawn = atomicAdd(&nextUnit[16 * part], 1u);
   for (;;) {
     const int u = __builtin_amdgcn_readfirstlane((int)drawn) * APPLY_COUNTERS + part;
     if (u >= nUnits) {
+#if MM_COUNTER_PROBE_LOADS
+        const int nx = next_live_counter(nextUnit, APPLY_COUNTERS, part, nUnits);
+        if (nx < 0) break;
+        part = nx;
+#else
         if (++dry == APPLY_COUNTERS) break;
         part = (part + 1) % APPLY_COUNTERS;
+#endif
     }
     if (lane == 0) drawn = atomicAdd(&nextUnit[16 * part], 1u);
     if (u >= nUnits) continue;

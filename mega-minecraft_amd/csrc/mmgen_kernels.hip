@@ -631,6 +631,7 @@ k_cave_biomes(const float* __restrict__ hf, const int2* __restrict__ chunkPos, m
     };
 
     int part = (int)((CB_THREADS / 64) * blockIdx.x + wave) % CB_COUNTERS, dry = 0;
+    (void)dry;
     unsigned drawn = 0u;
     if (lane == 0) drawn = atomicAdd(&work[16 * part], 1u);
     bool more = true;                                          // units left to draw
@@ -674,8 +675,14 @@ k_cave_biomes(const float* __restrict__ hf, const int2* __restrict__ chunkPos, m
         if (slot >= MMGEN_MAX_CAVE_LAYERS_PER_COLUMN) {              // next unit
             const int u = __builtin_amdgcn_readfirstlane((int)drawn) * CB_COUNTERS + part;
             if (u >= nUnits) {
+#if MM_COUNTER_PROBE_LOADS
+                const int nx = next_live_counter(work, CB_COUNTERS, part, nUnits);
+                if (nx < 0) { more = false; continue; }
+                part = nx;
+#else
                 if (++dry == CB_COUNTERS) { more = false; continue; }
                 part = (part + 1) % CB_COUNTERS;
+#endif
             }
             if (lane == 0) drawn = atomicAdd(&work[16 * part], 1u);  // the next draw is in flight while this unit is walked
             if (u >= nUnits) continue;
@@ -1269,6 +1276,7 @@ k_fill_cave(const float* __restrict__ hf, const int2* __restrict__ chunkPos, uin
 
     const int total = batchStart[nRows], nRanges = (total + range - 1) / range;
     int part = (int)((FILLC_THREADS / 64) * blockIdx.x + wave) % FILL_COUNTERS, dry = 0;
+    (void)dry;
     unsigned drawn = 0u;
     if (lane == 0) drawn = atomicAdd(&work[16 * part], 1u);
     bool more = true;                                              // ranges left to draw
@@ -1370,8 +1378,14 @@ k_fill_cave(const float* __restrict__ hf, const int2* __restrict__ chunkPos, uin
         if (b >= b1) {                                             // next range
             const int g = __builtin_amdgcn_readfirstlane((int)drawn) * FILL_COUNTERS + part;
             if (g >= nRanges) {
+#if MM_COUNTER_PROBE_LOADS
+                const int nx = next_live_counter(work, FILL_COUNTERS, part, nRanges);
+                if (nx < 0) { more = false; continue; }
+                part = nx;
+#else
                 if (++dry == FILL_COUNTERS) { more = false; continue; }
                 part = (part + 1) % FILL_COUNTERS;
+#endif
             }
             if (lane == 0) drawn = atomicAdd(&work[16 * part], 1u);        // the next draw is in flight while this range is worked on
             if (g >= nRanges) continue;

@@ -13,7 +13,7 @@ enum KernelId {
     KID_EROSION_GATHER, KID_ERODE_INIT, KID_ERODE_PASS, KID_ERODE_WRITEBACK, KID_EROSION_SCATTER,
     KID_FEATURE_PLACEMENTS, KID_GATHER_PLACEMENTS, KID_APPLY_FEATURES, KID_DECORATORS, KID_FEATURE_BOX,
     KID_SELECT, KID_RING_NEED, KID_COPY_PLACEMENTS, KID_RING_PACK, KID_RING_UNPACK,
-    KID_MESH_COUNT, KID_MESH_FILL, KID_PACK_COUNT, KID_PACK_FILL, KID_UNPACK,
+    KID_MESH_COUNT, KID_MESH_FILL, KID_PACK_COUNT, KID_PACK_FILL, KID_UNPACK, KID_ERODE_RESCUE,
     KID_COUNT
 };
 

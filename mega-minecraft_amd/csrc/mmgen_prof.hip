@@ -20,7 +20,7 @@ const char* const kKernelNames[KID_COUNT] = {
     "k_erosion_gather", "k_erode_init", "k_erode_zones", "k_erode_writeback", "k_erosion_scatter",
     "k_feature_placements", "k_gather_placements", "k_apply_features", "k_decorators", "k_feature_box",
     "k_select", "k_ring_need", "k_copy_placements", "k_ring_pack", "k_ring_unpack",
-    "k_mesh_count", "k_mesh_fill", "k_pack_count", "k_pack_fill", "k_unpack"};
+    "k_mesh_count", "k_mesh_fill", "k_pack_count", "k_pack_fill", "k_unpack", "k_erode_rescue"};
 
 hipEvent_t get_event()
 {

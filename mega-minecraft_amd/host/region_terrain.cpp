@@ -32,10 +32,23 @@ void RegionTerrain::copySync(const Lane& L, void* dst, const void* src, size_t b
     RT_CALL(hipStreamSynchronize(L.stream), what);
 }
 
+// host -> device without a synchronisation: staged in the lane's pinned arena, copied on the lane's stream (stream order does the rest).
+// An upload that does not fit what is left of the arena falls back to the blocking copy.
+void RegionTerrain::uploadAsync(Lane& L, void* dst, const void* src, size_t bytes, const char* what)
+{
+    const size_t need = (bytes + 63) / 64 * 64;
+    if (!L.h_pin || L.pinUsed + need > L.pinCap) { copySync(L, dst, src, bytes, hipMemcpyHostToDevice, what); return; }
+    char* stage = L.h_pin + L.pinUsed;
+    L.pinUsed += need;
+    std::memcpy(stage, src, bytes);
+    RT_CALL(hipMemcpyAsync(dst, stage, bytes, hipMemcpyHostToDevice, L.stream), what);
+}
+
 RegionTerrain::~RegionTerrain()
 {
     for (Lane& L : lanes) {
         (void)hipSetDevice(L.device);
+        if (L.h_pin) (void)hipHostFree(L.h_pin);
         if (L.region) mmgen_region_destroy(L.region);
         if (L.d_pool) (void)hipFree(L.d_pool);
         if (L.d_stage) (void)hipFree(L.d_stage);
@@ -72,6 +85,8 @@ void RegionTerrain::init()
         RT_CALL(hipMalloc((void**)&L.d_cacheCnt, L.cacheCells * 2 * sizeof(int32_t)), "hipMalloc (placement cache) failed");
         L.freePlacementSlots.resize(L.cacheCells);
         for (size_t i = 0; i < L.cacheCells; ++i) L.freePlacementSlots[i] = (int)(L.cacheCells - 1 - i);
+        L.pinCap = 1 << 20;
+        RT_CALL(hipHostMalloc((void**)&L.h_pin, L.pinCap, hipHostMallocDefault), "hipHostMalloc (upload arena) failed");
     }
     use(lanes[0]);
 }
@@ -193,7 +208,7 @@ void RegionTerrain::generateRect(int lane, int cx0, int cz0, int nx, int nz)
             lists.reserve(2 * (ni + ne));
             lists.insert(lists.end(), impSrc.begin(), impSrc.end()); lists.insert(lists.end(), impDst.begin(), impDst.end());
             lists.insert(lists.end(), expSrc.begin(), expSrc.end()); lists.insert(lists.end(), expDst.begin(), expDst.end());
-            copySync(L, wk, lists.data(), lists.size() * 4, hipMemcpyHostToDevice, "H2D failed");
+            uploadAsync(L, wk, lists.data(), lists.size() * 4, "H2D failed");
         }
         if (ni) RT_CALL(mmgen_copy_placements(L.d_cacheFp, L.d_cacheCfp, L.d_cacheCnt, wk, gfp, gcfp, gcnt, wk + ni, (int)ni, st), "mmgen_copy_placements failed");
         if (ne) RT_CALL(mmgen_copy_placements(gfp, gcfp, gcnt, wk + 2 * ni, L.d_cacheFp, L.d_cacheCfp, L.d_cacheCnt, wk + 2 * ni + ne, (int)ne, st), "mmgen_copy_placements failed");
@@ -213,13 +228,13 @@ void RegionTerrain::generateRect(int lane, int cx0, int cz0, int nx, int nz)
         // wire format: count, prefix on the host, fill, one copy of ~10 KB per chunk, decode into the Chunk objects below
         const size_t oSlots = 0, oRuns = oSlots + n * 4, oBytes = oRuns + n * 512, oOff = (oBytes + n * 4 + 7) / 8 * 8, total = oOff + n * 8;
         char* w = (char*)ensure(L.d_meshWork, L.meshWorkCap, total);
-        copySync(L, w + oSlots, slots.data(), n * 4, hipMemcpyHostToDevice, "H2D failed");
+        uploadAsync(L, w + oSlots, slots.data(), n * 4, "H2D failed");
         RT_CALL(mmgen_pack_count(L.d_pool, (int32_t*)(w + oSlots), (int)n, (uint16_t*)(w + oRuns), (uint32_t*)(w + oBytes), st), "mmgen_pack_count failed");
         packBytes.resize(n); packOff.resize(n);
         copySync(L, packBytes.data(), w + oBytes, n * 4, hipMemcpyDeviceToHost, "D2H failed");
         uint64_t totalBytes = 0;
         for (size_t i = 0; i < n; ++i) { packOff[i] = totalBytes; totalBytes += packBytes[i]; }
-        copySync(L, w + oOff, packOff.data(), n * 8, hipMemcpyHostToDevice, "H2D failed");
+        uploadAsync(L, w + oOff, packOff.data(), n * 8, "H2D failed");
         char* o = (char*)ensure(L.d_meshOut, L.meshOutCap, totalBytes + 64);
         RT_CALL(mmgen_pack_fill(L.d_pool, (int32_t*)(w + oSlots), (int)n, (uint16_t*)(w + oRuns), (uint64_t*)(w + oOff), (uint8_t*)o, st), "mmgen_pack_fill failed");
         L.hostStage.resize(totalBytes);
@@ -362,14 +377,14 @@ void RegionTerrain::meshLane(int lane)
         hPos[2 * i] = meta[7 * i + 5]; hPos[2 * i + 1] = meta[7 * i + 6];
     }
     static_assert(sizeof(int32_t) == 4, "layout of the work area");
-    copySync(L, w + oIdx, hIn.data(), (size_t)n * 28, hipMemcpyHostToDevice, "H2D failed");
+    uploadAsync(L, w + oIdx, hIn.data(), (size_t)n * 28, "H2D failed");
     RT_CALL(mmgen_mesh_count(L.d_pool, (int32_t*)(w + oIdx), (int32_t*)(w + oNb), n, (uint32_t*)(w + oCol), (uint32_t*)(w + oCnt), st), "mmgen_mesh_count failed");
     std::vector<uint32_t> cnt(n);
     copySync(L, cnt.data(), w + oCnt, (size_t)n * 4, hipMemcpyDeviceToHost, "D2H failed");
     std::vector<uint64_t> off(n);
     uint64_t totalVerts = 0;
     for (int i = 0; i < n; ++i) { off[i] = totalVerts; totalVerts += cnt[i]; }
-    copySync(L, w + oOff, off.data(), (size_t)n * 8, hipMemcpyHostToDevice, "H2D failed");
+    uploadAsync(L, w + oOff, off.data(), (size_t)n * 8, "H2D failed");
     const size_t vb = (size_t)totalVerts * sizeof(Vertex), ib = (size_t)totalVerts / 4 * 6 * sizeof(unsigned int);
     char* o = (char*)ensure(L.d_meshOut, L.meshOutCap, vb + ib + 64);
     if (totalVerts)
@@ -405,7 +420,7 @@ void RegionTerrain::tick(float)
 {
     lastGenerated = lastMeshed = lastRegions = lastDropped = lastRingReused = lastRingComputed = 0;
     lastBlockBytesD2H = 0;
-    for (Lane& L : lanes) L.lastGenerated = 0;
+    for (Lane& L : lanes) { L.lastGenerated = 0; L.pinUsed = 0; }
     if (!planned || !(plannedFor == currentChunkPos)) { plannedFor = currentChunkPos; planned = true; pending = true; dropFarChunks(); }
     if (!pending) return;
 

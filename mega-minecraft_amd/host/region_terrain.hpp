@@ -95,10 +95,15 @@ private:
         void* d_idxWork = nullptr; size_t idxWorkCap = 0;
         int lastGenerated = 0;
         long long totalGenerated = 0;
+        // pinned arena for the small host -> device uploads of a tick (index lists, mesh inputs, vertex offsets): an asynchronous copy from
+        // pinned memory needs no synchronisation before the host goes on (a blocking copy from pageable memory is a 15 - 25 us round trip,
+        // four of them per tick).  Bump-allocated, reset at the start of a tick (the previous tick ended with a synchronisation).
+        char* h_pin = nullptr; size_t pinCap = 0, pinUsed = 0;
     };
     std::vector<Lane> lanes;
     void use(const Lane& L);
     void copySync(const Lane& L, void* dst, const void* src, size_t bytes, hipMemcpyKind kind, const char* what);
+    void uploadAsync(Lane& L, void* dst, const void* src, size_t bytes, const char* what);
     void generateRect(int lane, int cx0, int cz0, int nx, int nz);
     void dropFarChunks();
     void meshReady();

@@ -324,6 +324,24 @@ def test_config5_world_8_tiles_equals_single_region(mmgen_pkg):
     assert int(torch.unique(single[::97]).numel()) > 40
 
 
+@pytest.mark.parametrize("name", ["world_digests_jungle", "world_digests_border"])
+def test_two_more_worlds_equal_the_oracle_chunk_for_chunk(mmgen_pkg, name):
+    """Two more 65 536-chunk worlds, each generated as one region and held to the CPU oracle's per-chunk digests (tools/gen_world_digests.py on
+    the GPU box's host threads, profiles/r06e_world_digests_*): [1400, 1656) x [-1240, -984) - jungle / swamp / mesa country around the chunks
+    most tests use - and [1920, 2176) x [-128, 128), which straddles the pruning domain's border at block 32 768 (chunk 2 048): the rows
+    beyond it take k_fill_far and the unpruned cave / rasteriser paths, the rows inside the pruned ones, in one launch."""
+    import importlib
+    import os
+    import torch
+    d = importlib.import_module("mega-minecraft_amd.distributed")
+    cx0, cz0, gold = d.load_world_digests(os.path.join(os.path.dirname(__file__), "golden", name + ".npz"))
+    nz, nx = gold.shape
+    assert (nx, nz) == (256, 256)
+    got = d.chunk_digests(mmgen_pkg.MMGen(0).generate_region(cx0, cz0, nx, nz)["blocks"], torch).cpu().numpy().reshape(nz, nx)
+    bad = np.argwhere(got != gold)
+    assert bad.size == 0, f"{name}: {len(bad)} of 65536 chunks differ from the oracle, first {[(cx0 + int(x), cz0 + int(z)) for z, x in bad[:8]]}"
+
+
 def test_cpp_chunk_api_matches_region_path(mmgen_pkg):
     """The C++ mirror of the reference's Chunk stage API (host/chunk.hpp: generateHeightfields, gatherHeightfield, generateLayers,
     erodeZone, generateCaves, generateFeaturePlacements, gatherFeaturePlacements, fill) driven like Terrain::tick for one zone gives

@@ -64,7 +64,9 @@ def test_hot_kernels_keep_their_occupancy_budgets():
         m = k(name)
         assert m["lds"] <= cu_lds // 6 // 1280 * 1280 and m["vgpr"] <= 80, (name, m)
     assert k("k_cave_voxels")["scratch"] == 0 and k("k_cave_biomes")["scratch"] == 0
-    assert k("k_fill_cave")["scratch"] <= 16                       # eight dwords spilled in the range-draw block, none in the noise loops
+    # four dwords: the per-lane address and the limit of next_live_counter's probe, stored once in the prologue and reloaded only in the
+    # block that runs when a wave's work counter has gone dry (a handful of times per wave); none in the noise loops
+    assert k("k_fill_cave")["scratch"] <= 32
     # eight waves per SIMD
     m = k("k_fill_base")
     assert m["vgpr"] <= 64 and m["scratch"] == 0 and m["lds"] <= cu_lds // 8, m
