@@ -198,6 +198,9 @@ void RegionTerrain::generateRect(int lane, int cx0, int cz0, int nx, int nz)
                     if (!inR) ++lastRingComputed;
                 }
             }
+        // the output is known before the begin: it then issues the base fill itself, as soon as the caves' extents and the eroded layers
+        // exist - beside the cave biomes, the placement pass and the host's work on the placement cache below - instead of at the finish
+        RT_CALL(mmgen_region_set_output(L.region, dst), "mmgen_region_set_output failed");
         RT_CALL(mmgen_region_begin(L.region, cx0, cz0, nx, nz, flags, mask.data(), st), "mmgen_region_begin failed");
         FeaturePlacement* gfp; CaveFeaturePlacement* gcfp; int32_t* gcnt; int gx0, gz0, w, h;
         RT_CALL(mmgen_region_placement_buffers(L.region, &gfp, &gcfp, &gcnt, &gx0, &gz0, &w, &h), "mmgen_region_placement_buffers failed");
