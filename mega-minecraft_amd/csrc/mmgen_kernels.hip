@@ -322,9 +322,12 @@ struct CellTile {
 #ifndef MM_CAVE_WAVES
 #define MM_CAVE_WAVES 6
 #endif
-__attribute__((amdgpu_waves_per_eu(MM_CAVE_WAVES, MM_CAVE_WAVES)))
-__global__ void __launch_bounds__(CAVE_THREADS)
-k_cave_voxels(const float* __restrict__ hf, const float2* __restrict__ colInfo, const int2* __restrict__ chunkPos,
+// THREADS: 256 for launches that fill the chip (a row's ~2 000 listed voxels are nine per thread: 6 workgroups x 4 waves per CU).  A SMALL
+// launch - a streaming strip: ~1 200 rows, all resident at once - is as slow as its slowest row, nine dependent warp + Worley evaluations
+// deep; k_cave_voxels_wide runs the same row with 512 threads (the phases' loops stride by THREADS, the per-column walk stays with the first
+// 256), which halves that depth: 0.19 -> 0.1x ms of a 1.07 ms tick.  Same lists, same LDS, same results (list order is irrelevant).
+template <int THREADS>
+MM_DEV void cave_voxels_body(const float* __restrict__ hf, const float2* __restrict__ colInfo, const int2* __restrict__ chunkPos,
               mmgen_cave_layer* __restrict__ caveLayers, const int* __restrict__ chunkList, const uint8_t* __restrict__ colNeed /*nullable, lazy ring*/)
 {
     __shared__ float s_cells[3 * CELL_N];
@@ -356,7 +359,7 @@ k_cave_voxels(const float* __restrict__ hf, const float2* __restrict__ colInfo, 
         for (int k = 0; k < 16; ++k) rowNeed |= ((w[k >> 2] >> (8 * (k & 3))) & 255u) ? (1u << k) : 0u;
     }
     if (!rowNeed) {                                            // nothing to evaluate: all 16 columns keep the default layers
-        for (int i = t; i < 16 * 3 * MMGEN_MAX_CAVE_LAYERS_PER_COLUMN; i += CAVE_THREADS)
+        for (int i = t; i < 16 * 3 * MMGEN_MAX_CAVE_LAYERS_PER_COLUMN; i += THREADS)
             ((int*)(caveLayers + (size_t)MMGEN_MAX_CAVE_LAYERS_PER_COLUMN * (chunk * 256 + 16 * row)))[i] = ((i % 3) == 2) ? 0 : 384;
         return;
     }
@@ -368,12 +371,12 @@ k_cave_voxels(const float* __restrict__ hf, const float2* __restrict__ colInfo, 
     tile.ox = (int)__builtin_floorf(((float)cp.x * 0.0050f) * 1.f) - 3;
     tile.oy = -3;
     tile.oz = (int)__builtin_floorf(((float)(cp.y + row) * 0.0050f) * 1.f) - 3;
-    for (int i = t; i < CELL_N; i += CAVE_THREADS) {
+    for (int i = t; i < CELL_N; i += THREADS) {
         const int iz = i % CELL_NZ, iy = (i / CELL_NZ) % CELL_NY, ix = i / (CELL_NZ * CELL_NY);
         const f3 p = rand3from3((float)(tile.ox + ix), (float)(tile.oy + iy), (float)(tile.oz + iz));
         s_cells[3 * i] = p.x; s_cells[3 * i + 1] = p.y; s_cells[3 * i + 2] = p.z;
     }
-    for (int i = t; i < CAVE_ROW * 6; i += CAVE_THREADS) s_solid[i / 6][i % 6] = 0ull;
+    for (int i = t; i < CAVE_ROW * 6; i += THREADS) s_solid[i / 6][i % 6] = 0ull;
     if (t < CAVE_ROW) {
         const int col = chunk * 256 + colBase + t;
         const float2 ci = colInfo[col];
@@ -394,7 +397,7 @@ k_cave_voxels(const float* __restrict__ hf, const float2* __restrict__ colInfo, 
     // every slot's default {384, 384, biomes 0}, whole lines, long before the runs overwrite a few of them (the barriers in between order the stores)
     {
         int* rowLayersEarly = (int*)(caveLayers + (size_t)MMGEN_MAX_CAVE_LAYERS_PER_COLUMN * (chunk * 256 + colBase));
-        for (int i = t; i < CAVE_ROW * 3 * MMGEN_MAX_CAVE_LAYERS_PER_COLUMN; i += CAVE_THREADS) rowLayersEarly[i] = ((i % 3) == 2) ? 0 : 384;
+        for (int i = t; i < CAVE_ROW * 3 * MMGEN_MAX_CAVE_LAYERS_PER_COLUMN; i += THREADS) rowLayersEarly[i] = ((i % 3) == 2) ? 0 : 384;
     }
     // analytic part, y in [144, 384): solid iff y <= topSolid and not (y > ravineY)   (topRatio == 0 there)
     if (t < CAVE_ROW * 4) {    // 4 lanes per column fill words 2..5 (word 2 holds y 128..191: bits >= 16 only)
@@ -414,8 +417,8 @@ k_cave_voxels(const float* __restrict__ hf, const float2* __restrict__ colInfo, 
     const bool prune = prune_domain(cp.x, cp.y + row);          // the row's 16 columns: x in [cp.x, cp.x + 15] (cp.x a multiple of 16), z = cp.y + row
     const float b3 = prune ? MM_SIMPLEX3_BOUND : 3.402823466e+38f;
     const float kCaveFaMax = prune ? 0.9375f * MM_SIMPLEX3_BOUND : 1e30f;      // outside the domain: a bound no noise reaches
-    static_assert(CAVE_THREADS == 256 && CAVE_ROW == 16 && CAVE_YEVAL == 144, "the walk below: thread t = column t % 16, y = t / 16 + 16 i, i < 9");
-    {
+    static_assert(THREADS >= 256 && THREADS % 64 == 0 && CAVE_ROW == 16 && CAVE_YEVAL == 144, "the walk below: thread t < 256 = column t % 16, y = t / 16 + 16 i, i < 9");
+    if (THREADS == 256 || t < 256) {
     // y-major walk (the lists come out ordered by depth): a thread keeps its column, a wave covers four consecutive y of the 16 columns
     // per step.  Nothing touches LDS inside the walk: the solid bits gather in registers (y + 16 i lies in 32-bit word i / 2), the four
     // lanes of a column OR theirs together and one of them writes the words; the list positions come from ballots, with ONE counter
@@ -516,7 +519,7 @@ k_cave_voxels(const float* __restrict__ hf, const float2* __restrict__ colInfo, 
         if (below_huge_bound(v, n, huge)) carve(v, n, huge);
     };
     const int count1 = s_count[0];
-    for (int i = t; i < count1; i += CAVE_THREADS) {
+    for (int i = t; i < count1; i += THREADS) {
         const int e = s_list1[i];
         const int c = e / CAVE_YEVAL, y = e - c * CAVE_YEVAL;
         const int idx2d = colBase + c;
@@ -541,7 +544,7 @@ k_cave_voxels(const float* __restrict__ hf, const float2* __restrict__ colInfo, 
     }
     __syncthreads();
     const int count2 = imin(s_count[1], CAVE_L2_CAP);
-    for (int i = t; i < count2; i += CAVE_THREADS) {
+    for (int i = t; i < count2; i += THREADS) {
         const VoxelTerms v = terms(s_list2[i]);
         float huge;
         if (!below_huge_bound(v, s_thr[i], huge)) continue;
@@ -551,7 +554,7 @@ k_cave_voxels(const float* __restrict__ hf, const float2* __restrict__ colInfo, 
     }
     __syncthreads();
     const int count3 = imin(s_count[2], CAVE_L3_CAP);
-    for (int k = t; k < count3; k += CAVE_THREADS) {
+    for (int k = t; k < count3; k += THREADS) {
         const int i = s_list3[k];
         carve(terms(s_list2[i]), s_thr[i], s_huge[k]);
     }
@@ -580,6 +583,26 @@ k_cave_voxels(const float* __restrict__ hf, const float2* __restrict__ colInfo, 
             ++rank;
         }
     }
+}
+
+__attribute__((amdgpu_waves_per_eu(MM_CAVE_WAVES, MM_CAVE_WAVES)))
+__global__ void __launch_bounds__(CAVE_THREADS)
+k_cave_voxels(const float* __restrict__ hf, const float2* __restrict__ colInfo, const int2* __restrict__ chunkPos,
+              mmgen_cave_layer* __restrict__ caveLayers, const int* __restrict__ chunkList, const uint8_t* __restrict__ colNeed)
+{
+    cave_voxels_body<CAVE_THREADS>(hf, colInfo, chunkPos, caveLayers, chunkList, colNeed);
+}
+
+#define CAVE_THREADS_WIDE 512
+#ifndef CAVE_WIDE_MAX_ROWS
+#define CAVE_WIDE_MAX_ROWS 3072                     // launches of at most this many rows (192 chunks) take the wide kernel: two rounds of the chip's 1 536 workgroups
+#endif
+__attribute__((amdgpu_waves_per_eu(MM_CAVE_WAVES, MM_CAVE_WAVES)))
+__global__ void __launch_bounds__(CAVE_THREADS_WIDE)
+k_cave_voxels_wide(const float* __restrict__ hf, const float2* __restrict__ colInfo, const int2* __restrict__ chunkPos,
+                   mmgen_cave_layer* __restrict__ caveLayers, const int* __restrict__ chunkList, const uint8_t* __restrict__ colNeed)
+{
+    cave_voxels_body<CAVE_THREADS_WIDE>(hf, colInfo, chunkPos, caveLayers, chunkList, colNeed);
 }
 
 // Cave biomes of the layers' end blocks: at most 2 getCaveBiome evaluations per occupied layer slot, and only a few of a column's
@@ -1549,7 +1572,11 @@ int launch_caves(const float* hf, const float* bw, const int32_t* pos, int n, mm
     // spin on each other), one lane watches its started-workgroups counter for a moment: an event only orders the two launches' eligibility,
     // and whichever dispatcher is faster then wins the slots (measured: without this the order flips with a 90 us change upstream)
     if (waitCounter && waitTarget) LAUNCH(KID_CAVE_COLUMNS, mm::k_wait_counter, dim3(1), dim3(64), s, waitCounter, waitTarget);
-    LAUNCH(KID_CAVE_VOXELS, mm::k_cave_voxels, dim3(n * 16), dim3(CAVE_THREADS), s, hf, (const float2*)colInfoScratch, (const int2*)pos, caveLayers, chunkList, colNeed);
+    static const int wideMax = [] { const char* e = getenv("MMGEN_CAVE_WIDE_MAX_ROWS"); return e ? atoi(e) : CAVE_WIDE_MAX_ROWS; }();      // (A/B: 0 = never)
+    if (n * 16 <= wideMax)
+        LAUNCH(KID_CAVE_VOXELS, mm::k_cave_voxels_wide, dim3(n * 16), dim3(CAVE_THREADS_WIDE), s, hf, (const float2*)colInfoScratch, (const int2*)pos, caveLayers, chunkList, colNeed);
+    else
+        LAUNCH(KID_CAVE_VOXELS, mm::k_cave_voxels, dim3(n * 16), dim3(CAVE_THREADS), s, hf, (const float2*)colInfoScratch, (const int2*)pos, caveLayers, chunkList, colNeed);
     // the layers' extents are final here (what the base fill reads); their biomes follow
     if (afterVoxels) { const hipError_t ee = hipEventRecord(afterVoxels, s); if (ee != hipSuccess) return (int)ee; }
     const int cus = device_cus();

@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <new>
 
 namespace mmhost {
 
@@ -21,6 +22,14 @@ RegionTerrain::RegionTerrain(size_t poolChunks, std::vector<int> devices) : pool
     }
     lanes.resize(devices.size());
     for (size_t i = 0; i < devices.size(); ++i) lanes[i].device = devices[i];
+}
+
+RegionTerrain::ChunkPtr RegionTerrain::newChunk(ivec2 worldChunkPos)
+{
+    void* mem;
+    if (!chunkStore.free.empty()) { mem = chunkStore.free.back(); chunkStore.free.pop_back(); }
+    else mem = ::operator new(sizeof(Chunk));
+    return ChunkPtr(new (mem) Chunk(worldChunkPos), ChunkRecycler{&chunkStore});
 }
 
 void RegionTerrain::use(const Lane& L) { RT_CALL(hipSetDevice(L.device), "hipSetDevice failed"); }
@@ -264,7 +273,7 @@ void RegionTerrain::generateRect(int lane, int cx0, int cz0, int nx, int nz)
             const ivec2 c = {cx0 + x, cz0 + z};
             const size_t i = (size_t)x + (size_t)nx * z;
             Cell cell;
-            cell.chunk = std::make_unique<Chunk>(c);
+            cell.chunk = newChunk(c);
             cell.slot = slots[i];
             cell.meshed = false;
             cell.lane = lane;
