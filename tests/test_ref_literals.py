@@ -118,7 +118,7 @@ DEVICE_MAP = {
     "rng.hpp::fbm3From3": ([CS + "mm_noise.cuh"], [r"f3\s+fbm3from3\s*\([^)]*\)\s*\{"], None),
     "rng.hpp::simplex2From2": ([CS + "mm_noise.cuh"], [r"f2\s+simplex2from2\s*\([^)]*\)\s*\{"], None),
     "rng.hpp::specialCaveNoise": ([CS + "mm_noise.cuh"], [r"float\s+special_cave_noise\s*\([^)]*\)\s*\{"], None),
-    "chunk.cu::shouldGenerateCaveAtBlock": ([CS + "mmgen_kernels.hip"], [r"\bk_cave_columns\s*\([^)]*\)\s*\{", r"\bk_cave_voxels\s*\([^{]*\)\s*\{", r"float\s+cave_huge\s*\([^)]*\)\s*\{"], None),
+    "chunk.cu::shouldGenerateCaveAtBlock": ([CS + "mmgen_kernels.hip"], [r"\bk_cave_columns\s*\([^)]*\)\s*\{", r"\bcave_voxels_body\s*\([^{]*\)\s*\{", r"float\s+cave_huge\s*\([^)]*\)\s*\{"], None),
     "chunk.cu::getStratifiedMaterialThickness": ([CS + "mmgen_kernels.hip"], [r"float\s+stratified_thickness\s*\([^)]*\)\s*\{"], None),
     "chunk.cu::isFeaturePos": ([CS + "mmgen_features.hip"], [r"bool\s+is_feature_pos\s*\([^)]*\)\s*\{"], None),
     "chunk.cu::generateColumnFeaturePlacements": ([CS + "mmgen_features.hip"], [r"void\s+column_placements\s*\([^{]*\)\s*\{"], None),
