@@ -3,7 +3,7 @@
 tag=${1:-t}
 root=${GRAFT_REPO_ROOT:-$PWD}; out=$root/gpurun_out; mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-B="python3 $root/bench.py --steps 3 --warmup 1 --cpu-side 0 --serial --no-kernel-events --no-cpp-host --no-streaming"
+B="python3 $root/bench.py --steps 3 --warmup 1 --cpu-side 0 --serial --no-kernel-events --no-cpp-host --no-streaming --no-baseline-configs"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/${tag}_pmc_fetch -- $B > $out/${tag}_pmc_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/${tag}_pmc_write -- $B > $out/${tag}_pmc_write.log 2>&1
 python3 - <<PY

@@ -12,7 +12,7 @@ root=${GRAFT_REPO_ROOT:-$PWD}
 out=$root/gpurun_out
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-B="python3 $root/bench.py --steps 3 --warmup 1 --cpu-side 0 --serial --no-kernel-events --no-cpp-host --no-streaming $*"      # serial schedule: one kernel at a time, counters and durations attribute cleanly
+B="python3 $root/bench.py --steps 3 --warmup 1 --cpu-side 0 --serial --no-kernel-events --no-cpp-host --no-streaming --no-baseline-configs $*"      # serial schedule: one kernel at a time, counters and durations attribute cleanly
 if [ "$what" = stats ] || [ "$what" = all ]; then
   rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_full_stats -- $B > $out/${tag}_full_stats.log 2>&1
   f=$(ls $out/${tag}_full_stats/*/*kernel_stats.csv | head -1); cp $f $out/${tag}_full_kernel_stats.csv
