@@ -254,6 +254,16 @@ int mmgen_mesh_count(const uint8_t* d_blocks, const int32_t* d_chunk_idx, const 
                      uint32_t* d_chunk_verts, void* stream);
 int mmgen_mesh_fill(const uint8_t* d_blocks, const int32_t* d_chunk_idx, const int32_t* d_neighbor_idx, const int32_t* d_chunk_world_block_pos, int n,
                     const uint32_t* d_column_verts, const uint64_t* d_vert_offset, mmgen_vertex* d_verts, uint32_t* d_idx, void* stream);
+/* The same without a host round trip between the count and the fill (a streaming tick: the host neither reads the counts nor uploads the
+ * offsets before the fill is enqueued):
+ *   mmgen_mesh_offsets      d_vert_offset[c] = exclusive prefix of d_chunk_verts on the device, d_total[0] = their sum;
+ *   mmgen_mesh_fill_capped  mmgen_mesh_fill that writes nothing for a chunk whose vertices would end beyond capacity_verts (the caller sized
+ *                           d_verts / d_idx for capacity_verts vertices from what earlier ticks needed; it reads d_total afterwards, and when
+ *                           that exceeds the capacity it grows the buffers and repeats the three calls). */
+int mmgen_mesh_offsets(const uint32_t* d_chunk_verts, int n, uint64_t* d_vert_offset, uint64_t* d_total, void* stream);
+int mmgen_mesh_fill_capped(const uint8_t* d_blocks, const int32_t* d_chunk_idx, const int32_t* d_neighbor_idx, const int32_t* d_chunk_world_block_pos, int n,
+                           const uint32_t* d_column_verts, const uint64_t* d_vert_offset, uint64_t capacity_verts, mmgen_vertex* d_verts, uint32_t* d_idx,
+                           void* stream);
 
 /* ---- region wire format (the reference has none) ---------------------------------------------
  * A chunk's 98 304 block ids as per-column run-length pairs: u16 runsOfColumn[256], then for each column (x + 16 z, the blocks[]

@@ -283,7 +283,8 @@ MM_DEV VertexWords vertex_words(uint32_t r, int m, int j, const float2* s_jitter
 __global__ void __launch_bounds__(256)
 k_mesh_fill(const uint8_t* __restrict__ blocks, const int32_t* __restrict__ chunkIdx, const int32_t* __restrict__ neighborIdx,
             const int2* __restrict__ chunkWorldBlockPos, const uint32_t* __restrict__ columnVerts, const uint64_t* __restrict__ vertOffset, mmgen_vertex* __restrict__ verts,
-            uint32_t* __restrict__ idx, int parts /*workgroups per chunk (gridDim.y): part p emits columns [256 p / parts, 256 (p + 1) / parts)*/)
+            uint32_t* __restrict__ idx, int parts /*workgroups per chunk (gridDim.y): part p emits columns [256 p / parts, 256 (p + 1) / parts)*/,
+            unsigned long long capacityVerts /*0 = the caller sized the buffers from the counts; else a chunk that would end beyond it writes nothing*/)
 {
     __shared__ Planes P;
     __shared__ uint8_t s_cls[256];
@@ -316,6 +317,7 @@ k_mesh_fill(const uint8_t* __restrict__ blocks, const int32_t* __restrict__ chun
         s_jitter[t] = make_float2(0.4f * (r.x - 0.5f), 0.4f * (r.y - 0.5f));
     }
     const uint64_t vbase = vertOffset[o];
+    if (capacityVerts && vbase + 4ull * total > capacityVerts) return;      // (workgroup-uniform: every part of the chunk leaves)
     uint32_t* vout = (uint32_t*)(verts + vbase);
     uint32_t* iout = idx + (vbase / 4) * 6;
     const uint8_t* col = blocks + (size_t)MMGEN_BLOCKS_PER_CHUNK * c + 384 * t;
@@ -357,6 +359,34 @@ k_mesh_fill(const uint8_t* __restrict__ blocks, const int32_t* __restrict__ chun
     }
 }
 
+// exclusive prefix of the chunks' vertex counts (one workgroup: a streaming strip has 33 chunks, a pool a few thousand)
+__global__ void __launch_bounds__(256)
+k_mesh_offsets(const uint32_t* __restrict__ chunkVerts, int n, uint64_t* __restrict__ vertOffset, uint64_t* __restrict__ total)
+{
+    __shared__ unsigned long long s_scan[256];
+    __shared__ unsigned long long s_carry;
+    const int t = threadIdx.x;
+    if (t == 0) s_carry = 0ull;
+    __syncthreads();
+    for (int base = 0; base < n; base += 256) {
+        const unsigned long long mine = base + t < n ? chunkVerts[base + t] : 0u;
+        s_scan[t] = mine;
+        __syncthreads();
+        for (int off = 1; off < 256; off <<= 1) {
+            const unsigned long long v = t >= off ? s_scan[t - off] : 0ull;
+            __syncthreads();
+            s_scan[t] += v;
+            __syncthreads();
+        }
+        const unsigned long long carry = s_carry;
+        if (base + t < n) vertOffset[base + t] = carry + s_scan[t] - mine;
+        __syncthreads();
+        if (t == 255) s_carry = carry + s_scan[255];
+        __syncthreads();
+    }
+    if (t == 0) *total = s_carry;
+}
+
 }  // namespace mm
 
 extern "C" {
@@ -370,8 +400,8 @@ int mmgen_mesh_count(const uint8_t* d_blocks, const int32_t* d_chunk_idx, const 
     return (int)hipGetLastError();
 }
 
-int mmgen_mesh_fill(const uint8_t* d_blocks, const int32_t* d_chunk_idx, const int32_t* d_neighbor_idx, const int32_t* d_chunk_world_block_pos, int n,
-                    const uint32_t* d_column_verts, const uint64_t* d_vert_offset, mmgen_vertex* d_verts, uint32_t* d_idx, void* stream)
+static int mesh_fill_launch(const uint8_t* d_blocks, const int32_t* d_chunk_idx, const int32_t* d_neighbor_idx, const int32_t* d_chunk_world_block_pos, int n,
+                            const uint32_t* d_column_verts, const uint64_t* d_vert_offset, unsigned long long capacity, mmgen_vertex* d_verts, uint32_t* d_idx, void* stream)
 {
     if (n < 0 || (n > 0 && (!d_blocks || !d_chunk_world_block_pos || !d_column_verts || !d_vert_offset || !d_verts || !d_idx)))
         return (int)hipErrorInvalidValue;
@@ -379,7 +409,28 @@ int mmgen_mesh_fill(const uint8_t* d_blocks, const int32_t* d_chunk_idx, const i
     int parts = 1;                                        // ~512 workgroups at least, at most 8 per chunk
     while (parts < 8 && n * parts * 2 <= 512) parts *= 2;
     MMK_LAUNCH_NORET(mmk::KID_MESH_FILL, mm::k_mesh_fill, dim3(n, parts), dim3(256), (hipStream_t)stream, d_blocks, d_chunk_idx, d_neighbor_idx, (const int2*)d_chunk_world_block_pos,
-                       d_column_verts, d_vert_offset, d_verts, d_idx, parts);
+                       d_column_verts, d_vert_offset, d_verts, d_idx, parts, capacity);
+    return (int)hipGetLastError();
+}
+
+int mmgen_mesh_fill(const uint8_t* d_blocks, const int32_t* d_chunk_idx, const int32_t* d_neighbor_idx, const int32_t* d_chunk_world_block_pos, int n,
+                    const uint32_t* d_column_verts, const uint64_t* d_vert_offset, mmgen_vertex* d_verts, uint32_t* d_idx, void* stream)
+{
+    return mesh_fill_launch(d_blocks, d_chunk_idx, d_neighbor_idx, d_chunk_world_block_pos, n, d_column_verts, d_vert_offset, 0ull, d_verts, d_idx, stream);
+}
+
+int mmgen_mesh_fill_capped(const uint8_t* d_blocks, const int32_t* d_chunk_idx, const int32_t* d_neighbor_idx, const int32_t* d_chunk_world_block_pos, int n,
+                           const uint32_t* d_column_verts, const uint64_t* d_vert_offset, uint64_t capacity_verts, mmgen_vertex* d_verts, uint32_t* d_idx,
+                           void* stream)
+{
+    if (capacity_verts == 0) return (int)hipErrorInvalidValue;
+    return mesh_fill_launch(d_blocks, d_chunk_idx, d_neighbor_idx, d_chunk_world_block_pos, n, d_column_verts, d_vert_offset, capacity_verts, d_verts, d_idx, stream);
+}
+
+int mmgen_mesh_offsets(const uint32_t* d_chunk_verts, int n, uint64_t* d_vert_offset, uint64_t* d_total, void* stream)
+{
+    if (n < 0 || !d_total || (n > 0 && (!d_chunk_verts || !d_vert_offset))) return (int)hipErrorInvalidValue;
+    MMK_LAUNCH_NORET(mmk::KID_MESH_COUNT, mm::k_mesh_offsets, dim3(1), dim3(256), (hipStream_t)stream, d_chunk_verts, n, d_vert_offset, d_total);
     return (int)hipGetLastError();
 }
 

@@ -378,7 +378,7 @@ void RegionTerrain::meshLane(int lane)
     if (n == 0) return;
     // device work area: chunk idx [n], neighbour idx [n][4], positions [n][2], column counts [n][256], chunk counts [n], offsets [n] (u64)
     const size_t oIdx = 0, oNb = oIdx + (size_t)n * 4, oPos = oNb + (size_t)n * 16, oCol = oPos + (size_t)n * 8, oCnt = oCol + (size_t)n * 1024,
-                 oOff = (oCnt + (size_t)n * 4 + 7) / 8 * 8, total = oOff + (size_t)n * 8;
+                 oOff = (oCnt + (size_t)n * 4 + 7) / 8 * 8, oTot = oOff + (size_t)n * 8, total = oTot + 8;
     char* w = (char*)ensure(L.d_meshWork, L.meshWorkCap, total);
     // the three input arrays are adjacent in the work area: one copy (a blocking copy from pageable memory is 20 - 30 us of a 1.5 ms tick)
     std::vector<int32_t> hIn((size_t)n * 7);
@@ -392,24 +392,48 @@ void RegionTerrain::meshLane(int lane)
     uploadAsync(L, w + oIdx, hIn.data(), (size_t)n * 28, "H2D failed");
     RT_CALL(mmgen_mesh_count(L.d_pool, (int32_t*)(w + oIdx), (int32_t*)(w + oNb), n, (uint32_t*)(w + oCol), (uint32_t*)(w + oCnt), st), "mmgen_mesh_count failed");
     std::vector<uint32_t> cnt(n);
-    copySync(L, cnt.data(), w + oCnt, (size_t)n * 4, hipMemcpyDeviceToHost, "D2H failed");
     std::vector<uint64_t> off(n);
     uint64_t totalVerts = 0;
-    for (int i = 0; i < n; ++i) { off[i] = totalVerts; totalVerts += cnt[i]; }
-    uploadAsync(L, w + oOff, off.data(), (size_t)n * 8, "H2D failed");
-    const size_t vb = (size_t)totalVerts * sizeof(Vertex), ib = (size_t)totalVerts / 4 * 6 * sizeof(unsigned int);
-    char* o = (char*)ensure(L.d_meshOut, L.meshOutCap, vb + ib + 64);
-    if (totalVerts)
-        RT_CALL(mmgen_mesh_fill(L.d_pool, (int32_t*)(w + oIdx), (int32_t*)(w + oNb), (int32_t*)(w + oPos), n, (uint32_t*)(w + oCol), (uint64_t*)(w + oOff),
-                                (Vertex*)o, (uint32_t*)(o + vb), st),
-                "mmgen_mesh_fill failed");
-    if (copyToHost && totalVerts) {
-        L.hostStage.resize(vb + ib);
-        copySync(L, L.hostStage.data(), o, vb + ib, hipMemcpyDeviceToHost, "D2H mesh failed");
-    } else if (L.stream) {
-        RT_CALL(hipStreamSynchronize(L.stream), "mesh build failed");
+    size_t vb = 0, ib = 0;
+    char* o = nullptr;
+    if (!copyToHost && n <= 128) {
+        // device resident, a strip: no host round trip between the count and the fill.  The offsets are scanned on the device, the output
+        // buffers are sized from what earlier ticks needed per chunk, and the fill leaves out any chunk that would end beyond them; the
+        // counts and the total are read once, behind the fill - a total beyond the capacity grows it and repeats the (rare) tick's mesh
+        for (;;) {
+            const uint64_t capacity = (uint64_t)n * L.meshVertsPerChunkCap;
+            vb = (size_t)capacity * sizeof(Vertex); ib = (size_t)capacity / 4 * 6 * sizeof(unsigned int);
+            o = (char*)ensure(L.d_meshOut, L.meshOutCap, vb + ib + 64);
+            RT_CALL(mmgen_mesh_offsets((uint32_t*)(w + oCnt), n, (uint64_t*)(w + oOff), (uint64_t*)(w + oTot), st), "mmgen_mesh_offsets failed");
+            RT_CALL(mmgen_mesh_fill_capped(L.d_pool, (int32_t*)(w + oIdx), (int32_t*)(w + oNb), (int32_t*)(w + oPos), n, (uint32_t*)(w + oCol), (uint64_t*)(w + oOff),
+                                           capacity, (Vertex*)o, (uint32_t*)(o + vb), st), "mmgen_mesh_fill_capped failed");
+            RT_CALL(hipMemcpyAsync(cnt.data(), w + oCnt, (size_t)n * 4, hipMemcpyDeviceToHost, st), "D2H failed");
+            copySync(L, &totalVerts, w + oTot, 8, hipMemcpyDeviceToHost, "mesh build failed");      // (waits for the whole tick's work on this lane)
+            uint32_t most = 0;
+            for (int i = 0; i < n; ++i) most = std::max(most, cnt[i]);
+            if (totalVerts <= capacity) { L.meshVertsPerChunkCap = std::max<uint64_t>(L.meshVertsPerChunkCap, (uint64_t)most + most / 4); break; }
+            L.meshVertsPerChunkCap = std::max<uint64_t>(2 * L.meshVertsPerChunkCap, (totalVerts + n - 1) / n * 2);
+        }
+        uint64_t run = 0;
+        for (int i = 0; i < n; ++i) { off[i] = run; run += cnt[i]; }
     } else {
-        RT_CALL(hipDeviceSynchronize(), "mesh build failed");
+        copySync(L, cnt.data(), w + oCnt, (size_t)n * 4, hipMemcpyDeviceToHost, "D2H failed");
+        for (int i = 0; i < n; ++i) { off[i] = totalVerts; totalVerts += cnt[i]; }
+        uploadAsync(L, w + oOff, off.data(), (size_t)n * 8, "H2D failed");
+        vb = (size_t)totalVerts * sizeof(Vertex); ib = (size_t)totalVerts / 4 * 6 * sizeof(unsigned int);
+        o = (char*)ensure(L.d_meshOut, L.meshOutCap, vb + ib + 64);
+        if (totalVerts)
+            RT_CALL(mmgen_mesh_fill(L.d_pool, (int32_t*)(w + oIdx), (int32_t*)(w + oNb), (int32_t*)(w + oPos), n, (uint32_t*)(w + oCol), (uint64_t*)(w + oOff),
+                                    (Vertex*)o, (uint32_t*)(o + vb), st),
+                    "mmgen_mesh_fill failed");
+        if (copyToHost && totalVerts) {
+            L.hostStage.resize(vb + ib);
+            copySync(L, L.hostStage.data(), o, vb + ib, hipMemcpyDeviceToHost, "D2H mesh failed");
+        } else if (L.stream) {
+            RT_CALL(hipStreamSynchronize(L.stream), "mesh build failed");
+        } else {
+            RT_CALL(hipDeviceSynchronize(), "mesh build failed");
+        }
     }
     L.generationOutstanding = false;    // (either branch waited for everything the lane's stream held)
     for (int i = 0; i < n; ++i) {
@@ -433,16 +457,35 @@ void RegionTerrain::tick(float)
     lastGenerated = lastMeshed = lastRegions = lastDropped = lastRingReused = lastRingComputed = 0;
     lastBlockBytesD2H = 0;
     for (Lane& L : lanes) { L.lastGenerated = 0; L.pinUsed = 0; }
-    if (!planned || !(plannedFor == currentChunkPos)) { plannedFor = currentChunkPos; planned = true; pending = true; dropFarChunks(); }
+    const int R = chunkVbosGenRadius + 1, S = 2 * R + 1;
+    if (!planned || !(plannedFor == currentChunkPos)) {
+        plannedFor = currentChunkPos; planned = true; pending = true;
+        // the far chunks are looked for (a walk over every cell and every cached placement list) when the player has moved four chunks
+        // since the last look, not at every step: what is dropped a few steps later is the same set, and a pool that is running low
+        // forces the look at once.  (This planning runs before anything of the tick is enqueued: the GPU idles through it.)
+        size_t lowest = poolChunks;
+        for (const Lane& L : lanes) lowest = std::min(lowest, L.freeSlots.size());
+        if (!droppedOnce || std::max(std::abs(plannedFor.x - droppedAt.x), std::abs(plannedFor.y - droppedAt.y)) >= 4 || lowest < (size_t)S * S) {
+            dropFarChunks();
+            droppedAt = plannedFor; droppedOnce = true;
+            // (the last completed square is only known to be whole while no look from further than dropRadius - R away has happened)
+            if (std::max(std::abs(plannedFor.x - completeAt.x), std::abs(plannedFor.y - completeAt.y)) + R > dropRadius) completeValid = false;
+        }
+    }
     if (!pending) return;
 
-    // missing cells of the generation square (drawable radius + the ring the border meshes look at)
-    const int R = chunkVbosGenRadius + 1, S = 2 * R + 1;
+    // missing cells of the generation square (drawable radius + the ring the border meshes look at).  When the previous plan was
+    // completed around a position close by, the cells of ITS square exist (nothing within dropRadius is ever dropped): only the newly
+    // exposed strips are looked up
     std::vector<uint8_t> missing((size_t)S * S, 0);
     int numMissing = 0;
+    const bool near = completeValid && std::max(std::abs(plannedFor.x - completeAt.x), std::abs(plannedFor.y - completeAt.y)) <= dropRadius - R - 4;
     for (int z = 0; z < S; ++z)
-        for (int x = 0; x < S; ++x)
-            if (!cells.count({plannedFor.x - R + x, plannedFor.y - R + z})) { missing[(size_t)x + (size_t)S * z] = 1; ++numMissing; }
+        for (int x = 0; x < S; ++x) {
+            const int cx = plannedFor.x - R + x, cz = plannedFor.y - R + z;
+            if (near && std::abs(cx - completeAt.x) <= R && std::abs(cz - completeAt.y) <= R) continue;
+            if (!cells.count({cx, cz})) { missing[(size_t)x + (size_t)S * z] = 1; ++numMissing; }
+        }
 
     // greedy rectangle cover: maximal x-run of the first missing cell, extended down while the whole run is missing
     int budget = maxChunksPerTick;
@@ -482,6 +525,7 @@ void RegionTerrain::tick(float)
         }
     use(lanes[0]);
     pending = numMissing > 0;
+    if (!pending) { completeAt = plannedFor; completeValid = true; }
 }
 
 }  // namespace mmhost

@@ -82,6 +82,8 @@ private:
     std::unordered_set<Chunk*> drawable;
     ivec2 currentChunkPos{0, 0}, plannedFor{0, 0};
     bool planned = false, pending = true;
+    ivec2 droppedAt{0, 0}, completeAt{0, 0};      // where the far chunks were last looked for; the centre of the last completed plan
+    bool droppedOnce = false, completeValid = false;
     size_t poolChunks;                    // per lane
     static constexpr size_t kGhostSlots = 512;      // per lane, behind the pool: other lanes' chunks that this lane's meshes look at in one tick
 
@@ -94,6 +96,7 @@ private:
         std::vector<int> freeSlots;           // sorted descending: slots are handed out in ascending order, so fresh pools fill contiguously
         uint8_t* d_stage = nullptr; size_t stageChunks = 0;      // region output when the free slots are not one contiguous run
         void* d_meshOut = nullptr; size_t meshOutCap = 0;
+        uint64_t meshVertsPerChunkCap = 49152;      // output capacity per chunk of a strip's capped mesh fill: grows to 1.25 x the largest chunk seen
         void* d_meshWork = nullptr; size_t meshWorkCap = 0;
         std::vector<uint8_t> hostStage;
         // placement-list cache (device): one slot per chunk whose lists this lane knows, same per-cell layout as the region's placement grid

@@ -210,6 +210,32 @@ class MMGen:
                                                  self._p(verts), self._p(idx), self._stream()), "mmgen_mesh_fill")
         return dict(verts=verts[:total], idx=idx[:total * 3 // 2], chunk_verts=chv, vert_offset=off)
 
+    def create_vbos_capped(self, blocks, world_block_pos, nx, nz, capacity_verts):
+        """The round-trip-free form (mmgen_mesh_count -> mmgen_mesh_offsets -> mmgen_mesh_fill_capped): offsets scanned on the device, buffers
+        sized for `capacity_verts` vertices and pre-filled with a sentinel.  Returns dict(verts [capacity, 10], idx, chunk_verts, vert_offset,
+        total) - chunks that would end beyond the capacity are left untouched."""
+        t = self.torch
+        n = blocks.shape[0]
+        vp, i32, u64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_uint64
+        self.lib.mmgen_mesh_count.argtypes = [vp, vp, vp, i32, vp, vp, vp]
+        self.lib.mmgen_mesh_offsets.argtypes = [vp, i32, vp, vp, vp]
+        self.lib.mmgen_mesh_fill_capped.argtypes = [vp, vp, vp, vp, i32, vp, vp, u64, vp, vp, vp]
+        c = t.arange(n, dtype=t.int32, device=blocks.device)
+        x, z = c % nx, c // nx
+        neg = t.full_like(c, -1)
+        nb = t.stack([t.where(z < nz - 1, c + nx, neg), t.where(x < nx - 1, c + 1, neg), t.where(z > 0, c - nx, neg), t.where(x > 0, c - 1, neg)], dim=1).contiguous()
+        colv = self._empty((n, 256), t.int32)
+        chv = self._empty((n,), t.int32)
+        off = self._empty((n,), t.int64)
+        total = self._empty((1,), t.int64)
+        verts = t.full((capacity_verts, 10), -7.0, dtype=t.float32, device=blocks.device)
+        idx = t.full((capacity_verts * 3 // 2,), -7, dtype=t.int32, device=blocks.device)
+        self._check(self.lib.mmgen_mesh_count(self._p(blocks), None, self._p(nb), n, self._p(colv), self._p(chv), self._stream()), "mmgen_mesh_count")
+        self._check(self.lib.mmgen_mesh_offsets(self._p(chv), n, self._p(off), self._p(total), self._stream()), "mmgen_mesh_offsets")
+        self._check(self.lib.mmgen_mesh_fill_capped(self._p(blocks), None, self._p(nb), self._p(world_block_pos), n, self._p(colv), self._p(off), capacity_verts,
+                                                    self._p(verts), self._p(idx), self._stream()), "mmgen_mesh_fill_capped")
+        return dict(verts=verts, idx=idx, chunk_verts=chv, vert_offset=off, total=int(total.item()))
+
     # ------------------------------------------------------------------ region wire format (run-length pairs per column)
     def pack(self, blocks):
         """blocks uint8 [n, 98304] on the device -> dict(data uint8 [total], chunk_bytes int32 [n], chunk_offset int64 [n])."""

@@ -193,6 +193,31 @@ def test_mesh_is_the_same_however_many_workgroups_share_a_chunk(gen):
 
 
 @pytest.mark.gpu
+def test_capped_mesh_fill_with_device_side_offsets(gen):
+    """mmgen_mesh_offsets + mmgen_mesh_fill_capped (the streaming tick's form: no host round trip between count and fill): with room for
+    everything the vertex and index streams equal mmgen_mesh_fill's with host-made offsets; with room for less, exactly the chunks that end
+    within the capacity are written, the others' ranges keep the caller's bytes, and the total says how much room the repeat needs."""
+    import torch
+    nx, nz = 5, 4
+    reg = gen.generate_region(1486, -1112, nx, nz)
+    pos = gen.positions([(1486 + x, -1112 + z) for z in range(nz) for x in range(nx)])
+    ref = gen.create_vbos(reg["blocks"], pos, nx, nz)
+    total = int(ref["verts"].shape[0])
+    assert total > 100000
+    full = gen.create_vbos_capped(reg["blocks"], pos, nx, nz, total + 1000)
+    assert full["total"] == total and torch.equal(full["vert_offset"], ref["vert_offset"]) and torch.equal(full["chunk_verts"], ref["chunk_verts"])
+    assert torch.equal(full["verts"][:total].view(torch.int32), ref["verts"].view(torch.int32)) and torch.equal(full["idx"][:total * 3 // 2], ref["idx"])
+    assert bool((full["verts"][total:] == -7.0).all())
+    ends = (ref["vert_offset"] + ref["chunk_verts"]).cpu().tolist()
+    cap = ends[11] + 3                                       # chunks 0 .. 11 end within it, chunk 12 does not
+    part = gen.create_vbos_capped(reg["blocks"], pos, nx, nz, cap)
+    assert part["total"] == total
+    assert torch.equal(part["verts"][:ends[11]].view(torch.int32), ref["verts"][:ends[11]].view(torch.int32))
+    assert torch.equal(part["idx"][:ends[11] * 3 // 2], ref["idx"][:ends[11] * 3 // 2])
+    assert bool((part["verts"][ends[11]:] == -7.0).all()) and bool((part["idx"][ends[11] * 3 // 2:] == -7).all())
+
+
+@pytest.mark.gpu
 def test_mesh_edge_cases(gen, oracle):
     """Empty batch, all-AIR chunk, lone chunks (no neighbours: NULL index array), explicit neighbour indices, full stone chunk."""
     import torch
