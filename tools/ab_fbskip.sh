@@ -1,0 +1,11 @@
+#!/bin/bash
+# removal experiment on k_fill_base (MM_FB_SKIP: 1 no list appends, 2 no layer search, 4 no biome draw, 8 no place_block_base at all, 3 = 1 + 2): its time alone
+# (serial pass) and the step beside everything else.  The variants' blocks are wrong; only the times mean something.
+for lib in mega-minecraft_amd/libmmgen.so build_ab/libmmgen_fbskip1.so build_ab/libmmgen_fbskip2.so build_ab/libmmgen_fbskip3.so build_ab/libmmgen_fbskip4.so build_ab/libmmgen_fbskip8.so; do
+  echo "== $lib"
+  MMGEN_LIB=$lib python3 tools/bench_brief.py --steps 16 --no-baseline-configs 2>&1 | python3 -c "
+import sys,re
+t=sys.stdin.read()
+m=re.search(r'ms_per_step ([\d.]+)', t); fb=re.search(r'k_fill_base=([\d.]+)', t); fc=re.search(r'k_fill_cave=([\d.]+)', t)
+print('  step', m and m.group(1), ' k_fill_base alone', fb and fb.group(1), ' k_fill_cave alone', fc and fc.group(1))"
+done
