@@ -324,12 +324,14 @@ def test_config5_world_8_tiles_equals_single_region(mmgen_pkg):
     assert int(torch.unique(single[::97]).numel()) > 40
 
 
-@pytest.mark.parametrize("name", ["world_digests_jungle", "world_digests_border"])
-def test_two_more_worlds_equal_the_oracle_chunk_for_chunk(mmgen_pkg, name):
-    """Two more 65 536-chunk worlds, each generated as one region and held to the CPU oracle's per-chunk digests (tools/gen_world_digests.py on
+@pytest.mark.parametrize("name", ["world_digests_jungle", "world_digests_border", "world_digests_edge"])
+def test_three_more_worlds_equal_the_oracle_chunk_for_chunk(mmgen_pkg, name):
+    """Three more 65 536-chunk worlds, each generated as one region and held to the CPU oracle's per-chunk digests (tools/gen_world_digests.py on
     the GPU box's host threads, profiles/r06e_world_digests_*): [1400, 1656) x [-1240, -984) - jungle / swamp / mesa country around the chunks
     most tests use - and [1920, 2176) x [-128, 128), which straddles the pruning domain's border at block 32 768 (chunk 2 048): the rows
-    beyond it take k_fill_far and the unpruned cave / rasteriser paths, the rows inside the pruned ones, in one launch."""
+    beyond it take k_fill_far and the unpruned cave / rasteriser paths, the rows inside the pruned ones, in one launch; and
+    [39 999 872, 40 000 128) x [-128, 128): block coordinates of 6.4e8, where float32 steps by 64 - every lattice hash outside its table
+    domain, 308 870 columns of the oracle's run in the canonical no-layer case (r06n_world_digests_edge_*)."""
     import importlib
     import os
     import torch

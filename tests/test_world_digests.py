@@ -15,10 +15,11 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 def test_the_other_golden_worlds_are_the_oracles_too(oracle):
     """world_digests_jungle.npz ([1400, 1656) x [-1240, -984)) and world_digests_border.npz ([1920, 2176) x [-128, 128), across the pruning
-    domain's border): one sampled chunk of each, regenerated here as a 1 x 1 region."""
+    domain's border) and world_digests_edge.npz ([39 999 872, 40 000 128) x [-128, 128): block coordinates of 6.4e8): one sampled chunk of each, regenerated
+    here as a 1 x 1 region."""
     d = importlib.import_module("mega-minecraft_amd.distributed")
     gen = importlib.import_module("gen_world_digests")
-    for name, (cx, cz) in (("world_digests_jungle", (1488, -1110)), ("world_digests_border", (2048, 17))):
+    for name, (cx, cz) in (("world_digests_jungle", (1488, -1110)), ("world_digests_border", (2048, 17)), ("world_digests_edge", (40000000, 5))):
         cx0, cz0, dig = d.load_world_digests(os.path.join(GOLDEN, name + ".npz"))
         blocks = oracle.generate_region(cx, cz, 1, 1, erosion=True, features=True, decorators=True, lean=True)["blocks"]
         assert int(gen.chunk_digests_np(blocks)[0]) == int(dig[cz - cz0, cx - cx0]), (name, cx, cz)
