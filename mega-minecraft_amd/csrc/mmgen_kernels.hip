@@ -773,7 +773,7 @@ MM_DEV void depth_codes(const unsigned long long* colMask, int y, unsigned& bdc,
 }
 
 #ifndef MM_FB_SKIP
-#define MM_FB_SKIP 0              // removal experiments on k_fill_base (results are wrong when set): 1 no list appends, 2 no layer search, 4 no biome draw, 8 no place_block_base
+#define MM_FB_SKIP 0              // removal experiments on k_fill_base (results are wrong when set): 1 no list appends, 2 no layer search, 4 no biome draw, 8 no place_block_base, 16 no noise tables
 #endif
 struct BaseBlock { uint8_t block; bool needCave; int bottomDepth, topDepth; };
 
@@ -1195,7 +1195,7 @@ k_fill_base(const float* __restrict__ hf, const float* __restrict__ bw, const fl
     }
     __syncthreads();
     // simplex tables only for the rows in which a biome with a noise rule has weight (a biome is only drawn at positive weight)
-    if (s_needTables) noise_tables_init();
+    if (s_needTables && !(MM_FB_SKIP & 16)) noise_tables_init();
     uint8_t* outBase = blocks + (size_t)MMGEN_BLOCKS_PER_CHUNK * outChunk + 384 * idxBase;     // the 16 columns are contiguous: 6 144 bytes
     unsigned* list = rowLists + (size_t)FILL_VOX * lrow;
 

@@ -1,7 +1,8 @@
 #!/bin/bash
-# removal experiment on k_fill_base (MM_FB_SKIP: 1 no list appends, 2 no layer search, 4 no biome draw, 8 no place_block_base at all, 3 = 1 + 2): its time alone
-# (serial pass) and the step beside everything else.  The variants' blocks are wrong; only the times mean something.
-for lib in mega-minecraft_amd/libmmgen.so build_ab/libmmgen_fbskip1.so build_ab/libmmgen_fbskip2.so build_ab/libmmgen_fbskip3.so build_ab/libmmgen_fbskip4.so build_ab/libmmgen_fbskip8.so; do
+# removal experiment on k_fill_base (MM_FB_SKIP: 1 no list appends, 2 no layer search, 4 no biome draw, 8 no place_block_base at all, 16 no noise tables): its
+# time alone (serial pass) and the step beside everything else.  The variants' blocks are wrong; only the times mean something.
+#   tools/ab_fbskip.sh build_ab/libmmgen_fbskip1.so ...
+for lib in mega-minecraft_amd/libmmgen.so "$@"; do
   echo "== $lib"
   MMGEN_LIB=$lib python3 tools/bench_brief.py --steps 16 --no-baseline-configs 2>&1 | python3 -c "
 import sys,re
