@@ -772,9 +772,6 @@ MM_DEV void depth_codes(const unsigned long long* colMask, int y, unsigned& bdc,
     tdc = dn ? (unsigned)imin(__builtin_clz(dn), 30) : 31u;
 }
 
-#ifndef MM_FB_SKIP
-#define MM_FB_SKIP 0              // removal experiments on k_fill_base (results are wrong when set): 1 no list appends, 2 no layer search, 4 no biome draw, 8 no place_block_base, 16 no noise tables
-#endif
 struct BaseBlock { uint8_t block; bool needCave; int bottomDepth, topDepth; };
 
 // The column's biome weights in the compact form getRandomBiome (biomeFuncs.hpp:39-53) can be walked in: biome 0 (returned by a draw of
@@ -836,7 +833,7 @@ MM_DEV BaseBlock place_block_base(const ColumnBiomes& cbi, const float* s_lh, co
     const bool isTop = fy >= height - 1.f;
     const bool isWater = fy > height && y <= MMGEN_SEA_LEVEL;
     int randBiome = MMBIO_PLAINS;                             // a biome without rules
-    if (!(MM_FB_SKIP & 4) && (isTop || y >= cbi.drawMinY || (isWater && cbi.drawWater))) {
+    if (isTop || y >= cbi.drawMinY || (isWater && cbi.drawWater)) {
         MinStd rng = rng3(wx, y, wz);
         randBiome = random_biome(cbi, rng.u01());
     }
@@ -877,7 +874,6 @@ MM_DEV BaseBlock place_block_base(const ColumnBiomes& cbi, const float* s_lh, co
 
     const int l0 = (fy >= s_lh[MMGEN_NUM_FORWARD_MATERIALS]) ? MMGEN_NUM_FORWARD_MATERIALS : 0;
     int layer = -1;
-    if (MM_FB_SKIP & 2) layer = (y >> 3) % 20; else
     if (cbi.layersSorted) {
         // Both runs of layer starts - forward 0 .. 9, backward + eroded 10 .. 20 (the last entry is the height) - are non-decreasing in
         // nearly every column.  Then the first l >= l0 with s_lh[l] <= fy < s_lh[l + 1] is the last layer of fy's run that starts at or
@@ -1195,7 +1191,7 @@ k_fill_base(const float* __restrict__ hf, const float* __restrict__ bw, const fl
     }
     __syncthreads();
     // simplex tables only for the rows in which a biome with a noise rule has weight (a biome is only drawn at positive weight)
-    if (s_needTables && !(MM_FB_SKIP & 16)) noise_tables_init();
+    if (s_needTables) noise_tables_init();
     uint8_t* outBase = blocks + (size_t)MMGEN_BLOCKS_PER_CHUNK * outChunk + 384 * idxBase;     // the 16 columns are contiguous: 6 144 bytes
     unsigned* list = rowLists + (size_t)FILL_VOX * lrow;
 
@@ -1219,18 +1215,14 @@ k_fill_base(const float* __restrict__ hf, const float* __restrict__ bw, const fl
         // block-rule noises out of the loop into six VGPRs
         asm volatile("" : "+v"(wz));
         const ColumnBiomes cbi = {s_nzN[c], s_ocean[c] != 0, s_nzIdx[c], s_nzW[c], s_bw[c], s_drawMinY[c], (s_drawWater[c] & 1) != 0, (s_drawWater[c] & 2) != 0};
-#if MM_FB_SKIP & 8
-        BaseBlock r; r.block = (uint8_t)(y & 127); r.needCave = (y < 100);
-#else
         const BaseBlock r = place_block_base<true>(cbi, s_lh[c], s_cave[c], y, s_lh[c][MMGEN_NUM_MATERIALS], wx, wz);
         outBase[v] = r.block;                                       // k_fill_cave only writes the voxels it changes
-        if (r.needCave && !(MM_FB_SKIP & 1)) {
+        if (r.needCave) {
             unsigned bdc, tdc;
             depth_codes(s_cave[c], y, bdc, tdc);
             list[atomicAdd(&s_count, 1)] = (unsigned)v | ((unsigned)r.block << FILL_VBITS) | (bdc << (FILL_VBITS + 8)) | (tdc << (FILL_VBITS + 13));
         }
     }
-#endif
     __syncthreads();
     if (t == 0) rowCounts[lrow] = s_count;
 }
