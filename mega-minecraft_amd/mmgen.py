@@ -27,6 +27,13 @@ def build(verbose=False):
 def load_library():
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(f"{LIB_PATH} not found: build it with `make -C mega-minecraft_amd/csrc` (no CPU fallback exists)")
+    # torch first: libmmgen.so needs libamdhip64.so.N, and the loader gives it whichever copy is in the process already.  Loaded before
+    # torch it binds /opt/rocm's runtime, torch then brings its own bundled copy, and the process ends up with two HIP runtimes of which
+    # ours sees no device (hipErrorNoDevice from mmgen_init: found with build() followed by smoke() in one process, round 6).
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = ctypes.CDLL(LIB_PATH)
     vp, i32 = ctypes.c_void_p, ctypes.c_int
     lib.mmgen_init.argtypes = [i32]
