@@ -2,6 +2,7 @@
 import ctypes
 import os
 import re
+import sys
 
 from conftest import ROOT
 
@@ -60,3 +61,14 @@ def test_product_never_imports_oracle():
                         if f.endswith(".py") and not re.search(r"^\s*(import|from)\b|CDLL|LoadLibrary|subprocess|open\(", line):
                             continue            # prose in docstrings may mention the oracle; code that could load it may not
                         assert not bad.search(code), f"{os.path.join(d, f)}:{n} references the oracle: {line.strip()}"
+
+
+def test_the_library_is_loaded_behind_torch():
+    """libmmgen.so needs libamdhip64.so.N and gets whichever copy the process holds already: loaded before torch it binds /opt/rocm's runtime,
+    torch then brings its bundled one, and mmgen_init sees no device (build() followed by smoke() in one process, round 6).  load_library()
+    therefore imports torch first: in a fresh interpreter that has not imported it, it is in sys.modules once the library is loaded."""
+    import subprocess
+    code = ("import importlib, sys; sys.path.insert(0, %r); assert 'torch' not in sys.modules; "
+            "p = importlib.import_module('mega-minecraft_amd'); p.load_library(); assert 'torch' in sys.modules; print('ok')" % ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
