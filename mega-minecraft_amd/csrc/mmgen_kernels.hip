@@ -619,9 +619,12 @@ k_cave_voxels_wide(const float* __restrict__ hf, const float2* __restrict__ colI
 #ifndef MM_CB_WAVES
 #define MM_CB_WAVES 6
 #endif
-__attribute__((amdgpu_waves_per_eu(MM_CB_WAVES, MM_CB_WAVES)))
-__global__ void __launch_bounds__(CB_THREADS)
-k_cave_biomes(const float* __restrict__ hf, const int2* __restrict__ chunkPos, mmgen_cave_layer* __restrict__ caveLayers,
+// UNIT_COLS: 64 (lane = column, one slot per step) for launches that give every wave many units; 16 for small ones (a streaming strip has
+// ~300 units of 64 columns for 1 024 waves: one round, as long as its slowest unit): a unit is then 16 columns and a step covers FOUR
+// consecutive slots of them (lane = column + 16 * slot offset), so there are four times the units, each a quarter of the walk.  The items
+// are the same; only which wave evaluates them changes.
+template <int UNIT_COLS>
+MM_DEV void cave_biomes_body(const float* __restrict__ hf, const int2* __restrict__ chunkPos, mmgen_cave_layer* __restrict__ caveLayers,
               const int* __restrict__ chunkList, int nUnits, unsigned* __restrict__ work)
 {
     __shared__ uint2 s_s1[CB_THREADS / 64][CB_S1_CAP];         // .x = list index << 14 | column << 6 | slot << 1 | top, .y = y of the block
@@ -713,24 +716,47 @@ k_cave_biomes(const float* __restrict__ hf, const int2* __restrict__ chunkPos, m
         }
         // one slot of the unit's 64 columns (lane = column): a used slot has one item (its bottom block) or two (a layer open to the sky
         // has no top block: top biome NONE); used slots come first in a column, the walk ends when no column has one left
-        constexpr int unitsPerChunk = 256 / CB_UNIT_COLS;
-        const int li = unit / unitsPerChunk, col = CB_UNIT_COLS * (unit % unitsPerChunk) + lane;
+        constexpr int unitsPerChunk = 256 / UNIT_COLS, slotsPerStep = 64 / UNIT_COLS;
+        static_assert(UNIT_COLS == 64 || UNIT_COLS == 16, "lane = column + UNIT_COLS * slot offset");
+        const int li = unit / unitsPerChunk, col = UNIT_COLS * (unit % unitsPerChunk) + lane % UNIT_COLS;
+        const int mySlot = slot + lane / UNIT_COLS;
+        const bool inRange = UNIT_COLS == 64 || mySlot < MMGEN_MAX_CAVE_LAYERS_PER_COLUMN;
         const int chunk = chunkList ? chunkList[li] : li;
-        mmgen_cave_layer* l = caveLayers + ((size_t)256 * chunk + col) * MMGEN_MAX_CAVE_LAYERS_PER_COLUMN + slot;
-        const int start = l->start, end = l->end;
+        mmgen_cave_layer* l = caveLayers + ((size_t)256 * chunk + col) * MMGEN_MAX_CAVE_LAYERS_PER_COLUMN + (inRange ? mySlot : 0);
+        const int start = inRange ? l->start : 384, end = l->end;
         const bool used = start != 384, two = used && end != 384;
         const unsigned long long um = __ballot(used), tm = __ballot(two);
-        if (um == 0ull) { slot = MMGEN_MAX_CAVE_LAYERS_PER_COLUMN; continue; }
+        if (um == 0ull) { slot = MMGEN_MAX_CAVE_LAYERS_PER_COLUMN; continue; }      // (used slots come first in a column: none in this step, none later)
         if (used) {
             if (!two) l->top_biome = (uint8_t)MMCB_NONE;
-            const unsigned id = ((unsigned)li << 14) | ((unsigned)col << 6) | ((unsigned)slot << 1);
+            const unsigned id = ((unsigned)li << 14) | ((unsigned)col << 6) | ((unsigned)mySlot << 1);
             const int at = n1 + __popcll(um & below) + __popcll(tm & below);
             s1[at] = make_uint2(id, (unsigned)start);
             if (two) s1[at + 1] = make_uint2(id | 1u, (unsigned)(end + 1));
         }
         n1 += __popcll(um) + __popcll(tm);
-        ++slot;
+        slot += slotsPerStep;
     }
+}
+
+__attribute__((amdgpu_waves_per_eu(MM_CB_WAVES, MM_CB_WAVES)))
+__global__ void __launch_bounds__(CB_THREADS)
+k_cave_biomes(const float* __restrict__ hf, const int2* __restrict__ chunkPos, mmgen_cave_layer* __restrict__ caveLayers,
+              const int* __restrict__ chunkList, int nUnits, unsigned* __restrict__ work)
+{
+    cave_biomes_body<CB_UNIT_COLS>(hf, chunkPos, caveLayers, chunkList, nUnits, work);
+}
+
+#define CB_UNIT_COLS_SMALL 16
+#ifndef CB_SMALL_MAX_CHUNKS
+#define CB_SMALL_MAX_CHUNKS 512                      // launches of at most this many chunks take the 16-column units
+#endif
+__attribute__((amdgpu_waves_per_eu(MM_CB_WAVES, MM_CB_WAVES)))
+__global__ void __launch_bounds__(CB_THREADS)
+k_cave_biomes_small(const float* __restrict__ hf, const int2* __restrict__ chunkPos, mmgen_cave_layer* __restrict__ caveLayers,
+                    const int* __restrict__ chunkList, int nUnits, unsigned* __restrict__ work)
+{
+    cave_biomes_body<CB_UNIT_COLS_SMALL>(hf, chunkPos, caveLayers, chunkList, nUnits, work);
 }
 
 // =========================================================================================================
@@ -1581,10 +1607,16 @@ int launch_caves(const float* hf, const float* bw, const int32_t* pos, int n, mm
     if (afterVoxels) { const hipError_t ee = hipEventRecord(afterVoxels, s); if (ee != hipSuccess) return (int)ee; }
     const int cus = device_cus();
     if (!cus) return (int)hipErrorInvalidDevice;
-    const long long units = (long long)n * (256 / CB_UNIT_COLS), fit = (long long)cus * (biomeWorkgroupsPerCu > 0 && biomeWorkgroupsPerCu < MM_CB_WAVES ? biomeWorkgroupsPerCu : MM_CB_WAVES);   // persistent: MM_CB_WAVES 4-wave workgroups per CU at most
-    if (units >= (1LL << 18) * (256 / CB_UNIT_COLS)) return (int)hipErrorInvalidValue;                  // item ids carry the list index in 18 bits
-    LAUNCH(KID_CAVE_BIOMES, mm::k_cave_biomes, dim3((unsigned)(units / 4 + 1 < fit ? units / 4 + 1 : fit)), dim3(CB_THREADS), s, hf, (const int2*)pos, caveLayers, chunkList,
-           (int)units, cbWork);
+    static const int smallMax = [] { const char* e = getenv("MMGEN_CB_SMALL_MAX_CHUNKS"); return e ? atoi(e) : CB_SMALL_MAX_CHUNKS; }();      // (A/B: 0 = never)
+    const bool small = n <= smallMax;
+    const int unitCols = small ? CB_UNIT_COLS_SMALL : CB_UNIT_COLS;
+    const long long units = (long long)n * (256 / unitCols), fit = (long long)cus * (biomeWorkgroupsPerCu > 0 && biomeWorkgroupsPerCu < MM_CB_WAVES ? biomeWorkgroupsPerCu : MM_CB_WAVES);   // persistent: MM_CB_WAVES 4-wave workgroups per CU at most
+    if (n >= (1 << 18)) return (int)hipErrorInvalidValue;                  // item ids carry the list index in 18 bits
+    const dim3 grid((unsigned)(units / 4 + 1 < fit ? units / 4 + 1 : fit));
+    if (small)
+        LAUNCH(KID_CAVE_BIOMES, mm::k_cave_biomes_small, grid, dim3(CB_THREADS), s, hf, (const int2*)pos, caveLayers, chunkList, (int)units, cbWork);
+    else
+        LAUNCH(KID_CAVE_BIOMES, mm::k_cave_biomes, grid, dim3(CB_THREADS), s, hf, (const int2*)pos, caveLayers, chunkList, (int)units, cbWork);
     return 0;
 }
 
