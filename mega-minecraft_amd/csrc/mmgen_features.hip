@@ -755,7 +755,7 @@ MM_DEV int reach_of(int feat)
 
 // One round of filter_unit's walk: entries r0 .. r0 + 63 of `list`; the placements that can reach the unit are appended at s_unit[base ..]
 // (the caller keeps 64 slots free).  Returns the number appended; ended = the list ends inside this round (first NONE, or its capacity).
-template <class Entry, int LIST_CAP, bool CAVE>
+template <class Entry, int LIST_CAP, bool CAVE, int UW, int UH>
 MM_DEV int filter_round(const Entry* __restrict__ list, int r0, int wx0, int wz0, int4* s_unit, int base, bool& ended)
 {
     static_assert(LIST_CAP % 64 == 0, "whole rounds");
@@ -767,7 +767,7 @@ MM_DEV int filter_round(const Entry* __restrict__ list, int r0, int wx0, int wz0
     const unsigned long long noneMask = __ballot(feat == 0);                // the lists end at the first NONE
     const int firstNone = noneMask ? (int)__builtin_ctzll(noneMask) : 64;
     const int reach = reach_of<CAVE>(feat);
-    const bool cand = lane < firstNone && wx0 - fx <= reach && fx - (wx0 + APPLY_UNIT_W - 1) <= reach && wz0 - fz <= reach && fz - (wz0 + APPLY_UNIT_H - 1) <= reach;
+    const bool cand = lane < firstNone && wx0 - fx <= reach && fx - (wx0 + UW - 1) <= reach && wz0 - fz <= reach && fz - (wz0 + UH - 1) <= reach;
     const unsigned long long cm = __ballot(cand);
     if (cand)
         s_unit[base + __popcll(cm & ((1ull << lane) - 1ull))] =
@@ -799,17 +799,19 @@ MM_DEV int filter_round(const Entry* __restrict__ list, int r0, int wx0, int wz0
 //   D. the claimed voxels are written back.
 // On generated terrain a unit is one A, one B and one C step; lists of any length (the 2 048 / 4 096 entries of the reference) only mean
 // more flushes.  No workgroup barrier after the noise tables are in LDS.
-__attribute__((amdgpu_waves_per_eu(MM_APPLY_WAVES, MM_APPLY_WAVES)))
-__global__ void __launch_bounds__(APPLY_THREADS)
-k_apply_features(uint8_t* __restrict__ blocks, const int2* __restrict__ chunkPos, const mmgen_feature_placement* __restrict__ gfp,
+// UW x UH = the unit's shape: 4 x 2 columns for launches that give every wave dozens of units (the optimum of round 3's sweep); 2 x 1 for
+// small ones (k_apply_features_small: a streaming strip's 1 120 units of 4 x 2 are one round for 4 096 waves, as long as its slowest unit -
+// a jungle unit's items are two thirds of that), where four times the units of a quarter of the columns spread the items over the idle waves.
+template <int UW, int UH>
+MM_DEV void apply_features_body(uint8_t* __restrict__ blocks, const int2* __restrict__ chunkPos, const mmgen_feature_placement* __restrict__ gfp,
                  const mmgen_cave_feature_placement* __restrict__ gcfp, const int* __restrict__ bounds, const int* __restrict__ srcIdx, int nUnits,
                  unsigned* __restrict__ nextUnit)
 {
     __shared__ int4 s_unit[APPLY_COLS][APPLY_UNIT_CAP];    // per wave: the gathered placements, surface then cave
     __shared__ unsigned s_ent[APPLY_COLS][APPLY_ENT_CAP];  // per wave: placement | column << 7 | lowest y << 11 | (voxels - 1) << 20
     __shared__ unsigned short s_pref[APPLY_COLS][APPLY_ENT_CAP + 2];      // exclusive prefix of the pairs' voxel counts (+ the total)
-    __shared__ __attribute__((aligned(16))) uint8_t s_claim[APPLY_COLS][APPLY_UNIT_NCOL * 384];      // per voxel: the block of the first placement that claimed it, or 255
-    __shared__ unsigned s_air[APPLY_COLS][APPLY_UNIT_NCOL * 384 / 32];      // per voxel: the base block is AIR (all the item test needs of it)
+    __shared__ __attribute__((aligned(16))) uint8_t s_claim[APPLY_COLS][(UW * UH) * 384];      // per voxel: the block of the first placement that claimed it, or 255
+    __shared__ unsigned s_air[APPLY_COLS][(UW * UH) * 384 / 32];      // per voxel: the base block is AIR (all the item test needs of it)
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;      // wave index in an SGPR: so are chunk and column
     // the simplex tables (14 KB) are staged ONCE per workgroup (most units of a generated world have a coral, a fungus or a redwood in reach)
     noise_tables_init();
@@ -818,8 +820,8 @@ k_apply_features(uint8_t* __restrict__ blocks, const int2* __restrict__ chunkPos
     unsigned short* pref = s_pref[wave];
     uint8_t* claim = s_claim[wave];
     unsigned* air = s_air[wave];
-    constexpr int ROW_WORDS = APPLY_UNIT_W * 384 / 4;
-    static_assert(64 <= APPLY_UNIT_CAP && 64 <= APPLY_ENT_CAP && 64 * 384 <= APPLY_ITEM_CAP && 64 % APPLY_UNIT_NCOL == 0, "a round of 64 always fits an empty buffer, and holds whole placements");
+    constexpr int ROW_WORDS = UW * 384 / 4;
+    static_assert(64 <= APPLY_UNIT_CAP && 64 <= APPLY_ENT_CAP && 64 * 384 <= APPLY_ITEM_CAP && 64 % (UW * UH) == 0, "a round of 64 always fits an empty buffer, and holds whole placements");
     // Units cost anything between nothing (ocean) and ~100 us (jungle) and a wave only gets a few dozen: a fixed assignment leaves most
     // waves idle while the unluckiest finishes (measured: 5.2 ms instead of 3.0).  The waves draw their units from counters instead;
     // the next draw is in flight while the current unit is worked on.  ONE counter serialises at ~11 ns per draw in L2 (measured: 1.5 ms
@@ -843,8 +845,8 @@ k_apply_features(uint8_t* __restrict__ blocks, const int2* __restrict__ chunkPos
     }
     if (lane == 0) drawn = atomicAdd(&nextUnit[16 * part], 1u);
     if (u >= nUnits) continue;
-    const int chunk = u / APPLY_UNITS_PER_CHUNK, uu = u % APPLY_UNITS_PER_CHUNK;      // dense output / list index; positions are read at srcIdx[chunk]
-    const int x0 = APPLY_UNIT_W * (uu % (16 / APPLY_UNIT_W)), z0 = APPLY_UNIT_H * (uu / (16 / APPLY_UNIT_W));
+    const int chunk = u / ((16 / UW) * (16 / UH)), uu = u % ((16 / UW) * (16 / UH));      // dense output / list index; positions are read at srcIdx[chunk]
+    const int x0 = UW * (uu % (16 / UW)), z0 = UH * (uu / (16 / UW));
     const mmgen_feature_placement* listS = gfp + (size_t)MMGEN_MAX_GATHERED_FEATURES_PER_CHUNK * chunk;
     const mmgen_cave_feature_placement* listC = gcfp + (size_t)MMGEN_MAX_GATHERED_CAVE_FEATURES_PER_CHUNK * chunk;
     const int2 cp = chunkPos[srcIdx ? srcIdx[chunk] : chunk];
@@ -863,10 +865,10 @@ k_apply_features(uint8_t* __restrict__ blocks, const int2* __restrict__ chunkPos
         while (phase < 2 && nU + 64 <= APPLY_UNIT_CAP) {
             bool ended;
             if (phase == 0) {
-                const int n = filter_round<mmgen_feature_placement, MMGEN_MAX_GATHERED_FEATURES_PER_CHUNK, false>(listS, r0, wx0, wz0, unit, nU, ended);
+                const int n = filter_round<mmgen_feature_placement, MMGEN_MAX_GATHERED_FEATURES_PER_CHUNK, false, UW, UH>(listS, r0, wx0, wz0, unit, nU, ended);
                 nU += n; nUS += n;
             } else {
-                nU += filter_round<mmgen_cave_feature_placement, MMGEN_MAX_GATHERED_CAVE_FEATURES_PER_CHUNK, true>(listC, r0, wx0, wz0, unit, nU, ended);
+                nU += filter_round<mmgen_cave_feature_placement, MMGEN_MAX_GATHERED_CAVE_FEATURES_PER_CHUNK, true, UW, UH>(listC, r0, wx0, wz0, unit, nU, ended);
             }
             r0 += 64;
             if (ended) { r0 = 0; phase = (phase == 0 && doC) ? 1 : 2; }
@@ -875,17 +877,17 @@ k_apply_features(uint8_t* __restrict__ blocks, const int2* __restrict__ chunkPos
         wave_lds_sync();
 
         // ---- B + C. pairs of the gathered placements, items whenever the pair buffer fills up and at the end
-        const int nPairs = nU * APPLY_UNIT_NCOL;
+        const int nPairs = nU * (UW * UH);
         int nEnt = 0, total = 0;
         for (int p0 = 0;;) {
             const bool pairsDone = p0 >= nPairs;
             if (pairsDone || nEnt + 64 > APPLY_ENT_CAP || total + 64 * 384 > APPLY_ITEM_CAP) {
                 if (total > 0) {
                     if (!staged) {
-                        // the unit's air bits (APPLY_UNIT_W x 384 contiguous bytes per row; one mask word = 32 voxels = two 16-byte loads), claims cleared
+                        // the unit's air bits (UW x 384 contiguous bytes per row; one mask word = 32 voxels = two 16-byte loads), claims cleared
                         static_assert(MMB_AIR == 0, "zero-byte test below");
 #pragma unroll
-                        for (int cz = 0; cz < APPLY_UNIT_H; ++cz) {
+                        for (int cz = 0; cz < UH; ++cz) {
                             for (int m = lane; m < ROW_WORDS / 8; m += 64) {
                                 const uint4* src = (const uint4*)(unitBlocks + 384 * 16 * cz) + 2 * m;
                                 unsigned bits = 0u;
@@ -921,7 +923,7 @@ k_apply_features(uint8_t* __restrict__ blocks, const int2* __restrict__ chunkPos
                             v = 384 * c + y;
                             const int4 rc = unit[k];
                             if (((air[v >> 5] >> (v & 31)) & 1u) || ((rc.z >> 14) & 1)) {
-                                const int fy = rc.z & 511, feature = (rc.z >> 9) & 31, wx = wx0 + c % APPLY_UNIT_W, wz = wz0 + c / APPLY_UNIT_W;
+                                const int fy = rc.z & 511, feature = (rc.z >> 9) & 31, wx = wx0 + c % UW, wz = wz0 + c / UW;
                                 placed = k >= nUS ? place_cave_feature(feature, rc.x, fy, rc.y, (rc.z >> 15) & 511, wx, y, wz, (uint32_t)rc.w, fb)
                                                   : place_feature(feature, rc.x, fy, rc.y, wx, y, wz, (uint32_t)rc.w, fb);
                             }
@@ -942,12 +944,12 @@ k_apply_features(uint8_t* __restrict__ blocks, const int2* __restrict__ chunkPos
                 if (pairsDone) break;
             }
             // one round of 64 (placement, column) pairs = whole placements, placement-major
-            const int p = p0 + lane, k = p / APPLY_UNIT_NCOL, c = p % APPLY_UNIT_NCOL;
+            const int p = p0 + lane, k = p / (UW * UH), c = p % (UW * UH);
             int n = 0, lo = 0;
             if (p < nPairs) {
                 const int4 rc = unit[k];
                 const int fx = rc.x, fz = rc.y, fy = rc.z & 511, feat = (rc.z >> 9) & 31, reach = rc.z >> 24;
-                const int wx = wx0 + c % APPLY_UNIT_W, wz = wz0 + c / APPLY_UNIT_W;
+                const int wx = wx0 + c % UW, wz = wz0 + c / UW;
                 if (iabs(wx - fx) <= reach && iabs(wz - fz) <= reach) {
                     const bool cave = k >= nUS;
                     const bool noiseBounds = prune_domain(wx, wz);      // the two extents that use a simplex bound (coral ellipsoids, glowstone)
@@ -981,7 +983,7 @@ k_apply_features(uint8_t* __restrict__ blocks, const int2* __restrict__ chunkPos
     // ---- D. the claimed voxels back to the chunk
     wave_lds_sync();
 #pragma unroll
-    for (int cz = 0; cz < APPLY_UNIT_H; ++cz)
+    for (int cz = 0; cz < UH; ++cz)
         for (int i = lane; i < ROW_WORDS; i += 64) {
             const uint32_t cl = ((const uint32_t*)claim)[ROW_WORDS * cz + i];
             if (cl != 0xffffffffu) {
@@ -994,6 +996,29 @@ k_apply_features(uint8_t* __restrict__ blocks, const int2* __restrict__ chunkPos
         }
     wave_lds_sync();                                       // the wave's LDS lists are re-used by its next unit
   }
+}
+
+__attribute__((amdgpu_waves_per_eu(MM_APPLY_WAVES, MM_APPLY_WAVES)))
+__global__ void __launch_bounds__(APPLY_THREADS)
+k_apply_features(uint8_t* __restrict__ blocks, const int2* __restrict__ chunkPos, const mmgen_feature_placement* __restrict__ gfp,
+                 const mmgen_cave_feature_placement* __restrict__ gcfp, const int* __restrict__ bounds, const int* __restrict__ srcIdx, int nUnits,
+                 unsigned* __restrict__ nextUnit)
+{
+    apply_features_body<APPLY_UNIT_W, APPLY_UNIT_H>(blocks, chunkPos, gfp, gcfp, bounds, srcIdx, nUnits, nextUnit);
+}
+
+#define APPLY_SMALL_W 2
+#define APPLY_SMALL_H 1
+#ifndef APPLY_SMALL_MAX_CHUNKS
+#define APPLY_SMALL_MAX_CHUNKS 256                  // launches of at most this many chunks take the 2 x 1 units (256 chunks x 128 units = 8 per wave)
+#endif
+__attribute__((amdgpu_waves_per_eu(MM_APPLY_WAVES, MM_APPLY_WAVES)))
+__global__ void __launch_bounds__(APPLY_THREADS)
+k_apply_features_small(uint8_t* __restrict__ blocks, const int2* __restrict__ chunkPos, const mmgen_feature_placement* __restrict__ gfp,
+                       const mmgen_cave_feature_placement* __restrict__ gcfp, const int* __restrict__ bounds, const int* __restrict__ srcIdx, int nUnits,
+                       unsigned* __restrict__ nextUnit)
+{
+    apply_features_body<APPLY_SMALL_W, APPLY_SMALL_H>(blocks, chunkPos, gfp, gcfp, bounds, srcIdx, nUnits, nextUnit);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1227,14 +1252,21 @@ int launch_apply_features(uint8_t* blocks, const int32_t* pos, int n, const mmge
     const int cus = device_cus();
     if (!cus) return (int)hipErrorInvalidDevice;
     // persistent: MM_APPLY_WAVES waves per SIMD = that many 4-wave workgroups per CU; every wave walks its own units
-    const long long units = (long long)n * APPLY_UNITS_PER_CHUNK, groups = (units + APPLY_COLS - 1) / APPLY_COLS, fit = (long long)cus * MM_APPLY_WAVES;
+    static const int smallMax = [] { const char* e = getenv("MMGEN_APPLY_SMALL_MAX_CHUNKS"); return e ? atoi(e) : APPLY_SMALL_MAX_CHUNKS; }();      // (A/B: 0 = never)
+    const bool small = n <= smallMax;
+    const long long units = (long long)n * (small ? (16 / APPLY_SMALL_W) * (16 / APPLY_SMALL_H) : APPLY_UNITS_PER_CHUNK), groups = (units + APPLY_COLS - 1) / APPLY_COLS,
+                    fit = (long long)cus * MM_APPLY_WAVES;
     if (units > 0x7fffffffLL) return (int)hipErrorInvalidValue;
     if (!workCleared) {            // (the region's gather kernel clears them on its way)
         const hipError_t e = hipMemsetAsync(workCounter, 0, apply_work_bytes(), s);
         if (e != hipSuccess) return (int)e;
     }
-    LAUNCH(KID_APPLY_FEATURES, mm::k_apply_features, dim3((unsigned)(groups < fit ? groups : fit)), dim3(APPLY_THREADS), s, blocks, (const int2*)pos, gfp, gcfp,
-           bounds, srcIdx, (int)units, workCounter);
+    if (small)
+        LAUNCH(KID_APPLY_FEATURES, mm::k_apply_features_small, dim3((unsigned)(groups < fit ? groups : fit)), dim3(APPLY_THREADS), s, blocks, (const int2*)pos, gfp, gcfp,
+               bounds, srcIdx, (int)units, workCounter);
+    else
+        LAUNCH(KID_APPLY_FEATURES, mm::k_apply_features, dim3((unsigned)(groups < fit ? groups : fit)), dim3(APPLY_THREADS), s, blocks, (const int2*)pos, gfp, gcfp,
+               bounds, srcIdx, (int)units, workCounter);
     return 0;
 }
 
