@@ -1,5 +1,6 @@
 #!/bin/bash
-# removal experiment on k_fill_base (MM_FB_SKIP: 1 no list appends, 2 no layer search, 4 no biome draw, 8 no place_block_base at all, 16 no noise tables): its
+# removal experiment on k_fill_base (the MM_FB_SKIP hooks live in commit b3c4048 only - their literals fail tests/test_ref_literals.py -: check it out,
+# build the variants with tools/build_variant.sh <name> "-DMM_FB_SKIP=<bits>", run this; MM_FB_SKIP: 1 no list appends, 2 no layer search, 4 no biome draw, 8 no place_block_base at all, 16 no noise tables): its
 # time alone (serial pass) and the step beside everything else.  The variants' blocks are wrong; only the times mean something.
 #   tools/ab_fbskip.sh build_ab/libmmgen_fbskip1.so ...
 for lib in mega-minecraft_amd/libmmgen.so "$@"; do
