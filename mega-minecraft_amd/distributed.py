@@ -219,7 +219,7 @@ def chunk_digests(blocks, torch):
     """One 64-bit digest per chunk of block ids ([chunks, 98304] uint8, device or host tensor) as int64 [chunks], computed where the tensor
     lives: sum over the chunk's 8-byte words w of word * (2 w + 1) K1 (mod 2^64).  Every multiplier is odd, so a changed, moved or swapped
     word changes it.  tests/golden/world_digests.npz holds these for every chunk of the [-128, 128)^2 world as the CPU ORACLE generates it
-    (tools/gen_world_digests.py): BASELINE configs 4 and 5 at full size and every tile of bench.py's layouts are compared chunk by chunk."""
+    (tests/golden/make_world_digests.py): BASELINE configs 4 and 5 at full size and every tile of bench.py's layouts are compared chunk by chunk."""
     n = blocks.shape[0]
     words = blocks.contiguous().view(torch.int64).view(n, -1)
     mw = (2 * torch.arange(words.shape[1], dtype=torch.int64, device=words.device) + 1) * _K_WORD

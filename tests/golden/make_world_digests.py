@@ -6,11 +6,11 @@ full-size tests and bench.py's tiles_bit_exact hold the device to, chunk by chun
 
 The world is generated in pieces (default 64 x 64 chunks; a chunk is a function of its position only, so the piece size is free and
 --piece 32 / 128 must give the same file: tests/test_world_digests.py regenerates sampled chunks from 2 x 2 regions).
-    python tools/gen_world_digests.py [--piece 64] [--threads N] [--world -128 -128 256 256] out.npz
+    python tests/golden/make_world_digests.py [--piece 64] [--threads N] [--world -128 -128 256 256] out.npz
 About 29 000 core-seconds (caves 0.25, fill 0.11 core-s per chunk, 1.3 core-s per erosion zone, ring overhead 1.2 - 1.5 x)."""
 import argparse, os, sys, time
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 from oracle_binding import Oracle          # noqa: E402  (the checker: this tool makes test fixtures)
 

@@ -305,7 +305,7 @@ def test_tile_checksum_is_position_dependent_and_goldens_cover_the_bench_layouts
     mw = (2 * torch.arange(8, dtype=torch.int64) + 1) * d._K_WORD
     mc = (2 * torch.arange(1030, dtype=torch.int64) + 1) * d._K_CHUNK
     assert d.tile_checksum(many, torch) == int((((words * mw).sum(1)) * mc).sum().item()) & 0xFFFFFFFFFFFFFFFF
-    # per-chunk digests: tile_checksum is checksum_of_digests(chunk_digests); the numpy statement tools/gen_world_digests.py uses agrees
+    # per-chunk digests: tile_checksum is checksum_of_digests(chunk_digests); the numpy statement tests/golden/make_world_digests.py uses agrees
     dig = d.chunk_digests(blocks, torch)
     assert d.checksum_of_digests(dig, torch) == base
     wnp = blocks.numpy().view(np.int64).reshape(5, -1)

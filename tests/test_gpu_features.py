@@ -230,7 +230,7 @@ def _world_digests(d):
 
 
 def _assert_chunks_equal_oracle_digests(d, torch, blocks, cx0, cz0, nx, nz, what):
-    """Every chunk of the rectangle against the ORACLE's digest of that chunk (tests/golden/world_digests.npz, tools/gen_world_digests.py:
+    """Every chunk of the rectangle against the ORACLE's digest of that chunk (tests/golden/world_digests.npz, tests/golden/make_world_digests.py:
     the CPU oracle over the whole [-128, 128)^2 world, no HIP code involved)."""
     gold = d.golden_tile_digests(_world_digests(d), cx0, cz0, nx, nz)
     assert gold is not None
@@ -326,7 +326,7 @@ def test_config5_world_8_tiles_equals_single_region(mmgen_pkg):
 
 @pytest.mark.parametrize("name", ["world_digests_jungle", "world_digests_border", "world_digests_edge"])
 def test_three_more_worlds_equal_the_oracle_chunk_for_chunk(mmgen_pkg, name):
-    """Three more 65 536-chunk worlds, each generated as one region and held to the CPU oracle's per-chunk digests (tools/gen_world_digests.py on
+    """Three more 65 536-chunk worlds, each generated as one region and held to the CPU oracle's per-chunk digests (tests/golden/make_world_digests.py on
     the GPU box's host threads, profiles/r06e_world_digests_*): [1400, 1656) x [-1240, -984) - jungle / swamp / mesa country around the chunks
     most tests use - and [1920, 2176) x [-128, 128), which straddles the pruning domain's border at block 32 768 (chunk 2 048): the rows
     beyond it take k_fill_far and the unpruned cave / rasteriser paths, the rows inside the pruned ones, in one launch; and

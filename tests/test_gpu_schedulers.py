@@ -6,7 +6,7 @@ Three hosts stream the world around a player over the same C ABI and write one l
   * mmgen_terrain_demo - host/terrain.cpp, the mirror of that scheduler;
   * mmgen_region_terrain_demo - host/region_terrain.cpp, the region-batched streaming scheduler.
 Every drawable chunk's block digest must equal the ORACLE's digest of that chunk (tests/golden/world_digests.npz, made by
-tools/gen_world_digests.py with no HIP code involved), and the vertex / index bytes of 36 chunks around the player must equal the oracle's
+tests/golden/make_world_digests.py with no HIP code involved), and the vertex / index bytes of 36 chunks around the player must equal the oracle's
 Chunk::createVBOs restatement (oracle/mmo_mesh.cpp) run on the oracle's own blocks."""
 import importlib
 import os

@@ -1,5 +1,5 @@
 """tests/golden/world_digests.npz - the CPU oracle's digest of every chunk of the 65 536-chunk world [-128, 128)^2 (BASELINE config 5; it
-contains config 4's world and every tile of bench.py's layouts), written by tools/gen_world_digests.py on the GPU box's 256 host threads
+contains config 4's world and every tile of bench.py's layouts), written by tests/golden/make_world_digests.py on the GPU box's 256 host threads
 with no HIP code involved (log: profiles/r06_world_digests_oracle_gen.log).  Here: the file is what it says - the oracle, run again on this
 machine on sampled chunks as 1 x 1 regions (a different piece size than the 64 x 64 pieces it was made from), reproduces the digests."""
 import importlib
@@ -10,7 +10,7 @@ import numpy as np
 
 from conftest import ROOT, GOLDEN
 
-sys.path.insert(0, os.path.join(ROOT, "tools"))
+sys.path.insert(0, GOLDEN)
 
 
 def test_the_other_golden_worlds_are_the_oracles_too(oracle):
@@ -18,7 +18,7 @@ def test_the_other_golden_worlds_are_the_oracles_too(oracle):
     domain's border) and world_digests_edge.npz ([39 999 872, 40 000 128) x [-128, 128): block coordinates of 6.4e8): one sampled chunk of each, regenerated
     here as a 1 x 1 region."""
     d = importlib.import_module("mega-minecraft_amd.distributed")
-    gen = importlib.import_module("gen_world_digests")
+    gen = importlib.import_module("make_world_digests")
     for name, (cx, cz) in (("world_digests_jungle", (1488, -1110)), ("world_digests_border", (2048, 17)), ("world_digests_edge", (40000000, 5))):
         cx0, cz0, dig = d.load_world_digests(os.path.join(GOLDEN, name + ".npz"))
         blocks = oracle.generate_region(cx, cz, 1, 1, erosion=True, features=True, decorators=True, lean=True)["blocks"]
@@ -27,7 +27,7 @@ def test_the_other_golden_worlds_are_the_oracles_too(oracle):
 
 def test_golden_world_digests_are_the_oracles(oracle):
     d = importlib.import_module("mega-minecraft_amd.distributed")
-    gen = importlib.import_module("gen_world_digests")
+    gen = importlib.import_module("make_world_digests")
     cx0, cz0, dig = d.load_world_digests(os.path.join(GOLDEN, "world_digests.npz"))
     rng = np.random.default_rng(20261003)
     # two random chunks, a world corner, and the chunk the first full-world diff of the device against these digests found wrong (round 6)

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""GPU box: the HIP path's 65 536-chunk world [-128, 128)^2 (one region) against the ORACLE's per-chunk digests (tools/gen_world_digests.py ->
+"""GPU box: the HIP path's 65 536-chunk world [-128, 128)^2 (one region) against the ORACLE's per-chunk digests (tests/golden/make_world_digests.py ->
 tests/golden/world_digests.npz), every chunk.  Prints the number of differing chunks and the first few positions; exit code 1 on any.
     python tools/check_world_digests.py [digests.npz]"""
 import importlib, os, sys
