@@ -170,7 +170,14 @@ class TileContext:
         if dist is None or self.loopback or not hasattr(dist, "all_reduce") or not hasattr(dist, "get_world_size") or dist.get_world_size() <= 1:
             return self.overflow
         v = self.overflow.clone()
-        dist.all_reduce(v, op=dist.ReduceOp.MAX)
+        try:
+            dist.all_reduce(v, op=dist.ReduceOp.MAX)
+        except (RuntimeError, ValueError, TypeError) as e:           # a backend without integer MAX: every rank lands here alike, and keeps its own word
+            if not getattr(self, "_verdict_warned", False):
+                self._verdict_warned = True
+                import sys
+                print(f"mmgen: the ring-overflow verdict is not agreed over the ranks ({e!r}); a rank that overflows raises alone", file=sys.stderr)
+            return self.overflow
         return v
 
     def check(self, dist=None):
