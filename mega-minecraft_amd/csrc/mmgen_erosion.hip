@@ -83,9 +83,15 @@ struct F4 { float x, y, z, w; };
 #define MM_DRAIN_VMEM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 #define MM_AUX_SC1 16
 #define MM_BUF_OOB 0xFFFFFFF0u            /* beyond every descriptor's range: the load returns zeros and moves nothing */
+#ifndef MM_ERODE_LOAD_AUX
+#define MM_ERODE_LOAD_AUX MM_AUX_SC1
+#endif
+#ifndef MM_ERODE_ROUND_INV
+#define MM_ERODE_ROUND_INV 0
+#endif
 MM_DEV F4 ld4_dev(__amdgpu_buffer_rsrc_t rs, unsigned byteOff)
 {
-    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)byteOff, 0, MM_AUX_SC1);
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)byteOff, 0, MM_ERODE_LOAD_AUX);
     return F4{__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
 }
 // A zone is relaxed by workgroups of ONE XCD (k_erode_zones reads HW_REG_XCC_ID and forms its groups per XCD): its planes travel through
@@ -95,11 +101,15 @@ MM_DEV F4 ld4_dev(__amdgpu_buffer_rsrc_t rs, unsigned byteOff)
 #ifndef MM_ERODE_STORE_AUX
 #define MM_ERODE_STORE_AUX 0
 #endif
+template <int AUX = MM_ERODE_STORE_AUX>
 MM_DEV void st4_dev(__amdgpu_buffer_rsrc_t rs, unsigned byteOff, const F4& f)
 {
     const u32x4 v = {__float_as_uint(f.x), __float_as_uint(f.y), __float_as_uint(f.z), __float_as_uint(f.w)};
-    __builtin_amdgcn_raw_buffer_store_b128(v, rs, (int)byteOff, 0, MM_ERODE_STORE_AUX);
+    __builtin_amdgcn_raw_buffer_store_b128(v, rs, (int)byteOff, 0, AUX);
 }
+#ifndef MM_ERODE_FIRST_AUX
+#define MM_ERODE_FIRST_AUX MM_ERODE_STORE_AUX          /* the "state after the first pass" plane, read only by zones whose first pass changed nothing */
+#endif
 
 // Geometry of a tile's traffic.  Loads: the rows of the extended tile as aligned 16-byte pieces (columns [gx0 - PAD, gx0 - PAD + 4 SEGS) of
 // the grid; the PAD + (4 SEGS - EXT - PAD) columns outside the extended tile are dropped), ROWS x SEGS pieces per plane, three planes
@@ -345,7 +355,7 @@ MM_DEV unsigned relax_tile(__amdgpu_buffer_rsrc_t work, const RoundPlanes& rp, i
             // the state after a layer's first pass is the layer's final state if that pass changed no column of the ZONE (next_phase): kept
             // in the layer's third plane by the tiles whose own centre it left alone (if it moved one, the zone's mask says so and the plane
             // is not looked at).  Plane 0 is read-only until the barrier behind the next pass.
-            if (!(any & 2) && tid < 256) st4_dev(work, 4u * (rp.startFirst + centre_offset(tileX, tileZ, tid)), centre_piece(s_s[0], tid));
+            if (!(any & 2) && tid < 256) st4_dev<MM_ERODE_FIRST_AUX>(work, 4u * (rp.startFirst + centre_offset(tileX, tileZ, tid)), centre_piece(s_s[0], tid));
         } else if (!(any & 1)) break;      // a pass (other than a first pass) that changes no live cell of the tile is the identity from here on
     }
     // results of the centre
@@ -578,6 +588,9 @@ MM_DEV void erode_zones_body(const float* __restrict__ gatheredBase, size_t gath
             if (!erosion_spin(&st->barrier, (unsigned)perZone * (unsigned)(t + 1), err, errHost, 0x80000000u | ((unsigned)zone << 8) | ((unsigned)t & 255u), timeoutTicks))
                 s_abort = 1;
         }
+#if MM_ERODE_ROUND_INV
+        if (tid == 0) { asm volatile("buffer_inv sc1\n\ts_waitcnt vmcnt(0)" ::: "memory"); }
+#endif
         __syncthreads();
         if (s_abort) return;
     }
