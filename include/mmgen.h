@@ -259,8 +259,13 @@ int mmgen_mesh_fill(const uint8_t* d_blocks, const int32_t* d_chunk_idx, const i
  *   mmgen_mesh_offsets      d_vert_offset[c] = exclusive prefix of d_chunk_verts on the device, d_total[0] = their sum;
  *   mmgen_mesh_fill_capped  mmgen_mesh_fill that writes nothing for a chunk whose vertices would end beyond capacity_verts (the caller sized
  *                           d_verts / d_idx for capacity_verts vertices from what earlier ticks needed; it reads d_total afterwards, and when
- *                           that exceeds the capacity it grows the buffers and repeats the three calls). */
+ *                           that exceeds the capacity it grows the buffers and repeats the three calls);
+ *   mmgen_mesh_fill_strip   both in ONE launch for 1 <= n <= 256 chunks (a streaming tick's strip): every workgroup sums the counts of the
+ *                           chunks before its own (d_chunk_verts from mmgen_mesh_count), d_vert_offset / d_total are OUTPUTS. */
 int mmgen_mesh_offsets(const uint32_t* d_chunk_verts, int n, uint64_t* d_vert_offset, uint64_t* d_total, void* stream);
+int mmgen_mesh_fill_strip(const uint8_t* d_blocks, const int32_t* d_chunk_idx, const int32_t* d_neighbor_idx, const int32_t* d_chunk_world_block_pos, int n,
+                          const uint32_t* d_column_verts, const uint32_t* d_chunk_verts, uint64_t* d_vert_offset, uint64_t* d_total, uint64_t capacity_verts,
+                          mmgen_vertex* d_verts, uint32_t* d_idx, void* stream);
 int mmgen_mesh_fill_capped(const uint8_t* d_blocks, const int32_t* d_chunk_idx, const int32_t* d_neighbor_idx, const int32_t* d_chunk_world_block_pos, int n,
                            const uint32_t* d_column_verts, const uint64_t* d_vert_offset, uint64_t capacity_verts, mmgen_vertex* d_verts, uint32_t* d_idx,
                            void* stream);

@@ -284,7 +284,10 @@ __global__ void __launch_bounds__(256)
 k_mesh_fill(const uint8_t* __restrict__ blocks, const int32_t* __restrict__ chunkIdx, const int32_t* __restrict__ neighborIdx,
             const int2* __restrict__ chunkWorldBlockPos, const uint32_t* __restrict__ columnVerts, const uint64_t* __restrict__ vertOffset, mmgen_vertex* __restrict__ verts,
             uint32_t* __restrict__ idx, int parts /*workgroups per chunk (gridDim.y): part p emits columns [256 p / parts, 256 (p + 1) / parts)*/,
-            unsigned long long capacityVerts /*0 = the caller sized the buffers from the counts; else a chunk that would end beyond it writes nothing*/)
+            unsigned long long capacityVerts /*0 = the caller sized the buffers from the counts; else a chunk that would end beyond it writes nothing*/,
+            const uint32_t* __restrict__ chunkVerts /*non-null (a strip: gridDim.x <= 256): the chunk's offset is summed here from the chunks' counts;
+                                                       vertOffsetOut[chunk] and totalOut receive what mmgen_mesh_offsets would have written*/,
+            uint64_t* __restrict__ vertOffsetOut, uint64_t* __restrict__ totalOut)
 {
     __shared__ Planes P;
     __shared__ uint8_t s_cls[256];
@@ -300,6 +303,25 @@ k_mesh_fill(const uint8_t* __restrict__ blocks, const int32_t* __restrict__ chun
     if (t < MMB_NUM_BLOCKS) s_data[t] = kBlockData[t];
     if (t < 72) s_dv[t] = kMeshDirVert[t / 3][t % 3];
     if (t < 18) s_dir[t] = kMeshDir[t / 3][t % 3];
+    __shared__ unsigned long long s_base;
+    if (chunkVerts) {
+        // exclusive prefix of the chunks before this one (and, in the last chunk's first part, the total): <= 256 counts, one per lane
+        const int nChunks = (int)gridDim.x;
+        const unsigned long long cv = t < nChunks ? chunkVerts[t] : 0u;
+        unsigned long long before = t < o ? cv : 0ull, all = cv;
+        for (int d = 32; d > 0; d >>= 1) { before += __shfl_xor(before, d); all += __shfl_xor(all, d); }
+        __shared__ unsigned long long s_part[2][4];
+        if ((t & 63) == 0) { s_part[0][t >> 6] = before; s_part[1][t >> 6] = all; }
+        __syncthreads();
+        if (t == 0) {
+            const unsigned long long b = s_part[0][0] + s_part[0][1] + s_part[0][2] + s_part[0][3];
+            s_base = b;
+            if (blockIdx.y == 0) {
+                vertOffsetOut[o] = b;
+                if (o == nChunks - 1) *totalOut = s_part[1][0] + s_part[1][1] + s_part[1][2] + s_part[1][3];
+            }
+        }
+    }
     const uint32_t mine = columnVerts[256 * o + t] / 4u;
     s_scan[t] = mine;
     __syncthreads();
@@ -316,7 +338,7 @@ k_mesh_fill(const uint8_t* __restrict__ blocks, const int32_t* __restrict__ chun
         const f2 r = rand2from2((float)(wb.x + (t & 15)), (float)(wb.y + (t >> 4)));
         s_jitter[t] = make_float2(0.4f * (r.x - 0.5f), 0.4f * (r.y - 0.5f));
     }
-    const uint64_t vbase = vertOffset[o];
+    const uint64_t vbase = chunkVerts ? (uint64_t)s_base : vertOffset[o];
     if (capacityVerts && vbase + 4ull * total > capacityVerts) return;      // (workgroup-uniform: every part of the chunk leaves)
     uint32_t* vout = (uint32_t*)(verts + vbase);
     uint32_t* iout = idx + (vbase / 4) * 6;
@@ -401,15 +423,16 @@ int mmgen_mesh_count(const uint8_t* d_blocks, const int32_t* d_chunk_idx, const 
 }
 
 static int mesh_fill_launch(const uint8_t* d_blocks, const int32_t* d_chunk_idx, const int32_t* d_neighbor_idx, const int32_t* d_chunk_world_block_pos, int n,
-                            const uint32_t* d_column_verts, const uint64_t* d_vert_offset, unsigned long long capacity, mmgen_vertex* d_verts, uint32_t* d_idx, void* stream)
+                            const uint32_t* d_column_verts, const uint64_t* d_vert_offset, unsigned long long capacity, mmgen_vertex* d_verts, uint32_t* d_idx, void* stream,
+                            const uint32_t* d_chunk_verts = nullptr, uint64_t* d_vert_offset_out = nullptr, uint64_t* d_total_out = nullptr)
 {
-    if (n < 0 || (n > 0 && (!d_blocks || !d_chunk_world_block_pos || !d_column_verts || !d_vert_offset || !d_verts || !d_idx)))
+    if (n < 0 || (n > 0 && (!d_blocks || !d_chunk_world_block_pos || !d_column_verts || !(d_vert_offset || d_chunk_verts) || !d_verts || !d_idx)))
         return (int)hipErrorInvalidValue;
     if (n == 0) return 0;
     int parts = 1;                                        // ~512 workgroups at least, at most 8 per chunk
     while (parts < 8 && n * parts * 2 <= 512) parts *= 2;
     MMK_LAUNCH_NORET(mmk::KID_MESH_FILL, mm::k_mesh_fill, dim3(n, parts), dim3(256), (hipStream_t)stream, d_blocks, d_chunk_idx, d_neighbor_idx, (const int2*)d_chunk_world_block_pos,
-                       d_column_verts, d_vert_offset, d_verts, d_idx, parts, capacity);
+                       d_column_verts, d_vert_offset, d_verts, d_idx, parts, capacity, d_chunk_verts, d_vert_offset_out, d_total_out);
     return (int)hipGetLastError();
 }
 
@@ -425,6 +448,15 @@ int mmgen_mesh_fill_capped(const uint8_t* d_blocks, const int32_t* d_chunk_idx, 
 {
     if (capacity_verts == 0) return (int)hipErrorInvalidValue;
     return mesh_fill_launch(d_blocks, d_chunk_idx, d_neighbor_idx, d_chunk_world_block_pos, n, d_column_verts, d_vert_offset, capacity_verts, d_verts, d_idx, stream);
+}
+
+int mmgen_mesh_fill_strip(const uint8_t* d_blocks, const int32_t* d_chunk_idx, const int32_t* d_neighbor_idx, const int32_t* d_chunk_world_block_pos, int n,
+                          const uint32_t* d_column_verts, const uint32_t* d_chunk_verts, uint64_t* d_vert_offset, uint64_t* d_total, uint64_t capacity_verts,
+                          mmgen_vertex* d_verts, uint32_t* d_idx, void* stream)
+{
+    if (capacity_verts == 0 || n < 1 || n > 256 || !d_chunk_verts || !d_vert_offset || !d_total) return (int)hipErrorInvalidValue;
+    return mesh_fill_launch(d_blocks, d_chunk_idx, d_neighbor_idx, d_chunk_world_block_pos, n, d_column_verts, nullptr, capacity_verts, d_verts, d_idx, stream,
+                            d_chunk_verts, d_vert_offset, d_total);
 }
 
 int mmgen_mesh_offsets(const uint32_t* d_chunk_verts, int n, uint64_t* d_vert_offset, uint64_t* d_total, void* stream)

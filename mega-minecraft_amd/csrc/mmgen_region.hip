@@ -14,6 +14,7 @@
 //   gather / fill / features / decorators on R.
 #include <hip/hip_runtime.h>
 #include <map>
+#include <utility>
 #include <vector>
 #include <cstdio>
 #include <cstring>
@@ -44,8 +45,14 @@ struct DevBuf {
     template <class T> T* as() const { return (T*)p; }
 };
 
+// A layout table: a view into the region's table arena (HostStage::place), not an allocation of its own.
+struct Table {
+    void* p = nullptr;
+    template <class T> T* as() const { return (T*)p; }
+};
+
 // Host side of the layout's index tables: two pinned slots used alternately.  A layout's tables are written into one slot and copied
-// from there by asynchronous copies on the caller's stream; the slot is not written again before the event behind those copies has
+// from there by ONE asynchronous copy on the caller's stream (the device arena has the slot's layout); the slot is not written again before the event behind those copies has
 // fired (two layouts later: long over).  From pageable vectors every copy staged through the runtime and the call ended with a stream
 // synchronisation - per tick of a streaming host (a new strip every tick) that was a tenth of the step.
 struct HostStage {
@@ -69,15 +76,18 @@ struct HostStage {
         return 0;
     }
     static size_t padded(size_t bytes) { return (bytes + 255) / 256 * 256; }
-    int upload(DevBuf& dst, const void* src, size_t bytes, hipStream_t s)
+    // the table into the slot; its device address is the same offset of `devBase` (the whole slot travels with ONE copy: flush)
+    int place(Table& dst, const void* src, size_t bytes, char* devBase)
     {
+        dst.p = nullptr;
         if (!bytes) return 0;
         if (used + padded(bytes) > cap) return (int)hipErrorInvalidValue;
-        char* h = slot[cur] + used;
+        std::memcpy(slot[cur] + used, src, bytes);
+        dst.p = devBase + used;
         used += padded(bytes);
-        std::memcpy(h, src, bytes);
-        return (int)hipMemcpyAsync(dst.p, h, bytes, hipMemcpyHostToDevice, s);
+        return 0;
     }
+    int flush(char* devBase, hipStream_t s) { return used ? (int)hipMemcpyAsync(devBase, slot[cur], used, hipMemcpyHostToDevice, s) : 0; }
     int end(hipStream_t s) { return (int)hipEventRecord(ev[cur], s); }
     void release()
     {
@@ -260,9 +270,18 @@ struct mmgen_region {
     int ax0 = 0, az0 = 0, anx = 0, anz = 0, na = 0;
     int nCompute = 0, nZones = 0, nLazy = 0;
     bool began = false;
-    DevBuf posA, hfA, bwA, gathA, layersA;
+    DevBuf hfA, bwA, gathA, layersA;
     DevBuf layersP, caveP, colInfo, fp, cfp, counts;
-    DevBuf zoneIdx, zoneIdxOut, erodeWork, erodeState, computeList, targets, gfp, gcfp, bounds, fillQueue, cellLazy, colNeed, applyWork;
+    // the list lengths of the NEXT step: cleared by this step's finish on the caller's stream, where it runs beside the rasterisers, so that a
+    // begin whose caller provides ring cells (they must read as empty until it has written them) swaps buffers instead of putting a 5 us
+    // memset in front of its first kernel.  countsSpareClean = bytes of it known to be zero (0: dirty or absent)
+    DevBuf countsSpare;
+    size_t countsSpareClean = 0;
+    DevBuf erodeWork, erodeState, gfp, gcfp, bounds, fillQueue, colNeed, applyWork;
+    // the layout's tables: views into ONE device arena that mirrors the pinned slot they are built in, so that a new layout costs one
+    // host-to-device copy instead of one per table (six to nine 5 us copies per tick of a streaming host, back to back in front of its first kernel)
+    DevBuf tableArena;
+    Table posA, computeList, targets, cellLazy, zoneIdx, zoneIdxOut, hitSlots, hitIdxOut, missSlots;
     bool passesPending = false;
     hipEvent_t evPasses = nullptr;      // behind the erosion branch of the last begin: hostMax[2] (its largest pass count) is valid once it has fired
     // layout cache: the host-built index tables (positions, A->P selection, compute list, zone gather / scatter lists, fill targets)
@@ -288,7 +307,7 @@ struct mmgen_region {
     int nHitZones = 0, nMissZones = 0;
     long long zoneHits = 0, zoneMisses = 0;             // since the cache was (re)sized
     HostStage stage;                                    // pinned host side of the layout's tables
-    DevBuf hitSlots, hitIdxOut, missSlots;              // device: [nHit] slot, [nHit][144] P index or -1; [nMiss] slot or -1
+    // (tables hitSlots [nHit] slot, hitIdxOut [nHit][144] P index or -1, missSlots [nMiss] slot or -1: above)
     const unsigned* fillStarted = nullptr;      // started-workgroups word of the early fill's k_fill_cave (one slice) and the value it reaches
     unsigned fillStartedTarget = 0u;
     bool filled = false;          // mmgen_region_fill already ran for the current begin
@@ -353,9 +372,8 @@ struct mmgen_region {
             for (hipEvent_t x : ev) if (x) (void)hipEventDestroy(x);
             for (int i = 0; i < kMaxSlices; ++i) if (evFill[i]) (void)hipEventDestroy(evFill[i]);
         }
-        DevBuf* all[] = {&posA, &hfA, &bwA, &gathA, &layersA, &layersP, &caveP, &colInfo, &fp, &cfp, &counts, &zoneIdx,
-                         &zoneIdxOut, &erodeWork, &erodeState, &computeList, &targets, &gfp, &gcfp, &bounds, &fillQueue, &cellLazy, &colNeed, &applyWork,
-                         &zoneCache, &hitSlots, &hitIdxOut, &missSlots};
+        DevBuf* all[] = {&tableArena, &hfA, &bwA, &gathA, &layersA, &layersP, &caveP, &colInfo, &fp, &cfp, &counts, &countsSpare,
+                         &erodeWork, &erodeState, &gfp, &gcfp, &bounds, &fillQueue, &colNeed, &applyWork, &zoneCache};
         for (DevBuf* b : all) b->release();
     }
 };
@@ -555,40 +573,30 @@ static int region_layout(mmgen_region* r, int cx0, int cz0, int nx, int nz, unsi
             ho[(size_t)z * 144 + cx + 12 * cz] = (gx >= 0 && gx < r->pnx && gz >= 0 && gz < r->pnz) ? gx + r->pnx * gz : -1;
         }
 
-    CK(r->posA.ensure(sizeof(int32_t) * 2 * na));
-    CK(r->computeList.ensure(sizeof(int) * np));
-    CK(r->targets.ensure(sizeof(int) * nr));
     {
         using HS = HostStage;
         const size_t total = HS::padded(sizeof(int32_t) * 2 * na) + HS::padded(sizeof(int) * r->nCompute) + HS::padded(sizeof(int) * nr) + HS::padded(np) +
                              HS::padded(sizeof(int) * zi.size()) + HS::padded(sizeof(int) * zo.size()) + HS::padded(sizeof(int) * hitSlot.size()) +
                              HS::padded(sizeof(int) * ho.size()) + HS::padded(sizeof(int) * missSlot.size());
         CK(r->stage.begin(total));
+        CK(r->tableArena.ensure(total));
     }
-    CK(r->stage.upload(r->posA, posA.data(), sizeof(int32_t) * 2 * na, s));
-    CK(r->stage.upload(r->computeList, computeList.data(), sizeof(int) * r->nCompute, s));
-    CK(r->stage.upload(r->targets, targets.data(), sizeof(int) * nr, s));
+    char* const dev = r->tableArena.as<char>();
+    CK(r->stage.place(r->posA, posA.data(), sizeof(int32_t) * 2 * na, dev));
+    CK(r->stage.place(r->computeList, computeList.data(), sizeof(int) * r->nCompute, dev));
+    CK(r->stage.place(r->targets, targets.data(), sizeof(int) * nr, dev));
+    r->cellLazy.p = nullptr;
     if (r->nLazy) {
-        CK(r->cellLazy.ensure(np));
         CK(r->colNeed.ensure((size_t)256 * np));
-        CK(r->stage.upload(r->cellLazy, lazy.data(), np, s));
+        CK(r->stage.place(r->cellLazy, lazy.data(), np, dev));
     }
-    if (Z) {
-        CK(r->zoneIdx.ensure(sizeof(int) * zi.size()));
-        CK(r->zoneIdxOut.ensure(sizeof(int) * zo.size()));
-        CK(r->stage.upload(r->zoneIdx, zi.data(), sizeof(int) * zi.size(), s));
-        CK(r->stage.upload(r->zoneIdxOut, zo.data(), sizeof(int) * zo.size(), s));
-    }
-    if (r->nHitZones) {
-        CK(r->hitSlots.ensure(sizeof(int) * hitSlot.size()));
-        CK(r->hitIdxOut.ensure(sizeof(int) * ho.size()));
-        CK(r->stage.upload(r->hitSlots, hitSlot.data(), sizeof(int) * hitSlot.size(), s));
-        CK(r->stage.upload(r->hitIdxOut, ho.data(), sizeof(int) * ho.size(), s));
-    }
-    if (zoneCaching && Z) {
-        CK(r->missSlots.ensure(sizeof(int) * missSlot.size()));
-        CK(r->stage.upload(r->missSlots, missSlot.data(), sizeof(int) * missSlot.size(), s));
-    }
+    CK(r->stage.place(r->zoneIdx, zi.data(), sizeof(int) * zi.size(), dev));
+    CK(r->stage.place(r->zoneIdxOut, zo.data(), sizeof(int) * zo.size(), dev));
+    CK(r->stage.place(r->hitSlots, hitSlot.data(), sizeof(int) * hitSlot.size(), dev));
+    CK(r->stage.place(r->hitIdxOut, ho.data(), sizeof(int) * ho.size(), dev));
+    r->missSlots.p = nullptr;
+    if (zoneCaching && Z) CK(r->stage.place(r->missSlots, missSlot.data(), sizeof(int) * missSlot.size(), dev));
+    CK(r->stage.flush(dev, s));
     CK(r->stage.end(s));             // (no synchronisation: the host side of the tables is the pinned slot, not these vectors)
 
     r->kcx0 = cx0; r->kcz0 = cz0; r->knx = nx; r->knz = nz; r->kflags = flags; r->kHasMask = h_local_mask != nullptr;
@@ -686,7 +694,15 @@ int mmgen_region_begin(mmgen_region* r, int cx0, int cz0, int nx, int nz, unsign
     if (features) {
         CK(r->fp.ensure(sizeof(mmgen_feature_placement) * MMGEN_FP_CAP * (size_t)np));
         CK(r->cfp.ensure(sizeof(mmgen_cave_feature_placement) * MMGEN_CFP_CAP * (size_t)np));
-        CK(r->counts.ensure(sizeof(int) * 2 * np));
+        // cells the caller provides (mask 0) read as empty until it has written them; every computed cell's lengths are stored by F1
+        const size_t countBytes = sizeof(int) * 2 * (size_t)np;
+        if (r->nCompute < np && r->countsSpareClean >= countBytes) {
+            std::swap(r->counts, r->countsSpare);       // (the last finish cleared it behind its gather: stream order)
+            r->countsSpareClean = 0;
+        } else {
+            CK(r->counts.ensure(countBytes));
+            if (r->nCompute < np) CK(hipMemsetAsync(r->counts.p, 0, countBytes, s));
+        }
     }
 
     // ---- K1 + K2 on the raw area A.  With erosion the P grid's layers exist twice (raw in A for the zones' padding, eroded in P): K2 stores
@@ -771,8 +787,6 @@ int mmgen_region_begin(mmgen_region* r, int cx0, int cz0, int nx, int nz, unsign
     // ---- F1 placements (eroded layers + cave layers of every computed cell)
     if (features) {
         mmk::StageRange sr("mmgen:feature_placements");
-        // cells the caller provides (mask 0) read as empty until it has written them; every computed cell's lengths are stored by the kernel
-        if (r->nCompute < np) CK(hipMemsetAsync(r->counts.p, 0, sizeof(int) * 2 * np, s));
         CK(mmk::launch_feature_placements(hfP, bwP, layersP, r->caveP.as<mmgen_cave_layer>(), posP, r->nCompute, r->fp.as<mmgen_feature_placement>(),
                                           r->cfp.as<mmgen_cave_feature_placement>(), r->counts.as<int>(), list, colNeed, s));
         if (par) CK(hipEventRecord(r->evF1, s));
@@ -925,6 +939,14 @@ int mmgen_region_finish(mmgen_region* r, uint8_t* d_blocks, float* d_heightfield
                                          r->bounds.as<int>(), posP, s, r->devMax.as<int>() + 1, r->hostMaxDev, r->devMax.as<int>(),
                                          (unsigned*)r->applyWork.p, (int)(mmk::apply_work_bytes() * r->kMaxSlices / 4), hfP, d_heightfields));
         d_heightfields = nullptr;                       // (copied by the gather)
+        if (par && r->nCompute < r->np) {
+            // the next step's list lengths (see countsSpare): same size as this step's, cleared here beside the rasterisers
+            const size_t countBytes = sizeof(int) * 2 * (size_t)r->np;
+            r->countsSpareClean = 0;
+            CK(r->countsSpare.ensure(countBytes));
+            CK(hipMemsetAsync(r->countsSpare.p, 0, countBytes, s));
+            r->countsSpareClean = countBytes;
+        }
     }
     if (par) { CK(hipEventRecord(r->evGather, s)); CK(hipStreamWaitEvent(sA, r->evGather, 0)); }
     // rasterisers + decorators slice by slice behind that slice's base fill

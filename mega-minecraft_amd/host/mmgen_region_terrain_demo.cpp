@@ -81,6 +81,7 @@ static StreamFigures stream_scenario(bool copyToHost, ivec2 home, int steps, int
     t.setCurrentChunkPos(home);
     auto t0 = Clock::now();
     do { t.tick(1.f / 60.f); f.loadChunks += t.lastGenerated; f.loadMeshed += t.lastMeshed; f.d2hBytes += t.lastBlockBytesD2H; } while (!t.allQueuesEmpty());
+    { const int booked = t.lastMeshed; t.finish(); f.loadMeshed += t.lastMeshed - booked; }      // (a device-resident strip's mesh is booked by the next call)
     HipUtils::checkError("hipDeviceSynchronize", (int)hipDeviceSynchronize());
     f.loadMs = 1e3 * secondsSince(t0);
     t0 = Clock::now();
@@ -91,6 +92,7 @@ static StreamFigures stream_scenario(bool copyToHost, ivec2 home, int steps, int
             f.walkChunks += t.lastGenerated; f.walkMeshed += t.lastMeshed; f.ringComputed += t.lastRingComputed; f.ringReused += t.lastRingReused;
         } while (!t.allQueuesEmpty());
     }
+    { const int booked = t.lastMeshed; t.finish(); f.walkMeshed += t.lastMeshed - booked; }
     HipUtils::checkError("hipDeviceSynchronize", (int)hipDeviceSynchronize());
     f.walkMs = 1e3 * secondsSince(t0);
     t.zoneCacheStats(f.zoneHits, f.zoneMisses);
@@ -186,6 +188,7 @@ int main(int argc, char** argv)
                 resident.tick(1.f / 60.f);
                 generated += resident.lastGenerated; meshed += resident.lastMeshed; reused += resident.lastRingReused; computed += resident.lastRingComputed;
             } while (!resident.allQueuesEmpty());
+            { const int booked = resident.lastMeshed; resident.finish(); meshed += resident.lastMeshed - booked; }
             const double s = secondsSince(t0);
             std::printf("device-resident leg %d: %d chunks generated, %d meshed in %.1f ms (%.0f generated chunks/s incl. meshing); ring cells: %d computed, %d from the placement cache\n",
                         leg, generated, meshed, 1e3 * s, generated / s, computed, reused);

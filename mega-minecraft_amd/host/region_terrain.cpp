@@ -1,5 +1,8 @@
 // mmgen host side — region-batched streaming scheduler (see region_terrain.hpp).
 #include "region_terrain.hpp"
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include "chunk_digest.hpp"
 #include <algorithm>
 #include <cstdlib>
@@ -7,6 +10,18 @@
 #include <new>
 
 namespace mmhost {
+
+// MMHOST_TICK_PROFILE=1: where the host spends a tick (printed when the terrain is destroyed): planning, the region calls, the mesher's
+// calls, waiting for the device
+namespace {
+struct TickProfile {
+    double plan = 0, gen = 0, mesh = 0, wait = 0, total = 0; long long ticks = 0;
+    double cPlan = 0, cGen = 0, cMesh = 0, cWait = 0;      // the current tick's (kept only if it generated a strip: at most 128 chunks)
+    const bool on = std::getenv("MMHOST_TICK_PROFILE") != nullptr;
+    static double now() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+} g_tp;
+}
+
 
 namespace {
 const ivec2 kDir4[4] = {{0, 1}, {1, 0}, {0, -1}, {-1, 0}};      // N (+z), E (+x), S (-z), W (-x): Chunk::neighbors order (util/enums.hpp:40-47)
@@ -43,21 +58,33 @@ void RegionTerrain::copySync(const Lane& L, void* dst, const void* src, size_t b
 
 // host -> device without a synchronisation: staged in the lane's pinned arena, copied on the lane's stream (stream order does the rest).
 // An upload that does not fit what is left of the arena falls back to the blocking copy.
-void RegionTerrain::uploadAsync(Lane& L, void* dst, const void* src, size_t bytes, const char* what)
+void RegionTerrain::uploadAsync(Lane& L, void* dst, const void* src, size_t bytes, const char* what) { uploadAsyncOn(L, L.stream, dst, src, bytes, what); }
+void RegionTerrain::uploadAsyncOn(Lane& L, hipStream_t st, void* dst, const void* src, size_t bytes, const char* what)
 {
     const size_t need = (bytes + 63) / 64 * 64;
-    if (!L.h_pin || L.pinUsed + need > L.pinCap) { copySync(L, dst, src, bytes, hipMemcpyHostToDevice, what); return; }
+    if (!L.h_pin || L.pinUsed + need > L.pinLimit) {
+        RT_CALL(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st), what);
+        RT_CALL(hipStreamSynchronize(st), what);
+        return;
+    }
     char* stage = L.h_pin + L.pinUsed;
     L.pinUsed += need;
     std::memcpy(stage, src, bytes);
-    RT_CALL(hipMemcpyAsync(dst, stage, bytes, hipMemcpyHostToDevice, L.stream), what);
+    RT_CALL(hipMemcpyAsync(dst, stage, bytes, hipMemcpyHostToDevice, st), what);
 }
 
 RegionTerrain::~RegionTerrain()
 {
+    if (g_tp.on && g_tp.ticks) {
+        std::fprintf(stderr, "RegionTerrain: %lld ticks, us per tick: total %.1f = planning %.1f + region calls %.1f + mesher (incl. waiting %.1f for the previous strip) %.1f + rest\n",
+                     g_tp.ticks, g_tp.total / g_tp.ticks, g_tp.plan / g_tp.ticks, g_tp.gen / g_tp.ticks, g_tp.wait / g_tp.ticks, g_tp.mesh / g_tp.ticks);
+        g_tp.plan = g_tp.gen = g_tp.mesh = g_tp.wait = g_tp.total = 0; g_tp.ticks = 0;
+    }
     for (Lane& L : lanes) {
         (void)hipSetDevice(L.device);
+        if (L.evMesh) { (void)hipEventSynchronize(L.evMesh); (void)hipEventDestroy(L.evMesh); }
         if (L.h_pin) (void)hipHostFree(L.h_pin);
+        if (L.h_back) (void)hipHostFree(L.h_back);
         if (L.region) mmgen_region_destroy(L.region);
         if (L.d_pool) (void)hipFree(L.d_pool);
         if (L.d_stage) (void)hipFree(L.d_stage);
@@ -96,6 +123,8 @@ void RegionTerrain::init()
         for (size_t i = 0; i < L.cacheCells; ++i) L.freePlacementSlots[i] = (int)(L.cacheCells - 1 - i);
         L.pinCap = 1 << 20;
         RT_CALL(hipHostMalloc((void**)&L.h_pin, L.pinCap, hipHostMallocDefault), "hipHostMalloc (upload arena) failed");
+        RT_CALL(hipHostMalloc((void**)&L.h_back, 8192, hipHostMallocDefault), "hipHostMalloc (mesh read-back) failed");
+        RT_CALL(hipEventCreateWithFlags(&L.evMesh, hipEventDisableTiming), "hipEventCreate failed");
     }
     use(lanes[0]);
 }
@@ -141,7 +170,55 @@ Chunk* RegionTerrain::findChunk(ivec2 c)
     return it == cells.end() ? nullptr : it->second.chunk.get();
 }
 
-std::unordered_set<Chunk*> RegionTerrain::getDrawableChunks() { return drawable; }
+std::unordered_set<Chunk*> RegionTerrain::getDrawableChunks() { finish(); return drawable; }
+
+// a strip's enqueued mesh: wait for its counts, book its chunks.  Too small a fill (rare: the buffers are sized from what earlier ticks
+// needed per chunk) leaves the chunks unmeshed again with the capacity grown; the next meshReady repeats them.
+bool RegionTerrain::completeMesh(Lane& L)
+{
+    if (!L.pm.active) return true;
+    use(L);
+    { const double tw = g_tp.on ? TickProfile::now() : 0; RT_CALL(hipEventSynchronize(L.evMesh), "mesh build failed"); if (g_tp.on) g_tp.cWait += TickProfile::now() - tw; }
+    L.pm.active = false;
+    L.generationOutstanding = false;                   // (the event lies behind everything the lane's stream held when the mesh was enqueued)
+    const int n = (int)L.pm.work.size();
+    const uint32_t* cnt = (const uint32_t*)L.h_back;
+    uint64_t totalVerts = 0;
+    std::memcpy(&totalVerts, L.h_back + L.pm.totalAt, 8);
+    uint32_t most = 0;
+    for (int i = 0; i < n; ++i) most = std::max(most, cnt[i]);
+    if (totalVerts > L.pm.capacity) {
+        L.meshVertsPerChunkCap = std::max<uint64_t>(2 * L.meshVertsPerChunkCap, (totalVerts + n - 1) / n * 2);
+        for (Cell* c : L.pm.work) c->meshed = false;
+        return false;
+    }
+    L.meshVertsPerChunkCap = std::max<uint64_t>(L.meshVertsPerChunkCap, (uint64_t)most + most / 4);
+    for (int i = 0; i < n; ++i) {
+        Chunk* c = L.pm.work[i]->chunk.get();
+        c->idxCount = (int)(cnt[i] / 4 * 6);
+        c->setState(ChunkState::DRAWABLE);
+        drawable.insert(c);
+    }
+    lastMeshed += n;
+    return true;
+}
+
+void RegionTerrain::finish()
+{
+    for (int round = 0; round < 8; ++round) {
+        bool whole = true;
+        for (Lane& L : lanes) whole = completeMesh(L) && whole;
+        if (whole) break;
+        meshReady();                                   // a fill that did not fit: again, with the larger buffers
+    }
+    for (Lane& L : lanes)
+        if (L.generationOutstanding) {
+            use(L);
+            if (L.stream) RT_CALL(hipStreamSynchronize(L.stream), "region generation failed"); else RT_CALL(hipDeviceSynchronize(), "region generation failed");
+            L.generationOutstanding = false;
+        }
+    use(lanes[0]);
+}
 
 // one region call: all stages for the rectangle; blocks go straight into pool slots when the next free slots are one contiguous run
 // (always, until something has been dropped), else through a staging buffer and one device copy per run of consecutive slots
@@ -302,6 +379,7 @@ void RegionTerrain::generateRect(int lane, int cx0, int cz0, int nx, int nz)
 // chunk lifetime: destroy what is far from the player, recycle its pool slot, unlink it from its neighbours
 void RegionTerrain::dropFarChunks()
 {
+    for (Lane& L : lanes) (void)completeMesh(L);       // (a pending mesh points at its cells)
     for (auto it = cells.begin(); it != cells.end();) {
         const int dx = it->first.first - plannedFor.x, dz = it->first.second - plannedFor.y;
         if (std::max(std::abs(dx), std::abs(dz)) <= dropRadius) { ++it; continue; }
@@ -338,6 +416,7 @@ void RegionTerrain::meshReady()
 void RegionTerrain::meshLane(int lane)
 {
     Lane& L = lanes[lane];
+    (void)completeMesh(L);              // last tick's strip (long over by now: this tick's planning and generation calls lie in between)
     use(L);
     hipStream_t st = L.stream;
     std::vector<Cell*> work;
@@ -389,6 +468,10 @@ void RegionTerrain::meshLane(int lane)
         hPos[2 * i] = meta[7 * i + 5]; hPos[2 * i + 1] = meta[7 * i + 6];
     }
     static_assert(sizeof(int32_t) == 4, "layout of the work area");
+    // a device-resident strip: its mesh is enqueued here and booked by the next tick (completeMesh).  (On a stream of its own, beside the
+    // next tick's region call, a tick took 2.1 - 2.7 ms instead of 0.8: every hand-over between the null stream and another queue costs
+    // tens of microseconds on a chip this empty - profiles/LOG.md round 6.)
+    const bool deferred = !copyToHost && n <= 128 && L.h_back && oTot + 8 - oCnt <= 8192;
     uploadAsync(L, w + oIdx, hIn.data(), (size_t)n * 28, "H2D failed");
     RT_CALL(mmgen_mesh_count(L.d_pool, (int32_t*)(w + oIdx), (int32_t*)(w + oNb), n, (uint32_t*)(w + oCol), (uint32_t*)(w + oCnt), st), "mmgen_mesh_count failed");
     std::vector<uint32_t> cnt(n);
@@ -396,10 +479,22 @@ void RegionTerrain::meshLane(int lane)
     uint64_t totalVerts = 0;
     size_t vb = 0, ib = 0;
     char* o = nullptr;
-    if (!copyToHost && n <= 128) {
-        // device resident, a strip: no host round trip between the count and the fill.  The offsets are scanned on the device, the output
-        // buffers are sized from what earlier ticks needed per chunk, and the fill leaves out any chunk that would end beyond them; the
-        // counts and the total are read once, behind the fill - a total beyond the capacity grows it and repeats the (rare) tick's mesh
+    if (deferred) {
+        // device resident, a strip: no host round trip between the count and the fill, and none behind the fill either.  The offsets are
+        // summed inside the fill (mmgen_mesh_fill_strip), the output buffers are sized from what earlier ticks needed per chunk, the fill leaves out any chunk
+        // that would end beyond them; counts, offsets and the total (adjacent in the work area) come back with ONE copy into pinned
+        // memory, and the tick ends here: completeMesh books the chunks when the next tick (or finish) gets to it
+        const uint64_t capacity = (uint64_t)n * L.meshVertsPerChunkCap;
+        vb = (size_t)capacity * sizeof(Vertex); ib = (size_t)capacity / 4 * 6 * sizeof(unsigned int);
+        o = (char*)ensure(L.d_meshOut, L.meshOutCap, vb + ib + 64);
+        RT_CALL(mmgen_mesh_fill_strip(L.d_pool, (int32_t*)(w + oIdx), (int32_t*)(w + oNb), (int32_t*)(w + oPos), n, (uint32_t*)(w + oCol), (uint32_t*)(w + oCnt),
+                                      (uint64_t*)(w + oOff), (uint64_t*)(w + oTot), capacity, (Vertex*)o, (uint32_t*)(o + vb), st), "mmgen_mesh_fill_strip failed");
+        RT_CALL(hipMemcpyAsync(L.h_back, w + oCnt, oTot + 8 - oCnt, hipMemcpyDeviceToHost, st), "D2H failed");
+        RT_CALL(hipEventRecord(L.evMesh, st), "hipEventRecord failed");
+        for (Cell* c : work) c->meshed = true;          // (not picked again; drawable once booked)
+        L.pm.active = true; L.pm.work = work; L.pm.capacity = capacity; L.pm.totalAt = oTot - oCnt;
+        return;
+    } else if (!copyToHost && n <= 128) {
         for (;;) {
             const uint64_t capacity = (uint64_t)n * L.meshVertsPerChunkCap;
             vb = (size_t)capacity * sizeof(Vertex); ib = (size_t)capacity / 4 * 6 * sizeof(unsigned int);
@@ -407,8 +502,18 @@ void RegionTerrain::meshLane(int lane)
             RT_CALL(mmgen_mesh_offsets((uint32_t*)(w + oCnt), n, (uint64_t*)(w + oOff), (uint64_t*)(w + oTot), st), "mmgen_mesh_offsets failed");
             RT_CALL(mmgen_mesh_fill_capped(L.d_pool, (int32_t*)(w + oIdx), (int32_t*)(w + oNb), (int32_t*)(w + oPos), n, (uint32_t*)(w + oCol), (uint64_t*)(w + oOff),
                                            capacity, (Vertex*)o, (uint32_t*)(o + vb), st), "mmgen_mesh_fill_capped failed");
-            RT_CALL(hipMemcpyAsync(cnt.data(), w + oCnt, (size_t)n * 4, hipMemcpyDeviceToHost, st), "D2H failed");
-            copySync(L, &totalVerts, w + oTot, 8, hipMemcpyDeviceToHost, "mesh build failed");      // (waits for the whole tick's work on this lane)
+            // counts, offsets and the total are adjacent in the work area: ONE copy into the pinned arena (two copies to pageable memory were
+            // 5 + 5 us of transfers 22 us apart at the very end of the tick)
+            const size_t span = oTot + 8 - oCnt, need = (span + 63) / 64 * 64;
+            if (L.h_pin && L.pinUsed + need <= L.pinLimit) {
+                char* back = L.h_pin + L.pinUsed;                                          // (not kept: the next round of this loop, if any, re-uses it)
+                copySync(L, back, w + oCnt, span, hipMemcpyDeviceToHost, "mesh build failed");      // (waits for the whole tick's work on this lane)
+                std::memcpy(cnt.data(), back, (size_t)n * 4);
+                std::memcpy(&totalVerts, back + (oTot - oCnt), 8);
+            } else {
+                RT_CALL(hipMemcpyAsync(cnt.data(), w + oCnt, (size_t)n * 4, hipMemcpyDeviceToHost, st), "D2H failed");
+                copySync(L, &totalVerts, w + oTot, 8, hipMemcpyDeviceToHost, "mesh build failed");
+            }
             uint32_t most = 0;
             for (int i = 0; i < n; ++i) most = std::max(most, cnt[i]);
             if (totalVerts <= capacity) { L.meshVertsPerChunkCap = std::max<uint64_t>(L.meshVertsPerChunkCap, (uint64_t)most + most / 4); break; }
@@ -454,9 +559,18 @@ void RegionTerrain::meshLane(int lane)
 
 void RegionTerrain::tick(float)
 {
+    const double tp0 = g_tp.on ? TickProfile::now() : 0;
+    struct Total { double t0; const int* gen; ~Total() { if (g_tp.on && *gen > 0 && *gen <= 128) { g_tp.total += TickProfile::now() - t0; ++g_tp.ticks; g_tp.plan += g_tp.cPlan; g_tp.gen += g_tp.cGen; g_tp.mesh += g_tp.cMesh; g_tp.wait += g_tp.cWait; } g_tp.cPlan = g_tp.cGen = g_tp.cMesh = g_tp.cWait = 0; } } totalGuard{tp0, &lastGenerated};
     lastGenerated = lastMeshed = lastRegions = lastDropped = lastRingReused = lastRingComputed = 0;
     lastBlockBytesD2H = 0;
-    for (Lane& L : lanes) { L.lastGenerated = 0; L.pinUsed = 0; }
+    ++tickCount;
+    for (Lane& L : lanes) {
+        L.lastGenerated = 0;
+        // (what the tick before the last one staged in this half has been read: that tick either ended with a synchronisation or left a
+        // strip's mesh pending, which the last tick completed before it enqueued its own)
+        L.pinUsed = (tickCount & 1) ? L.pinCap / 2 : 0;
+        L.pinLimit = L.pinUsed + L.pinCap / 2;
+    }
     const int R = chunkVbosGenRadius + 1, S = 2 * R + 1;
     if (!planned || !(plannedFor == currentChunkPos)) {
         plannedFor = currentChunkPos; planned = true; pending = true;
@@ -472,7 +586,8 @@ void RegionTerrain::tick(float)
             if (std::max(std::abs(plannedFor.x - completeAt.x), std::abs(plannedFor.y - completeAt.y)) + R > dropRadius) completeValid = false;
         }
     }
-    if (!pending) return;
+    if (g_tp.on) g_tp.cPlan += TickProfile::now() - tp0;
+    if (!pending) { finish(); return; }                // (nothing to generate: what the last tick left enqueued is booked now)
 
     // missing cells of the generation square (drawable radius + the ring the border meshes look at).  When the previous plan was
     // completed around a position close by, the cells of ITS square exist (nothing within dropRadius is ever dropped): only the newly
@@ -510,15 +625,17 @@ void RegionTerrain::tick(float)
                 int lane = 0;
                 for (int l = 1; l < nl; ++l)
                     if (lanes[l].lastGenerated < lanes[lane].lastGenerated || (lanes[l].lastGenerated == lanes[lane].lastGenerated && lanes[l].totalGenerated < lanes[lane].totalGenerated)) lane = l;
+                const double tg = g_tp.on ? TickProfile::now() : 0;
                 generateRect(lane, plannedFor.x - R + x, plannedFor.y - R + z + z0, nx, z1 - z0);
+                if (g_tp.on) g_tp.cGen += TickProfile::now() - tg;
             }
             for (int j = 0; j < nz; ++j) for (int i = 0; i < nx; ++i) missing[(size_t)(x + i) + (size_t)S * (z + j)] = 0;
             numMissing -= nx * nz;
             budget -= nx * nz;
         }
-    meshReady();
+    { const double tm = g_tp.on ? TickProfile::now() : 0; meshReady(); if (g_tp.on) g_tp.cMesh += TickProfile::now() - tm; }
     for (Lane& L : lanes)
-        if (L.generationOutstanding) {
+        if (L.generationOutstanding && !L.pm.active) {
             use(L);
             if (L.stream) RT_CALL(hipStreamSynchronize(L.stream), "region generation failed"); else RT_CALL(hipDeviceSynchronize(), "region generation failed");
             L.generationOutstanding = false;

@@ -45,6 +45,11 @@ public:
     static int getMaxNumDrawableChunks() { return (2 * chunkVbosGenRadius + 1) * (2 * chunkVbosGenRadius + 1); }
 
     bool allQueuesEmpty() const { return !pending; }
+    // Device-resident strips (copyToHost = false, at most 128 chunks to mesh) end a tick with their mesh ENQUEUED: the counts come back with
+    // one small copy whose completion the next tick - or getDrawableChunks / finish - waits for, after its own planning, so the host plans
+    // tick i + 1 while the device finishes tick i (the reference's ticks are asynchronous in the same way: a chunk becomes drawable
+    // when its stage events have fired, terrain.cpp:587-640).  finish(): everything enqueued is complete and booked.
+    void finish();
     Chunk* findChunk(ivec2 worldChunkPos);
     size_t numChunks() const { return cells.size(); }
 
@@ -82,6 +87,7 @@ private:
     std::unordered_set<Chunk*> drawable;
     ivec2 currentChunkPos{0, 0}, plannedFor{0, 0};
     bool planned = false, pending = true;
+    unsigned long long tickCount = 0;
     ivec2 droppedAt{0, 0}, completeAt{0, 0};      // where the far chunks were last looked for; the centre of the last completed plan
     bool droppedOnce = false, completeValid = false;
     size_t poolChunks;                    // per lane
@@ -112,16 +118,23 @@ private:
         // pinned arena for the small host -> device uploads of a tick (index lists, mesh inputs, vertex offsets): an asynchronous copy from
         // pinned memory needs no synchronisation before the host goes on (a blocking copy from pageable memory is a 15 - 25 us round trip,
         // four of them per tick).  Bump-allocated, reset at the start of a tick (the previous tick ended with a synchronisation).
-        char* h_pin = nullptr; size_t pinCap = 0, pinUsed = 0;
+        char* h_pin = nullptr; size_t pinCap = 0, pinUsed = 0, pinLimit = 0;      // (a tick uses one half of the arena, the next tick the other: an
+                                                                                  // enqueued strip's uploads are still to be read when the next tick stages its own)
+        // a strip's mesh that has been enqueued but not booked yet (completeMesh): its chunks, what the fill could hold, where the counts land
+        struct PendingMesh { bool active = false; std::vector<Cell*> work; uint64_t capacity = 0; size_t totalAt = 0; } pm;
+        hipEvent_t evMesh = nullptr;          // behind the read-back of the pending mesh's counts
+        char* h_back = nullptr;               // pinned: counts [n] .. total of the pending mesh (8 KB)
     };
     std::vector<Lane> lanes;
     void use(const Lane& L);
     void copySync(const Lane& L, void* dst, const void* src, size_t bytes, hipMemcpyKind kind, const char* what);
     void uploadAsync(Lane& L, void* dst, const void* src, size_t bytes, const char* what);
+    void uploadAsyncOn(Lane& L, hipStream_t st, void* dst, const void* src, size_t bytes, const char* what);
     void generateRect(int lane, int cx0, int cz0, int nx, int nz);
     void dropFarChunks();
     void meshReady();
     void meshLane(int lane);
+    bool completeMesh(Lane& L);          // false: the fill's buffers were too small - its chunks are unmeshed again, the capacity has grown
     void* ensure(void*& p, size_t& cap, size_t bytes);
 };
 

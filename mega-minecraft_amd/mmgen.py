@@ -217,10 +217,11 @@ class MMGen:
                                                  self._p(verts), self._p(idx), self._stream()), "mmgen_mesh_fill")
         return dict(verts=verts[:total], idx=idx[:total * 3 // 2], chunk_verts=chv, vert_offset=off)
 
-    def create_vbos_capped(self, blocks, world_block_pos, nx, nz, capacity_verts):
+    def create_vbos_capped(self, blocks, world_block_pos, nx, nz, capacity_verts, strip=False):
         """The round-trip-free form (mmgen_mesh_count -> mmgen_mesh_offsets -> mmgen_mesh_fill_capped): offsets scanned on the device, buffers
         sized for `capacity_verts` vertices and pre-filled with a sentinel.  Returns dict(verts [capacity, 10], idx, chunk_verts, vert_offset,
-        total) - chunks that would end beyond the capacity are left untouched."""
+        total) - chunks that would end beyond the capacity are left untouched.  strip=True: mmgen_mesh_fill_strip, the offsets summed inside
+        the fill (at most 256 chunks)."""
         t = self.torch
         n = blocks.shape[0]
         vp, i32, u64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_uint64
@@ -238,6 +239,12 @@ class MMGen:
         verts = t.full((capacity_verts, 10), -7.0, dtype=t.float32, device=blocks.device)
         idx = t.full((capacity_verts * 3 // 2,), -7, dtype=t.int32, device=blocks.device)
         self._check(self.lib.mmgen_mesh_count(self._p(blocks), None, self._p(nb), n, self._p(colv), self._p(chv), self._stream()), "mmgen_mesh_count")
+        if strip:
+            self.lib.mmgen_mesh_fill_strip.argtypes = [vp, vp, vp, vp, i32, vp, vp, vp, vp, u64, vp, vp, vp]
+            off.fill_(-1); total.fill_(-1)
+            self._check(self.lib.mmgen_mesh_fill_strip(self._p(blocks), None, self._p(nb), self._p(world_block_pos), n, self._p(colv), self._p(chv), self._p(off),
+                                                       self._p(total), capacity_verts, self._p(verts), self._p(idx), self._stream()), "mmgen_mesh_fill_strip")
+            return dict(verts=verts, idx=idx, chunk_verts=chv, vert_offset=off, total=int(total.item()))
         self._check(self.lib.mmgen_mesh_offsets(self._p(chv), n, self._p(off), self._p(total), self._stream()), "mmgen_mesh_offsets")
         self._check(self.lib.mmgen_mesh_fill_capped(self._p(blocks), None, self._p(nb), self._p(world_block_pos), n, self._p(colv), self._p(off), capacity_verts,
                                                     self._p(verts), self._p(idx), self._stream()), "mmgen_mesh_fill_capped")

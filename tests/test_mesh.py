@@ -215,6 +215,12 @@ def test_capped_mesh_fill_with_device_side_offsets(gen):
     assert torch.equal(part["verts"][:ends[11]].view(torch.int32), ref["verts"][:ends[11]].view(torch.int32))
     assert torch.equal(part["idx"][:ends[11] * 3 // 2], ref["idx"][:ends[11] * 3 // 2])
     assert bool((part["verts"][ends[11]:] == -7.0).all()) and bool((part["idx"][ends[11] * 3 // 2:] == -7).all())
+    # mmgen_mesh_fill_strip: the same with the offsets summed inside the fill (one launch; offsets and total are outputs)
+    for capacity in (total + 1000, cap):
+        one = gen.create_vbos_capped(reg["blocks"], pos, nx, nz, capacity, strip=True)
+        two = full if capacity != cap else part
+        assert one["total"] == total and torch.equal(one["vert_offset"], ref["vert_offset"])
+        assert torch.equal(one["verts"].view(torch.int32), two["verts"].view(torch.int32)) and torch.equal(one["idx"], two["idx"])
 
 
 @pytest.mark.gpu
