@@ -939,16 +939,17 @@ int mmgen_region_finish(mmgen_region* r, uint8_t* d_blocks, float* d_heightfield
                                          r->bounds.as<int>(), posP, s, r->devMax.as<int>() + 1, r->hostMaxDev, r->devMax.as<int>(),
                                          (unsigned*)r->applyWork.p, (int)(mmk::apply_work_bytes() * r->kMaxSlices / 4), hfP, d_heightfields));
         d_heightfields = nullptr;                       // (copied by the gather)
-        if (par && r->nCompute < r->np) {
-            // the next step's list lengths (see countsSpare): same size as this step's, cleared here beside the rasterisers
-            const size_t countBytes = sizeof(int) * 2 * (size_t)r->np;
-            r->countsSpareClean = 0;
-            CK(r->countsSpare.ensure(countBytes));
-            CK(hipMemsetAsync(r->countsSpare.p, 0, countBytes, s));
-            r->countsSpareClean = countBytes;
-        }
     }
     if (par) { CK(hipEventRecord(r->evGather, s)); CK(hipStreamWaitEvent(sA, r->evGather, 0)); }
+    if (par && features && r->nCompute < r->np) {
+        // the next step's list lengths (see countsSpare): same size as this step's, cleared here - behind the event the rasterisers wait
+        // for, so beside them, not in front of them
+        const size_t countBytes = sizeof(int) * 2 * (size_t)r->np;
+        r->countsSpareClean = 0;
+        CK(r->countsSpare.ensure(countBytes));
+        CK(hipMemsetAsync(r->countsSpare.p, 0, countBytes, s));
+        r->countsSpareClean = countBytes;
+    }
     // rasterisers + decorators slice by slice behind that slice's base fill
     for (int i = 0; i < r->nSlices; ++i) {
         const int c0 = r->sliceRow[i] * r->nx, n = (r->sliceRow[i + 1] - r->sliceRow[i]) * r->nx;

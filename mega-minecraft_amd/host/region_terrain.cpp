@@ -471,9 +471,23 @@ void RegionTerrain::meshLane(int lane)
     // a device-resident strip: its mesh is enqueued here and booked by the next tick (completeMesh).  (On a stream of its own, beside the
     // next tick's region call, a tick took 2.1 - 2.7 ms instead of 0.8: every hand-over between the null stream and another queue costs
     // tens of microseconds on a chip this empty - profiles/LOG.md round 6.)
-    const bool deferred = !copyToHost && n <= 128 && L.h_back && oTot + 8 - oCnt <= 8192;
-    uploadAsync(L, w + oIdx, hIn.data(), (size_t)n * 28, "H2D failed");
-    RT_CALL(mmgen_mesh_count(L.d_pool, (int32_t*)(w + oIdx), (int32_t*)(w + oNb), n, (uint32_t*)(w + oCol), (uint32_t*)(w + oCnt), st), "mmgen_mesh_count failed");
+    const size_t inNeed = ((size_t)n * 28 + 63) / 64 * 64;
+    const bool deferred = !copyToHost && n <= 128 && L.h_back && oTot + 8 - oCnt <= 8192 && L.h_pin && L.pinUsed + inNeed <= L.pinLimit;
+    // The strip's kernels read their few inputs (a slot, four neighbour slots and a position per chunk) straight from the pinned arena and write
+    // the chunks' counts, offsets and the total straight into pinned memory (hipHostMalloc memory has one address on both sides): a 1 KB copy in
+    // each direction is 5 us of transfer and twice that of gaps in a chain of thirty dependent launches, a few PCIe reads inside a kernel are not
+    int32_t *kIdx = (int32_t*)(w + oIdx), *kNb = (int32_t*)(w + oNb), *kPos = (int32_t*)(w + oPos);
+    uint32_t* kCnt = (uint32_t*)(w + oCnt);
+    if (deferred) {
+        char* in = L.h_pin + L.pinUsed;                    // (this tick's half of the arena: intact until the next tick has booked this mesh)
+        L.pinUsed += inNeed;
+        std::memcpy(in, hIn.data(), (size_t)n * 28);
+        kIdx = (int32_t*)in; kNb = kIdx + n; kPos = kNb + (size_t)n * 4;
+        kCnt = (uint32_t*)L.h_back;
+    } else {
+        uploadAsync(L, w + oIdx, hIn.data(), (size_t)n * 28, "H2D failed");
+    }
+    RT_CALL(mmgen_mesh_count(L.d_pool, kIdx, kNb, n, (uint32_t*)(w + oCol), kCnt, st), "mmgen_mesh_count failed");
     std::vector<uint32_t> cnt(n);
     std::vector<uint64_t> off(n);
     uint64_t totalVerts = 0;
@@ -482,14 +496,13 @@ void RegionTerrain::meshLane(int lane)
     if (deferred) {
         // device resident, a strip: no host round trip between the count and the fill, and none behind the fill either.  The offsets are
         // summed inside the fill (mmgen_mesh_fill_strip), the output buffers are sized from what earlier ticks needed per chunk, the fill leaves out any chunk
-        // that would end beyond them; counts, offsets and the total (adjacent in the work area) come back with ONE copy into pinned
-        // memory, and the tick ends here: completeMesh books the chunks when the next tick (or finish) gets to it
+        // that would end beyond them; counts, offsets and the total are written into pinned memory by the kernels themselves, and the tick
+        // ends here: completeMesh books the chunks when the next tick (or finish) gets to it
         const uint64_t capacity = (uint64_t)n * L.meshVertsPerChunkCap;
         vb = (size_t)capacity * sizeof(Vertex); ib = (size_t)capacity / 4 * 6 * sizeof(unsigned int);
         o = (char*)ensure(L.d_meshOut, L.meshOutCap, vb + ib + 64);
-        RT_CALL(mmgen_mesh_fill_strip(L.d_pool, (int32_t*)(w + oIdx), (int32_t*)(w + oNb), (int32_t*)(w + oPos), n, (uint32_t*)(w + oCol), (uint32_t*)(w + oCnt),
-                                      (uint64_t*)(w + oOff), (uint64_t*)(w + oTot), capacity, (Vertex*)o, (uint32_t*)(o + vb), st), "mmgen_mesh_fill_strip failed");
-        RT_CALL(hipMemcpyAsync(L.h_back, w + oCnt, oTot + 8 - oCnt, hipMemcpyDeviceToHost, st), "D2H failed");
+        RT_CALL(mmgen_mesh_fill_strip(L.d_pool, kIdx, kNb, kPos, n, (uint32_t*)(w + oCol), kCnt, (uint64_t*)(L.h_back + (oOff - oCnt)), (uint64_t*)(L.h_back + (oTot - oCnt)),
+                                      capacity, (Vertex*)o, (uint32_t*)(o + vb), st), "mmgen_mesh_fill_strip failed");
         RT_CALL(hipEventRecord(L.evMesh, st), "hipEventRecord failed");
         for (Cell* c : work) c->meshed = true;          // (not picked again; drawable once booked)
         L.pm.active = true; L.pm.work = work; L.pm.capacity = capacity; L.pm.totalAt = oTot - oCnt;
