@@ -66,7 +66,7 @@ public:
     size_t poolInUse() const;
     int numLanes() const { return (int)lanes.size(); }
     int lastGeneratedOnLane(int lane) const { return lanes[lane].lastGenerated; }
-    // device-side results of lane 0's last mesh pass (valid until the next tick)
+    // device-side results of lane 0's last mesh pass (complete behind finish() / getDrawableChunks(); valid until the next tick)
     const Vertex* deviceVerts() const { return (const Vertex*)lanes[0].d_meshOut; }
     // test hook: digest (host/chunk_digest.hpp) of a chunk's blocks as they lie in its lane's pool - what a device-resident consumer would read
     uint64_t deviceBlocksDigest(ivec2 worldChunkPos);
