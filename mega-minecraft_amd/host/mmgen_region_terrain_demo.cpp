@@ -241,6 +241,30 @@ int main(int argc, char** argv)
             }
         std::printf("device-resident, %zu lanes vs one lane vs the mirror: %d of %d drawable chunks differ (pool digests, index counts)\n", devices.size(), differ, (2 * r + 1) * (2 * r + 1));
         bad += differ;
+        // the streaming form of the same square: loaded eight chunks to the west, then walked here one chunk per tick.  Every tick generates a
+        // 35-chunk strip whose mesh is only ENQUEUED by its tick and booked by the next (RegionTerrain::completeMesh); at the end every
+        // drawable chunk must be what the one-tick load above made of it
+        RegionTerrain walked;
+        walked.copyToHost = false;
+        walked.init();
+        int strips = 0, stripChunks = 0;
+        for (int k = -8; k <= 0; ++k) {
+            walked.setCurrentChunkPos({player.x + k, player.y});
+            do { walked.tick(1.f / 60.f); if (k > -8) { ++strips; stripChunks += walked.lastGenerated; } } while (!walked.allQueuesEmpty());
+        }
+        walked.finish();
+        int differWalk = 0;
+        for (int dz = -r; dz <= r; ++dz)
+            for (int dx = -r; dx <= r; ++dx) {
+                const ivec2 c = {player.x + dx, player.y + dz};
+                Chunk *a = walked.findChunk(c), *b = residentOne.findChunk(c);
+                if (!a || !b || a->getState() != ChunkState::DRAWABLE) { ++differWalk; continue; }
+                if (walked.deviceBlocksDigest(c) != residentOne.deviceBlocksDigest(c) || a->idxCount != b->idxCount) ++differWalk;
+            }
+        std::printf("device-resident walk (%d strip ticks, %d chunks, meshes booked by the following tick) vs the one-tick load: %d of %d drawable chunks differ\n", strips, stripChunks,
+                    differWalk, (2 * r + 1) * (2 * r + 1));
+        if (strips < 8 || stripChunks > 8 * 128) ++bad;          // (the walk must have gone through the strip path)
+        bad += differWalk;
     }
     {   // chunk lifetime: a pool of 2 600 slots serves a 2 x 16-step walk (each step regenerates a strip, far chunks are destroyed and
         // their slots recycled); back at the first position everything was dropped and regenerated, and must equal the mirror's chunks

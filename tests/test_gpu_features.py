@@ -374,7 +374,9 @@ def test_cpp_terrain_scheduler_streams_a_world(mmgen_pkg):
 def test_region_batched_scheduler_equals_action_time_scheduler(mmgen_pkg):
     """RegionTerrain (host/region_terrain.hpp: one device-resident region call per missing rectangle + pool meshing, budget in chunks)
     and Terrain (the drop-in mirror of the reference's action-time loop) stream the world around a player and then around a second
-    position: all 1 089 drawable chunks have identical blocks, vertices and indices in both (the demo compares in-process)."""
+    position: all 1 089 drawable chunks have identical blocks, vertices and indices in both (the demo compares in-process); device resident,
+    two lanes == one lane == the mirror, and a walk of one-chunk steps (the strip path: meshes enqueued by their tick, booked by the next)
+    ends at the same chunks as a one-tick load."""
     import os
     import subprocess
     exe = os.path.join(os.path.dirname(mmgen_pkg.LIB_PATH), "mmgen_region_terrain_demo")
@@ -383,6 +385,8 @@ def test_region_batched_scheduler_equals_action_time_scheduler(mmgen_pkg):
     print(r.stdout[-3000:])
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert "IDENTICAL" in r.stdout and "1089 drawable chunks compared" in r.stdout
+    # the streaming form (device resident, 35-chunk strips whose meshes are booked by the following tick) ends at the one-tick load's chunks
+    assert "vs the one-tick load: 0 of 1089 drawable chunks differ" in r.stdout
 
 
 def _two_process_worker(rank, world, port, layout_args, outdir):
