@@ -55,7 +55,7 @@ public:
 
     int maxChunksPerTick = 4096;          // generation budget of one tick, in chunks
     int dropRadius = 40;                  // chunks farther than this (Chebyshev) from the player are destroyed; = chunkMaxGenRadius of the reference
-    bool copyToHost = true;               // false: blocks and meshes stay on the device (renderer interop), Chunk::blocks / verts stay empty
+    bool copyToHost = true;               // false: blocks and meshes stay on the device (renderer interop), Chunk::blocks / verts stay empty (set before the first tick)
     int zoneCacheZones = 128;             // eroded zones kept on the device (151 MB; set before init(); 0 = relax every covering zone of every region anew)
     void zoneCacheStats(long long& hits, long long& misses) const;
     bool cachePlacements = true;          // keep the placement lists of generated chunks and feed them back as ring cells of later regions
